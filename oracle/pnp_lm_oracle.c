@@ -1,0 +1,328 @@
+/*
+ * CPU oracle for the weighted PnP solve (TEST INFRASTRUCTURE ONLY -- never the product path).
+ *
+ * Restates /root/reference/lib/pnp/cxx/ceres.cpp:15-177 in plain C99 + OpenMP and exports the same
+ * C ABI (`lib/pnp/cxx/ext.h:2-15`).  The optimiser itself lives in the third-party dependency
+ * Ceres Solver 2.1.0 (pinned by `scripts/build-ceres.sh:18-22`), whose source is NOT under
+ * /root/reference and cannot be built in this image (no Eigen/glog/SuiteSparse, no network), so its
+ * published default algorithm is restated here from the call site's options (ceres.cpp:118-125:
+ * DENSE_QR, max_num_iterations, function_tolerance; everything else default):
+ *
+ *   trust-region Levenberg-Marquardt, initial radius 1e4, max radius 1e16, min radius 1e-32,
+ *   min_relative_decrease 1e-3, Jacobi column scaling 1/(1+||J_j||) fixed at iteration 0,
+ *   LM diagonal = sqrt(clamp(diag(Js^T Js),1e-6,1e32)/radius), step = argmin ||Js y + r||^2 + ||D y||^2
+ *   by dense QR of [Js; D], radius /= max(1/3, 1-(2 rho-1)^3) on success, /= 2,4,8.. on failure,
+ *   stop: |dcost| <= ftol*cost (CONVERGENCE), ||dx|| <= 1e-8(||x||+1e-8) (CONVERGENCE),
+ *   max|g| <= 1e-10 (CONVERGENCE), iteration >= max_num_iterations (NO_CONVERGENCE -> invalid),
+ *   5 consecutive invalid steps (FAILURE -> invalid).
+ *
+ * PARITY UNPINNED against Ceres itself: the reference holds no test or golden vector for this
+ * boundary.  tests/test_oracle_pnp.py anchors it with known-answer tests instead
+ * (noise-free recovery, stationarity, SciPy least_squares cross-check, <3 points, full 2x2 icov).
+ *
+ * Residual model (ceres.cpp:15-65): p = R(aa) X + t; up = (p0 k0 + p1 k1)/p2, vp = (p0 k3 + p1 k4)/p2,
+ * du = up-(u-k2), dv = vp-(v-k5); r = [du*L00 + dv*L10, dv*L11]; no z clamp; doubles inside.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ceres/rotation.h QuaternionToAngleAxis (ceres.cpp:96) */
+static void quat_to_aa(const double q[4], double aa[3]) {
+    const double q1 = q[1], q2 = q[2], q3 = q[3];
+    const double s2 = q1 * q1 + q2 * q2 + q3 * q3;
+    if (s2 > 0.0) {
+        const double s = sqrt(s2), c = q[0];
+        const double two_theta = 2.0 * ((c < 0.0) ? atan2(-s, -c) : atan2(s, c));
+        const double k = two_theta / s;
+        aa[0] = q1 * k; aa[1] = q2 * k; aa[2] = q3 * k;
+    } else {
+        aa[0] = q1 * 2.0; aa[1] = q2 * 2.0; aa[2] = q3 * 2.0;
+    }
+}
+
+/* ceres/rotation.h AngleAxisToQuaternion (ceres.cpp:131) */
+static void aa_to_quat(const double aa[3], double q[4]) {
+    const double t2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    if (t2 > 0.0) {
+        const double t = sqrt(t2), h = t * 0.5, k = sin(h) / t;
+        q[0] = cos(h); q[1] = aa[0] * k; q[2] = aa[1] * k; q[3] = aa[2] * k;
+    } else {
+        q[0] = 1.0; q[1] = aa[0] * 0.5; q[2] = aa[1] * 0.5; q[3] = aa[2] * 0.5;
+    }
+}
+
+typedef struct {
+    int n;
+    const float *u, *X, *L;
+    double cam[6];
+} problem_t;
+
+/* residuals (2n) and, if J != NULL, the 2n x 6 row-major Jacobian w.r.t. (aa, t).
+ * AngleAxisRotatePoint (ceres.cpp:37) incl. its small-angle branch; derivative = exact derivative of the
+ * same branch (what the Jet autodiff of ceres.cpp:59 produces). returns 0 if any value is non-finite. */
+static int evaluate(const problem_t *P, const double x[6], double *r, double *J, double *cost) {
+    const double *aa = x, *t = x + 3;
+    const double theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    const int big = theta2 > DBL_EPSILON;
+    double th = 0, c = 1, s = 0, w[3] = {0, 0, 0};
+    if (big) {
+        th = sqrt(theta2); c = cos(th); s = sin(th);
+        w[0] = aa[0] / th; w[1] = aa[1] / th; w[2] = aa[2] / th;
+    }
+    const double *k = P->cam;
+    double sum = 0;
+    int ok = 1;
+    for (int i = 0; i < P->n; ++i) {
+        const double p[3] = {P->X[3 * i], P->X[3 * i + 1], P->X[3 * i + 2]};
+        double f[3], D[3][3];
+        if (big) {
+            const double wxp[3] = {w[1] * p[2] - w[2] * p[1], w[2] * p[0] - w[0] * p[2], w[0] * p[1] - w[1] * p[0]};
+            const double wp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+            const double tmp = wp * (1.0 - c);
+            for (int a = 0; a < 3; ++a) f[a] = p[a] * c + wxp[a] * s + w[a] * tmp;
+            if (J) {
+                /* d f/d theta (x) w^T + d f/d w * (I - w w^T)/theta */
+                double dth[3], M[3][3];
+                for (int a = 0; a < 3; ++a) dth[a] = -p[a] * s + wxp[a] * c + w[a] * wp * s;
+                /* M = -[p]x s + (wp I + w p^T)(1-c) */
+                const double px[3][3] = {{0, -p[2], p[1]}, {p[2], 0, -p[0]}, {-p[1], p[0], 0}};
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b)
+                        M[a][b] = -px[a][b] * s + ((a == b ? wp : 0.0) + w[a] * p[b]) * (1.0 - c);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        double acc = 0;
+                        for (int d = 0; d < 3; ++d) acc += M[a][d] * ((d == b ? 1.0 : 0.0) - w[d] * w[b]);
+                        D[a][b] = dth[a] * w[b] + acc / th;
+                    }
+            }
+        } else {
+            f[0] = p[0] + aa[1] * p[2] - aa[2] * p[1];
+            f[1] = p[1] + aa[2] * p[0] - aa[0] * p[2];
+            f[2] = p[2] + aa[0] * p[1] - aa[1] * p[0];
+            if (J) {
+                const double npx[3][3] = {{0, p[2], -p[1]}, {-p[2], 0, p[0]}, {p[1], -p[0], 0}};
+                memcpy(D, npx, sizeof(D));
+            }
+        }
+        const double q0 = f[0] + t[0], q1 = f[1] + t[1], q2 = f[2] + t[2];
+        const double nu = q0 * k[0] + q1 * k[1], nv = q0 * k[3] + q1 * k[4];
+        const double up = nu / q2, vp = nv / q2;
+        const double du = up - ((double)P->u[2 * i] - k[2]);
+        const double dv = vp - ((double)P->u[2 * i + 1] - k[5]);
+        const double a = P->L[4 * i], b = P->L[4 * i + 2], cc = P->L[4 * i + 3];
+        const double r0 = du * a + dv * b, r1 = dv * cc;
+        r[2 * i] = r0; r[2 * i + 1] = r1;
+        sum += r0 * r0 + r1 * r1;
+        if (!isfinite(r0) || !isfinite(r1)) ok = 0;
+        if (J) {
+            const double dup[3] = {k[0] / q2, k[1] / q2, -nu / (q2 * q2)};
+            const double dvp[3] = {k[3] / q2, k[4] / q2, -nv / (q2 * q2)};
+            double d0[3], d1[3];
+            for (int m = 0; m < 3; ++m) { d0[m] = a * dup[m] + b * dvp[m]; d1[m] = cc * dvp[m]; }
+            double *J0 = J + 12 * i, *J1 = J0 + 6;
+            for (int m = 0; m < 3; ++m) {
+                J0[m] = d0[0] * D[0][m] + d0[1] * D[1][m] + d0[2] * D[2][m];
+                J1[m] = d1[0] * D[0][m] + d1[1] * D[1][m] + d1[2] * D[2][m];
+                J0[3 + m] = d0[m];
+                J1[3 + m] = d1[m];
+                if (!isfinite(J0[m]) || !isfinite(J1[m]) || !isfinite(d0[m]) || !isfinite(d1[m])) ok = 0;
+            }
+        }
+    }
+    *cost = 0.5 * sum;
+    return ok;
+}
+
+/* least squares  min ||A y - b||  for A (m x 6, row-major, overwritten), b (m, overwritten) by Householder QR.
+ * returns 0 on rank deficiency / non-finite. (DENSE_QR, ceres.cpp:119) */
+static int qr_solve6(double *A, double *b, int m, double y[6]) {
+    for (int j = 0; j < 6; ++j) {
+        double nrm = 0;
+        for (int i = j; i < m; ++i) nrm += A[i * 6 + j] * A[i * 6 + j];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0) || !isfinite(nrm)) return 0;
+        const double alpha = A[j * 6 + j] > 0 ? -nrm : nrm;
+        const double v0 = A[j * 6 + j] - alpha;
+        double vnorm2 = v0 * v0;
+        for (int i = j + 1; i < m; ++i) vnorm2 += A[i * 6 + j] * A[i * 6 + j];
+        if (vnorm2 > 0) {
+            for (int c = j + 1; c < 6; ++c) {
+                double d = v0 * A[j * 6 + c];
+                for (int i = j + 1; i < m; ++i) d += A[i * 6 + j] * A[i * 6 + c];
+                d = 2 * d / vnorm2;
+                A[j * 6 + c] -= d * v0;
+                for (int i = j + 1; i < m; ++i) A[i * 6 + c] -= d * A[i * 6 + j];
+            }
+            double d = v0 * b[j];
+            for (int i = j + 1; i < m; ++i) d += A[i * 6 + j] * b[i];
+            d = 2 * d / vnorm2;
+            b[j] -= d * v0;
+            for (int i = j + 1; i < m; ++i) b[i] -= d * A[i * 6 + j];
+        }
+        A[j * 6 + j] = alpha;
+    }
+    for (int j = 5; j >= 0; --j) {
+        double acc = b[j];
+        for (int c = j + 1; c < 6; ++c) acc -= A[j * 6 + c] * y[c];
+        y[j] = acc / A[j * 6 + j];
+        if (!isfinite(y[j])) return 0;
+    }
+    return 1;
+}
+
+void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d, const float *pts3d,
+                   const float *icov_sqrtL, int ptCnt, int maxIterCnt, float function_tolerance, int printSummary,
+                   float *result_tr, int *ret) {
+    if (ptCnt < 3) { /* ceres.cpp:84-91 */
+        *ret = 1;
+        *result_tr = 1;
+        if (printSummary) printf("skipped problem with less than 3 points\n");
+        return;
+    }
+    problem_t P;
+    P.n = ptCnt; P.u = pts2d; P.X = pts3d; P.L = icov_sqrtL;
+    for (int i = 0; i < 6; ++i) P.cam[i] = cam_K[i];
+    double x[6], quat[4] = {io_state_quat[0], io_state_quat[1], io_state_quat[2], io_state_quat[3]};
+    quat_to_aa(quat, x);
+    for (int i = 0; i < 3; ++i) x[3 + i] = io_state_quat[4 + i];
+
+    const int m = 2 * ptCnt;
+    double *r = (double *)malloc(sizeof(double) * (size_t)(m + 6) * 2);
+    double *rc = r + (m + 6);
+    double *J = (double *)malloc(sizeof(double) * (size_t)(m + 6) * 6 * 2);
+    double *Aw = J + (size_t)(m + 6) * 6;
+
+    const double ftol = function_tolerance, ptol = 1e-8, gtol = 1e-10;
+    const double min_rel_decrease = 1e-3, max_radius = 1e16, min_radius = 1e-32;
+    double radius = 1e4, decrease_factor = 2.0;
+    double x_cost = 0, scale[6], g[6], gmax = 0, x_norm = 0;
+    int converged = 0, failed = 0, iter = 0, n_invalid = 0;
+
+    if (!evaluate(&P, x, r, J, &x_cost)) failed = 1; /* "Initial residual and Jacobian evaluation failed." */
+    if (!failed) {
+        for (int j = 0; j < 6; ++j) {
+            double cn = 0;
+            g[j] = 0;
+            for (int i = 0; i < m; ++i) { cn += J[i * 6 + j] * J[i * 6 + j]; g[j] += J[i * 6 + j] * r[i]; }
+            scale[j] = 1.0 / (1.0 + sqrt(cn));
+        }
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < 6; ++j) J[i * 6 + j] *= scale[j];
+        gmax = 0; x_norm = 0;
+        for (int j = 0; j < 6; ++j) { gmax = fmax(gmax, fabs(g[j])); x_norm += x[j] * x[j]; }
+        x_norm = sqrt(x_norm);
+    }
+    while (!failed && !converged) {
+        /* FinalizeIterationAndCheckIfMinimizerCanContinue */
+        if (iter >= maxIterCnt) break;                 /* NO_CONVERGENCE */
+        if (gmax <= gtol) { converged = 1; break; }    /* gradient tolerance */
+        if (radius <= min_radius) { converged = 1; break; }
+        ++iter;
+        /* LevenbergMarquardtStrategy::ComputeStep */
+        double y[6], step[6], delta[6], xc[6];
+        for (int j = 0; j < 6; ++j) {
+            double cn = 0;
+            for (int i = 0; i < m; ++i) cn += J[i * 6 + j] * J[i * 6 + j];
+            cn = fmin(fmax(cn, 1e-6), 1e32);
+            const double d = sqrt(cn / radius);
+            for (int c = 0; c < 6; ++c) Aw[(size_t)(m + j) * 6 + c] = (c == j) ? d : 0.0;
+            rc[m + j] = 0;
+        }
+        memcpy(Aw, J, sizeof(double) * (size_t)m * 6);
+        memcpy(rc, r, sizeof(double) * (size_t)m);
+        int step_ok = qr_solve6(Aw, rc, m + 6, y);
+        double model_cost_change = 0;
+        if (step_ok) {
+            for (int j = 0; j < 6; ++j) step[j] = -y[j];
+            for (int i = 0; i < m; ++i) {
+                double mr = 0;
+                for (int j = 0; j < 6; ++j) mr += J[i * 6 + j] * step[j];
+                model_cost_change -= mr * (r[i] + mr / 2.0);
+            }
+            step_ok = model_cost_change > 0.0;
+        }
+        if (!step_ok) { /* HandleInvalidStep */
+            if (++n_invalid >= 5) { failed = 1; break; }
+            radius /= decrease_factor; decrease_factor *= 2.0;
+            continue;
+        }
+        n_invalid = 0;
+        double step_norm = 0;
+        for (int j = 0; j < 6; ++j) { delta[j] = step[j] * scale[j]; xc[j] = x[j] + delta[j]; step_norm += delta[j] * delta[j]; }
+        step_norm = sqrt(step_norm);
+        double cand_cost;
+        if (!evaluate(&P, xc, rc, NULL, &cand_cost)) cand_cost = DBL_MAX;
+        if (step_norm <= ptol * (x_norm + ptol)) { converged = 1; break; }          /* ParameterToleranceReached */
+        const double cost_change = x_cost - cand_cost;
+        if (fabs(cost_change) <= ftol * x_cost) { converged = 1; break; }           /* FunctionToleranceReached */
+        const double rel = cost_change / model_cost_change;
+        if (rel > min_rel_decrease) { /* HandleSuccessfulStep */
+            memcpy(x, xc, sizeof(xc));
+            x_norm = 0;
+            for (int j = 0; j < 6; ++j) x_norm += x[j] * x[j];
+            x_norm = sqrt(x_norm);
+            if (!evaluate(&P, x, r, J, &x_cost)) { failed = 1; break; }
+            gmax = 0;
+            for (int j = 0; j < 6; ++j) {
+                g[j] = 0;
+                for (int i = 0; i < m; ++i) g[j] += J[i * 6 + j] * r[i];
+                gmax = fmax(gmax, fabs(g[j]));
+            }
+            for (int i = 0; i < m; ++i)
+                for (int j = 0; j < 6; ++j) J[i * 6 + j] *= scale[j];
+            const double tq = 2.0 * rel - 1.0;
+            radius = radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
+            radius = fmin(max_radius, radius);
+            decrease_factor = 2.0;
+        } else {
+            radius /= decrease_factor; decrease_factor *= 2.0;
+        }
+        if (printSummary) printf("iter %d cost %.9e radius %.3e\n", iter, x_cost, radius);
+    }
+    free(r); free(J);
+    const int invalid = !(converged && !failed);
+    *ret = invalid;
+    *result_tr = (float)radius;
+    if (invalid) return; /* ceres.cpp:134-138: state untouched unless CONVERGENCE */
+    aa_to_quat(x, quat);
+    for (int i = 0; i < 4; ++i) io_state_quat[i] = (float)quat[i];
+    for (int i = 0; i < 3; ++i) io_state_quat[4 + i] = (float)x[3 + i];
+}
+
+void pnp_ceres_f32_omp(float **init_states, float **cam_Ks, float **pts2ds, float **pts3ds, float **icov_sqrtLs,
+                       int *ptCnts, int maxIterCnt, float function_tolerance, int printSummary, float *result_trs,
+                       int *rets, int job_count, int num_threads) {
+    if (num_threads > 1) { /* ceres.cpp:159-169 */
+#ifdef _OPENMP
+        omp_set_num_threads(num_threads);
+#endif
+#pragma omp parallel for
+        for (int i = 0; i < job_count; ++i)
+            pnp_ceres_f32(init_states[i], cam_Ks[i], pts2ds[i], pts3ds[i], icov_sqrtLs[i], ptCnts[i], maxIterCnt,
+                          function_tolerance, printSummary, result_trs + i, rets + i);
+    } else {
+        for (int i = 0; i < job_count; ++i)
+            pnp_ceres_f32(init_states[i], cam_Ks[i], pts2ds[i], pts3ds[i], icov_sqrtLs[i], ptCnts[i], maxIterCnt,
+                          function_tolerance, printSummary, result_trs + i, rets + i);
+    }
+}
+
+/* Contiguous-batch convenience for tests/bench (same solver; avoids building pointer arrays in Python). */
+void pnp_oracle_batched_f32(float *states, const float *Ks, const float *pts2d, const float *pts3d, const float *sqrtL,
+                            const int *ptCnts, int nmax, int maxIterCnt, float function_tolerance, float *result_trs,
+                            int *rets, int job_count, int num_threads) {
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#endif
+#pragma omp parallel for if (num_threads > 1)
+    for (int i = 0; i < job_count; ++i)
+        pnp_ceres_f32(states + 7 * (size_t)i, Ks + 9 * (size_t)i, pts2d + 2 * (size_t)i * nmax, pts3d + 3 * (size_t)i * nmax,
+                      sqrtL + 4 * (size_t)i * nmax, ptCnts[i], maxIterCnt, function_tolerance, 0, result_trs + i, rets + i);
+}
