@@ -1,0 +1,84 @@
+/*
+ * lc_amd -- C ABI of the MI355X (gfx950) hot path of fulliu/lc.
+ *
+ * One shared library (liblc_amd.so, built from lc_amd/csrc/ by `python __graft_entry__.py build`) exports
+ *   (1) the reference's OWN native entry point, symbol-for-symbol, so the reference's cffi binding
+ *       (lib/pnp/pnp_ceres.py:93-140) can load this library instead of its Ceres extension, and
+ *   (2) device-pointer entry points for the three fused kernels, which the Python host layer (lc_amd/*.py,
+ *       mirroring lib/cov_mixed.py, lib/pnp/cer_solver.py, ptnet.py) binds with ctypes.
+ * Plain pointers and sizes only; no torch types.  All `float*`/`int*` of the device API are DEVICE pointers,
+ * `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream.
+ * Return value: 0 on success, non-zero on error (lc_amd_last_error() gives the text).
+ */
+#ifndef LC_AMD_H
+#define LC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_AMD_VERSION 1
+#define LC_AMD_LOSS_AUX_STRIDE 40 /* per sample: prior_error, cov_err, linear_err, not_spd, Hinv[36] */
+
+int lc_amd_version(void);
+const char *lc_amd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) Reference ABI -- replaces /root/reference/lib/pnp/cxx/ext.h:2-15 (implemented in
+ *     lib/pnp/cxx/ceres.cpp:147-177 on top of Ceres 2.1.0).  HOST pointers, arrays-of-pointers, one entry per job:
+ *       init_states[i] : 7 floats w,x,y,z,tx,ty,tz -- updated IN PLACE only when rets[i]==0 (ceres.cpp:134-144)
+ *       cam_Ks[i]      : row-major 3x3, first 6 floats read (ceres.cpp:99-101)
+ *       pts2ds[i]      : ptCnts[i] x 2,  pts3ds[i] : ptCnts[i] x 3
+ *       icov_sqrtLs[i] : ptCnts[i] x 2 x 2 row-major lower factor, element [0][1] ignored (ceres.cpp:25-27)
+ *       rets[i]        : 0 ok / 1 invalid (fewer than 3 points, or the solve did not end in CONVERGENCE)
+ *       result_trs[i]  : final trust-region radius (1 when skipped)
+ *     Caller owns every buffer; nothing outlives the call; no exceptions/errno.  num_threads is accepted for
+ *     signature compatibility and ignored: all jobs run concurrently on the GPU, one wavefront per job.
+ *     If no GPU can be used the call prints to stderr and marks every job invalid (there is NO CPU fallback).
+ * ------------------------------------------------------------------------------------------------ */
+void pnp_ceres_f32_omp(float **init_states, float **cam_Ks, float **pts2ds, float **pts3ds, float **icov_sqrtLs,
+                       int *ptCnts, int maxIterCnt, float function_tolerance, int printSummary, float *result_trs,
+                       int *rets, int job_count, int num_threads);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2a) Batched weighted PnP on device-resident, zero-padded batches -- the GPU form of what
+ *      lib/pnp/cer_solver.py:22-44 builds before calling the solver (so no device->host round trip).
+ *      K (B,3,3)  pts3d (B,Nmax,3)  pts2d (B,Nmax,2)  counts (B) or NULL (= Nmax)
+ *      exactly one of: sqrtL (B,Nmax,2,2) lower factor | sqrt_diag (B,Nmax,2) its diagonal (cer_solver.py:37-40)
+ *      states (B,7) in/out (same in-place rule), result_tr (B), rets (B), iters (B) or NULL
+ * ------------------------------------------------------------------------------------------------ */
+int lc_pnp_lm_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *sqrt_diag,
+                  const int *counts, float *states, float *result_tr, int *rets, int *iters, int B, int Nmax,
+                  int max_iter, float function_tolerance, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2b) Linear-covariance loss, forward + backward in one launch -- replaces the autograd graph of
+ *      lib/cov_mixed.py:100-150 Loss_cov_mixed (cov_2d=False).  K (B,3,3) pose (B,7) pts3d (B,N,3) pts2d (B,N,2)
+ *      inv_std (B,N,2) valid (B,N)|NULL bbox_3d (B,8,3) grad_out (B)|NULL(=1)
+ *      -> loss (B); d_pts2d,d_inv_std (B,N,2) (both NULL = forward only); d_pts3d (B,N,3)|NULL; aux (B,40)|NULL
+ *      Gradients are d(sum_b grad_out[b]*loss[b]) / d(input).
+ * ------------------------------------------------------------------------------------------------ */
+int lc_cov_loss_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,
+                            const float *inv_std, const float *valid, const float *bbox_3d, const float *grad_out,
+                            int B, int N, float max_err_len, float rel_thresh, float w_e_thresh, float *loss,
+                            float *d_pts2d, float *d_inv_std, float *d_pts3d, float *aux, void *stream);
+
+/* dst[b, :] = scale[b] * src[b, :]  for up to three (B,row_len) tensors in one launch (autograd's chain-rule step) */
+int lc_scale_rows_f32(const float *scale, int B, const float *src0, float *dst0, int len0, const float *src1, float *dst1,
+                      int len1, const float *src2, float *dst2, int len2, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2c) Sparse keypoint head -- replaces ptnet.py:59-66 + ptnet.py:85-115.  in (M,H,W): logits (is_prob=0; the
+ *      spatial softmax of ptnet.py:61 is fused) or probabilities (is_prob=1; ptnet.softargmax_2d_std itself).
+ *      -> mean (M,2) [x,y], std (M,2), stats (M,4) saved for backward.
+ * ------------------------------------------------------------------------------------------------ */
+int lc_softargmax2d_fwd_f32(const float *in, int M, int H, int W, int is_prob, float *mean, float *std, float *stats,
+                            void *stream);
+int lc_softargmax2d_bwd_f32(const float *in, const float *mean, const float *std, const float *stats,
+                            const float *g_mean, const float *g_std, int M, int H, int W, int is_prob, float *g_in,
+                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LC_AMD_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of liblc_amd.so (the C ABI declared in include/lc_amd.h).
+
+The product path has NO CPU fallback: if the library is missing, or a tensor is not a float32 HIP tensor,
+the callers below raise.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_void_p
+
+import torch
+
+from . import build as _build
+
+_LIB = None
+
+_F = ctypes.POINTER(c_float)
+_FP = ctypes.POINTER(_F)
+_I = ctypes.POINTER(c_int)
+
+_SIGNATURES = {
+    "lc_amd_version": (c_int, []),
+    "lc_amd_last_error": (ctypes.c_char_p, []),
+    "pnp_ceres_f32_omp": (None, [_FP, _FP, _FP, _FP, _FP, _I, c_int, c_float, c_int, _F, _I, c_int, c_int]),
+    "lc_pnp_lm_f32": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "lc_cov_loss_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 6),
+    "lc_scale_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_int, c_void_p]),
+    "lc_softargmax2d_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lc_softargmax2d_bwd_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib_path() -> str:
+    return os.environ.get("LC_AMD_LIB", _build.SO_PATH)
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first if the .so is absent and hipcc is available). Raises if it cannot be loaded."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"lc_amd: {path} is missing; run `python __graft_entry__.py build`")
+        _build.build()
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().lc_amd_last_error().decode(errors="replace")
+        raise RuntimeError(f"lc_amd.{what} failed (code {rc}): {msg}")
+
+
+def require_hip_f32(name: str, t: torch.Tensor) -> torch.Tensor:
+    """The kernels take contiguous float32 device tensors -- anything else is an error, never a silent fallback."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"lc_amd: {name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"lc_amd: {name} is on {t.device}; the HIP path needs tensors on the MI355X "
+                           f"(there is no CPU fallback in the product path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"lc_amd: {name} must be float32 (reference I/O precision), got {t.dtype}")
+    return t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

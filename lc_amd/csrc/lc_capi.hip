@@ -1,0 +1,232 @@
+// C ABI of liblc_amd.so (declared in include/lc_amd.h): argument checking, the host shim that gives the
+// reference's `pnp_ceres_f32_omp` symbol a GPU body, and the tiny row-scale kernel used by autograd's chain rule.
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lc_amd.h"
+#include "lc_common.h"
+#include "lc_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define LC_HIP_OK(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(10, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+__global__ void lc_scale_rows_kernel(const float* __restrict__ scale, int B, const float* s0, float* d0, int l0,
+                                     const float* s1, float* d1, int l1, const float* s2, float* d2, int l2) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n0 = (size_t)B * l0, n1 = (size_t)B * l1, n2 = (size_t)B * l2;
+    if (i < n0) {
+        d0[i] = scale[i / l0] * s0[i];
+    } else if (i < n0 + n1) {
+        const size_t j = i - n0;
+        d1[j] = scale[j / l1] * s1[j];
+    } else if (i < n0 + n1 + n2) {
+        const size_t j = i - n0 - n1;
+        d2[j] = scale[j / l2] * s2[j];
+    }
+}
+
+// Workspace of the host shim (pinned staging + device buffers), grown on demand and reused across calls.
+struct PnpHostWorkspace {
+    std::mutex mu;
+    size_t cap_jobs = 0, cap_pts = 0;
+    char* host = nullptr;
+    char* dev = nullptr;
+    size_t bytes = 0;
+    hipStream_t stream = nullptr;
+
+    static size_t layout(size_t B, size_t P, size_t off[8]) {
+        size_t o = 0;
+        auto take = [&](size_t n) { size_t r = o; o += (n + 255) & ~size_t(255); return r; };
+        off[0] = take(B * 9 * 4);       // K
+        off[1] = take(B * P * 3 * 4);   // pts3d
+        off[2] = take(B * P * 2 * 4);   // pts2d
+        off[3] = take(B * P * 4 * 4);   // sqrtL
+        off[4] = take(B * 4);           // counts
+        off[5] = take(B * 7 * 4);       // states
+        off[6] = take(B * 4);           // result_tr
+        off[7] = take(B * 4);           // rets
+        return o;
+    }
+    int ensure(size_t B, size_t P) {
+        if (!stream) LC_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (B <= cap_jobs && P <= cap_pts) return 0;
+        size_t nb = B > cap_jobs ? B : cap_jobs, np = P > cap_pts ? P : cap_pts;
+        size_t off[8];
+        const size_t need = layout(nb, np, off);
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        host = dev = nullptr;
+        cap_jobs = cap_pts = 0;
+        LC_HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&host), need, hipHostMallocDefault));
+        LC_HIP_OK(hipMalloc(reinterpret_cast<void**>(&dev), need));
+        bytes = need;
+        cap_jobs = nb;
+        cap_pts = np;
+        return 0;
+    }
+};
+PnpHostWorkspace g_ws;
+
+int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pts3ds, float** icov_sqrtLs, int* ptCnts,
+                 int maxIterCnt, float ftol, float* result_trs, int* rets, int B) {
+    int pmax = 1;
+    for (int i = 0; i < B; ++i) pmax = ptCnts[i] > pmax ? ptCnts[i] : pmax;
+    std::lock_guard<std::mutex> lock(g_ws.mu);
+    if (int rc = g_ws.ensure(B, pmax)) return rc;
+    const size_t P = pmax;
+    size_t off[8];
+    const size_t used = PnpHostWorkspace::layout(B, P, off);
+    char* h = g_ws.host;
+    float* hK = reinterpret_cast<float*>(h + off[0]);
+    float* hX = reinterpret_cast<float*>(h + off[1]);
+    float* hU = reinterpret_cast<float*>(h + off[2]);
+    float* hL = reinterpret_cast<float*>(h + off[3]);
+    int* hC = reinterpret_cast<int*>(h + off[4]);
+    float* hS = reinterpret_cast<float*>(h + off[5]);
+    for (int i = 0; i < B; ++i) {
+        const int n = ptCnts[i] > 0 ? ptCnts[i] : 0;
+        std::memcpy(hK + 9 * (size_t)i, cam_Ks[i], 6 * sizeof(float));  // only 6 floats are guaranteed readable
+        hK[9 * (size_t)i + 6] = 0; hK[9 * (size_t)i + 7] = 0; hK[9 * (size_t)i + 8] = 1;
+        std::memcpy(hX + 3 * P * i, pts3ds[i], sizeof(float) * 3 * n);
+        std::memcpy(hU + 2 * P * i, pts2ds[i], sizeof(float) * 2 * n);
+        std::memcpy(hL + 4 * P * i, icov_sqrtLs[i], sizeof(float) * 4 * n);
+        if ((size_t)n < P) {
+            std::memset(hX + 3 * P * i + 3 * n, 0, sizeof(float) * 3 * (P - n));
+            std::memset(hU + 2 * P * i + 2 * n, 0, sizeof(float) * 2 * (P - n));
+            std::memset(hL + 4 * P * i + 4 * n, 0, sizeof(float) * 4 * (P - n));
+        }
+        hC[i] = ptCnts[i];
+        std::memcpy(hS + 7 * (size_t)i, init_states[i], 7 * sizeof(float));
+    }
+    char* d = g_ws.dev;
+    hipStream_t st = g_ws.stream;
+    LC_HIP_OK(hipMemcpyAsync(d, h, off[6], hipMemcpyHostToDevice, st));  // everything up to and including states
+    lc::PnpParams p{};
+    p.K = reinterpret_cast<float*>(d + off[0]);
+    p.pts3d = reinterpret_cast<float*>(d + off[1]);
+    p.pts2d = reinterpret_cast<float*>(d + off[2]);
+    p.sqrtL = reinterpret_cast<float*>(d + off[3]);
+    p.sqrt_diag = nullptr;
+    p.counts = reinterpret_cast<int*>(d + off[4]);
+    p.states = reinterpret_cast<float*>(d + off[5]);
+    p.result_tr = reinterpret_cast<float*>(d + off[6]);
+    p.rets = reinterpret_cast<int*>(d + off[7]);
+    p.iters = nullptr;
+    p.B = B; p.Nmax = (int)P; p.max_iter = maxIterCnt; p.ftol = ftol;
+    if (lc::launch_pnp_lm(p, st)) return fail(11, "pnp kernel launch failed");
+    LC_HIP_OK(hipMemcpyAsync(h + off[5], d + off[5], used - off[5], hipMemcpyDeviceToHost, st));
+    LC_HIP_OK(hipStreamSynchronize(st));
+    const float* oS = reinterpret_cast<float*>(h + off[5]);
+    const float* oT = reinterpret_cast<float*>(h + off[6]);
+    const int* oR = reinterpret_cast<int*>(h + off[7]);
+    for (int i = 0; i < B; ++i) {
+        rets[i] = oR[i];
+        result_trs[i] = oT[i];
+        if (oR[i] == 0) std::memcpy(init_states[i], oS + 7 * (size_t)i, 7 * sizeof(float));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lc_amd_version(void) { return LC_AMD_VERSION; }
+const char* lc_amd_last_error(void) { return g_err.c_str(); }
+
+void pnp_ceres_f32_omp(float** init_states, float** cam_Ks, float** pts2ds, float** pts3ds, float** icov_sqrtLs,
+                       int* ptCnts, int maxIterCnt, float function_tolerance, int printSummary, float* result_trs,
+                       int* rets, int job_count, int num_threads) {
+    (void)num_threads;
+    if (job_count <= 0) return;
+    const int rc = pnp_host_run(init_states, cam_Ks, pts2ds, pts3ds, icov_sqrtLs, ptCnts, maxIterCnt, function_tolerance,
+                                result_trs, rets, job_count);
+    if (rc != 0) {
+        std::fprintf(stderr, "lc_amd: pnp_ceres_f32_omp failed on the GPU path (%s); marking %d jobs invalid\n",
+                     g_err.c_str(), job_count);
+        for (int i = 0; i < job_count; ++i) { rets[i] = 1; result_trs[i] = 1.f; }
+        return;
+    }
+    if (printSummary) {
+        for (int i = 0; i < job_count; ++i)
+            std::printf("lc_amd pnp job %d: points=%d invalid=%d trust_region_radius=%g\n", i, ptCnts[i], rets[i], result_trs[i]);
+    }
+}
+
+int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* sqrt_diag,
+                  const int* counts, float* states, float* result_tr, int* rets, int* iters, int B, int Nmax, int max_iter,
+                  float function_tolerance, void* stream) {
+    if (B < 0 || Nmax < 0) return fail(1, "negative size");
+    if ((sqrtL == nullptr) == (sqrt_diag == nullptr)) return fail(1, "exactly one of sqrtL / sqrt_diag must be given");
+    if (B == 0) return 0;
+    if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
+    lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, states, result_tr, rets, iters, B, Nmax, max_iter, function_tolerance};
+    if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
+    return 0;
+}
+
+int lc_cov_loss_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
+                            const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
+                            float rel_thresh, float w_e_thresh, float* loss, float* d_pts2d, float* d_inv_std, float* d_pts3d,
+                            float* aux, void* stream) {
+    if (B < 0 || N <= 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss) return fail(1, "null pointer");
+    if ((d_pts2d == nullptr) != (d_inv_std == nullptr)) return fail(1, "d_pts2d and d_inv_std must both be given or both be NULL");
+    if (d_pts3d && !d_pts2d) return fail(1, "d_pts3d needs d_pts2d/d_inv_std");
+    lc::LossParams p{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, aux,
+                     B, N, max_err_len, rel_thresh, w_e_thresh};
+    if (lc::launch_cov_loss(p, static_cast<hipStream_t>(stream))) return fail(11, "loss kernel launch failed");
+    return 0;
+}
+
+int lc_scale_rows_f32(const float* scale, int B, const float* src0, float* dst0, int len0, const float* src1, float* dst1,
+                      int len1, const float* src2, float* dst2, int len2, void* stream) {
+    if (B <= 0) return 0;
+    if (!src0) len0 = 0;
+    if (!src1) len1 = 0;
+    if (!src2) len2 = 0;
+    const size_t total = (size_t)B * ((size_t)len0 + len1 + len2);
+    if (total == 0) return 0;
+    const int threads = 256;
+    const size_t blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(lc_scale_rows_kernel, dim3((unsigned)blocks), dim3(threads), 0, static_cast<hipStream_t>(stream), scale, B,
+                       src0, dst0, len0 > 0 ? len0 : 1, src1, dst1, len1 > 0 ? len1 : 1, src2, dst2, len2 > 0 ? len2 : 1);
+    return hipGetLastError() == hipSuccess ? 0 : fail(11, "scale kernel launch failed");
+}
+
+int lc_softargmax2d_fwd_f32(const float* in, int M, int H, int W, int is_prob, float* mean, float* std, float* stats, void* stream) {
+    if (M < 0 || H <= 0 || W <= 0) return fail(1, "bad size");
+    if (M == 0) return 0;
+    if (!in || !mean || !std || !stats) return fail(1, "null pointer");
+    lc::HeadParams p{in, mean, std, stats, M, H, W, is_prob};
+    const int rc = lc::launch_head_fwd(p, static_cast<hipStream_t>(stream));
+    if (rc == 3) return fail(3, "map too large for the single-pass soft-argmax kernel");
+    return rc ? fail(11, "head kernel launch failed") : 0;
+}
+
+int lc_softargmax2d_bwd_f32(const float* in, const float* mean, const float* std, const float* stats, const float* g_mean,
+                            const float* g_std, int M, int H, int W, int is_prob, float* g_in, void* stream) {
+    if (M < 0 || H <= 0 || W <= 0) return fail(1, "bad size");
+    if (M == 0) return 0;
+    if (!in || !mean || !std || !stats || !g_mean || !g_std || !g_in) return fail(1, "null pointer");
+    lc::HeadBwdParams p{in, mean, std, stats, g_mean, g_std, g_in, M, H, W, is_prob};
+    return lc::launch_head_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "head backward launch failed") : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// Sparse keypoint head: spatial softmax + soft-argmax mean/std in ONE pass over the logits (HBM-bound).
+//
+// Replaces ptnet.py:59-66 (flatten -> softmax -> reshape) + ptnet.py:85-115 (softargmax_1d_cov x2, softargmax_2d_std):
+// the reference materialises the (B,S,H,W) probability tensor and runs ~12 torch ops over it; here one workgroup owns
+// one (H,W) map, keeps it in registers, stages exp(x-max) once through LDS for the row/column marginals, and writes
+// 4 floats (+4 saved statistics).  Backward is a pure streaming kernel: with lse, mean and variance saved,
+//   d/dlogit[h,w] = p[h,w] * (qx[w] + qy[h] - <p,q>),  qx[w] = g_mx w + g_vx (w-mx)^2,  <p,q> = g_mx mx + g_vx vx + (y terms)
+// so the map is read once and the gradient written once: 3 x H x W x 4 bytes per map fwd+bwd in total.
+#include "lc_common.h"
+#include "lc_kernels.h"
+
+namespace lc {
+namespace {
+
+constexpr int kHeadThreads = 256;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+// NV: vectors per thread, VEC: 4 (float4, needs W % 4 == 0) or 1
+template <int NV, int VEC>
+__global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_kernel(const HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = p.H, W = p.W, HW = H * W, ld = W + 1;
+    float* prob = smem;                   // [H][W+1] unnormalised exp
+    float* px = smem + H * ld;            // [W]
+    float* py = px + W;                   // [H]
+    float* redf = py + H;                 // [8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t m = blockIdx.x;
+    const float* in = p.in + m * HW;
+
+    float x[NV * VEC];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int e = (tid + k * kHeadThreads) * VEC;
+        if (e < HW) {
+            if constexpr (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(in + e);
+                x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+            } else {
+                x[k] = in[e];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) x[VEC * k + j] = -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) lmax = fmaxf(lmax, x[VEC * k + j]);
+    }
+    float bmax;
+    if (p.is_prob) {
+        bmax = 0.f;
+    } else {
+        lmax = wave_max(lmax);
+        if (lane == 0) redf[wave] = lmax;
+        __syncthreads();
+        bmax = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int e = (tid + k * kHeadThreads) * VEC;
+        if (e < HW) {
+            const int h = e / W, w = e - h * W;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float ex = p.is_prob ? x[VEC * k + j] : __expf(x[VEC * k + j] - bmax);
+                prob[h * ld + w + j] = ex;
+                lsum += ex;
+            }
+        }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) redf[4 + wave] = lsum;
+    __syncthreads();
+    const float bsum = (redf[4] + redf[5]) + (redf[6] + redf[7]);
+    const float inv = p.is_prob ? 1.f : 1.f / bsum;
+    // marginals (prob2d.sum(-2), prob2d.sum(-1), ptnet.py:107-108)
+    for (int j = tid; j < W + H; j += kHeadThreads) {
+        float s = 0.f;
+        if (j < W) {
+            for (int h = 0; h < H; ++h) s += prob[h * ld + j];
+            px[j] = s * inv;
+        } else {
+            const int h = j - W;
+            for (int w = 0; w < W; ++w) s += prob[h * ld + w];
+            py[h] = s * inv;
+        }
+    }
+    __syncthreads();
+    // softargmax_1d_cov (ptnet.py:85-97): wave 0 -> x, wave 1 -> y
+    if (wave < 2) {
+        const float* pr = wave == 0 ? px : py;
+        const int n = wave == 0 ? W : H;
+        float mu = 0.f;
+        for (int i = lane; i < n; i += kWave) mu += (float)i * pr[i];
+        mu = wave_sum(mu);
+        float var = 0.f;
+        for (int i = lane; i < n; i += kWave) {
+            const float d = (float)i - mu;
+            var += d * d * pr[i];
+        }
+        var = wave_sum(var);
+        if (lane == 0) {
+            p.mean[m * 2 + wave] = mu;
+            p.std[m * 2 + wave] = sqrtf(var + 1e-6f);
+            p.stats[m * 4 + 1 + wave] = var;
+            if (wave == 0) {
+                p.stats[m * 4] = p.is_prob ? bsum : bmax + __logf(bsum);
+                p.stats[m * 4 + 3] = 0.f;
+            }
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwdParams p) {
+    const int H = p.H, W = p.W, HW = H * W;
+    const size_t m = blockIdx.x;
+    const float* in = p.in + m * HW;
+    float* out = p.g_in + m * HW;
+    const float mx = p.mean[m * 2], my = p.mean[m * 2 + 1];
+    const float sx = p.std[m * 2], sy = p.std[m * 2 + 1];
+    const float s0 = p.stats[m * 4], vx = p.stats[m * 4 + 1], vy = p.stats[m * 4 + 2];
+    const float gmx = p.g_mean[m * 2], gmy = p.g_mean[m * 2 + 1];
+    const float gvx = p.g_std[m * 2] / (2.f * sx), gvy = p.g_std[m * 2 + 1] / (2.f * sy);  // d sqrt(var+1e-6)
+    const bool is_prob = p.is_prob != 0;
+    // logits: <p,q>;  prob input: -2 g_v m (1 - sum p) multiplies the coordinate (d var/d mean term, ptnet.py:94-96)
+    const float cdot = gmx * mx + gmy * my + gvx * vx + gvy * vy;
+    const float ex = is_prob ? -2.f * gvx * mx * (1.f - s0) : 0.f;
+    const float ey = is_prob ? -2.f * gvy * my * (1.f - s0) : 0.f;
+    for (int e = threadIdx.x * VEC; e < HW; e += kHeadThreads * VEC) {
+        const int h = e / W, w0 = e - h * W;
+        const float dy = (float)h - my;
+        const float qy = gmy * (float)h + gvy * dy * dy + ey * (float)h;
+        float xin[VEC], g[VEC];
+        if constexpr (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(in + e);
+            xin[0] = v.x; xin[1] = v.y; xin[2] = v.z; xin[3] = v.w;
+        } else {
+            xin[0] = in[e];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float wf = (float)(w0 + j);
+            const float dx = wf - mx;
+            const float q = gmx * wf + gvx * dx * dx + ex * wf + qy;
+            g[j] = is_prob ? q : __expf(xin[j] - s0) * (q - cdot);
+        }
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(out + e) = make_float4(g[0], g[1], g[2], g[3]);
+        } else {
+            out[e] = g[0];
+        }
+    }
+}
+
+template <int VEC>
+int launch_fwd_nv(const HeadParams& p, hipStream_t stream, int nv, size_t smem) {
+#define LC_HEAD_CASE(NVV)                                                                                       \
+    case NVV:                                                                                                   \
+        if (smem > 48 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lc_head_fwd_kernel<NVV, VEC>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                   \
+        hipLaunchKernelGGL((lc_head_fwd_kernel<NVV, VEC>), dim3(p.M), dim3(kHeadThreads), smem, stream, p);      \
+        break;
+    switch (nv) {
+        LC_HEAD_CASE(1) LC_HEAD_CASE(2) LC_HEAD_CASE(4) LC_HEAD_CASE(8) LC_HEAD_CASE(16) LC_HEAD_CASE(32)
+        default: return 3;
+    }
+#undef LC_HEAD_CASE
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace
+
+int launch_head_fwd(const HeadParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    const int HW = p.H * p.W;
+    const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
+    const int vec = vec4 ? 4 : 1;
+    int nv = (HW + kHeadThreads * vec - 1) / (kHeadThreads * vec);
+    int nvp = 1;
+    while (nvp < nv) nvp <<= 1;
+    const size_t smem = sizeof(float) * ((size_t)p.H * (p.W + 1) + p.W + p.H + 8);
+    if (smem > 160 * 1024 || nvp > 32) return 3;  // map too large for the single-pass design
+    return vec4 ? launch_fwd_nv<4>(p, stream, nvp, smem) : launch_fwd_nv<1>(p, stream, nvp, smem);
+}
+
+int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    const bool vec4 = (p.W % 4 == 0) && (((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.g_in)) & 15) == 0);
+    if (vec4)
+        hipLaunchKernelGGL(lc_head_bwd_kernel<4>, dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+    else
+        hipLaunchKernelGGL(lc_head_bwd_kernel<1>, dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace lc

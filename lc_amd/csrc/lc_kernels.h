@@ -1,0 +1,67 @@
+// Internal launch interface between the C ABI (lc_capi.hip) and the kernels. Not installed; see include/lc_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lc {
+
+constexpr int kLossAuxStride = 40;  // P, C, L, not_spd, Hinv[36]
+
+struct LossParams {
+    const float* K;         // (B,3,3)
+    const float* pose;      // (B,7) w,x,y,z,tx,ty,tz
+    const float* pts3d;     // (B,N,3)
+    const float* pts2d;     // (B,N,2)
+    const float* inv_std;   // (B,N,2)
+    const float* valid;     // (B,N) or null
+    const float* bbox;      // (B,8,3)
+    const float* grad_out;  // (B,) or null (== ones)
+    float* loss;            // (B,)
+    float* d_pts2d;         // (B,N,2) or null (forward only)
+    float* d_inv_std;       // (B,N,2)
+    float* d_pts3d;         // (B,N,3) or null
+    float* aux;             // (B,kLossAuxStride) or null
+    int B, N;
+    float max_err_len, rel_thresh, w_e_thresh;
+};
+int launch_cov_loss(const LossParams& p, hipStream_t stream);
+
+struct PnpParams {
+    const float* K;       // (B,3,3)
+    const float* pts2d;   // (B,Nmax,2)
+    const float* pts3d;   // (B,Nmax,3)
+    const float* sqrtL;   // (B,Nmax,2,2) lower factor of the 2x2 information matrix, or
+    const float* sqrt_diag;  // (B,Nmax,2) its diagonal when the factor is diagonal (sqrtL == null)
+    const int* counts;    // (B,) valid points per pose, or null (== Nmax)
+    float* states;        // (B,7) in: start, out: optimum (untouched unless converged)
+    float* result_tr;     // (B,) final trust-region radius
+    int* rets;            // (B,) 0 ok / 1 invalid
+    int* iters;           // (B,) LM iterations used, or null
+    int B, Nmax, max_iter;
+    float ftol;
+};
+int launch_pnp_lm(const PnpParams& p, hipStream_t stream);
+
+struct HeadParams {
+    const float* in;      // (M,H,W) logits (or probabilities when is_prob)
+    float* mean;          // (M,2) x,y
+    float* std;           // (M,2)
+    float* stats;         // (M,4): lse (or sum p), var_x, var_y, unused -- saved for backward
+    int M, H, W;
+    int is_prob;
+};
+int launch_head_fwd(const HeadParams& p, hipStream_t stream);
+
+struct HeadBwdParams {
+    const float* in;       // (M,H,W)
+    const float* mean;     // (M,2)
+    const float* std;      // (M,2)
+    const float* stats;    // (M,4)
+    const float* g_mean;   // (M,2)
+    const float* g_std;    // (M,2)
+    float* g_in;           // (M,H,W)
+    int M, H, W;
+    int is_prob;
+};
+int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream);
+
+}  // namespace lc

@@ -1,0 +1,169 @@
+"""`losses.py` call surface of the reference on the HIP hot path.
+
+Keeps the names `train.py:31,58-59` / `test.py:12` use -- `Loss_fn`, `dense_pnp_matching_from_xyz`, `nn_out_to_xyz` --
+with the same arguments, return values and buffer names (`weight_grad_clipper.max_norm`), so a checkpointed
+`model.loss_fn` loads strictly.  The pose term goes through `lc_amd.cov_mixed.Loss_cov_mixed`
+(one fused HIP launch); the surrounding warm-up blending, weight softmax, strided sub-sampling and Laplace keypoint NLL
+are cheap torch glue exactly as in `losses.py:142-161,261-386`.
+
+Not in this round (SURVEY.md 8f "next" row f3): the ZebraPose binary-code branch (`xyz_noc_bin`,
+`losses.py:163-184,196-216`), which needs `floatbits.py`; it raises NotImplementedError.
+"""
+from __future__ import annotations
+
+from operator import itemgetter
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import transforms as xforms
+from .cov_mixed import Loss_cov_mixed
+from .grad import NormClipper
+
+
+def nn_out_to_xyz(nn_out: Tensor = None, noc_scale_xfd: Tensor = None, *, raw_bits_gt=None, noc_mask=None,
+                  model_transform=None, bit_cnt=None, inference=False) -> Tensor:
+    """(B,3,H,W) continuous xyz head -> (B,H,W,3) in mm (`losses.py:17-47`, continuous branch)."""
+    if bit_cnt is not None:
+        raise NotImplementedError("lc_amd: binary-code (ZebraPose) outputs are a 'next' row (SURVEY 8f f3)")
+    assert model_transform is None, "Model transform not implemented for continuous xyz output"
+    return nn_out.permute(0, 2, 3, 1) * noc_scale_xfd[:, None, None, :]
+
+
+def dense_pnp_matching_from_xyz(xyz_out: Tensor, weights_out: Tensor, valid_msk_full: Tensor, xyz_scale: Tensor, sample=2,
+                                top_left=None):
+    """Strided sub-sampling of the dense head into 2D-3D correspondences (`losses.py:142-161`).
+
+    xyz_out (*,3,H,W), weights_out (*,2,H,W), valid_msk_full (*,H,W)|None, xyz_scale (*,3)|None
+    -> pts2d (*,N,2) (pixel grid, constant), inv_std2d (*,N,2), pts3d (*,N,3), valid (*,N)|None, N = ceil(H/s)*ceil(W/s).
+    The random phase uses `np.random.randint` like the reference so seeded runs line up.
+    """
+    top, left = np.random.randint(0, sample, size=2) if top_left is None else top_left
+    uv_grid = xforms.gen_uv(xyz_out.shape[-2:], xyz_out.device)
+    pts2d = uv_grid[..., top::sample, left::sample, :].flatten(start_dim=-3, end_dim=-2)
+    inv_std2d = weights_out[..., top::sample, left::sample].flatten(start_dim=-2).mT
+    pts3d = xyz_out[..., top::sample, left::sample].flatten(start_dim=-2).mT
+    if xyz_scale is not None:
+        pts3d = pts3d * xyz_scale.unsqueeze(-2)
+    valid_msk = valid_msk_full[..., top::sample, left::sample].flatten(start_dim=-2) if valid_msk_full is not None else None
+    return pts2d.expand_as(inv_std2d), inv_std2d, pts3d, valid_msk
+
+
+class Loss_seg_L1(nn.Module):
+    """`losses.py:219-236`."""
+
+    def forward(self, input: Tensor, target: Tensor, weight: Tensor = None, reduction: str = "mean"):
+        err = (input.sigmoid() - target).abs()
+        if weight is not None:
+            err = err * weight
+        if reduction != "mean":
+            raise NotImplementedError
+        return err.mean()
+
+
+def pose_loss_factor(cfg, step, steps_per_epoch) -> float:
+    """Warm-up ramp of the LC loss (`losses.py:270-274,296-302`)."""
+    full_step = max(cfg.get("pose_loss_start_step", 0), cfg.get("pose_loss_start_epoch", 0) * steps_per_epoch)
+    nz_step = cfg.get("loss_pose_nz_step", 0)
+    return max(0, min((step - nz_step + 1) / (max(full_step - nz_step, 0) + 1e-5), 1))
+
+
+class Loss_fn(nn.Module):
+    """Drop-in for `losses.Loss_fn` (`losses.py:239-386`): `forward(gt_dict, out_dict, epoch, step, steps_per_epoch)`
+    -> `(loss_dict, w_loss_dict)`.  `group`: optional process group; when the batch is sharded over ranks the
+    NormClippers all-reduce their squared norm over it."""
+
+    def __init__(self, cfg, cfg_global, total_bit_cnt=0, group=None) -> None:
+        super().__init__()
+        self.cfg = cfg
+        pose_cfg = cfg.pose_loss_cfg
+        self.weight_grad_clipper = NormClipper(group=group) if pose_cfg.get("clip_weight_grad", True) else None
+        self.scale_grad_clipper = NormClipper(rel_thresh=2, group=group) if pose_cfg.get("clip_scale_grad", False) else None
+        self.pts_grad_clipper = NormClipper(rel_thresh=2, group=group) if pose_cfg.get("clip_pts_grad", False) else None
+        self.cfg_global = cfg_global
+        if total_bit_cnt > 0:
+            raise NotImplementedError("lc_amd: binary-code (ZebraPose) loss is a 'next' row (SURVEY 8f f3)")
+        seg_loss_type = cfg.get("seg_loss_type", "BCE")
+        if seg_loss_type.lower() == "bce":
+            self.seg_loss_fn = F.binary_cross_entropy_with_logits
+        elif seg_loss_type.lower() == "l1":
+            self.seg_loss_fn = Loss_seg_L1()
+
+    def forward(self, gt_dict, out_dict, epoch, step, steps_per_epoch):
+        cfg = self.cfg
+        msk_noc, msk_vis = itemgetter("msk_noc", "msk_vis")(gt_dict)
+        loss_dict = {}
+
+        if "pts2d" in out_dict:  # sparse (keypoint) case, losses.py:267-279
+            loss_kpts = self.sparse_kpt_loss(cfg, gt_dict, out_dict)
+            loss_dict["loss_kpts"] = loss_kpts
+            if cfg.get("w_loss_pose", 0) > 0:
+                factor = pose_loss_factor(cfg, step, steps_per_epoch)
+                loss_pose = self.sparse_pose_loss(cfg, gt_dict, out_dict)
+                loss_dict["loss_pose"] = factor * loss_pose + (1 - factor) * loss_kpts
+            w_loss_dict = {k: v * cfg.get("w_" + k, 0) for k, v in loss_dict.items() if cfg.get("w_" + k, 0) > 0}
+            return loss_dict, w_loss_dict
+
+        # dense case, losses.py:281-316
+        if "xyz_noc_bin" in out_dict:
+            raise NotImplementedError("lc_amd: binary-code (ZebraPose) loss is a 'next' row (SURVEY 8f f3)")
+        if "xyz_noc" in out_dict:
+            noc_msked, noc_gt = out_dict["xyz_noc"] * msk_noc.unsqueeze(-3), gt_dict["xyz_noc_tgt"]
+            loss_dict["loss_noc"] = F.l1_loss(noc_msked, noc_gt, reduction="mean")
+        loss_dict["loss_seg"] = self.seg_loss_fn(out_dict["msk_vis_logits"], msk_vis.unsqueeze(-3), reduction="mean")
+
+        loss_pose = self.dense_pose_loss(cfg.pose_loss_cfg, gt_dict, out_dict)
+        factor = pose_loss_factor(cfg, step, steps_per_epoch)
+        if factor != 1:
+            weight_logits = out_dict["xyz_weight_logits"]
+            msk_vis_tgt = msk_vis.unsqueeze(-3).expand_as(weight_logits)
+            loss_weight_seg = self.seg_loss_fn(weight_logits, msk_vis_tgt, reduction="mean")
+            loss_pose = factor * loss_pose + (1 - factor) * loss_weight_seg
+        loss_dict["loss_pose"] = loss_pose
+
+        loss_dict = {k: v.mean() if len(v.shape) > 0 else v for k, v in loss_dict.items() if isinstance(v, Tensor)}
+        w_loss_dict = {k: v * cfg.get("w_" + k, 0) for k, v in loss_dict.items() if cfg.get("w_" + k, 0) > 0}
+        return loss_dict, w_loss_dict
+
+    def sparse_kpt_loss(self, cfg, gt_dict, out_dict):
+        """Laplace NLL of the keypoints, mean(log sigma + |u - proj|/sigma) (`losses.py:318-326`)."""
+        pts2d, pts2d_std = itemgetter("pts2d", "pts2d_std")(out_dict)
+        pose_best, K, pts3d = itemgetter("pose_best", "out_K", "pts3d")(gt_dict)
+        pts2d_proj = xforms.project_apply(K, pts3d, *xforms.quaternion_rep_to_RT(pose_best))
+        err = (pts2d - pts2d_proj).abs()
+        return (torch.log(pts2d_std) + err / pts2d_std).mean()
+
+    def sparse_pose_loss(self, cfg, gt_dict, out_dict):
+        """`losses.py:329-334`."""
+        pts2d, pts2d_std = itemgetter("pts2d", "pts2d_std")(out_dict)
+        pose_best, K, pts3d, bbox_3d = itemgetter("pose_best", "out_K", "pts3d", "bbox_3d")(gt_dict)
+        return Loss_cov_mixed(K, pose_best, pts3d, pts2d, 1 / pts2d_std, None, bbox_3d=bbox_3d).mean()
+
+    def dense_pose_loss(self, cfg, gt_dict, out_dict):
+        """`losses.py:336-386` (GDR-Net structure)."""
+        noc_scale = gt_dict["noc_scale"]
+        pose_best, K, bbox_3d = itemgetter("pose_best", "out_K", "bbox_3d")(gt_dict)
+
+        xyz_weight_logits: Tensor = out_dict["xyz_weight_logits"]
+        if self.weight_grad_clipper is not None and xyz_weight_logits.requires_grad:
+            xyz_weight_logits.register_hook(lambda grad: self.weight_grad_clipper.clip(grad))
+        xyz_weights_scale: Tensor = out_dict["xyz_weights_scale"]
+        if self.scale_grad_clipper is not None and xyz_weights_scale.requires_grad:
+            xyz_weights_scale.register_hook(lambda grad: self.scale_grad_clipper.clip(grad))
+
+        # one softmax over all 2*H*W logits, times the per-sample scale (losses.py:355-356)
+        raw = xyz_weight_logits.reshape(xyz_weight_logits.shape[:-3] + (1, -1)).softmax(dim=-1)
+        xyz_weights = raw.reshape_as(xyz_weight_logits) * xyz_weights_scale
+
+        den_pts2d, den_inv_std2d, den_pts3d, _ = dense_pnp_matching_from_xyz(
+            out_dict["xyz_noc"], xyz_weights, gt_dict["msk_vis"], noc_scale, sample=cfg.get("dense_sample", 2))
+        den_valid_msk = torch.ones_like(den_pts3d[..., 0])
+        if self.pts_grad_clipper is not None and den_pts3d.requires_grad:
+            den_pts3d.register_hook(lambda grad: self.pts_grad_clipper.clip(grad))
+
+        loss_cov = Loss_cov_mixed(K, pose_best, den_pts3d, den_pts2d, den_inv_std2d, den_valid_msk, bbox_3d=bbox_3d,
+                                  max_err_len=cfg.get("max_err_len", 32))
+        return loss_cov.mean()

@@ -1,0 +1,95 @@
+"""`lib.pnp.pnp_ceres` call surface (`lib/pnp/pnp_ceres.py:6-140`) on the HIP batched LM solver.
+
+Two routes, same results:
+  * tensors already on the GPU  -> `lc_pnp_lm_f32` on device-resident zero-padded batches (no host round trip);
+  * CPU tensors / numpy arrays  -> the reference's own ABI `pnp_ceres_f32_omp` (arrays of host pointers), whose body
+    in liblc_amd.so stages the jobs to the GPU.  This is exactly what the reference's cffi marshaller calls.
+Returns `(state, result_tr, invalid_flags)` like the reference (`:61`): float32 (B,7), float32 (B,), int32 (B,).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _to_np(val):
+    if not isinstance(val, np.ndarray):
+        val = val.detach().to(device="cpu").numpy()
+    return val
+
+
+def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6,
+                 return_iters=False):
+    """Device route. cam_mat (B,3,3) pts3d (B,N,3) pts2d (B,N,2) start (B,7); sqrtL (B,N,2,2) lower factor or
+    (B,N,2) diagonal; n_points (B,) int or None."""
+    lib = _lib.load()
+    K = _lib.require_hip_f32("cam_mat", cam_mat)
+    X = _lib.require_hip_f32("pts3d", pts3d)
+    U = _lib.require_hip_f32("pts2d", pts2d)
+    L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)
+    B, N = X.shape[:2]
+    state = _lib.require_hip_f32("start", start).clone()
+    dev = X.device
+    counts = None
+    if n_points is not None:
+        counts = torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
+    tr = torch.empty(B, device=dev, dtype=torch.float32)
+    ret = torch.empty(B, device=dev, dtype=torch.int32)
+    iters = torch.empty(B, device=dev, dtype=torch.int32) if return_iters else None
+    full = L.dim() == 4
+    with torch.cuda.device(dev):
+        rc = lib.lc_pnp_lm_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
+                               None if full else _lib.ptr(L), _lib.ptr(counts), _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret),
+                               _lib.ptr(iters), B, N, int(max_iter_count), float(function_tolerance), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_lm_f32")
+    return (state, tr, ret, iters) if return_iters else (state, tr, ret)
+
+
+def _solve_host_lists(state, pts3d, pts2d, sqrtL, cam_mat, point_counts, worker_count=1, max_iter_count=300, **kwargs):
+    """`_pnp_ceres_omp_f32` (pnp_ceres.py:74-140): per-job contiguous float32 arrays -> `pnp_ceres_f32_omp`."""
+    lib = _lib.load()
+    job_cnt = len(state)
+    state = np.stack([np.ascontiguousarray(s, np.float32) for s in state]).astype(np.float32)
+    keep = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (cam_mat, pts2d, pts3d, sqrtL)]
+    fp = ctypes.POINTER(ctypes.c_float)
+    PA = fp * job_cnt
+    as_ptr = lambda a: a.ctypes.data_as(fp)
+    states = PA(*[as_ptr(state[i]) for i in range(job_cnt)])
+    ptrs = [PA(*[as_ptr(a) for a in lst]) for lst in keep]
+    result_tr = np.zeros(job_cnt, np.float32)
+    flags = np.zeros(job_cnt, np.int32)
+    counts = np.asarray(point_counts, dtype=np.int32)
+    lib.pnp_ceres_f32_omp(states, ptrs[0], ptrs[1], ptrs[2], ptrs[3], counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                          int(max_iter_count), float(kwargs.get("function_tolerance", 1e-6)), int(kwargs.get("print_summary", 0)),
+                          as_ptr(result_tr), flags.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), job_cnt, int(worker_count))
+    return state, result_tr, flags
+
+
+def solve(cam_mat, pts3d, pts2d, pts2d_icov_sqrtL, start, n_points=None, *, max_iter_count=50, num_workers=1, **kwargs):
+    """Drop-in for `lib.pnp.pnp_ceres.solve` (pnp_ceres.py:6-61); batched tensors or per-job lists, or one un-batched job."""
+    single = False
+    state = start
+    on_gpu = isinstance(pts3d, torch.Tensor) and pts3d.is_cuda and isinstance(state, torch.Tensor) and state.dim() == 2
+    if on_gpu:
+        return solve_device(cam_mat, pts3d, pts2d, pts2d_icov_sqrtL, state, n_points, max_iter_count=max_iter_count,
+                            function_tolerance=kwargs.get("function_tolerance", 1e-6))
+    if not isinstance(state, (list, tuple)) and len(state.shape) == 1:
+        single = True
+        if tuple(pts2d.shape) == tuple(pts2d_icov_sqrtL.shape):
+            pts2d_icov_sqrtL = torch.diag_embed(torch.as_tensor(pts2d_icov_sqrtL))
+        n_points = [int(n_points)] if n_points is not None else [pts2d.shape[0]]
+        state, pts3d, pts2d, pts2d_icov_sqrtL, cam_mat = ([_to_np(v)] for v in (state, pts3d, pts2d, pts2d_icov_sqrtL, cam_mat))
+    else:
+        if tuple(pts2d[0].shape) == tuple(pts2d_icov_sqrtL[0].shape):
+            pts2d_icov_sqrtL = [torch.diag_embed(torch.as_tensor(c)) for c in pts2d_icov_sqrtL]
+        state, pts3d, pts2d, pts2d_icov_sqrtL, cam_mat = ([_to_np(v) for v in lst] for lst in
+                                                          (state, pts3d, pts2d, pts2d_icov_sqrtL, cam_mat))
+        n_points = [int(n) for n in n_points] if n_points is not None else [int(c.shape[0]) for c in pts2d]
+    outs = _solve_host_lists(state, pts3d, pts2d, pts2d_icov_sqrtL, cam_mat, n_points, worker_count=num_workers,
+                             max_iter_count=max_iter_count, **kwargs)
+    outs = [torch.from_numpy(o) for o in outs]
+    return outs if not single else [o[0] for o in outs]

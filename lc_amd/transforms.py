@@ -1,0 +1,44 @@
+"""Pose / projection helpers with the reference's exact conventions (`lib/transforms/transforms.py`,
+`lib/transforms/rotation_conversions.py:39-68`).  Cheap torch glue used by the loss surface, not a hot op."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+
+def quaternion_to_matrix(quaternions: Tensor) -> Tensor:
+    """wxyz -> R with the reference's two_s = 2/||q|| (sic, rotation_conversions.py:52)."""
+    r, i, j, k = torch.unbind(quaternions, -1)
+    two_s = 2.0 / torch.linalg.vector_norm(quaternions, dim=-1)
+    o = torch.stack(
+        (
+            1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+            two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+            two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j),
+        ),
+        -1,
+    )
+    return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
+def quaternion_rep_to_RT(quaternion_reps: Tensor):
+    """(*,7) w,x,y,z,tx,ty,tz -> R (*,3,3), t (*,3)   (transforms.py:6-32)"""
+    return quaternion_to_matrix(quaternion_reps[..., :4]), quaternion_reps[..., 4:7]
+
+
+def project_apply(cam_K: Tensor, pts_3d: Tensor, R: Tensor = None, t: Tensor = None, min_z: float = 0.1) -> Tensor:
+    """Pinhole projection with the full 3x3 K and z clamped at min_z (transforms.py:47-63)."""
+    if R is not None:
+        pts_3d = pts_3d @ R.mT + t.squeeze(-1)[..., None, :]
+    xformed = pts_3d @ cam_K.transpose(-1, -2)
+    z = xformed[..., 2:3].clamp(min=min_z)
+    return xformed[..., :2] / z
+
+
+def gen_uv(shape_hw, device=None, dtype=None) -> Tensor:
+    """(H, W, 2) pixel grid, (x, y) order (transforms.py:66-74)."""
+    H, W = shape_hw[-2:]
+    xs = torch.arange(0, W - 0.5, device=device, dtype=dtype)
+    ys = torch.arange(0, H - 0.5, device=device, dtype=dtype)
+    x, y = torch.meshgrid((xs, ys), indexing="xy")
+    return torch.stack((x, y), dim=-1)

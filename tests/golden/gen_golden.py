@@ -174,8 +174,7 @@ def gen_head():
     _stub_modules()
     import ptnet
 
-    for name, (B, S, H, W, seed) in dict(b4_s16_64x64=(4, 16, 64, 64, 0), b2_s64_64x64=(2, 64, 64, 64, 1),
-                                         b2_s3_32x48=(2, 3, 32, 48, 2)).items():
+    for name, (B, S, H, W, seed) in dict(b2_s4_64x64=(2, 4, 64, 64, 0), b2_s3_32x48=(2, 3, 32, 48, 2)).items():
         logits = synth.make_head_logits(B, S, H, W, seed=seed)
         g = torch.Generator().manual_seed(99 + seed)
         ct_mean = torch.randn(B, S, 2, generator=g)

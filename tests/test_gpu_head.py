@@ -1,0 +1,74 @@
+"""GPU parity of the fused spatial-softmax + soft-argmax kernels against golden vectors from ptnet.py (fp32 and fp64)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import golden_files, case_name, rel_err
+
+pytestmark = pytest.mark.gpu
+FILES = golden_files("head_")
+
+
+@pytest.mark.parametrize("path", FILES, ids=[case_name(p, "head_") for p in FILES])
+def test_head_vs_golden(path):
+    from lc_amd.ptnet import spatial_softargmax_2d_std, softargmax_2d_std
+
+    z = np.load(path)
+    dev = torch.device("cuda:0")
+    lg = torch.from_numpy(z["in_logits"]).to(dev).requires_grad_(True)
+    ctm, cts = torch.from_numpy(z["in_ct_mean"]).to(dev), torch.from_numpy(z["in_ct_std"]).to(dev)
+    mean, std = spatial_softargmax_2d_std(lg)
+    (gl,) = torch.autograd.grad([mean, std], [lg], [ctm, cts])
+    # pixel-unit outputs in [0, 63]: 2e-4 px abs (fp32 reference itself sits ~1e-5 from fp64)
+    assert (mean.detach().cpu().double() - torch.from_numpy(z["f64_mean"])).abs().max().item() <= 2e-4
+    assert (std.detach().cpu().double() - torch.from_numpy(z["f64_std"])).abs().max().item() <= 2e-4
+    assert rel_err(gl.cpu(), z["f64_g_logits"]) <= 2e-4
+    assert rel_err(gl.cpu(), z["f32_g_logits"]) <= 2e-4
+    # the function on its own (probabilities in), ptnet.py:100-115
+    pr = torch.from_numpy(z["f32_prob"]).to(dev).requires_grad_(True)
+    m2, s2 = softargmax_2d_std(pr)
+    (gp,) = torch.autograd.grad([m2, s2], [pr], [ctm, cts])
+    assert (m2.detach().cpu().double() - torch.from_numpy(z["f64_mean"])).abs().max().item() <= 2e-4
+    assert (s2.detach().cpu().double() - torch.from_numpy(z["f64_std"])).abs().max().item() <= 2e-4
+    assert rel_err(gp.cpu(), z["f32_g_prob"]) <= 2e-4
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 2, 128, 128), (1, 1, 16, 20), (2, 3, 30, 50)])
+def test_head_odd_shapes_vs_torch(shape):
+    """Non-power-of-two / non-multiple-of-4 maps (scalar path) and the 128x128 zlmo size, vs a float64 torch restatement."""
+    from lc_amd.ptnet import spatial_softargmax_2d_std
+    from oracle.softargmax_oracle import spatial_softargmax_2d_std as orc
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    lg = (torch.randn(shape, generator=g) * 3)
+    ctm, cts = torch.randn(shape[:2] + (2,), generator=g), torch.randn(shape[:2] + (2,), generator=g)
+    x = lg.to(dev).requires_grad_(True)
+    mean, std = spatial_softargmax_2d_std(x)
+    (gl,) = torch.autograd.grad([mean, std], [x], [ctm.to(dev), cts.to(dev)])
+    x64 = lg.double().requires_grad_(True)
+    m64, s64 = orc(x64)
+    (g64,) = torch.autograd.grad([m64, s64], [x64], [ctm.double(), cts.double()])
+    assert (mean.detach().cpu().double() - m64.detach()).abs().max().item() <= 3e-4
+    assert (std.detach().cpu().double() - s64.detach()).abs().max().item() <= 3e-4
+    assert rel_err(gl.cpu(), g64) <= 3e-4
+
+
+def test_head_full_size_properties():
+    """BASELINE head size (256,64,64,64): probabilities sum to one => sum of the logit-gradient over each map is ~0;
+    a one-hot-ish map returns its peak location; shifting the logits by a constant changes nothing."""
+    from lc_amd.ptnet import spatial_softargmax_2d_std
+    from lc_amd import synth
+
+    dev = torch.device("cuda:0")
+    lg = synth.make_head_logits(256, 64, 64, 64, seed=3).to(dev).requires_grad_(True)
+    mean, std = spatial_softargmax_2d_std(lg)
+    (g,) = torch.autograd.grad([mean.sum() + std.sum()], [lg])
+    assert g.flatten(-2).sum(-1).abs().max().item() <= 1e-3
+    m2, s2 = spatial_softargmax_2d_std(lg.detach() + 7.5)
+    assert (m2 - mean).abs().max().item() <= 1e-4 and (s2 - std).abs().max().item() <= 1e-4
+    spike = torch.full((4, 1, 64, 64), -30.0, device=dev)
+    spike[:, :, 17, 42] = 30.0
+    m3, s3 = spatial_softargmax_2d_std(spike)
+    assert torch.allclose(m3, torch.tensor([42.0, 17.0], device=dev).expand(4, 1, 2), atol=1e-4)
+    assert (s3 - 1e-3).abs().max().item() <= 1e-4  # sqrt(0 + 1e-6)

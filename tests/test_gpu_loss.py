@@ -1,0 +1,105 @@
+"""GPU parity of the fused LC-loss kernel (through the C ABI) against the oracle and the reference's golden vectors.
+
+Tolerances: loss <= 1e-4 abs (relative to max(1,|loss|)), gradients <= 1e-3 rel-max -- the reference's
+own fp32 path drifts 4.5e-5 / 7e-5 from its fp64 path; the kernel computes in fp64 internally and is compared with the
+fp64 goldens at a tighter bound and with the fp32 goldens at the stated one.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import golden_files, case_name, load_loss_case, rel_err
+
+pytestmark = pytest.mark.gpu
+FILES = golden_files("lc_loss_")
+
+
+def _run(ins, kwargs, want3, use_autograd=True):
+    from lc_amd.cov_mixed import Loss_cov_mixed, loss_cov_mixed_fused
+
+    dev = torch.device("cuda:0")
+    d = {k: v.to(dev) for k, v in ins.items()}
+    if use_autograd:
+        u = d["pts2d"].clone().requires_grad_(True)
+        s = d["inv_std"].clone().requires_grad_(True)
+        X = d["pts3d"].clone().requires_grad_(want3)
+        loss = Loss_cov_mixed(d["K"], d["pose"], X, u, s, d.get("valid"), bbox_3d=d["bbox_3d"], **kwargs)
+        gs = torch.autograd.grad(loss, [u, s] + ([X] if want3 else []), d["grad_out"])
+        return loss.detach().cpu(), gs[0].cpu(), gs[1].cpu(), (gs[2].cpu() if want3 else None), None
+    loss, du, ds, dx, aux = loss_cov_mixed_fused(d["K"], d["pose"], d["pts3d"], d["pts2d"], d["inv_std"], d.get("valid"),
+                                                 d["bbox_3d"], grad_out=d["grad_out"], want_pts3d=want3, want_aux=True, **kwargs)
+    return loss.cpu(), du.cpu(), ds.cpu(), (dx.cpu() if want3 else None), aux.cpu()
+
+
+@pytest.mark.parametrize("path", FILES, ids=[case_name(p, "lc_loss_") for p in FILES])
+@pytest.mark.parametrize("autograd", [True, False], ids=["autograd", "fused"])
+def test_loss_kernel_vs_golden(path, autograd):
+    z, ins, kwargs, want3 = load_loss_case(path, torch.float32)
+    loss, gu, gs, gx, aux = _run(ins, kwargs, want3, autograd)
+    for tag, tl, tg in (("f64", 3e-5, 3e-4), ("f32", 1e-4, 1e-3)):
+        ref = torch.from_numpy(z[f"{tag}_loss"]).double()
+        assert ((loss.double() - ref).abs() / ref.abs().clamp_min(1)).max().item() <= tl, tag
+        assert rel_err(gu, z[f"{tag}_g_pts2d"]) <= tg, tag
+        assert rel_err(gs, z[f"{tag}_g_inv_std"]) <= tg, tag
+        if want3:
+            assert rel_err(gx, z[f"{tag}_g_pts3d"]) <= tg, tag
+    if aux is not None and "f64_Hinv" in z.files:
+        Hinv = aux[:, 4:].reshape(-1, 6, 6).double()
+        assert rel_err(Hinv, z["f64_Hinv"]) <= 1e-4
+
+
+@pytest.mark.parametrize("B,N,seed", [(1, 3, 0), (7, 5, 1), (3, 64, 2), (2, 65, 3), (2, 200, 4), (2, 257, 5), (1, 1849, 6), (33, 100, 7)])
+def test_loss_kernel_vs_oracle_shapes(B, N, seed):
+    """Ragged / odd sizes through both kernel variants (registers: N<=256, block-stride: N>256), with a valid mask."""
+    from lc_amd import synth
+    from oracle import lc_loss_oracle as orc
+
+    b = synth.make_batch(B, N, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    valid = (torch.rand(B, N, generator=g) > 0.2).float()
+    valid[:, :3] = 1
+    go = torch.rand(B, generator=g) + 0.5
+    ins = dict(b, valid=valid, grad_out=go)
+    loss, gu, gs, gx, _ = _run(ins, {}, True, True)
+    b64 = {k: v.double() for k, v in ins.items()}
+    rl, ru, rs, rx = orc.loss_and_grads(b64["K"], b64["pose"], b64["pts3d"], b64["pts2d"], b64["inv_std"], b64["valid"],
+                                        b64["bbox_3d"], grad_out=b64["grad_out"], want_pts3d=True)
+    assert ((loss.double() - rl).abs() / rl.abs().clamp_min(1)).max().item() <= 3e-5
+    assert rel_err(gu, ru) <= 3e-4 and rel_err(gs, rs) <= 3e-4 and rel_err(gx, rx) <= 3e-4
+
+
+def test_loss_full_size_properties():
+    """BASELINE size (B=256,N=64) and beyond: size-independent properties of the path.
+    (a) per-sample independence: a batch equals the concatenation of its halves, bit for bit;
+    (b) the fused cotangent path equals autograd's two-launch path; (c) permutation of the points leaves the loss
+    unchanged to rounding; (d) linearity of the gradient in grad_out."""
+    from lc_amd import synth
+    from lc_amd.cov_mixed import loss_cov_mixed_fused
+
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(4096, 64, seed=11).items()}
+    args = (b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], None, b["bbox_3d"])
+    loss, du, ds, dx, _ = loss_cov_mixed_fused(*args)
+    assert torch.isfinite(loss).all()
+    h = 2048
+    l1, du1, _, _, _ = loss_cov_mixed_fused(*[a[:h] if a is not None else None for a in args])
+    l2, du2, _, _, _ = loss_cov_mixed_fused(*[a[h:] if a is not None else None for a in args])
+    assert torch.equal(torch.cat((l1, l2)), loss) and torch.equal(torch.cat((du1, du2)), du)
+    go = torch.rand(4096, device=dev) + 0.5
+    _, du_g, ds_g, dx_g, _ = loss_cov_mixed_fused(*args, grad_out=go)
+    assert torch.allclose(du_g, du * go[:, None, None], rtol=1e-5, atol=1e-12)
+    assert torch.allclose(dx_g, dx * go[:, None, None], rtol=1e-5, atol=1e-12)
+    perm = torch.randperm(64, device=dev)
+    lp, dup, _, _, _ = loss_cov_mixed_fused(b["K"], b["pose"], b["pts3d"][:, perm], b["pts2d"][:, perm], b["inv_std"][:, perm],
+                                            None, b["bbox_3d"])
+    assert (lp - loss).abs().max().item() <= 1e-5
+    assert rel_err(dup.cpu(), du[:, perm].cpu()) <= 1e-4
+
+
+def test_loss_rejects_cpu_tensors():
+    from lc_amd import synth
+    from lc_amd.cov_mixed import Loss_cov_mixed
+
+    b = synth.make_batch(2, 8, seed=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Loss_cov_mixed(b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], None, bbox_3d=b["bbox_3d"])

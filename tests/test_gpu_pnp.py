@@ -1,0 +1,130 @@
+"""GPU parity of the batched LM weighted-PnP kernel against oracle/pnp_lm_oracle.c, through both C-ABI routes.
+
+Tolerance (north_star / BASELINE.md 3.6): max|dq| <= 1e-4 after sign alignment and ||dt||/||t|| <= 1e-4; both solvers follow
+the same schedule, so trust radius and invalid flags must agree too.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from lc_amd import synth
+from oracle import pnp_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def pose_err(a, b):
+    qa = a[:, :4] / np.linalg.norm(a[:, :4], axis=1, keepdims=True)
+    qb = b[:, :4] / np.linalg.norm(b[:, :4], axis=1, keepdims=True)
+    sgn = np.sign((qa * qb).sum(1, keepdims=True))
+    dq = np.abs(qa - sgn * qb).max(1)
+    dt = np.linalg.norm(a[:, 4:] - b[:, 4:], axis=1) / np.linalg.norm(b[:, 4:], axis=1)
+    return dq, dt
+
+
+def make(B, N, seed, **kw):
+    b = synth.make_batch(B, N, seed=seed, **kw)
+    return b, torch.diag_embed(b["inv_std"])
+
+
+@pytest.mark.parametrize("B,N,seed", [(256, 64, 0), (16, 16, 1), (8, 4, 2), (5, 100, 3), (3, 1024, 4)])
+def test_pnp_device_route_vs_oracle(B, N, seed):
+    from lc_amd.pnp import pnp_ceres
+
+    b, L = make(B, N, seed)
+    dev = torch.device("cuda:0")
+    st, tr, ret, iters = pnp_ceres.solve_device(b["K"].to(dev), b["pts3d"].to(dev), b["pts2d"].to(dev), L.to(dev), b["start"].to(dev),
+                                                return_iters=True)
+    so, tro, reto = pnp_oracle.solve_batched(b["start"].numpy(), b["K"].numpy(), b["pts2d"].numpy(), b["pts3d"].numpy(), L.numpy())
+    np.testing.assert_array_equal(ret.cpu().numpy(), reto)
+    dq, dt = pose_err(st.cpu().numpy(), so)
+    assert dq.max() <= 1e-4 and dt.max() <= 1e-4, (dq.max(), dt.max())
+    assert np.allclose(tr.cpu().numpy(), tro, rtol=1e-3)
+    assert (iters.cpu().numpy() >= 1).all()
+    # diagonal-factor entry point == full-factor entry point
+    st2, _, _ = pnp_ceres.solve_device(b["K"].to(dev), b["pts3d"].to(dev), b["pts2d"].to(dev), b["inv_std"].to(dev), b["start"].to(dev))
+    assert torch.equal(st2, st)
+
+
+def test_reference_abi_symbol_vs_oracle():
+    """Drive liblc_amd.so's `pnp_ceres_f32_omp` with the same pointer-array marshalling the reference's cffi code uses
+    (ragged counts, a <3-point job), and compare with the oracle's implementation of the same symbol."""
+    from lc_amd import _lib
+
+    b, L = make(12, 48, 5)
+    counts = [48, 40, 2, 17, 48, 3, 48, 48, 0, 48, 31, 48]
+    lists = lambda t: [t[i, :max(counts[i], 1)].numpy() for i in range(12)]
+    args = ([s for s in b["start"].numpy()], [k for k in b["K"].numpy()], lists(b["pts2d"]), lists(b["pts3d"]), lists(L), counts)
+    s_gpu, tr_gpu, ret_gpu = pnp_oracle.solve_pointer_arrays(*args, num_threads=4, symbol_lib=ctypes.CDLL(_lib.lib_path()))
+    s_cpu, tr_cpu, ret_cpu = pnp_oracle.solve_pointer_arrays(*args, num_threads=4)
+    np.testing.assert_array_equal(ret_gpu, ret_cpu)
+    assert ret_gpu[2] == 1 and ret_gpu[8] == 1 and tr_gpu[2] == 1 and tr_gpu[8] == 1
+    np.testing.assert_array_equal(s_gpu[[2, 8]], b["start"].numpy()[[2, 8]])  # untouched
+    ok = ret_cpu == 0
+    dq, dt = pose_err(s_gpu[ok], s_cpu[ok])
+    assert dq.max() <= 1e-4 and dt.max() <= 1e-4
+
+
+def test_cer_solver_surface():
+    """lib.pnp.cer_solver.solve semantics: ragged lists, NaN filtering, invalid -> start, full 2x2 information."""
+    from lc_amd.pnp import cer_solver
+
+    dev = torch.device("cuda:0")
+    b, L = make(6, 32, 6)
+    d = {k: v.to(dev) for k, v in b.items()}
+    n = [32, 20, 32, 2, 32, 9]
+    pts3d = [d["pts3d"][i, :n[i]] for i in range(6)]
+    pts2d = [d["pts2d"][i, :n[i]] for i in range(6)]
+    icov = [(d["inv_std"][i, :n[i]] ** 2) for i in range(6)]
+    pts2d[0] = pts2d[0].clone()
+    pts2d[0][3, 0] = float("nan")
+    inv, states = cer_solver.solve(d["K"], pts3d, pts2d, icov, list(d["start"]), num_workers=4, filter_input_nan=True)
+    assert states.shape == (6, 7) and states.device.type == "cuda"
+    assert inv["invalids"].tolist()[3] is True and torch.equal(states[3], d["start"][3])
+    # oracle on the same padded problem
+    P = 32
+    pad = lambda lst, w: torch.stack([torch.cat((t, t.new_zeros((P - len(t),) + t.shape[1:]))) for t in lst])
+    u_p = torch.nan_to_num(pad(pts2d, 2)).cpu()
+    so, _, reto = pnp_oracle.solve_batched(b["start"].numpy(), b["K"].numpy(), u_p.numpy(), pad(pts3d, 3).cpu().numpy(),
+                                           torch.diag_embed(pad(icov, 2).sqrt()).cpu().numpy(), counts=np.array(n, np.int32))
+    np.testing.assert_array_equal(inv["solver_invalids"].cpu().numpy(), reto.astype(bool))
+    ok = reto == 0
+    dq, dt = pose_err(states.cpu().numpy()[ok], so[ok])
+    assert dq.max() <= 1e-4 and dt.max() <= 1e-4
+    # full 2x2 information matrices
+    g = torch.Generator().manual_seed(1)
+    M = torch.randn(6, 32, 2, 2, generator=g)
+    icov_full = (M @ M.mT + 0.5 * torch.eye(2))
+    inv2, st2 = cer_solver.solve(d["K"], d["pts3d"], d["pts2d"], icov_full.to(dev), d["start"])
+    so2, _, ret2 = pnp_oracle.solve_batched(b["start"].numpy(), b["K"].numpy(), b["pts2d"].numpy(), b["pts3d"].numpy(),
+                                            torch.linalg.cholesky(icov_full).numpy())
+    np.testing.assert_array_equal(inv2["invalids"].cpu().numpy(), ret2.astype(bool))
+    dq, dt = pose_err(st2.cpu().numpy()[ret2 == 0], so2[ret2 == 0])
+    assert dq.max() <= 1e-4 and dt.max() <= 1e-4
+    # optimal_start short-circuit (cer_solver.py:33-34)
+    inv3, st3 = cer_solver.solve(d["K"], d["pts3d"], d["pts2d"], d["inv_std"] ** 2, d["start"], optimal_start=True)
+    assert torch.equal(st3, d["start"]) and not inv3["invalids"].any()
+
+
+def test_pnp_full_size_properties():
+    """B=4096 x N=64: (a) noise-free correspondences recover the GT pose from the perturbed start; (b) re-solving from
+    the solution is idempotent (converges immediately, pose moves < 1e-5); (c) max_iter=1 -> every job invalid, untouched."""
+    from lc_amd.pnp import pnp_ceres
+
+    dev = torch.device("cuda:0")
+    b = synth.make_batch(4096, 64, seed=21, outlier_frac=0.0, noise_px=0.0)
+    d = {k: v.to(dev) for k, v in b.items()}
+    st, tr, ret = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], d["inv_std"], d["start"])
+    assert int(ret.sum()) == 0
+    dq, dt = pose_err(st.cpu().numpy(), b["pose"].numpy())
+    assert dq.max() <= 5e-5 and dt.max() <= 5e-5
+    st2, _, ret2 = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], d["inv_std"], st)
+    assert int(ret2.sum()) == 0
+    dq, dt = pose_err(st2.cpu().numpy(), st.cpu().numpy())
+    assert dq.max() <= 1e-5 and dt.max() <= 1e-5
+    b = synth.make_batch(512, 64, seed=22)
+    d = {k: v.to(dev) for k, v in b.items()}
+    st3, _, ret3 = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], d["inv_std"], d["start"], max_iter_count=1)
+    assert int(ret3.sum()) == 512 and torch.equal(st3, d["start"])
