@@ -206,7 +206,7 @@ int lc_scale_rows_f32(const float* scale, int B, const float* src0, float* dst0,
     const int threads = 256;
     const size_t blocks = (total + threads - 1) / threads;
     hipLaunchKernelGGL(lc_scale_rows_kernel, dim3((unsigned)blocks), dim3(threads), 0, static_cast<hipStream_t>(stream), scale, B,
-                       src0, dst0, len0 > 0 ? len0 : 1, src1, dst1, len1 > 0 ? len1 : 1, src2, dst2, len2 > 0 ? len2 : 1);
+                       src0, dst0, len0, src1, dst1, len1, src2, dst2, len2);  // a zero length makes its branch unreachable
     return hipGetLastError() == hipSuccess ? 0 : fail(11, "scale kernel launch failed");
 }
 

@@ -34,16 +34,30 @@ def _run(ins, kwargs, want3, use_autograd=True):
 @pytest.mark.parametrize("path", FILES, ids=[case_name(p, "lc_loss_") for p in FILES])
 @pytest.mark.parametrize("autograd", [True, False], ids=["autograd", "fused"])
 def test_loss_kernel_vs_golden(path, autograd):
+    from oracle import lc_loss_oracle as orc
+
     z, ins, kwargs, want3 = load_loss_case(path, torch.float32)
     loss, gu, gs, gx, aux = _run(ins, kwargs, want3, autograd)
-    for tag, tl, tg in (("f64", 3e-5, 3e-4), ("f32", 1e-4, 1e-3)):
+    # (1) oracle in fp64 on the IDENTICAL (fp32-representable) inputs: isolates the kernel's own arithmetic
+    i64 = {k: v.double() for k, v in ins.items()}
+    rl, ru, rs, rx = orc.loss_and_grads(i64["K"], i64["pose"], i64["pts3d"], i64["pts2d"], i64["inv_std"], i64.get("valid"),
+                                        i64["bbox_3d"], grad_out=i64["grad_out"], want_pts3d=want3, **kwargs)
+    assert ((loss.double() - rl).abs() / rl.abs().clamp_min(1)).max().item() <= 1e-5
+    assert rel_err(gu, ru) <= 1e-4 and rel_err(gs, rs) <= 1e-4
+    if want3:
+        assert rel_err(gx, rx) <= 1e-4
+    # (2) the reference's own outputs.  The noise-free case is excluded here: with err == 0 the fp64 reference sits on
+    # exact zeros (c = w = 0 -> SPD fallback) that do not survive rounding the inputs to fp32, and the fp32 reference's
+    # err is pure round-off noise -- there is no stable value to compare with (the oracle check above covers it).
+    golden_tols = () if "noisefree" in path else (("f64", 3e-5, 3e-4), ("f32", 1e-4, 1e-3))
+    for tag, tl, tg in golden_tols:
         ref = torch.from_numpy(z[f"{tag}_loss"]).double()
         assert ((loss.double() - ref).abs() / ref.abs().clamp_min(1)).max().item() <= tl, tag
         assert rel_err(gu, z[f"{tag}_g_pts2d"]) <= tg, tag
         assert rel_err(gs, z[f"{tag}_g_inv_std"]) <= tg, tag
         if want3:
             assert rel_err(gx, z[f"{tag}_g_pts3d"]) <= tg, tag
-    if aux is not None and "f64_Hinv" in z.files:
+    if aux is not None and "f64_Hinv" in z.files and golden_tols:
         Hinv = aux[:, 4:].reshape(-1, 6, 6).double()
         assert rel_err(Hinv, z["f64_Hinv"]) <= 1e-4
 
