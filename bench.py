@@ -8,7 +8,7 @@ B=256 poses x N=64 correspondences per GPU (BASELINE.json metric, configs[1]), f
 One process per GPU; the batch is sharded by pose (every pose is independent: SURVEY.md 8e), so there is no data-path
 collective -- only the timing barrier/all-reduce.  Scaling is weak: each rank runs its own B=256 batch.
 A step = one launch of the fused loss kernel (loss + d/d pts2d, d/d inv_std, d/d pts3d for the `.mean()` cotangent) and one
-launch of the batched LM kernel, replayed from a hipGraph (use --eager for plain launches).  Rank 0 prints ONE JSON line.
+batched LM solve; the two are independent, so by default their workgroups share one grid (see --launch).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -39,17 +39,30 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
     from lc_amd import synth
     from oracle import lc_loss_oracle, pnp_oracle
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    avail = os.cpu_count() or 1
     b = synth.make_batch(B, N, seed=seed)
     L = torch.diag_embed(b["inv_std"]).numpy()
     npb = {k: v.numpy() for k, v in b.items()}
     go = torch.full((B,), 1.0 / B)
 
-    def one():
+    def one(nt):
         lc_loss_oracle.loss_and_grads(b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], None, b["bbox_3d"], grad_out=go)
-        pnp_oracle.solve_batched(npb["start"], npb["K"], npb["pts2d"], npb["pts3d"], L, num_threads=cores)
+        pnp_oracle.solve_batched(npb["start"], npb["K"], npb["pts2d"], npb["pts3d"], L, num_threads=nt)
 
+    # B=256 poses of ~5 KB each do not scale to hundreds of host threads: pick the fastest of a few thread counts
+    best = None
+    for nt in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        one(nt)
+        t0 = time.perf_counter()
+        one(nt)
+        dt1 = time.perf_counter() - t0
+        if best is None or dt1 < best[1]:
+            best = (nt, dt1)
+    cores = best[0]
+    torch.set_num_threads(cores)
+    one_ = one
+    one = lambda: one_(cores)  # noqa: E731
     one()  # warm-up (thread pools, page-in)
     t0 = time.perf_counter()
     n = 0
@@ -59,8 +72,9 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s or n >= 2000:
             break
     dt = time.perf_counter() - t0
-    return dict(value=B * n / dt, unit="poses/s", cores=cores, kind="port",
-                sample=f"{n} batches of B={B} N={N} (oracle: torch-CPU closed-form loss fwd+bwd + C/OpenMP LM), {dt:.1f} s")
+    return dict(value=B * n / dt, unit="poses/s", cores=cores, kind="port", host_cores_available=avail,
+                sample=f"{n} batches of B={B} N={N} (oracle: torch-CPU closed-form loss fwd+bwd + C/OpenMP LM, "
+                       f"{cores} threads = fastest of 4..64), {dt:.1f} s")
 
 
 def main():
@@ -70,7 +84,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="poses per GPU per step")
     ap.add_argument("--npts", type=int, default=64)
-    ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--launch", default="fused", choices=["fused", "eager", "eager2", "graph", "graph2", "graph_fused"],
+                    help="fused (default): loss and PnP workgroups share ONE grid (lc_pose_unit_f32); eager: two launches on "
+                         "one stream; eager2: LM solve forked onto a second stream; graph*: the same step replayed as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -109,22 +125,44 @@ def main():
         assert rc == 0
 
     def launch_pnp():
-        states.copy_(b["start"])  # the solver updates states in place; every step starts from the same perturbed pose
-        rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(sqrt_diag), None, P(states), P(tr), P(ret),
-                               None, B, N, 50, 1e-6, _lib.stream_ptr(dev))
+        # start poses are read-only input, states is output: every step solves from the same perturbed pose
+        rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(sqrt_diag), None, P(b["start"]), P(states), P(tr),
+                               P(ret), None, B, N, 50, 1e-6, _lib.stream_ptr(dev))
         assert rc == 0
 
-    def step_eager():
+    side = torch.cuda.Stream(dev)
+
+    def step_serial():
         launch_loss()
         launch_pnp()
 
-    graph = None
-    if not args.eager:
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+    def step_forked():
+        # the two kernels are independent (the loss linearises at the GT pose, the solve starts from `start`):
+        # fork the LM solve onto a second HIP stream, join at the end of the step
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
         with torch.cuda.stream(side):
+            launch_pnp()
+        launch_loss()
+        main.wait_stream(side)
+
+    def step_fused():
+        # one grid for both halves of the pose unit (lc_amd/csrc/lc_fused.hip)
+        rc = lib.lc_pose_unit_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]),
+                                  P(go), B, N, 32.0, 3.0, 4.0, P(loss), P(d_u), P(d_s), P(d_x), P(sqrt_diag), P(b["start"]),
+                                  P(states), P(tr), P(ret), 50, 1e-6, _lib.stream_ptr(dev))
+        assert rc == 0
+
+    if args.launch == "fused" and N > 64:
+        args.launch = "eager"
+    step_eager = {"eager": step_serial, "graph": step_serial, "fused": step_fused, "graph_fused": step_fused}.get(args.launch, step_forked)
+    graph = None
+    if args.launch.startswith("graph"):
+        warm = torch.cuda.Stream(dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(warm):
             step_eager()
-        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -164,18 +202,16 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / reps
 
-    def launch_pnp_only():
-        rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(sqrt_diag), None, P(states), P(tr), P(ret),
-                               None, B, N, 50, 1e-6, _lib.stream_ptr(dev))
-        assert rc == 0
-
     if rank == 0:
         t_loss = kernel_ms(launch_loss)
-        # PnP alone: restore the start pose outside the timed kernel by timing (copy+kernel) - (copy)
-        t_copy = kernel_ms(lambda: states.copy_(b["start"]))
-        t_pnp = max(kernel_ms(launch_pnp) - t_copy, 1e-6)
+        t_pnp = kernel_ms(launch_pnp)
         by_loss, by_pnp = algorithmic_bytes(N, True)
         dom = ("lc_cov_loss_kernel", t_loss, by_loss) if t_loss >= t_pnp else ("lc_pnp_lm_kernel", t_pnp, by_pnp)
+        kernel_us = {"lc_cov_loss_kernel": t_loss * 1e3, "lc_pnp_lm_kernel": t_pnp * 1e3}
+        if args.launch in ("fused", "graph_fused"):
+            t_unit = kernel_ms(step_fused)
+            dom = ("lc_pose_unit_kernel", t_unit, by_loss + by_pnp)
+            kernel_us["lc_pose_unit_kernel"] = t_unit * 1e3
         achieved = dom[2] * B / (dom[1] * 1e-3) / 1e9
         out = {
             "metric": "poses/sec (cov-loss fwd+bwd + weighted PnP), B=256 N=64",
@@ -192,11 +228,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic B={B} N={N} 2D-3D correspondences per GPU, HIP weighted-PnP + cov-loss",
                        "global_batch": B * world, "n_points": N, "sharding": f"poses over {world} rank(s), no data-path collective",
-                       "launch": "eager" if graph is None else "hipGraph replay"},
+                       "launch": args.launch},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "note": "latency/VALU-bound by construction (5 KB working set per pose, one wave per pose): see DESIGN.md",
-                         "kernel_us": {"lc_cov_loss_kernel": t_loss * 1e3, "lc_pnp_lm_kernel": t_pnp * 1e3},
+                         "kernel_us": kernel_us,
                          "algorithmic_bytes_per_pose": {"loss": by_loss, "pnp": by_pnp}},
         }
         if not args.no_cpu_baseline and world == 1:

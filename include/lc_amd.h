@@ -4,7 +4,7 @@
  * One shared library (liblc_amd.so, built from lc_amd/csrc/ by `python __graft_entry__.py build`) exports
  *   (1) the reference's OWN native entry point, symbol-for-symbol, so the reference's cffi binding
  *       (lib/pnp/pnp_ceres.py:93-140) can load this library instead of its Ceres extension, and
- *   (2) device-pointer entry points for the three fused kernels, which the Python host layer (lc_amd/*.py,
+ *   (2) device-pointer entry points for the three fused kernels, which the Python host layer (lc_amd/ *.py,
  *       mirroring lib/cov_mixed.py, lib/pnp/cer_solver.py, ptnet.py) binds with ctypes.
  * Plain pointers and sizes only; no torch types.  All `float*`/`int*` of the device API are DEVICE pointers,
  * `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream.
@@ -45,11 +45,14 @@ void pnp_ceres_f32_omp(float **init_states, float **cam_Ks, float **pts2ds, floa
  *      lib/pnp/cer_solver.py:22-44 builds before calling the solver (so no device->host round trip).
  *      K (B,3,3)  pts3d (B,Nmax,3)  pts2d (B,Nmax,2)  counts (B) or NULL (= Nmax)
  *      exactly one of: sqrtL (B,Nmax,2,2) lower factor | sqrt_diag (B,Nmax,2) its diagonal (cer_solver.py:37-40)
- *      states (B,7) in/out (same in-place rule), result_tr (B), rets (B), iters (B) or NULL
+ *      start (B,7) or NULL; states (B,7): with start==NULL (or start==states) the reference's in-place rule applies
+ *      (states holds the start pose on entry and is overwritten only for converged jobs); with a separate start,
+ *      states is output only: the optimum for converged jobs, a copy of start otherwise (cer_solver.py:51-52).
+ *      result_tr (B), rets (B), iters (B) or NULL
  * ------------------------------------------------------------------------------------------------ */
 int lc_pnp_lm_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *sqrt_diag,
-                  const int *counts, float *states, float *result_tr, int *rets, int *iters, int B, int Nmax,
-                  int max_iter, float function_tolerance, void *stream);
+                  const int *counts, const float *start, float *states, float *result_tr, int *rets, int *iters, int B,
+                  int Nmax, int max_iter, float function_tolerance, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2b) Linear-covariance loss, forward + backward in one launch -- replaces the autograd graph of
@@ -62,6 +65,17 @@ int lc_cov_loss_fwd_bwd_f32(const float *K, const float *pose, const float *pts3
                             const float *inv_std, const float *valid, const float *bbox_3d, const float *grad_out,
                             int B, int N, float max_err_len, float rel_thresh, float w_e_thresh, float *loss,
                             float *d_pts2d, float *d_inv_std, float *d_pts3d, float *aux, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2b') One "pose unit" per pose in ONE launch: (2b) on B samples and (2a) on the same B correspondence sets
+ *      (diagonal information factor pnp_sqrt_diag (B,N,2), start poses pnp_start (B,7) -> pnp_states (B,7)), N <= 64.
+ *      The two computations are independent; sharing a grid fills the chip at small B (bench.py's headline step).
+ * ------------------------------------------------------------------------------------------------ */
+int lc_pose_unit_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d, const float *inv_std,
+                     const float *valid, const float *bbox_3d, const float *grad_out, int B, int N, float max_err_len,
+                     float rel_thresh, float w_e_thresh, float *loss, float *d_pts2d, float *d_inv_std, float *d_pts3d,
+                     const float *pnp_sqrt_diag, const float *pnp_start, float *pnp_states, float *pnp_result_tr,
+                     int *pnp_rets, int pnp_max_iter, float pnp_function_tolerance, void *stream);
 
 /* dst[b, :] = scale[b] * src[b, :]  for up to three (B,row_len) tensors in one launch (autograd's chain-rule step) */
 int lc_scale_rows_f32(const float *scale, int B, const float *src0, float *dst0, int len0, const float *src1, float *dst1,

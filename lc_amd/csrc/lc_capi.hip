@@ -123,6 +123,7 @@ int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pt
     p.sqrtL = reinterpret_cast<float*>(d + off[3]);
     p.sqrt_diag = nullptr;
     p.counts = reinterpret_cast<int*>(d + off[4]);
+    p.start = nullptr;
     p.states = reinterpret_cast<float*>(d + off[5]);
     p.result_tr = reinterpret_cast<float*>(d + off[6]);
     p.rets = reinterpret_cast<int*>(d + off[7]);
@@ -169,13 +170,14 @@ void pnp_ceres_f32_omp(float** init_states, float** cam_Ks, float** pts2ds, floa
 }
 
 int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* sqrt_diag,
-                  const int* counts, float* states, float* result_tr, int* rets, int* iters, int B, int Nmax, int max_iter,
-                  float function_tolerance, void* stream) {
+                  const int* counts, const float* start, float* states, float* result_tr, int* rets, int* iters, int B, int Nmax,
+                  int max_iter, float function_tolerance, void* stream) {
     if (B < 0 || Nmax < 0) return fail(1, "negative size");
     if ((sqrtL == nullptr) == (sqrt_diag == nullptr)) return fail(1, "exactly one of sqrtL / sqrt_diag must be given");
     if (B == 0) return 0;
     if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
-    lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, states, result_tr, rets, iters, B, Nmax, max_iter, function_tolerance};
+    lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
+                    B, Nmax, max_iter, function_tolerance};
     if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
     return 0;
 }
@@ -192,6 +194,25 @@ int lc_cov_loss_fwd_bwd_f32(const float* K, const float* pose, const float* pts3
     lc::LossParams p{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, aux,
                      B, N, max_err_len, rel_thresh, w_e_thresh};
     if (lc::launch_cov_loss(p, static_cast<hipStream_t>(stream))) return fail(11, "loss kernel launch failed");
+    return 0;
+}
+
+int lc_pose_unit_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
+                     const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
+                     float rel_thresh, float w_e_thresh, float* loss, float* d_pts2d, float* d_inv_std, float* d_pts3d,
+                     const float* pnp_sqrt_diag, const float* pnp_start, float* pnp_states, float* pnp_result_tr, int* pnp_rets,
+                     int pnp_max_iter, float pnp_function_tolerance, void* stream) {
+    if (B < 0 || N <= 0) return fail(1, "bad size");
+    if (N > 64) return fail(3, "lc_pose_unit_f32 needs N <= 64; launch the two kernels separately");
+    if (B == 0) return 0;
+    if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss || !d_pts2d || !d_inv_std || !pnp_sqrt_diag ||
+        !pnp_start || !pnp_states || !pnp_result_tr || !pnp_rets)
+        return fail(1, "null pointer");
+    lc::LossParams lp{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, nullptr,
+                      B, N, max_err_len, rel_thresh, w_e_thresh};
+    lc::PnpParams pp{K, pts2d, pts3d, nullptr, pnp_sqrt_diag, nullptr, pnp_start == pnp_states ? nullptr : pnp_start, pnp_states,
+                     pnp_result_tr, pnp_rets, nullptr, B, N, pnp_max_iter, pnp_function_tolerance};
+    if (lc::launch_pose_unit(lp, pp, static_cast<hipStream_t>(stream))) return fail(11, "pose-unit kernel launch failed");
     return 0;
 }
 

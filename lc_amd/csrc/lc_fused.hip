@@ -1,0 +1,35 @@
+// "Pose unit" in ONE launch: the LC-loss forward+backward of B_loss samples and the weighted-PnP solve of B_pnp poses
+// are independent (the loss linearises at the ground-truth pose, the solve starts from its own initial pose), so their
+// workgroups share a grid: blocks [0, B_pnp) run pnp::solve_pose (the longer job, dispatched first), blocks
+// [B_pnp, B_pnp + B_loss) run loss::sample.  At B = 256 that puts 512 single-wave workgroups on the 256 CUs at once
+// instead of two half-empty launches back to back.  Only for N <= 64 (one wavefront per pose in both bodies).
+#include "lc_loss_body.h"
+#include "lc_pnp_body.h"
+
+namespace lc {
+namespace {
+
+union FusedShared {
+    loss::LossShared loss;
+    double bc[32];
+};
+
+__global__ __launch_bounds__(64) void lc_pose_unit_kernel(const LossParams lp, const PnpParams pp) {
+    __shared__ FusedShared sh;
+    if ((int)blockIdx.x < pp.B)
+        pnp::solve_pose<true>(pp, blockIdx.x, threadIdx.x, sh.bc);
+    else
+        loss::sample<true>(lp, (int)blockIdx.x - pp.B, sh.loss);
+}
+
+}  // namespace
+
+int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stream) {
+    if (lp.N > 64 || pp.Nmax > 64 || lp.N <= 0) return 3;
+    const int blocks = (lp.B > 0 ? lp.B : 0) + (pp.B > 0 ? pp.B : 0);
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(lc_pose_unit_kernel, dim3(blocks), dim3(64), 0, stream, lp, pp);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace lc

@@ -32,7 +32,8 @@ struct PnpParams {
     const float* sqrtL;   // (B,Nmax,2,2) lower factor of the 2x2 information matrix, or
     const float* sqrt_diag;  // (B,Nmax,2) its diagonal when the factor is diagonal (sqrtL == null)
     const int* counts;    // (B,) valid points per pose, or null (== Nmax)
-    float* states;        // (B,7) in: start, out: optimum (untouched unless converged)
+    const float* start;   // (B,7) start poses, or null: read them from `states` (in-place form)
+    float* states;        // (B,7) out: optimum if converged, else the start pose
     float* result_tr;     // (B,) final trust-region radius
     int* rets;            // (B,) 0 ok / 1 invalid
     int* iters;           // (B,) LM iterations used, or null
@@ -40,6 +41,8 @@ struct PnpParams {
     float ftol;
 };
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream);
+// both of the above in one grid (N <= 64 only; returns 3 otherwise)
+int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stream);
 
 struct HeadParams {
     const float* in;      // (M,H,W) logits (or probabilities when is_prob)

@@ -1,583 +1,13 @@
-// Fused linear-covariance pose loss, forward + analytic backward, one workgroup per sample.
-//
-// Replaces the ~1000-dispatch autograd graph of the reference's
-//   lib/cov_mixed.py:100-150 Loss_cov_mixed  (+ lib/nll/pnp_auto.py, lib/nll/pnp_utils.py, lib/transforms/*)
-// by ONE launch: every per-sample 2Nx6 Jacobian row lives in the registers of the lane that owns the point,
-// the 6x6 normal equations / covariance algebra lives in LDS (one matrix entry per lane), and the only HBM
-// traffic is the coalesced read of the (B,N,*) inputs and the write of loss + input gradients.
-//
-// Math (verified against the reference in oracle/lc_loss_oracle.py; symbols follow SURVEY.md 8a):
-//   e = clamp(u - proj);  c = th(|e|, 3 mean|e|);  w = th(s, sqrt(4 mean(s^2 c)/(c+1e-6)))
-//   H = sum w (J J^T + r Hess r);  S = H^-1 (or I if H is not SPD);  Mc = sum w^2 c J J^T;  v = sum w e J
-//   G = d(bbox corners)/d(pose);  P = mean_k sqrt(tr_k(G S G^T)); C = mean_k sqrt(tr_k(G S Mc S G^T)); L = mean_k |G_k S v|
-//   loss = log P + (C + L) / (2 P)
-// and its hand-derived reverse mode (see DESIGN.md "LC-loss backward").
-#include "lc_common.h"
-#include "lc_kernels.h"
+// Stand-alone launch of the fused LC-loss forward+backward (device body: lc_loss_body.h).
+#include "lc_loss_body.h"
 
 namespace lc {
 namespace {
 
-struct LossShared {
-    double red[16][48];   // cross-wave partials of the 48-value reduction
-    double small[16][4];  // cross-wave partials of the small reductions
-    double A0[36], A1[36];  // Gauss-Jordan ping-pong; S = H^-1 ends up in A0
-    double Mc[36], v[6];
-    double SM[36], U[36], sv[6];
-    double G[24 * 6], pd[24], cd[24], dl[24], sq[24];
-    double PhiP[36], PhiC[36], lam[6];
-    double T[36], Y[36], Sbar[36], Z[36];
-    double Hbar[36], Psi[36], mu[6];
-    int bad[2];
-};
-
-struct PoseConst {
-    double K[9];
-    double R[9];   // the matrix the reference uses (two_s = 2/|q|, rotation_conversions.py:52)
-    double Rt[9];  // proper rotation of the normalised quaternion
-    double rho;
-    double t[3];
-};
-
-__device__ __forceinline__ void quat_matrix(const double q[4], double two_s, double R[9]) {
-    const double r = q[0], i = q[1], j = q[2], k = q[3];
-    R[0] = 1 - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
-    R[3] = two_s * (i * j + k * r); R[4] = 1 - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
-    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1 - two_s * (i * i + j * j);
-}
-
-struct Proj {
-    double Xc[3];     // camera-frame point (unclamped)
-    double proj[2];   // project_apply output (z clamped at 0.1, transforms.py:47-63)
-    double zc;        // clamped depth of K*Xc
-    double zpass;     // 1 if the clamp passes gradient (xf_z >= 0.1)
-};
-
-__device__ __forceinline__ Proj project(const PoseConst& pc, const double X[3]) {
-    Proj o;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) o.Xc[d] = pc.R[3 * d] * X[0] + pc.R[3 * d + 1] * X[1] + pc.R[3 * d + 2] * X[2] + pc.t[d];
-    double xf[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) xf[d] = pc.K[3 * d] * o.Xc[0] + pc.K[3 * d + 1] * o.Xc[1] + pc.K[3 * d + 2] * o.Xc[2];
-    o.zpass = xf[2] >= 0.1 ? 1.0 : 0.0;
-    o.zc = xf[2] >= 0.1 ? xf[2] : 0.1;  // NaN propagates like torch.clamp? (NaN >= x false -> 0.1; inputs are finite)
-    o.proj[0] = xf[0] / o.zc;
-    o.proj[1] = xf[1] / o.zc;
-    return o;
-}
-
-// clamp_error (cov_mixed.py:16-24): cap the 2-vector length at max_len, identity gradient
-__device__ __forceinline__ void clamp_err(const double u[2], const double proj[2], double max_len, double e[2]) {
-    const double e0 = u[0] - proj[0], e1 = u[1] - proj[1];
-    const double len = sqrt(e0 * e0 + e1 * e1) + 1e-6;
-    const double f = (len - max_len) / len;
-    if (f > 0) {
-        e[0] = e0 - f * e0;
-        e[1] = e1 - f * e1;
-    } else {
-        e[0] = e0;
-        e[1] = e1;
-    }
-}
-
-// residual_with_jac6d (pnp_auto.py:13-56) at delta = 0, in closed form
-struct PointJac {
-    double J[2][6];
-    double r[2];
-    double iz, x0, y0;
-    double M0[9];  // -R [X]x
-};
-
-__device__ __forceinline__ PointJac point_jac(const PoseConst& pc, const double X[3], const Proj& pr) {
-    PointJac o;
-    o.iz = 1.0 / pr.Xc[2];
-    o.x0 = pr.Xc[0] * o.iz;
-    o.y0 = pr.Xc[1] * o.iz;
-    // M0 = R * [X]x^T,  [X]x^T = [[0, X2, -X1], [-X2, 0, X0], [X1, -X0, 0]]
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const double r0 = pc.R[3 * d], r1 = pc.R[3 * d + 1], r2 = pc.R[3 * d + 2];
-        o.M0[3 * d + 0] = -r1 * X[2] + r2 * X[1];
-        o.M0[3 * d + 1] = r0 * X[2] - r2 * X[0];
-        o.M0[3 * d + 2] = -r0 * X[1] + r1 * X[0];
-    }
-    double Ju[2][6];  // d uv0 / d delta = iz (T_a - uv0_a T_2), T = [M0 | I]
-#pragma unroll
-    for (int l = 0; l < 3; ++l) {
-        Ju[0][l] = o.iz * (o.M0[l] - o.x0 * o.M0[6 + l]);
-        Ju[1][l] = o.iz * (o.M0[3 + l] - o.y0 * o.M0[6 + l]);
-    }
-    Ju[0][3] = o.iz; Ju[0][4] = 0; Ju[0][5] = -o.iz * o.x0;
-    Ju[1][3] = 0; Ju[1][4] = o.iz; Ju[1][5] = -o.iz * o.y0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const double k0 = pc.K[3 * c], k1 = pc.K[3 * c + 1];
-#pragma unroll
-        for (int l = 0; l < 6; ++l) o.J[c][l] = k0 * Ju[0][l] + k1 * Ju[1][l];
-        o.r[c] = k0 * o.x0 + k1 * o.y0 + pc.K[3 * c + 2] - pr.proj[c];
-    }
-    return o;
-}
-
-template <int K>
-__device__ __forceinline__ void block_allreduce_small(double (&v)[K], double (*scratch)[4], int lane, int wave, int nw) {
-    wave_allreduce<K>(v);
-    if (nw > 1) {
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < K; ++i) scratch[wave][i] = v[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double s = 0;
-            for (int w = 0; w < nw; ++w) s += scratch[w][i];
-            v[i] = s;
-        }
-        __syncthreads();
-    }
-}
-
-// C = A * B for 6x6 row-major matrices in LDS; one output entry per thread (tid < 36)
-__device__ __forceinline__ double mm6_entry(const double* A, const double* B, int i, int j) {
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc += A[6 * i + k] * B[6 * k + j];
-    return acc;
-}
-
-__device__ __forceinline__ double mv6_entry(const double* A, const double* x, int i) {
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc += A[6 * i + k] * x[k];
-    return acc;
-}
-
-__device__ __forceinline__ double quad6(const double* M /*LDS 6x6 symmetric*/, const double* x) {
-    double acc = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double row = 0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) row += M[6 * i + j] * x[j];
-        acc += row * x[i];
-    }
-    return acc;
-}
-
-struct Pt {
-    double X[3], u[2], s[2], vld;
-};
-
-__device__ __forceinline__ Pt load_pt(const LossParams& p, size_t base, int n) {
-    Pt o;
-    const float* X = p.pts3d + (base + n) * 3;
-    const float2 u = *reinterpret_cast<const float2*>(p.pts2d + (base + n) * 2);
-    const float2 s = *reinterpret_cast<const float2*>(p.inv_std + (base + n) * 2);
-    o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
-    o.u[0] = u.x; o.u[1] = u.y;
-    o.s[0] = s.x; o.s[1] = s.y;
-    o.vld = p.valid ? (double)p.valid[base + n] : 1.0;
-    return o;
-}
-
-// REG: the block has at least N threads, each point's raw inputs and clamped error stay in registers.
-// !REG: block-stride over points; raw inputs are re-read (L1/L2 hits) and e re-derived in every pass.
 template <bool REG>
 __global__ __launch_bounds__(256) void lc_cov_loss_kernel(const LossParams p) {
-    __shared__ LossShared sh;
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    const int N = p.N;
-    const size_t base = (size_t)b * N;
-
-    PoseConst pc;
-    {
-        const float* Kp = p.K + 9 * (size_t)b;
-        const float* ps = p.pose + 7 * (size_t)b;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) pc.K[i] = Kp[i];
-        const double q[4] = {ps[0], ps[1], ps[2], ps[3]};
-        pc.rho = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-        quat_matrix(q, 2.0 / pc.rho, pc.R);
-        quat_matrix(q, 2.0 / (pc.rho * pc.rho), pc.Rt);
-        pc.t[0] = ps[4]; pc.t[1] = ps[5]; pc.t[2] = ps[6];
-    }
-    if (tid < 2) sh.bad[tid] = 0;
-
-    const double max_len = p.max_err_len, rel_thresh = p.rel_thresh, w_e_thresh = p.w_e_thresh;
-
-    Pt rp;          // REG only
-    double re[2];   // REG only: clamped error
-    bool active = false;
-    if constexpr (REG) {
-        active = tid < N;
-        if (active) rp = load_pt(p, base, tid);
-    }
-
-    // ---------------- pass 1: e, sum |e| (robust_weights_cov, cov_mixed.py:27-31) ----------------
-    double s1[3] = {0, 0, 0};
-    if constexpr (REG) {
-        if (active) {
-            const Proj pr = project(pc, rp.X);
-            clamp_err(rp.u, pr.proj, max_len, re);
-            s1[0] = fabs(re[0]) * rp.vld; s1[1] = fabs(re[1]) * rp.vld; s1[2] = rp.vld;
-        }
-    } else {
-        for (int n = tid; n < N; n += nthr) {
-            const Pt pt = load_pt(p, base, n);
-            const Proj pr = project(pc, pt.X);
-            double e[2];
-            clamp_err(pt.u, pr.proj, max_len, e);
-            s1[0] += fabs(e[0]) * pt.vld; s1[1] += fabs(e[1]) * pt.vld; s1[2] += pt.vld;
-        }
-    }
-    block_allreduce_small<3>(s1, sh.small, lane, wave, nw);
-    const double vcnt = p.valid ? s1[2] : (double)N;
-    const double dlt_e[2] = {s1[0] / vcnt * rel_thresh, s1[1] / vcnt * rel_thresh};  // Huber knee of |e|
-
-    // ---------------- pass 2: c, mean(s^2 c) (cov_mixed.py:32-36) ----------------
-    double s2[2] = {0, 0};
-    auto huber = [](double v, double d) { return v > d ? d * (2 * v - d) : v * v; };
-    auto load_e = [&](int n, double e[2]) {
-        // !REG: re-derive e in double (the float copy parked in d_pts2d would lose bits)
-        const Pt pt = load_pt(p, base, n);
-        const Proj pr = project(pc, pt.X);
-        clamp_err(pt.u, pr.proj, max_len, e);
-    };
-    if constexpr (REG) {
-        if (active) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) s2[c] = rp.s[c] * rp.s[c] * huber(fabs(re[c]), dlt_e[c]) * rp.vld;
-        }
-    } else {
-        for (int n = tid; n < N; n += nthr) {
-            double e[2];
-            load_e(n, e);
-            const float2 s = *reinterpret_cast<const float2*>(p.inv_std + (base + n) * 2);
-            const double vld = p.valid ? (double)p.valid[base + n] : 1.0;
-            s2[0] += (double)s.x * s.x * huber(fabs(e[0]), dlt_e[0]) * vld;
-            s2[1] += (double)s.y * s.y * huber(fabs(e[1]), dlt_e[1]) * vld;
-        }
-    }
-    block_allreduce_small<2>(s2, sh.small, lane, wave, nw);
-    const double mwe[2] = {s2[0] / vcnt * w_e_thresh, s2[1] / vcnt * w_e_thresh};
-
-    // ---------------- pass 3: accumulate H (21) | Mc (21) | v (6) ----------------
-    double acc[48];
-#pragma unroll
-    for (int i = 0; i < 48; ++i) acc[i] = 0;
-    auto accumulate = [&](const Pt& pt, const double e[2]) {
-        const Proj pr = project(pc, pt.X);
-        const PointJac pj = point_jac(pc, pt.X, pr);
-        double w[2], cc[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            cc[c] = huber(fabs(e[c]), dlt_e[c]);
-            const double ds = sqrt(mwe[c] / (cc[c] + 1e-6));
-            w[c] = huber(pt.s[c], ds);
-        }
-        // first-order part
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const double wc = w[c], w2c = w[c] * w[c] * cc[c], we = w[c] * e[c];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double wj = wc * pj.J[c][i], mj = w2c * pj.J[c][i];
-#pragma unroll
-                for (int j = i; j < 6; ++j) {
-                    acc[tri6(i, j)] += wj * pj.J[c][j];
-                    acc[21 + tri6(i, j)] += mj * pj.J[c][j];
-                }
-                acc[42 + i] += we * pj.J[c][i];
-            }
-        }
-        // second-order part  sum_c w_c r_c Hess(r_c)  (pnp_auto.py:59-83; exact 2nd derivative, see oracle)
-        const double rho0 = pc.K[0] * w[0] * pj.r[0] + pc.K[3] * w[1] * pj.r[1];
-        const double rho1 = pc.K[1] * w[0] * pj.r[0] + pc.K[4] * w[1] * pj.r[1];
-        const double iz2 = pj.iz * pj.iz;
-        const double qv[3] = {-rho0 * iz2, -rho1 * iz2, (rho0 * pj.x0 + rho1 * pj.y0) * iz2};
-        double tq[6], t2[6];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            tq[l] = pj.M0[l] * qv[0] + pj.M0[3 + l] * qv[1] + pj.M0[6 + l] * qv[2];
-            tq[3 + l] = qv[l];
-            t2[l] = pj.M0[6 + l];
-            t2[3 + l] = l == 2 ? 1.0 : 0.0;
-        }
-        const double pv[3] = {pj.iz * rho0, pj.iz * rho1, -pj.iz * (rho0 * pj.x0 + rho1 * pj.y0)};
-        double pi[3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) pi[l] = pc.R[l] * pv[0] + pc.R[3 + l] * pv[1] + pc.R[6 + l] * pv[2];
-        const double piX = pi[0] * pt.X[0] + pi[1] * pt.X[1] + pi[2] * pt.X[2];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int j = i; j < 6; ++j) {
-                double h = t2[i] * tq[j] + tq[i] * t2[j];
-                if (i < 3 && j < 3) h += 0.5 * (pi[i] * pt.X[j] + pt.X[i] * pi[j]) - (i == j ? piX : 0.0);
-                acc[tri6(i, j)] += h;
-            }
-        }
-    };
-    if constexpr (REG) {
-        if (active) accumulate(rp, re);
-    } else {
-        for (int n = tid; n < N; n += nthr) {
-            const Pt pt = load_pt(p, base, n);
-            const Proj pr = project(pc, pt.X);
-            double e[2];
-            clamp_err(pt.u, pr.proj, max_len, e);
-            accumulate(pt, e);
-        }
-    }
-    wave_reduce_scatter16<48>(acc, lane);
-    if ((lane & 3) == 0) {
-        const int bs = scatter16_base(lane, 3);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) sh.red[wave][bs + i] = acc[i];
-    }
-    __syncthreads();
-    if (tid < 48) {
-        double s = 0;
-        for (int w = 0; w < nw; ++w) s += sh.red[w][tid];
-        // expand packed upper triangles to full symmetric 6x6 (make_sure_symmetric, pnp_utils.py:134-137)
-        if (tid < 42) {
-            const int k = tid < 21 ? tid : tid - 21;
-            int i = 0, rem = k;
-            while (rem >= 6 - i) { rem -= 6 - i; ++i; }
-            const int j = i + rem;
-            double* dst = tid < 21 ? sh.A0 : sh.Mc;
-            dst[6 * i + j] = s;
-            dst[6 * j + i] = s;
-        } else {
-            sh.v[tid - 42] = s;
-        }
-    }
-    __syncthreads();
-
-    // ---------------- serial section, one matrix entry per lane ----------------
-    const int mi = tid / 6, mj = tid % 6;  // valid for tid < 36
-    // S = H^-1 by in-place Gauss-Jordan sweeps (pivots == squared Cholesky diagonal -> SPD test of safe_cholesky)
-    bool spd = true;
-#pragma unroll
-    for (int pz = 0; pz < 6; ++pz) {
-        const double* src = (pz & 1) ? sh.A1 : sh.A0;
-        double* dst = (pz & 1) ? sh.A0 : sh.A1;
-        const double piv = src[7 * pz];
-        spd = spd && (piv > 0);
-        if (tid < 36) {
-            const double ip = 1.0 / piv;
-            const double rowv = src[6 * pz + mj], colv = src[6 * mi + pz], cur = src[6 * mi + mj];
-            double out;
-            if (mi == pz && mj == pz) out = ip;
-            else if (mi == pz) out = rowv * ip;
-            else if (mj == pz) out = -colv * ip;
-            else out = cur - colv * rowv * ip;
-            dst[tid] = out;
-        }
-        __syncthreads();
-    }
-    if (!spd) {  // make_sure_SPD (pnp_utils.py:140-157): H := I, no gradient into H
-        if (tid < 36) sh.A0[tid] = (mi == mj) ? 1.0 : 0.0;
-        __syncthreads();
-    }
-    const double* S = sh.A0;
-    if (tid < 36) sh.SM[tid] = mm6_entry(S, sh.Mc, mi, mj);
-    else if (tid < 42) sh.sv[tid - 36] = mv6_entry(S, sh.v, tid - 36);
-    __syncthreads();
-    if (tid < 36) sh.U[tid] = mm6_entry(sh.SM, S, mi, mj);
-    __syncthreads();
-    // bbox Jacobian rows g_j = [ -rho (Rt[d,:] x b_k) | e_d ]  (jac_update2alter, cov_mixed.py:42-65)
-    if (tid < 24) {
-        const int k = tid / 3, d = tid % 3;
-        const float* bb = p.bbox + ((size_t)b * 8 + k) * 3;
-        const double bx = bb[0], by = bb[1], bz = bb[2];
-        // static selects (a runtime-indexed pc.Rt[3*d] would push the whole PoseConst to scratch)
-        const double r0 = d == 0 ? pc.Rt[0] : (d == 1 ? pc.Rt[3] : pc.Rt[6]);
-        const double r1 = d == 0 ? pc.Rt[1] : (d == 1 ? pc.Rt[4] : pc.Rt[7]);
-        const double r2 = d == 0 ? pc.Rt[2] : (d == 1 ? pc.Rt[5] : pc.Rt[8]);
-        double g[6];
-        g[0] = -pc.rho * (r1 * bz - r2 * by);
-        g[1] = -pc.rho * (r2 * bx - r0 * bz);
-        g[2] = -pc.rho * (r0 * by - r1 * bx);
-        g[3] = d == 0; g[4] = d == 1; g[5] = d == 2;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sh.G[6 * tid + i] = g[i];
-        const double pd = quad6(S, g), cd = quad6(sh.U, g);
-        double dl = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dl += g[i] * sh.sv[i];
-        sh.pd[tid] = pd; sh.cd[tid] = cd; sh.dl[tid] = dl;
-        if (!(pd > 0)) sh.bad[0] = 1;  // loss_cov_3d 'good' (cov_mixed.py:83-89)
-        if (!(cd > 0)) sh.bad[1] = 1;
-    }
-    __syncthreads();
-    if (tid < 24) {
-        const int q = tid >> 3, k = tid & 7;
-        const double* src = q == 0 ? sh.pd : (q == 1 ? sh.cd : sh.dl);
-        const double a0 = src[3 * k], a1 = src[3 * k + 1], a2 = src[3 * k + 2];
-        double val;
-        if (q == 2) val = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-        else val = sqrt(sh.bad[q] ? 1.0 : a0 + a1 + a2);
-        sh.sq[tid] = val;
-    }
-    __syncthreads();
-    double sP[8], sC[8], sL[8], Pm = 0, Cm = 0, Lm = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        sP[k] = sh.sq[k]; sC[k] = sh.sq[8 + k]; sL[k] = sh.sq[16 + k];
-        Pm += sP[k]; Cm += sC[k]; Lm += sL[k];
-    }
-    Pm *= 0.125; Cm *= 0.125; Lm *= 0.125;
-    const double loss = log(Pm) + 0.5 * (Cm + Lm) / Pm;
-    const double gout = p.grad_out ? (double)p.grad_out[b] : 1.0;
-    if (tid == 0) {
-        p.loss[b] = (float)loss;
-        if (p.aux) {
-            float* ax = p.aux + (size_t)b * kLossAuxStride;
-            ax[0] = (float)Pm; ax[1] = (float)Cm; ax[2] = (float)Lm; ax[3] = spd ? 0.f : 1.f;
-        }
-    }
-    if (p.aux && tid < 36) p.aux[(size_t)b * kLossAuxStride + 4 + tid] = (float)S[tid];
-    if (p.d_pts2d == nullptr) return;  // forward only
-
-    // ---------------- reverse mode of the serial section ----------------
-    const double aP = gout * (1.0 / Pm - 0.5 * (Cm + Lm) / (Pm * Pm));
-    const double aC = gout * 0.5 / Pm;  // = dloss/dC = dloss/dL
-    const bool badP = sh.bad[0] != 0, badC = sh.bad[1] != 0;
-    if (tid < 36) {
-        double fp = 0, fc = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double cP = badP ? 0.0 : aP / (16.0 * sP[k]);
-            const double cC = badC ? 0.0 : aC / (16.0 * sC[k]);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double gg = sh.G[6 * (3 * k + d) + mi] * sh.G[6 * (3 * k + d) + mj];
-                fp += cP * gg;
-                fc += cC * gg;
-            }
-        }
-        sh.PhiP[tid] = fp;
-        sh.PhiC[tid] = fc;
-    } else if (tid < 42) {
-        const int a = tid - 36;
-        double l = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double cL = sL[k] > 0 ? aC / (8.0 * sL[k]) : 0.0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) l += cL * sh.dl[3 * k + d] * sh.G[6 * (3 * k + d) + a];
-        }
-        sh.lam[a] = l;
-    }
-    __syncthreads();
-    if (tid < 36) {
-        sh.T[tid] = mm6_entry(sh.PhiC, sh.SM, mi, mj);
-        sh.Y[tid] = mm6_entry(S, sh.PhiC, mi, mj);
-    }
-    __syncthreads();
-    if (tid < 36)
-        sh.Sbar[tid] = sh.PhiP[tid] + sh.T[tid] + sh.T[6 * mj + mi] + 0.5 * (sh.lam[mi] * sh.v[mj] + sh.v[mi] * sh.lam[mj]);
-    __syncthreads();
-    if (tid < 36) sh.Z[tid] = mm6_entry(S, sh.Sbar, mi, mj);
-    __syncthreads();
-    if (tid < 36) {
-        sh.Hbar[tid] = spd ? -mm6_entry(sh.Z, S, mi, mj) : 0.0;
-        sh.Psi[tid] = mm6_entry(sh.Y, S, mi, mj);
-    } else if (tid < 42) {
-        sh.mu[tid - 36] = mv6_entry(S, sh.lam, tid - 36);
-    }
-    __syncthreads();
-
-    // ---------------- pass 4: per-point gradients ----------------
-    const double trHww = sh.Hbar[0] + sh.Hbar[7] + sh.Hbar[14];
-    auto backward_point = [&](const Pt& pt, const double e[2], int n) {
-        const Proj pr = project(pc, pt.X);
-        const PointJac pj = point_jac(pc, pt.X, pr);
-        double w[2], cc[2], dsk[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            cc[c] = huber(fabs(e[c]), dlt_e[c]);
-            dsk[c] = sqrt(mwe[c] / (cc[c] + 1e-6));
-            w[c] = huber(pt.s[c], dsk[c]);
-        }
-        // h2 = Hbar * t2, q3 = Hbar_ww X - tr(Hbar_ww) X
-        double t2[6], h2[6], q3[3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) { t2[l] = pj.M0[6 + l]; t2[3 + l] = l == 2 ? 1.0 : 0.0; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double a = 0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) a += sh.Hbar[6 * i + j] * t2[j];
-            h2[i] = a;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            q3[i] = sh.Hbar[6 * i] * pt.X[0] + sh.Hbar[6 * i + 1] * pt.X[1] + sh.Hbar[6 * i + 2] * pt.X[2] - trHww * pt.X[i];
-        const double iz2 = pj.iz * pj.iz;
-        double Bq[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const double qa[3] = {a == 0 ? -iz2 : 0.0, a == 1 ? -iz2 : 0.0, (a == 0 ? pj.x0 : pj.y0) * iz2};
-            double tqh = 0;
-#pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                tqh += (pj.M0[l] * qa[0] + pj.M0[3 + l] * qa[1] + pj.M0[6 + l] * qa[2]) * h2[l];
-                tqh += qa[l] * h2[3 + l];
-            }
-            const double pa[3] = {a == 0 ? pj.iz : 0.0, a == 1 ? pj.iz : 0.0, -pj.iz * (a == 0 ? pj.x0 : pj.y0)};
-            double piq = 0;
-#pragma unroll
-            for (int l = 0; l < 3; ++l) piq += (pc.R[l] * pa[0] + pc.R[3 + l] * pa[1] + pc.R[6 + l] * pa[2]) * q3[l];
-            Bq[a] = 2.0 * tqh + piq;
-        }
-        double gs[2], ge[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const double qH = quad6(sh.Hbar, pj.J[c]);
-            const double qPsi = quad6(sh.Psi, pj.J[c]);
-            double jm = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) jm += pj.J[c][i] * sh.mu[i];
-            const double wbar = qH + 2.0 * w[c] * cc[c] * qPsi + e[c] * jm +
-                                pj.r[c] * (pc.K[3 * c] * Bq[0] + pc.K[3 * c + 1] * Bq[1]);
-            const double cbar = w[c] * w[c] * qPsi;
-            gs[c] = wbar * (pt.s[c] > dsk[c] ? 2.0 * dsk[c] : 2.0 * pt.s[c]);
-            const double a = fabs(e[c]);
-            const double sgn = e[c] > 0 ? 1.0 : (e[c] < 0 ? -1.0 : 0.0);
-            ge[c] = cbar * (a > dlt_e[c] ? 2.0 * dlt_e[c] : 2.0 * a) * sgn;
-        }
-        *reinterpret_cast<float2*>(p.d_pts2d + (base + n) * 2) = make_float2((float)ge[0], (float)ge[1]);
-        *reinterpret_cast<float2*>(p.d_inv_std + (base + n) * 2) = make_float2((float)gs[0], (float)gs[1]);
-        if (p.d_pts3d) {
-            // err = u - proj: dX = -(d proj/d X)^T ge, d proj_a/dX = (KR[a,:] - zpass * proj_a KR[2,:]) / zc
-            double gx[3];
-#pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                const double kr0 = pc.K[0] * pc.R[l] + pc.K[1] * pc.R[3 + l] + pc.K[2] * pc.R[6 + l];
-                const double kr1 = pc.K[3] * pc.R[l] + pc.K[4] * pc.R[3 + l] + pc.K[5] * pc.R[6 + l];
-                const double kr2 = pc.K[6] * pc.R[l] + pc.K[7] * pc.R[3 + l] + pc.K[8] * pc.R[6 + l];
-                gx[l] = -((kr0 - pr.zpass * pr.proj[0] * kr2) * ge[0] + (kr1 - pr.zpass * pr.proj[1] * kr2) * ge[1]) / pr.zc;
-            }
-            float* o = p.d_pts3d + (base + n) * 3;
-            o[0] = (float)gx[0]; o[1] = (float)gx[1]; o[2] = (float)gx[2];
-        }
-    };
-    if constexpr (REG) {
-        if (active) backward_point(rp, re, tid);
-    } else {
-        for (int n = tid; n < N; n += nthr) {
-            const Pt pt = load_pt(p, base, n);
-            const Proj pr = project(pc, pt.X);
-            double e[2];
-            clamp_err(pt.u, pr.proj, max_len, e);
-            backward_point(pt, e, n);
-        }
-    }
+    __shared__ loss::LossShared sh;
+    loss::sample<REG>(p, blockIdx.x, sh);
 }
 
 }  // namespace

@@ -1,0 +1,340 @@
+// Device body of the batched weighted-PnP solve: one wavefront runs one pose's whole Levenberg-Marquardt solve.
+// Included by lc_pnp.hip (stand-alone kernel) and lc_fused.hip (loss + PnP in one launch).
+//
+// Replaces lib/pnp/cxx/ceres.cpp:72-145 (pnp_ceres_f32 -> ceres::Solve, DENSE_QR, autodiff Jets) and its OpenMP
+// batch driver (:147-177).  Residual model = ceres.cpp:15-65; optimiser = Ceres 2.1.0's default trust-region LM,
+// restated in oracle/pnp_lm_oracle.c (see that header for the schedule and the "parity unpinned" note).
+//
+// MI355X mapping: lane = correspondence (wave-stride when N > 64); the pose x = (angle-axis, t), the 6x6 normal
+// equations and the LM state are wave-uniform values every lane carries.  One evaluation per LM iteration:
+//   residuals in fp64 from R(x) X + t;  Jacobian rows from the closed form  J_rot = Jr(w)^T (X x R^T J_t)
+//   (d(R(w)X)/dw = -R [X]x Jr(w), Jr = right Jacobian of SO(3)) -- no per-point 3x3 derivative, no autodiff;
+//   J^T J (21) | J^T r (6) | r^T r (1) reduced with permlane-swap/DPP reduce-scatter + ONE LDS broadcast;
+//   damped, Jacobi-scaled 6x6 system solved in registers (LDL^T, fp64).
+// Only the final 7-float state, the trust radius and the flag go back to HBM.
+// Differences from the Ceres path that do not change the iterates beyond rounding: normal equations instead of QR
+// (Jacobi-scaled, fp64, cond ~1e4..1e6); the accepted point's Jacobian comes from the candidate evaluation (same x)
+// instead of a re-evaluation; model_cost_change from the normal-equation identity y.(g/2) + sum(d y^2)/2.
+#pragma once
+#include <cfloat>
+
+#include "lc_common.h"
+#include "lc_kernels.h"
+
+namespace lc {
+namespace pnp {
+
+struct Point {
+    double X[3];
+    double u, v;     // measurement minus principal point (ceres.cpp:23-24)
+    double a, b, c;  // L00, L10, L11 (ceres.cpp:25-27)
+};
+
+struct Rot {
+    double R[9];   // AngleAxisRotatePoint as a matrix (both branches of ceres/rotation.h)
+    double Rd[9];  // rotation used by the derivative (== R; identity in the small-angle branch)
+    double Jr[9];  // right Jacobian of SO(3) (identity in the small-angle branch)
+};
+
+__device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
+    const double th2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    const double x = aa[0], y = aa[1], z = aa[2];
+    if (th2 > DBL_EPSILON) {
+        const double th = sqrt(th2);
+        double s, c;
+        sincos(th, &s, &c);
+        const double ith = fast_rcp(th), ith2 = ith * ith;
+        const double A = s * ith, B = (1.0 - c) * ith2, C = (th - s) * ith2 * ith;
+        // R = c I + A [w]x + B w w^T
+        o.R[0] = c + B * x * x;     o.R[1] = B * x * y - A * z; o.R[2] = B * x * z + A * y;
+        o.R[3] = B * x * y + A * z; o.R[4] = c + B * y * y;     o.R[5] = B * y * z - A * x;
+        o.R[6] = B * x * z - A * y; o.R[7] = B * y * z + A * x; o.R[8] = c + B * z * z;
+        // Jr = (1 - C th2) I - B [w]x + C w w^T
+        const double d = 1.0 - C * th2;
+        o.Jr[0] = d + C * x * x;     o.Jr[1] = C * x * y + B * z; o.Jr[2] = C * x * z - B * y;
+        o.Jr[3] = C * x * y - B * z; o.Jr[4] = d + C * y * y;     o.Jr[5] = C * y * z + B * x;
+        o.Jr[6] = C * x * z + B * y; o.Jr[7] = C * y * z - B * x; o.Jr[8] = d + C * z * z;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o.Rd[i] = o.R[i];
+    } else {  // pt + aa x pt, derivative -[pt]x
+        o.R[0] = 1; o.R[1] = -z; o.R[2] = y;
+        o.R[3] = z; o.R[4] = 1; o.R[5] = -x;
+        o.R[6] = -y; o.R[7] = x; o.R[8] = 1;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o.Rd[i] = o.Jr[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+}
+
+// adds one correspondence's contribution to acc = [J^T J upper (21) | J^T r (6) | r^T r | pad]
+__device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt, const double t[3], const double k[6],
+                                                 double (&acc)[32]) {
+    double q[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) q[d] = rt.R[3 * d] * pt.X[0] + rt.R[3 * d + 1] * pt.X[1] + rt.R[3 * d + 2] * pt.X[2] + t[d];
+    const double iz = fast_rcp(q[2]);
+    const double up = (q[0] * k[0] + q[1] * k[1]) * iz, vp = (q[0] * k[3] + q[1] * k[4]) * iz;
+    const double du = up - pt.u, dv = vp - pt.v;
+    const double r[2] = {du * pt.a + dv * pt.b, dv * pt.c};
+    const double dup[3] = {k[0] * iz, k[1] * iz, -up * iz};
+    const double dvp[3] = {k[3] * iz, k[4] * iz, -vp * iz};
+    double J[2][6];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        J[0][3 + m] = pt.a * dup[m] + pt.b * dvp[m];
+        J[1][3 + m] = pt.c * dvp[m];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        double av[3], cr[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) av[m] = rt.Rd[m] * J[rr][3] + rt.Rd[3 + m] * J[rr][4] + rt.Rd[6 + m] * J[rr][5];  // Rd^T J_t
+        cr[0] = pt.X[1] * av[2] - pt.X[2] * av[1];
+        cr[1] = pt.X[2] * av[0] - pt.X[0] * av[2];
+        cr[2] = pt.X[0] * av[1] - pt.X[1] * av[0];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) J[rr][m] = rt.Jr[m] * cr[0] + rt.Jr[3 + m] * cr[1] + rt.Jr[6 + m] * cr[2];  // Jr^T (X x a)
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) acc[tri6(i, j)] += J[0][i] * J[0][j] + J[1][i] * J[1][j];
+        acc[21 + i] += J[0][i] * r[0] + J[1][i] * r[1];
+    }
+    acc[27] += r[0] * r[0] + r[1] * r[1];
+}
+
+// solve (A + diag(dg)) y = rhs for symmetric A (packed upper 21) by LDL^T; false if a pivot is not positive/finite
+__device__ __forceinline__ bool ldlt_solve6(const double (&A)[21], const double (&dg)[6], const double (&rhs)[6], double (&y)[6]) {
+    double L[6][6], Ld[6][6], id[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double dj = A[tri6(j, j)] + dg[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * Ld[j][k];
+        ok = ok && (dj > 0) && (dj < DBL_MAX);
+        id[j] = fast_rcp(dj);
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[tri6(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i][k] * Ld[j][k];
+            Ld[i][j] = v;            // L[i][j] * d[j]
+            L[i][j] = v * id[j];
+        }
+    }
+    double z[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = rhs[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= L[i][k] * z[k];
+        z[i] = v;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = z[i] * id[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) v -= L[k][i] * y[k];
+        y[i] = v;
+    }
+    return ok;
+}
+
+__device__ __forceinline__ Point load_point(const PnpParams& p, size_t base, int n, const double cam[6]) {
+    Point o;
+    const float* X = p.pts3d + (base + n) * 3;
+    const float2 u = *reinterpret_cast<const float2*>(p.pts2d + (base + n) * 2);
+    o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
+    o.u = (double)u.x - cam[2];
+    o.v = (double)u.y - cam[5];
+    if (p.sqrtL) {
+        const float4 L = *reinterpret_cast<const float4*>(p.sqrtL + (base + n) * 4);
+        o.a = L.x; o.b = L.z; o.c = L.w;
+    } else {
+        const float2 L = *reinterpret_cast<const float2*>(p.sqrt_diag + (base + n) * 2);
+        o.a = L.x; o.b = 0; o.c = L.y;
+    }
+    return o;
+}
+
+__device__ __forceinline__ double max_abs6(const double (&v)[6]) {
+    double m = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m = fmax(m, fabs(v[j]));
+    return m;
+}
+__device__ __forceinline__ double norm6(const double (&v)[6]) {
+    double m = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m += v[j] * v[j];
+    return sqrt(m);
+}
+
+// One pose per wavefront (64 threads). bc: 32 doubles of LDS owned by this wavefront.
+// REG: Nmax <= 64, each lane keeps its correspondence in registers across the whole solve.
+template <bool REG>
+__device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
+    const int n = p.counts ? p.counts[b] : p.Nmax;
+    const float* st_in = (p.start ? p.start : p.states) + 7 * (size_t)b;
+    if (n < 3) {  // ceres.cpp:84-91
+        if (lane == 0) {
+            p.rets[b] = 1;
+            p.result_tr[b] = 1.f;
+            if (p.iters) p.iters[b] = 0;
+        }
+        if (p.start && lane < 7) p.states[7 * (size_t)b + lane] = st_in[lane];
+        return;
+    }
+    const size_t base = (size_t)b * p.Nmax;
+    double cam[6];
+    {
+        const float* Kp = p.K + 9 * (size_t)b;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cam[i] = Kp[i];  // only the first 6 floats are read (ceres.cpp:99-101)
+    }
+    double x[6];
+    {
+        // QuaternionToAngleAxis (ceres.cpp:96)
+        const double q0 = st_in[0], q1 = st_in[1], q2 = st_in[2], q3 = st_in[3];
+        const double s2 = q1 * q1 + q2 * q2 + q3 * q3;
+        double kk = 2.0;
+        if (s2 > 0.0) {
+            const double s = sqrt(s2);
+            const double two_theta = 2.0 * ((q0 < 0.0) ? atan2(-s, -q0) : atan2(s, q0));
+            kk = two_theta / s;
+        }
+        x[0] = q1 * kk; x[1] = q2 * kk; x[2] = q3 * kk;
+        x[3] = st_in[4]; x[4] = st_in[5]; x[5] = st_in[6];
+    }
+    Point rp;
+    const bool active = lane < n;
+    if constexpr (REG) {
+        if (active) rp = load_point(p, base, lane, cam);
+    }
+
+    // full evaluation at xe: H (21), g (6), cost; returns false when anything is non-finite
+    auto evaluate = [&](const double (&xe)[6], double (&H)[21], double (&g)[6], double& cost) -> bool {
+        Rot rt;
+        make_rot(xe, rt);
+        const double t[3] = {xe[3], xe[4], xe[5]};
+        double acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = 0;
+        if constexpr (REG) {
+            if (active) accumulate_point(rp, rt, t, cam, acc);
+        } else {
+            for (int i = lane; i < n; i += kWave) accumulate_point(load_point(p, base, i, cam), rt, t, cam, acc);
+        }
+        wave_reduce_scatter16<32>(acc, lane);
+        __syncthreads();  // one-wave workgroup: orders this wave's LDS reads of the previous broadcast before the writes
+        if ((lane & 3) == 0) {
+            const int bs = scatter16_base(lane, 2);
+            bc[bs] = acc[0];
+            bc[bs + 1] = acc[1];
+        }
+        __syncthreads();
+        double chk = 0;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) H[i] = bc[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { g[i] = bc[21 + i]; chk += fabs(g[i]) + H[tri6(i, i)]; }
+        const double ss = bc[27];
+        cost = 0.5 * ss;
+        chk += ss;  // every term is >= 0: the sum is finite iff all residuals and Jacobian entries are
+        return chk <= DBL_MAX;
+    };
+
+    const double ftol = p.ftol, ptol = 1e-8, gtol = 1e-10;
+    double H[21], g[6], cost;
+    bool failed = !evaluate(x, H, g, cost);
+    double scale[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) scale[j] = 1.0 / (1.0 + sqrt(H[tri6(j, j)]));  // Jacobi scaling, fixed at iteration 0
+    double gmax = max_abs6(g), xnorm = norm6(x);
+    double radius = 1e4, dfac = 2.0;
+    int iter = 0, n_invalid = 0;
+    bool converged = false;
+
+    while (!failed && !converged) {
+        // FinalizeIterationAndCheckIfMinimizerCanContinue
+        if (iter >= p.max_iter) break;
+        if (gmax <= gtol || radius <= 1e-32) { converged = true; break; }
+        ++iter;
+        // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system
+        double As[21], dg[6], rhs[6], y[6];
+        const double inv_radius = fast_rcp(radius);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) As[tri6(i, j)] = H[tri6(i, j)] * scale[i] * scale[j];
+            rhs[i] = g[i] * scale[i];
+            dg[i] = fmin(fmax(As[tri6(i, i)], 1e-6), 1e32) * inv_radius;
+        }
+        bool step_ok = ldlt_solve6(As, dg, rhs, y);
+        // model_cost_change = y.rhs - y^T As y / 2 with (As + D) y = rhs  =>  (y.rhs + sum d_i y_i^2) / 2   (step = -y)
+        double mcc = 0, ysum = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            mcc += y[i] * (rhs[i] + dg[i] * y[i]);
+            ysum += fabs(y[i]);
+        }
+        mcc *= 0.5;
+        step_ok = step_ok && (ysum <= DBL_MAX) && (mcc > 0.0);
+        if (!step_ok) {  // HandleInvalidStep
+            if (++n_invalid >= 5) { failed = true; break; }
+            radius /= dfac; dfac *= 2.0;
+            continue;
+        }
+        n_invalid = 0;
+        double xc[6], delta[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { delta[j] = -y[j] * scale[j]; xc[j] = x[j] + delta[j]; }
+        const double step_norm = norm6(delta);
+        double Hc[21], gc[6], cost_c;
+        const bool cand_ok = evaluate(xc, Hc, gc, cost_c);
+        if (!cand_ok) cost_c = DBL_MAX;
+        if (step_norm <= ptol * (xnorm + ptol)) { converged = true; break; }  // ParameterToleranceReached
+        const double cost_change = cost - cost_c;
+        if (fabs(cost_change) <= ftol * cost) { converged = true; break; }    // FunctionToleranceReached
+        const double rel = cost_change * fast_rcp(mcc);
+        if (rel > 1e-3) {  // HandleSuccessfulStep
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { x[j] = xc[j]; g[j] = gc[j]; }
+#pragma unroll
+            for (int j = 0; j < 21; ++j) H[j] = Hc[j];
+            cost = cost_c;
+            xnorm = norm6(x);
+            gmax = max_abs6(g);
+            const double tq = 2.0 * rel - 1.0;
+            radius = fmin(1e16, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - tq * tq * tq)));
+            dfac = 2.0;
+        } else {
+            radius /= dfac; dfac *= 2.0;
+        }
+    }
+    const bool invalid = failed || !converged;
+    if (invalid && p.start && lane < 7) p.states[7 * (size_t)b + lane] = st_in[lane];
+    if (lane == 0) {
+        p.rets[b] = invalid ? 1 : 0;
+        p.result_tr[b] = (float)radius;
+        if (p.iters) p.iters[b] = iter;
+        if (!invalid) {  // ceres.cpp:131-144: AngleAxisToQuaternion, write back in place
+            float* st = p.states + 7 * (size_t)b;
+            const double t2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+            double q0 = 1.0, kk = 0.5;
+            if (t2 > 0.0) {
+                const double th = sqrt(t2), h = 0.5 * th;
+                double sh, ch;
+                sincos(h, &sh, &ch);
+                q0 = ch;
+                kk = sh / th;
+            }
+            st[0] = (float)q0; st[1] = (float)(x[0] * kk); st[2] = (float)(x[1] * kk); st[3] = (float)(x[2] * kk);
+            st[4] = (float)x[3]; st[5] = (float)x[4]; st[6] = (float)x[5];
+        }
+    }
+}
+
+}  // namespace pnp
+}  // namespace lc

@@ -32,7 +32,8 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     U = _lib.require_hip_f32("pts2d", pts2d)
     L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)
     B, N = X.shape[:2]
-    state = _lib.require_hip_f32("start", start).clone()
+    start = _lib.require_hip_f32("start", start)
+    state = torch.empty_like(start)
     dev = X.device
     counts = None
     if n_points is not None:
@@ -43,7 +44,7 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     full = L.dim() == 4
     with torch.cuda.device(dev):
         rc = lib.lc_pnp_lm_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
-                               None if full else _lib.ptr(L), _lib.ptr(counts), _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret),
+                               None if full else _lib.ptr(L), _lib.ptr(counts), _lib.ptr(start), _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret),
                                _lib.ptr(iters), B, N, int(max_iter_count), float(function_tolerance), _lib.stream_ptr(dev))
     _lib.check(rc, "lc_pnp_lm_f32")
     return (state, tr, ret, iters) if return_iters else (state, tr, ret)

@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     if (all || std::string(which) == "pnp") {
         float* tr; int* ret; int* it;
         CK(hipMalloc(&tr, B * 4)); CK(hipMalloc(&ret, B * 4)); CK(hipMalloc(&it, B * 4));
-        int rc = lc_pnp_lm_f32(dK, dX, dU, nullptr, dS, nullptr, dSt, tr, ret, it, B, N, 50, 1e-6f, nullptr);
+        int rc = lc_pnp_lm_f32(dK, dX, dU, nullptr, dS, nullptr, nullptr, dSt, tr, ret, it, B, N, 50, 1e-6f, nullptr);
         CK(hipDeviceSynchronize());
         std::vector<float> st(B * 7), htr(B); std::vector<int> hr(B), hi(B);
         CK(hipMemcpy(st.data(), dSt, B * 28, hipMemcpyDeviceToHost)); CK(hipMemcpy(htr.data(), tr, B * 4, hipMemcpyDeviceToHost));
