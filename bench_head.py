@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Keypoint-head benchmark: spatial softmax + soft-argmax forward+backward over logits (256,64,64,64) fp32
+(268 MB) resident in HBM.  HBM-bound: algorithmic traffic = read 1 MiB/sample forward + read 1 MiB + write 1 MiB backward.
+Prints one JSON line; bench.py imports measure_head() to attach the same numbers to its own line."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3):
+    from lc_amd import _lib
+
+    lib = _lib.load()
+    P = _lib.ptr
+    g = torch.Generator(device="cpu").manual_seed(0)
+    M = B * S
+    logits = torch.randn(M, H, W, generator=g).to(dev)  # synthetic logits of the repo's shape (values do not change traffic)
+    mean = torch.empty(M, 2, device=dev)
+    std = torch.empty(M, 2, device=dev)
+    stats = torch.empty(M, 4, device=dev)
+    g_mean = torch.randn(M, 2, generator=g).to(dev)
+    g_std = torch.randn(M, 2, generator=g).to(dev)
+    g_in = torch.empty_like(logits)
+    st = _lib.stream_ptr(dev)
+
+    def fwd():
+        assert lib.lc_softargmax2d_fwd_f32(P(logits), M, H, W, 0, P(mean), P(std), P(stats), st) == 0
+
+    def bwd():
+        assert lib.lc_softargmax2d_bwd_f32(P(logits), P(mean), P(std), P(stats), P(g_mean), P(g_std), M, H, W, 0, P(g_in), st) == 0
+
+    def step():
+        fwd()
+        bwd()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+
+    def ev(fn, reps=10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    t_f, t_b = ev(fwd), ev(bwd)
+    map_bytes = H * W * 4
+    by_f, by_b = M * map_bytes, 2 * M * map_bytes
+    return {
+        "metric": "keypoint-head samples/sec (spatial softmax + soft-argmax fwd+bwd)",
+        "value": B * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3,
+        "config": {"workload": f"logits ({B},{S},{H},{W}) fp32, synthetic"},
+        "roofline": {"bound": "hbm", "kernel": "lc_head_bwd_kernel", "achieved": by_b / (t_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": by_b / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "fwd": {"kernel": "lc_head_fwd_kernel", "achieved": by_f / (t_f * 1e-3) / 1e9,
+                             "frac": by_f / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": t_f},
+                     "bwd_ms": t_b, "algorithmic_bytes_per_sample": 3 * S * map_bytes},
+    }
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X")
+    print(json.dumps(measure_head(torch.device("cuda:0"), B=a.batch, steps=a.steps, warmup=a.warmup)))

@@ -37,32 +37,29 @@ struct Rot {
 };
 
 __device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
-    const double th2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    // branch-free on purpose: a two-branch version keeps `o` in scratch memory (104 B/lane of HBM traffic per evaluation)
     const double x = aa[0], y = aa[1], z = aa[2];
-    if (th2 > DBL_EPSILON) {
-        const double th = sqrt(th2);
-        double s, c;
-        sincos(th, &s, &c);
-        const double ith = fast_rcp(th), ith2 = ith * ith;
-        const double A = s * ith, B = (1.0 - c) * ith2, C = (th - s) * ith2 * ith;
-        // R = c I + A [w]x + B w w^T
-        o.R[0] = c + B * x * x;     o.R[1] = B * x * y - A * z; o.R[2] = B * x * z + A * y;
-        o.R[3] = B * x * y + A * z; o.R[4] = c + B * y * y;     o.R[5] = B * y * z - A * x;
-        o.R[6] = B * x * z - A * y; o.R[7] = B * y * z + A * x; o.R[8] = c + B * z * z;
-        // Jr = (1 - C th2) I - B [w]x + C w w^T
-        const double d = 1.0 - C * th2;
-        o.Jr[0] = d + C * x * x;     o.Jr[1] = C * x * y + B * z; o.Jr[2] = C * x * z - B * y;
-        o.Jr[3] = C * x * y - B * z; o.Jr[4] = d + C * y * y;     o.Jr[5] = C * y * z + B * x;
-        o.Jr[6] = C * x * z + B * y; o.Jr[7] = C * y * z - B * x; o.Jr[8] = d + C * z * z;
+    const double th2 = x * x + y * y + z * z;
+    const bool small = !(th2 > DBL_EPSILON);  // ceres/rotation.h AngleAxisRotatePoint: pt + aa x pt, derivative -[pt]x
+    const double th = sqrt(th2);
+    double s, c;
+    sincos(th, &s, &c);
+    const double ith = fast_rcp(th), ith2 = ith * ith;
+    const double A = small ? 1.0 : s * ith;
+    const double B = small ? 0.0 : (1.0 - c) * ith2;
+    const double C = small ? 0.0 : (th - s) * ith2 * ith;
+    const double cd = small ? 1.0 : c;
+    // R = c I + A [w]x + B w w^T
+    o.R[0] = cd + B * x * x;    o.R[1] = B * x * y - A * z; o.R[2] = B * x * z + A * y;
+    o.R[3] = B * x * y + A * z; o.R[4] = cd + B * y * y;    o.R[5] = B * y * z - A * x;
+    o.R[6] = B * x * z - A * y; o.R[7] = B * y * z + A * x; o.R[8] = cd + B * z * z;
+    // Jr = (1 - C th2) I - B [w]x + C w w^T   (identity in the small-angle branch)
+    const double d = 1.0 - C * th2;
+    o.Jr[0] = d + C * x * x;     o.Jr[1] = C * x * y + B * z; o.Jr[2] = C * x * z - B * y;
+    o.Jr[3] = C * x * y - B * z; o.Jr[4] = d + C * y * y;     o.Jr[5] = C * y * z + B * x;
+    o.Jr[6] = C * x * z + B * y; o.Jr[7] = C * y * z - B * x; o.Jr[8] = d + C * z * z;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) o.Rd[i] = o.R[i];
-    } else {  // pt + aa x pt, derivative -[pt]x
-        o.R[0] = 1; o.R[1] = -z; o.R[2] = y;
-        o.R[3] = z; o.R[4] = 1; o.R[5] = -x;
-        o.R[6] = -y; o.R[7] = x; o.R[8] = 1;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) o.Rd[i] = o.Jr[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    }
+    for (int i = 0; i < 9; ++i) o.Rd[i] = small ? ((i % 4 == 0) ? 1.0 : 0.0) : o.R[i];
 }
 
 // adds one correspondence's contribution to acc = [J^T J upper (21) | J^T r (6) | r^T r | pad]

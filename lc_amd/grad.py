@@ -18,7 +18,7 @@ def clip_norm(grads, max_norm, norm_type: float = 2.0, group=None):
         return torch.tensor(0.0), []
     if norm_type != 2.0:
         raise NotImplementedError("lc_amd NormClipper: only the 2-norm the reference uses is implemented")
-    sq = torch.stack([p.detach().float().pow(2).sum() for p in grads]).sum()
+    sq = torch.stack([p.detach().pow(2).sum() for p in grads]).sum()
     if group is not None:
         import torch.distributed as dist
 

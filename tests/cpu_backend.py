@@ -1,0 +1,51 @@
+"""Test-only backend: lets the HOST logic of lc_amd (autograd wiring, Loss_fn blending, cer_solver batching, sharding)
+run on CPU by swapping the three launch functions for the oracle.  The product code never does this."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lc_loss_oracle, pnp_oracle
+
+
+def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_len, rel_thresh, w_e_thresh, want_grads, want_pts3d,
+                 want_aux=False):
+    with torch.enable_grad():  # we are called from inside autograd.Function.forward (grad mode off)
+        loss, du, ds, dx = lc_loss_oracle.loss_and_grads(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out=grad_out,
+                                                         want_pts3d=want_pts3d, max_err_len=max_err_len, rel_thresh=rel_thresh,
+                                                         w_e_thresh=w_e_thresh)
+    if not want_grads:
+        du = ds = dx = None
+    return loss, du, ds, dx, None
+
+
+def _launch_scale(scale, srcs):
+    return [None if s is None else s * scale.view(-1, *([1] * (s.dim() - 1))) for s in srcs]
+
+
+def _solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6, return_iters=False):
+    L = sqrtL if sqrtL.dim() == 4 else torch.diag_embed(sqrtL)
+    counts = None if n_points is None else np.asarray(torch.as_tensor(n_points).cpu(), np.int32)
+    st, tr, ret = pnp_oracle.solve_batched(start.float().numpy(), cam_mat.float().numpy(), pts2d.float().numpy(), pts3d.float().numpy(),
+                                           L.float().numpy(), counts=counts, max_iter=max_iter_count, ftol=function_tolerance)
+    return torch.from_numpy(st), torch.from_numpy(tr), torch.from_numpy(ret)
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch):
+    from lc_amd import _lib, cov_mixed
+    from lc_amd.pnp import pnp_ceres
+
+    monkeypatch.setattr(_lib, "require_hip_f32", lambda name, t: t.contiguous())
+    monkeypatch.setattr(cov_mixed, "_launch_loss", _launch_loss)
+    monkeypatch.setattr(cov_mixed, "_launch_scale", _launch_scale)
+    monkeypatch.setattr(pnp_ceres, "solve_device", _solve_device)
+    orig_solve = pnp_ceres.solve
+
+    def solve(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, num_workers=1, **kw):
+        if isinstance(pts3d, torch.Tensor) and isinstance(start, torch.Tensor) and start.dim() == 2:
+            return _solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points, max_iter_count=max_iter_count,
+                                 function_tolerance=kw.get("function_tolerance", 1e-6))
+        return orig_solve(cam_mat, pts3d, pts2d, sqrtL, start, n_points, max_iter_count=max_iter_count, num_workers=num_workers, **kw)
+
+    monkeypatch.setattr(pnp_ceres, "solve", solve)
+    yield

@@ -1,0 +1,121 @@
+"""World-size-2 gloo test of the sharded path on CPU (the kernels are replaced by the oracle via tests/cpu_backend.py):
+sharding the batch over ranks + gradient all-reduce + NormClipper's whole-batch norm == the single-process full batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _patch_backend():
+    """What the `oracle_backend` fixture does, without pytest (we are in a spawned child)."""
+    from lc_amd import _lib, cov_mixed
+    from tests import cpu_backend
+
+    _lib.require_hip_f32 = lambda name, t: t.contiguous()
+    cov_mixed._launch_loss = cpu_backend._launch_loss
+    cov_mixed._launch_scale = cpu_backend._launch_scale
+
+
+def _model_and_batch(B, N, dtype=torch.float64):
+    from lc_amd import synth
+
+    b = {k: v.to(dtype) for k, v in synth.make_batch(B, N, seed=5).items()}
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(2, 2, dtype=dtype)  # a stand-in "network": pts2d = lin(pts2d_obs), std = softplus(head)
+    head = torch.nn.Parameter(torch.zeros(2, dtype=dtype))
+    with torch.no_grad():
+        lin.weight.copy_(torch.eye(2) + 0.01 * torch.randn(2, 2))
+        lin.bias.zero_()
+    return b, lin, head
+
+
+def _loss_on(b, lin, head, fn, global_B):
+    gt = dict(pose_best=b["pose"], out_K=b["K"], pts3d=b["pts3d"], bbox_3d=b["bbox_3d"], msk_noc=None, msk_vis=None)
+    out = dict(pts2d=lin(b["pts2d"]), pts2d_std=torch.nn.functional.softplus(head).expand_as(b["pts2d"]) + 0.5)
+    loss_dict, w = fn(gt, out, 0, 100, 10)
+    # Loss_fn means over the LOCAL batch; rescale so that the sum over ranks is the global-batch mean
+    local_B = b["pose"].shape[0]
+    return sum(w.values()) * (local_B / global_B)
+
+
+def _worker(rank, world, port, B, N, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _patch_backend()
+        from lc_amd import dist as lcd
+        from lc_amd.config import AttrDict
+        from lc_amd.grad import NormClipper
+        from lc_amd.losses import Loss_fn
+
+        b, lin, head = _model_and_batch(B, N)
+        shard = lcd.shard_batch(b, rank, world)
+        fn = Loss_fn(AttrDict(pose_loss_cfg=dict(clip_weight_grad=False), w_loss_kpts=1, w_loss_pose=0.7), AttrDict())
+        loss = _loss_on(shard, lin, head, fn, B)
+        loss.backward()
+        params = list(lin.parameters()) + [head]
+        lcd.allreduce_gradients(params, average=False, bucket_bytes=32)  # tiny buckets: exercises the multi-bucket path
+        gm = lcd.global_mean(loss.detach() * B, shard["pose"].shape[0])  # sum of per-sample losses on this rank / count
+        # whole-batch NormClipper: each rank clips its slice of one gradient tensor, norm all-reduced
+        g_full = torch.arange(1, 13, dtype=torch.float64).reshape(4, 3)
+        lo, hi = lcd.shard_range(4, rank, world)
+        clip = NormClipper(initial_max_norm=5.0, group=dist.group.WORLD)
+        clipped = clip.clip(g_full[lo:hi])
+        if rank == 0:
+            ret["grads"] = [p.grad.clone().numpy() for p in params]
+            ret["max_norm"] = float(clip.max_norm)
+            ret["clipped0"] = clipped.numpy()
+            ret["gm"] = float(gm)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_equals_full_batch():
+    B, N = 6, 12
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, N, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    # single process, full batch
+    _patch_backend()
+    from lc_amd.config import AttrDict
+    from lc_amd.grad import NormClipper
+    from lc_amd.losses import Loss_fn
+
+    b, lin, head = _model_and_batch(B, N)
+    fn = Loss_fn(AttrDict(pose_loss_cfg=dict(clip_weight_grad=False), w_loss_kpts=1, w_loss_pose=0.7), AttrDict())
+    loss = _loss_on(b, lin, head, fn, B)
+    loss.backward()
+    for got, p in zip(ret["grads"], list(lin.parameters()) + [head]):
+        np.testing.assert_allclose(got, p.grad.numpy(), rtol=1e-9, atol=1e-12)
+    g_full = torch.arange(1, 13, dtype=torch.float64).reshape(4, 3)
+    clip = NormClipper(initial_max_norm=5.0)
+    full_clipped = clip.clip(g_full)
+    assert abs(ret["max_norm"] - float(clip.max_norm)) <= 1e-12 * float(clip.max_norm)
+    np.testing.assert_allclose(ret["clipped0"], full_clipped[:2].numpy(), rtol=1e-12)
+
+
+def test_shard_range_covers_everything():
+    from lc_amd.dist import shard_range
+
+    for n in (0, 1, 7, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
