@@ -16,14 +16,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _patch_backend():
-    """What the `oracle_backend` fixture does, without pytest (we are in a spawned child)."""
+def _patch_backend(monkeypatch=None):
+    """What the `oracle_backend` fixture does; without pytest's monkeypatch in the spawned children."""
     from lc_amd import _lib, cov_mixed
     from tests import cpu_backend
 
-    _lib.require_hip_f32 = lambda name, t: t.contiguous()
-    cov_mixed._launch_loss = cpu_backend._launch_loss
-    cov_mixed._launch_scale = cpu_backend._launch_scale
+    setter = monkeypatch.setattr if monkeypatch is not None else setattr
+    setter(_lib, "require_hip_f32", lambda name, t: t.contiguous())
+    setter(cov_mixed, "_launch_loss", cpu_backend._launch_loss)
+    setter(cov_mixed, "_launch_scale", cpu_backend._launch_scale)
 
 
 def _model_and_batch(B, N, dtype=torch.float64):
@@ -80,7 +81,7 @@ def _worker(rank, world, port, B, N, ret):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharding_equals_full_batch():
+def test_two_rank_sharding_equals_full_batch(monkeypatch):
     B, N = 6, 12
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -92,7 +93,7 @@ def test_two_rank_sharding_equals_full_batch():
         p.join(180)
         assert p.exitcode == 0
     # single process, full batch
-    _patch_backend()
+    _patch_backend(monkeypatch)
     from lc_amd.config import AttrDict
     from lc_amd.grad import NormClipper
     from lc_amd.losses import Loss_fn
