@@ -25,10 +25,9 @@ struct LossShared {
     double small[16][4];  // cross-wave partials of the small reductions
     double A0[36], A1[36];  // Gauss-Jordan ping-pong; S = H^-1 ends up in A0
     double Mc[36], v[6];
-    double SM[36], U[36], sv[6];
-    double G[24 * 6], pd[24], cd[24], dl[24], sq[24];
-    double PhiP[36], PhiC[36], lam[6];
-    double T[36], Y[36], Sbar[36], Z[36];
+    double SM[36], sv[6];   // Mc*S, S*v
+    double G[24 * 6], pd[24], cd[24], dl[24], sq[24];  // G: rows h_j = S g_j
+    double T[36];           // W = Psi * Mc * S
     double Hbar[36], Psi[36], mu[6];
     int bad[2];
 };
@@ -206,6 +205,12 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         pc.t[0] = ps[4]; pc.t[1] = ps[5]; pc.t[2] = ps[6];
     }
     if (tid < 2) sh.bad[tid] = 0;
+    // bbox corner of this lane's Jacobian row, fetched now so its HBM latency hides under passes 1-3
+    double bbx = 0, bby = 0, bbz = 0;
+    if (tid < 24) {
+        const float* bb = p.bbox + ((size_t)b * 8 + tid / 3) * 3;
+        bbx = bb[0]; bby = bb[1]; bbz = bb[2];
+    }
 
     const double max_len = p.max_err_len, rel_thresh = p.rel_thresh, w_e_thresh = p.w_e_thresh;
 
@@ -369,7 +374,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         const double piv = src[7 * pz];
         spd = spd && (piv > 0);
         if (tid < 36) {
-            const double ip = 1.0 / piv;
+            const double ip = fast_rcp(piv);
             const double rowv = src[6 * pz + mj], colv = src[6 * mi + pz], cur = src[6 * mi + mj];
             double out;
             if (mi == pz && mj == pz) out = ip;
@@ -385,36 +390,41 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         __syncthreads();
     }
     const double* S = sh.A0;
-    if (tid < 36) sh.SM[tid] = mm6_entry(S, sh.Mc, mi, mj);
-    else if (tid < 42) sh.sv[tid - 36] = mv6_entry(S, sh.v, tid - 36);
-    __syncthreads();
-    if (tid < 36) sh.U[tid] = mm6_entry(sh.SM, S, mi, mj);
-    __syncthreads();
-    // bbox Jacobian rows g_j = [ -rho (Rt[d,:] x b_k) | e_d ]  (jac_update2alter, cov_mixed.py:42-65)
+    // step A: lanes 0..23 own one row g_j of the bbox Jacobian (jac_update2alter, cov_mixed.py:42-65):
+    //   h_j = S g_j;  diag(G S G^T)_j = g.h;  diag(G S Mc S G^T)_j = h^T Mc h;  (G S v)_j = h.v
+    // lanes 28..63 form McS = Mc * S meanwhile.
     if (tid < 24) {
-        const int k = tid / 3, d = tid % 3;
-        const float* bb = p.bbox + ((size_t)b * 8 + k) * 3;
-        const double bx = bb[0], by = bb[1], bz = bb[2];
+        const int d = tid % 3;
         // static selects (a runtime-indexed pc.Rt[3*d] would push the whole PoseConst to scratch)
         const double r0 = d == 0 ? pc.Rt[0] : (d == 1 ? pc.Rt[3] : pc.Rt[6]);
         const double r1 = d == 0 ? pc.Rt[1] : (d == 1 ? pc.Rt[4] : pc.Rt[7]);
         const double r2 = d == 0 ? pc.Rt[2] : (d == 1 ? pc.Rt[5] : pc.Rt[8]);
-        double g[6];
-        g[0] = -pc.rho * (r1 * bz - r2 * by);
-        g[1] = -pc.rho * (r2 * bx - r0 * bz);
-        g[2] = -pc.rho * (r0 * by - r1 * bx);
+        double g[6], h[6];
+        g[0] = -pc.rho * (r1 * bbz - r2 * bby);
+        g[1] = -pc.rho * (r2 * bbx - r0 * bbz);
+        g[2] = -pc.rho * (r0 * bby - r1 * bbx);
         g[3] = d == 0; g[4] = d == 1; g[5] = d == 2;
+        double pd = 0, dl = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) sh.G[6 * tid + i] = g[i];
-        const double pd = quad6(S, g), cd = quad6(sh.U, g);
-        double dl = 0;
+        for (int i = 0; i < 6; ++i) {
+            double a = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dl += g[i] * sh.sv[i];
+            for (int k = 0; k < 6; ++k) a += S[6 * i + k] * g[k];
+            h[i] = a;
+            sh.G[6 * tid + i] = a;  // G now holds the rows h_j
+            pd += g[i] * a;
+            dl += a * sh.v[i];
+        }
+        const double cd = quad6(sh.Mc, h);
         sh.pd[tid] = pd; sh.cd[tid] = cd; sh.dl[tid] = dl;
         if (!(pd > 0)) sh.bad[0] = 1;  // loss_cov_3d 'good' (cov_mixed.py:83-89)
         if (!(cd > 0)) sh.bad[1] = 1;
+    } else if (tid >= 28 && tid < 64) {
+        const int e = tid - 28;
+        sh.SM[e] = mm6_entry(sh.Mc, S, e / 6, e % 6);  // McS
     }
     __syncthreads();
+    // step B: sqrt of the 8 corner traces (P, C) and the 8 corner norms (L); S v on six idle lanes
     if (tid < 24) {
         const int q = tid >> 3, k = tid & 7;
         const double* src = q == 0 ? sh.pd : (q == 1 ? sh.cd : sh.dl);
@@ -423,6 +433,8 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         if (q == 2) val = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
         else val = sqrt(sh.bad[q] ? 1.0 : a0 + a1 + a2);
         sh.sq[tid] = val;
+    } else if (tid < 30) {
+        sh.sv[tid - 24] = mv6_entry(S, sh.v, tid - 24);
     }
     __syncthreads();
     double sP[8], sC[8], sL[8], Pm = 0, Cm = 0, Lm = 0;
@@ -432,7 +444,8 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         Pm += sP[k]; Cm += sC[k]; Lm += sL[k];
     }
     Pm *= 0.125; Cm *= 0.125; Lm *= 0.125;
-    const double loss = log(Pm) + 0.5 * (Cm + Lm) / Pm;
+    const double iP = 1.0 / Pm;
+    const double loss = log(Pm) + 0.5 * (Cm + Lm) * iP;
     const double gout = p.grad_out ? (double)p.grad_out[b] : 1.0;
     if (tid == 0) {
         p.loss[b] = (float)loss;
@@ -445,24 +458,26 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     if (p.d_pts2d == nullptr) return;  // forward only
 
     // ---------------- reverse mode of the serial section ----------------
-    const double aP = gout * (1.0 / Pm - 0.5 * (Cm + Lm) / (Pm * Pm));
-    const double aC = gout * 0.5 / Pm;  // = dloss/dC = dloss/dL
+    // With h_j = S g_j:  S Phi_P S = sum cP_j h h^T (PsiP),  Psi = S Phi_C S = sum cC_j h h^T,  mu = S lambda = sum cL_j dl_j h_j,
+    //   Hbar = -S Sbar S = -( PsiP + W + W^T + (mu sv^T + sv mu^T)/2 ),  W = Psi * (Mc S)
+    const double aP = gout * (iP - 0.5 * (Cm + Lm) * iP * iP);
+    const double aC = gout * 0.5 * iP;  // = dloss/dC = dloss/dL
     const bool badP = sh.bad[0] != 0, badC = sh.bad[1] != 0;
+    double psiP = 0;
     if (tid < 36) {
-        double fp = 0, fc = 0;
+        double fc = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const double cP = badP ? 0.0 : aP / (16.0 * sP[k]);
             const double cC = badC ? 0.0 : aC / (16.0 * sC[k]);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const double gg = sh.G[6 * (3 * k + d) + mi] * sh.G[6 * (3 * k + d) + mj];
-                fp += cP * gg;
-                fc += cC * gg;
+                const double hh = sh.G[6 * (3 * k + d) + mi] * sh.G[6 * (3 * k + d) + mj];
+                psiP += cP * hh;
+                fc += cC * hh;
             }
         }
-        sh.PhiP[tid] = fp;
-        sh.PhiC[tid] = fc;
+        sh.Psi[tid] = fc;
     } else if (tid < 42) {
         const int a = tid - 36;
         double l = 0;
@@ -472,29 +487,31 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 #pragma unroll
             for (int d = 0; d < 3; ++d) l += cL * sh.dl[3 * k + d] * sh.G[6 * (3 * k + d) + a];
         }
-        sh.lam[a] = l;
+        sh.mu[a] = l;
     }
     __syncthreads();
-    if (tid < 36) {
-        sh.T[tid] = mm6_entry(sh.PhiC, sh.SM, mi, mj);
-        sh.Y[tid] = mm6_entry(S, sh.PhiC, mi, mj);
-    }
-    __syncthreads();
-    if (tid < 36)
-        sh.Sbar[tid] = sh.PhiP[tid] + sh.T[tid] + sh.T[6 * mj + mi] + 0.5 * (sh.lam[mi] * sh.v[mj] + sh.v[mi] * sh.lam[mj]);
-    __syncthreads();
-    if (tid < 36) sh.Z[tid] = mm6_entry(S, sh.Sbar, mi, mj);
+    if (tid < 36) sh.T[tid] = mm6_entry(sh.Psi, sh.SM, mi, mj);  // W
     __syncthreads();
     if (tid < 36) {
-        sh.Hbar[tid] = spd ? -mm6_entry(sh.Z, S, mi, mj) : 0.0;
-        sh.Psi[tid] = mm6_entry(sh.Y, S, mi, mj);
-    } else if (tid < 42) {
-        sh.mu[tid - 36] = mv6_entry(S, sh.lam, tid - 36);
+        const double hb = -(psiP + sh.T[tid] + sh.T[6 * mj + mi] + 0.5 * (sh.mu[mi] * sh.sv[mj] + sh.sv[mi] * sh.mu[mj]));
+        sh.Hbar[tid] = spd ? hb : 0.0;
     }
     __syncthreads();
 
     // ---------------- pass 4: per-point gradients ----------------
-    const double trHww = sh.Hbar[0] + sh.Hbar[7] + sh.Hbar[14];
+    // symmetric 6x6 forms from registers: packed upper triangles with the off-diagonals doubled
+    double Hs[21], Ps[21], mu[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            const double f = i == j ? 1.0 : 2.0;
+            Hs[tri6(i, j)] = f * sh.Hbar[6 * i + j];
+            Ps[tri6(i, j)] = f * sh.Psi[6 * i + j];
+        }
+        mu[i] = sh.mu[i];
+    }
+    const double trHww = Hs[tri6(0, 0)] + Hs[tri6(1, 1)] + Hs[tri6(2, 2)];
     auto backward_point = [&](const Pt& pt, const double e[2], int n) {
         const Proj pr = project(pc, pt.X);
         const PointJac pj = point_jac(pc, pt.X, pr);
@@ -505,20 +522,13 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
             dsk[c] = sqrt(mwe[c] / (cc[c] + 1e-6));
             w[c] = huber(pt.s[c], dsk[c]);
         }
-        // h2 = Hbar * t2, q3 = Hbar_ww X - tr(Hbar_ww) X
-        double t2[6], h2[6], q3[3];
+        // h2 = Hbar * t2 with t2 = (M0[2,:], 0, 0, 1);  q3 = Hbar_ww X - tr(Hbar_ww) X   (Hs off-diagonals are doubled)
+        double h2[6], q3[3];
+        auto Hent = [&](int i, int j) { return i == j ? Hs[tri6(i, i)] : 0.5 * Hs[i < j ? tri6(i, j) : tri6(j, i)]; };
 #pragma unroll
-        for (int l = 0; l < 3; ++l) { t2[l] = pj.M0[6 + l]; t2[3 + l] = l == 2 ? 1.0 : 0.0; }
+        for (int i = 0; i < 6; ++i) h2[i] = Hent(i, 0) * pj.M0[6] + Hent(i, 1) * pj.M0[7] + Hent(i, 2) * pj.M0[8] + Hent(i, 5);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double a = 0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) a += sh.Hbar[6 * i + j] * t2[j];
-            h2[i] = a;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            q3[i] = sh.Hbar[6 * i] * pt.X[0] + sh.Hbar[6 * i + 1] * pt.X[1] + sh.Hbar[6 * i + 2] * pt.X[2] - trHww * pt.X[i];
+        for (int i = 0; i < 3; ++i) q3[i] = Hent(i, 0) * pt.X[0] + Hent(i, 1) * pt.X[1] + Hent(i, 2) * pt.X[2] - trHww * pt.X[i];
         const double iz2 = pj.iz * pj.iz;
         double Bq[2];
 #pragma unroll
@@ -539,11 +549,17 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         double gs[2], ge[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double qH = quad6(sh.Hbar, pj.J[c]);
-            const double qPsi = quad6(sh.Psi, pj.J[c]);
-            double jm = 0;
+            double qH = 0, qPsi = 0, jm = 0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) jm += pj.J[c][i] * sh.mu[i];
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = i; j < 6; ++j) {
+                    const double pp = pj.J[c][i] * pj.J[c][j];
+                    qH += Hs[tri6(i, j)] * pp;
+                    qPsi += Ps[tri6(i, j)] * pp;
+                }
+                jm += pj.J[c][i] * mu[i];
+            }
             const double wbar = qH + 2.0 * w[c] * cc[c] * qPsi + e[c] * jm +
                                 pj.r[c] * (pc.K[3 * c] * Bq[0] + pc.K[3 * c + 1] * Bq[1]);
             const double cbar = w[c] * w[c] * qPsi;
@@ -557,12 +573,13 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         if (p.d_pts3d) {
             // err = u - proj: dX = -(d proj/d X)^T ge, d proj_a/dX = (KR[a,:] - zpass * proj_a KR[2,:]) / zc
             double gx[3];
+            const double izc = 1.0 / pr.zc;
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 const double kr0 = pc.K[0] * pc.R[l] + pc.K[1] * pc.R[3 + l] + pc.K[2] * pc.R[6 + l];
                 const double kr1 = pc.K[3] * pc.R[l] + pc.K[4] * pc.R[3 + l] + pc.K[5] * pc.R[6 + l];
                 const double kr2 = pc.K[6] * pc.R[l] + pc.K[7] * pc.R[3 + l] + pc.K[8] * pc.R[6 + l];
-                gx[l] = -((kr0 - pr.zpass * pr.proj[0] * kr2) * ge[0] + (kr1 - pr.zpass * pr.proj[1] * kr2) * ge[1]) / pr.zc;
+                gx[l] = -((kr0 - pr.zpass * pr.proj[0] * kr2) * ge[0] + (kr1 - pr.zpass * pr.proj[1] * kr2) * ge[1]) * izc;
             }
             float* o = p.d_pts3d + (base + n) * 3;
             o[0] = (float)gx[0]; o[1] = (float)gx[1]; o[2] = (float)gx[2];

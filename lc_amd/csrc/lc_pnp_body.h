@@ -32,8 +32,8 @@ struct Point {
 
 struct Rot {
     double R[9];   // AngleAxisRotatePoint as a matrix (both branches of ceres/rotation.h)
-    double Rd[9];  // rotation used by the derivative (== R; identity in the small-angle branch)
-    double Jr[9];  // right Jacobian of SO(3) (identity in the small-angle branch)
+    double Jr[9];  // right Jacobian of SO(3) (identity in the small-angle branch, whose derivative is -R[pt]x with
+                   // R = I + [aa]x, |aa| < 1.5e-8: within 1e-8 of the -[pt]x the autodiff of that branch yields)
 };
 
 __device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
@@ -58,13 +58,12 @@ __device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
     o.Jr[0] = d + C * x * x;     o.Jr[1] = C * x * y + B * z; o.Jr[2] = C * x * z - B * y;
     o.Jr[3] = C * x * y - B * z; o.Jr[4] = d + C * y * y;     o.Jr[5] = C * y * z + B * x;
     o.Jr[6] = C * x * z + B * y; o.Jr[7] = C * y * z - B * x; o.Jr[8] = d + C * z * z;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o.Rd[i] = small ? ((i % 4 == 0) ? 1.0 : 0.0) : o.R[i];
 }
 
 // adds one correspondence's contribution to acc = [J^T J upper (21) | J^T r (6) | r^T r | pad]
+// (columns of J pre-multiplied by the Jacobi scaling sc: acc holds Js^T Js and Js^T r directly)
 __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt, const double t[3], const double k[6],
-                                                 double (&acc)[32]) {
+                                                 const double (&sc)[6], double (&acc)[32]) {
     double q[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) q[d] = rt.R[3 * d] * pt.X[0] + rt.R[3 * d + 1] * pt.X[1] + rt.R[3 * d + 2] * pt.X[2] + t[d];
@@ -84,12 +83,14 @@ __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt,
     for (int rr = 0; rr < 2; ++rr) {
         double av[3], cr[3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) av[m] = rt.Rd[m] * J[rr][3] + rt.Rd[3 + m] * J[rr][4] + rt.Rd[6 + m] * J[rr][5];  // Rd^T J_t
+        for (int m = 0; m < 3; ++m) av[m] = rt.R[m] * J[rr][3] + rt.R[3 + m] * J[rr][4] + rt.R[6 + m] * J[rr][5];  // R^T J_t
         cr[0] = pt.X[1] * av[2] - pt.X[2] * av[1];
         cr[1] = pt.X[2] * av[0] - pt.X[0] * av[2];
         cr[2] = pt.X[0] * av[1] - pt.X[1] * av[0];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) J[rr][m] = rt.Jr[m] * cr[0] + rt.Jr[3 + m] * cr[1] + rt.Jr[6 + m] * cr[2];  // Jr^T (X x a)
+        for (int m = 0; m < 3; ++m) J[rr][m] = (rt.Jr[m] * cr[0] + rt.Jr[3 + m] * cr[1] + rt.Jr[6 + m] * cr[2]) * sc[m];  // Jr^T (X x a)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) J[rr][3 + m] *= sc[3 + m];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -210,8 +211,8 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         if (active) rp = load_point(p, base, lane, cam);
     }
 
-    // full evaluation at xe: H (21), g (6), cost; returns false when anything is non-finite
-    auto evaluate = [&](const double (&xe)[6], double (&H)[21], double (&g)[6], double& cost) -> bool {
+    // full evaluation at xe with column scaling sc: H = Js^T Js (21), g = Js^T r (6), cost; false when anything is non-finite
+    auto evaluate = [&](const double (&xe)[6], const double (&sc)[6], double (&H)[21], double (&g)[6], double& cost) -> bool {
         Rot rt;
         make_rot(xe, rt);
         const double t[3] = {xe[3], xe[4], xe[5]};
@@ -219,9 +220,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc[i] = 0;
         if constexpr (REG) {
-            if (active) accumulate_point(rp, rt, t, cam, acc);
+            if (active) accumulate_point(rp, rt, t, cam, sc, acc);
         } else {
-            for (int i = lane; i < n; i += kWave) accumulate_point(load_point(p, base, i, cam), rt, t, cam, acc);
+            for (int i = lane; i < n; i += kWave) accumulate_point(load_point(p, base, i, cam), rt, t, cam, sc, acc);
         }
         wave_reduce_scatter16<32>(acc, lane);
         __syncthreads();  // one-wave workgroup: orders this wave's LDS reads of the previous broadcast before the writes
@@ -231,24 +232,44 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             bc[bs + 1] = acc[1];
         }
         __syncthreads();
-        double chk = 0;
 #pragma unroll
         for (int i = 0; i < 21; ++i) H[i] = bc[i];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { g[i] = bc[21 + i]; chk += fabs(g[i]) + H[tri6(i, i)]; }
+        for (int i = 0; i < 6; ++i) g[i] = bc[21 + i];
         const double ss = bc[27];
         cost = 0.5 * ss;
-        chk += ss;  // every term is >= 0: the sum is finite iff all residuals and Jacobian entries are
+        double chk = ss;  // every term is >= 0: the sum is finite iff all residuals and Jacobian entries are
+#pragma unroll
+        for (int i = 0; i < 6; ++i) chk += H[tri6(i, i)];
         return chk <= DBL_MAX;
     };
 
     const double ftol = p.ftol, ptol = 1e-8, gtol = 1e-10;
-    double H[21], g[6], cost;
-    bool failed = !evaluate(x, H, g, cost);
-    double scale[6];
+    double H[21], g[6], cost;  // of the Jacobi-scaled problem from here on
+    double scale[6], iscale[6];
+    bool failed;
+    {
+        const double one[6] = {1, 1, 1, 1, 1, 1};
+        failed = !evaluate(x, one, H, g, cost);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) scale[j] = 1.0 / (1.0 + sqrt(H[tri6(j, j)]));  // Jacobi scaling, fixed at iteration 0
-    double gmax = max_abs6(g), xnorm = norm6(x);
+        for (int j = 0; j < 6; ++j) {  // Jacobi scaling 1/(1+||J_j||), fixed at iteration 0
+            iscale[j] = 1.0 + sqrt(H[tri6(j, j)]);
+            scale[j] = fast_rcp(iscale[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) H[tri6(i, j)] *= scale[i] * scale[j];
+            g[i] *= scale[i];
+        }
+    }
+    auto grad_max = [&](const double (&gs)[6]) {  // max-norm of the UNSCALED gradient J^T r
+        double m = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m = fmax(m, fabs(gs[j]) * iscale[j]);
+        return m;
+    };
+    double gmax = grad_max(g), xnorm = norm6(x);
     double radius = 1e4, dfac = 2.0;
     int iter = 0, n_invalid = 0;
     bool converged = false;
@@ -259,21 +280,16 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         if (gmax <= gtol || radius <= 1e-32) { converged = true; break; }
         ++iter;
         // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system
-        double As[21], dg[6], rhs[6], y[6];
+        double dg[6], y[6];
         const double inv_radius = fast_rcp(radius);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int j = i; j < 6; ++j) As[tri6(i, j)] = H[tri6(i, j)] * scale[i] * scale[j];
-            rhs[i] = g[i] * scale[i];
-            dg[i] = fmin(fmax(As[tri6(i, i)], 1e-6), 1e32) * inv_radius;
-        }
-        bool step_ok = ldlt_solve6(As, dg, rhs, y);
-        // model_cost_change = y.rhs - y^T As y / 2 with (As + D) y = rhs  =>  (y.rhs + sum d_i y_i^2) / 2   (step = -y)
+        for (int i = 0; i < 6; ++i) dg[i] = fmin(fmax(H[tri6(i, i)], 1e-6), 1e32) * inv_radius;
+        bool step_ok = ldlt_solve6(H, dg, g, y);
+        // model_cost_change = y.g - y^T H y / 2 with (H + D) y = g  =>  (y.g + sum d_i y_i^2) / 2   (step = -y)
         double mcc = 0, ysum = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            mcc += y[i] * (rhs[i] + dg[i] * y[i]);
+            mcc += y[i] * (g[i] + dg[i] * y[i]);
             ysum += fabs(y[i]);
         }
         mcc *= 0.5;
@@ -289,7 +305,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         for (int j = 0; j < 6; ++j) { delta[j] = -y[j] * scale[j]; xc[j] = x[j] + delta[j]; }
         const double step_norm = norm6(delta);
         double Hc[21], gc[6], cost_c;
-        const bool cand_ok = evaluate(xc, Hc, gc, cost_c);
+        const bool cand_ok = evaluate(xc, scale, Hc, gc, cost_c);
         if (!cand_ok) cost_c = DBL_MAX;
         if (step_norm <= ptol * (xnorm + ptol)) { converged = true; break; }  // ParameterToleranceReached
         const double cost_change = cost - cost_c;
@@ -302,7 +318,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             for (int j = 0; j < 21; ++j) H[j] = Hc[j];
             cost = cost_c;
             xnorm = norm6(x);
-            gmax = max_abs6(g);
+            gmax = grad_max(g);
             const double tq = 2.0 * rel - 1.0;
             radius = fmin(1e16, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - tq * tq * tq)));
             dfac = 2.0;
