@@ -24,6 +24,12 @@ __device__ __forceinline__ double dpp_mov_f64(double old, double src) {
     return __hiloint2double(hi, lo);
 }
 
+// value of `v` in lane `src` (ds_bpermute: LDS crossbar, no LDS memory)
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const int lo = __shfl(__double2loint(v), src, kWave), hi = __shfl(__double2hiint(v), src, kWave);
+    return __hiloint2double(hi, lo);
+}
+
 // a' (returned in a) and b' after swapping a's upper 32 lanes with b's lower 32 lanes; a'+b' then holds, in the lower
 // half-wave, the two-half sum of a and, in the upper half-wave, the two-half sum of b.
 __device__ __forceinline__ double swap32_add(double a, double b) {

@@ -17,19 +17,33 @@
 #include "lc_common.h"
 #include "lc_kernels.h"
 
+// Diagnostic build only (-DLC_STAMPS, scripts/diag_stamps.py): s_memtime stamps per phase, written to p.aux which no
+// other code reads in that build.  The shipped library never defines LC_STAMPS.
+#ifdef LC_STAMPS
+#define LC_STAMP(i)                                                                              \
+    do {                                                                                         \
+        unsigned long long t_;                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.aux)[(size_t)b * 20 + (i)] = t_; \
+    } while (0)
+#else
+#define LC_STAMP(i) do {} while (0)
+#endif
+
 namespace lc {
 namespace loss {
 
 struct LossShared {
     double red[16][48];   // cross-wave partials of the 48-value reduction
     double small[16][4];  // cross-wave partials of the small reductions
-    double A0[36], A1[36];  // Gauss-Jordan ping-pong; S = H^-1 ends up in A0
-    double Mc[36], v[6];
+    double A0[36];          // S = H^-1
     double SM[36], sv[6];   // Mc*S, S*v
-    double G[24 * 6], pd[24], cd[24], dl[24], sq[24];  // G: rows h_j = S g_j
+    double G[24 * 6], pd[24], cd[24], dl[24], sq[24], isq[24];  // G: rows h_j = S g_j
     double T[36];           // W = Psi * Mc * S
     double Hbar[36], Psi[36], mu[6];
-    int bad[2];
+    int bad[4];  // [0],[1]: a non-positive diagonal in loss_cov_3d (P, C); [2]: H not SPD
 };
 
 struct PoseConst {
@@ -63,8 +77,9 @@ __device__ __forceinline__ Proj project(const PoseConst& pc, const double X[3]) 
     for (int d = 0; d < 3; ++d) xf[d] = pc.K[3 * d] * o.Xc[0] + pc.K[3 * d + 1] * o.Xc[1] + pc.K[3 * d + 2] * o.Xc[2];
     o.zpass = xf[2] >= 0.1 ? 1.0 : 0.0;
     o.zc = xf[2] >= 0.1 ? xf[2] : 0.1;  // NaN propagates like torch.clamp? (NaN >= x false -> 0.1; inputs are finite)
-    o.proj[0] = xf[0] / o.zc;
-    o.proj[1] = xf[1] / o.zc;
+    const double izc = fast_rcp(o.zc);  // zc >= 0.1
+    o.proj[0] = xf[0] * izc;
+    o.proj[1] = xf[1] * izc;
     return o;
 }
 
@@ -72,14 +87,10 @@ __device__ __forceinline__ Proj project(const PoseConst& pc, const double X[3]) 
 __device__ __forceinline__ void clamp_err(const double u[2], const double proj[2], double max_len, double e[2]) {
     const double e0 = u[0] - proj[0], e1 = u[1] - proj[1];
     const double len = sqrt(e0 * e0 + e1 * e1) + 1e-6;
-    const double f = (len - max_len) / len;
-    if (f > 0) {
-        e[0] = e0 - f * e0;
-        e[1] = e1 - f * e1;
-    } else {
-        e[0] = e0;
-        e[1] = e1;
-    }
+    // f = (len - max)/len > 0  <=>  len > max (len >= 1e-6 > 0);  e = err - f err
+    const double f = len > max_len ? (len - max_len) * fast_rcp(len) : 0.0;
+    e[0] = e0 - f * e0;
+    e[1] = e1 - f * e1;
 }
 
 // residual_with_jac6d (pnp_auto.py:13-56) at delta = 0, in closed form
@@ -192,6 +203,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     const int N = p.N;
     const size_t base = (size_t)b * N;
 
+    LC_STAMP(0);
     PoseConst pc;
     {
         const float* Kp = p.K + 9 * (size_t)b;
@@ -222,6 +234,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         if (active) rp = load_pt(p, base, tid);
     }
 
+    LC_STAMP(1);
     // ---------------- pass 1: e, sum |e| (robust_weights_cov, cov_mixed.py:27-31) ----------------
     double s1[3] = {0, 0, 0};
     if constexpr (REG) {
@@ -243,6 +256,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     const double vcnt = p.valid ? s1[2] : (double)N;
     const double dlt_e[2] = {s1[0] / vcnt * rel_thresh, s1[1] / vcnt * rel_thresh};  // Huber knee of |e|
 
+    LC_STAMP(2);
     // ---------------- pass 2: c, mean(s^2 c) (cov_mixed.py:32-36) ----------------
     double s2[2] = {0, 0};
     auto huber = [](double v, double d) { return v > d ? d * (2 * v - d) : v * v; };
@@ -270,6 +284,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     block_allreduce_small<2>(s2, sh.small, lane, wave, nw);
     const double mwe[2] = {s2[0] / vcnt * w_e_thresh, s2[1] / vcnt * w_e_thresh};
 
+    LC_STAMP(3);
     // ---------------- pass 3: accumulate H (21) | Mc (21) | v (6) ----------------
     double acc[48];
 #pragma unroll
@@ -338,6 +353,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
             accumulate(pt, e);
         }
     }
+    LC_STAMP(4);
     wave_reduce_scatter16<48>(acc, lane);
     if ((lane & 3) == 0) {
         const int bs = scatter16_base(lane, 3);
@@ -345,53 +361,50 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         for (int i = 0; i < 3; ++i) sh.red[wave][bs + i] = acc[i];
     }
     __syncthreads();
-    if (tid < 48) {
-        double s = 0;
-        for (int w = 0; w < nw; ++w) s += sh.red[w][tid];
-        // expand packed upper triangles to full symmetric 6x6 (make_sure_symmetric, pnp_utils.py:134-137)
-        if (tid < 42) {
-            const int k = tid < 21 ? tid : tid - 21;
-            int i = 0, rem = k;
-            while (rem >= 6 - i) { rem -= 6 - i; ++i; }
-            const int j = i + rem;
-            double* dst = tid < 21 ? sh.A0 : sh.Mc;
-            dst[6 * i + j] = s;
-            dst[6 * j + i] = s;
-        } else {
-            sh.v[tid - 42] = s;
+    if (nw > 1) {  // combine the waves' partials into sh.red[0]
+        if (tid < 48) {
+            double s = 0;
+            for (int w = 0; w < nw; ++w) s += sh.red[w][tid];
+            sh.red[0][tid] = s;
         }
+        __syncthreads();
+    }
+    // packed totals (upper triangles, so H and Mc are symmetric by construction: make_sure_symmetric, pnp_utils.py:134-137)
+    const double* Hp = &sh.red[0][0];    // H  (21)
+    const double* Mp = &sh.red[0][21];   // Mc (21)
+    const double* vp = &sh.red[0][42];   // v  (6)
+
+    LC_STAMP(5);
+    // ---------------- serial section, one matrix entry per lane ----------------
+    const int mi = (tid % 36) / 6, mj = tid % 6;  // (row, col) of this lane's entry; lanes >= 36 shadow lanes 0..27
+    // S = H^-1 by Gauss-Jordan sweeps held in REGISTERS of wave 0 (one entry per lane; pivot row / column entries come
+    // through ds_bpermute, no LDS round trip per sweep).  Pivots == squared Cholesky diagonal -> SPD test of safe_cholesky.
+    if (wave == 0) {
+        double cur = Hp[mi <= mj ? tri6(mi, mj) : tri6(mj, mi)];
+        bool ok = true;
+#pragma unroll
+        for (int pz = 0; pz < 6; ++pz) {
+            const double piv = shfl_f64(cur, 7 * pz);
+            const double rowv = shfl_f64(cur, 6 * pz + mj);
+            const double colv = shfl_f64(cur, 6 * mi + pz);
+            ok = ok && (piv > 0);
+            const double ip = fast_rcp(piv);
+            const double t = rowv * ip;
+            double out = cur - colv * t;
+            if (mj == pz) out = -colv * ip;
+            if (mi == pz) out = (mj == pz) ? ip : t;
+            cur = out;
+        }
+        if (!ok) cur = (mi == mj) ? 1.0 : 0.0;  // make_sure_SPD (pnp_utils.py:140-157): H := I, no gradient into H
+        if (tid < 36) sh.A0[tid] = cur;
+        if (tid == 0) sh.bad[2] = ok ? 0 : 1;
     }
     __syncthreads();
-
-    // ---------------- serial section, one matrix entry per lane ----------------
-    const int mi = tid / 6, mj = tid % 6;  // valid for tid < 36
-    // S = H^-1 by in-place Gauss-Jordan sweeps (pivots == squared Cholesky diagonal -> SPD test of safe_cholesky)
-    bool spd = true;
-#pragma unroll
-    for (int pz = 0; pz < 6; ++pz) {
-        const double* src = (pz & 1) ? sh.A1 : sh.A0;
-        double* dst = (pz & 1) ? sh.A0 : sh.A1;
-        const double piv = src[7 * pz];
-        spd = spd && (piv > 0);
-        if (tid < 36) {
-            const double ip = fast_rcp(piv);
-            const double rowv = src[6 * pz + mj], colv = src[6 * mi + pz], cur = src[6 * mi + mj];
-            double out;
-            if (mi == pz && mj == pz) out = ip;
-            else if (mi == pz) out = rowv * ip;
-            else if (mj == pz) out = -colv * ip;
-            else out = cur - colv * rowv * ip;
-            dst[tid] = out;
-        }
-        __syncthreads();
-    }
-    if (!spd) {  // make_sure_SPD (pnp_utils.py:140-157): H := I, no gradient into H
-        if (tid < 36) sh.A0[tid] = (mi == mj) ? 1.0 : 0.0;
-        __syncthreads();
-    }
+    const bool spd = sh.bad[2] == 0;
+    LC_STAMP(6);
     const double* S = sh.A0;
-    // step A: lanes 0..23 own one row g_j of the bbox Jacobian (jac_update2alter, cov_mixed.py:42-65):
-    //   h_j = S g_j;  diag(G S G^T)_j = g.h;  diag(G S Mc S G^T)_j = h^T Mc h;  (G S v)_j = h.v
+    // step A: lanes 0..23 own one row g_j = [ -rho (Rt[d,:] x b_k) | e_d ] of the bbox Jacobian (jac_update2alter,
+    // cov_mixed.py:42-65):  h_j = S g_j;  diag(G S G^T)_j = g.h;  diag(G S Mc S G^T)_j = h^T Mc h;  (G S v)_j = h.v
     // lanes 28..63 form McS = Mc * S meanwhile.
     if (tid < 24) {
         const int d = tid % 3;
@@ -399,32 +412,36 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         const double r0 = d == 0 ? pc.Rt[0] : (d == 1 ? pc.Rt[3] : pc.Rt[6]);
         const double r1 = d == 0 ? pc.Rt[1] : (d == 1 ? pc.Rt[4] : pc.Rt[7]);
         const double r2 = d == 0 ? pc.Rt[2] : (d == 1 ? pc.Rt[5] : pc.Rt[8]);
-        double g[6], h[6];
-        g[0] = -pc.rho * (r1 * bbz - r2 * bby);
-        g[1] = -pc.rho * (r2 * bbx - r0 * bbz);
-        g[2] = -pc.rho * (r0 * bby - r1 * bbx);
-        g[3] = d == 0; g[4] = d == 1; g[5] = d == 2;
-        double pd = 0, dl = 0;
+        const double g0 = -pc.rho * (r1 * bbz - r2 * bby);
+        const double g1 = -pc.rho * (r2 * bbx - r0 * bbz);
+        const double g2 = -pc.rho * (r0 * bby - r1 * bbx);
+        double h[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double a = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) a += S[6 * i + k] * g[k];
-            h[i] = a;
-            sh.G[6 * tid + i] = a;  // G now holds the rows h_j
-            pd += g[i] * a;
-            dl += a * sh.v[i];
+            h[i] = S[6 * i] * g0 + S[6 * i + 1] * g1 + S[6 * i + 2] * g2 + S[6 * i + 3 + d];  // g[3+d] = 1
+            sh.G[6 * tid + i] = h[i];  // G holds the rows h_j
         }
-        const double cd = quad6(sh.Mc, h);
+        const double pd = g0 * h[0] + g1 * h[1] + g2 * h[2] + (d == 0 ? h[3] : (d == 1 ? h[4] : h[5]));
+        double dl = 0, cd = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            dl += h[i] * vp[i];
+#pragma unroll
+            for (int j = i; j < 6; ++j) cd += (i == j ? 1.0 : 2.0) * Mp[tri6(i, j)] * (h[i] * h[j]);
+        }
         sh.pd[tid] = pd; sh.cd[tid] = cd; sh.dl[tid] = dl;
         if (!(pd > 0)) sh.bad[0] = 1;  // loss_cov_3d 'good' (cov_mixed.py:83-89)
         if (!(cd > 0)) sh.bad[1] = 1;
     } else if (tid >= 28 && tid < 64) {
-        const int e = tid - 28;
-        sh.SM[e] = mm6_entry(sh.Mc, S, e / 6, e % 6);  // McS
+        const int e = tid - 28, a = e / 6, c = e % 6;
+        double acc2 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc2 += Mp[a <= k ? tri6(a, k) : tri6(k, a)] * S[6 * k + c];
+        sh.SM[e] = acc2;  // McS
     }
     __syncthreads();
-    // step B: sqrt of the 8 corner traces (P, C) and the 8 corner norms (L); S v on six idle lanes
+    LC_STAMP(7);
+    // step B: sqrt of the 8 corner traces (P, C) and the 8 corner norms (L) and their reciprocals; S v on six idle lanes
     if (tid < 24) {
         const int q = tid >> 3, k = tid & 7;
         const double* src = q == 0 ? sh.pd : (q == 1 ? sh.cd : sh.dl);
@@ -433,10 +450,16 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         if (q == 2) val = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
         else val = sqrt(sh.bad[q] ? 1.0 : a0 + a1 + a2);
         sh.sq[tid] = val;
+        sh.isq[tid] = val > 0 ? 1.0 / val : 0.0;  // norm backward at 0 is 0 (torch.linalg.vector_norm)
     } else if (tid < 30) {
-        sh.sv[tid - 24] = mv6_entry(S, sh.v, tid - 24);
+        const int a = tid - 24;
+        double acc2 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc2 += S[6 * a + k] * vp[k];
+        sh.sv[a] = acc2;
     }
     __syncthreads();
+    LC_STAMP(8);
     double sP[8], sC[8], sL[8], Pm = 0, Cm = 0, Lm = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -449,14 +472,19 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     const double gout = p.grad_out ? (double)p.grad_out[b] : 1.0;
     if (tid == 0) {
         p.loss[b] = (float)loss;
+#ifndef LC_STAMPS
         if (p.aux) {
             float* ax = p.aux + (size_t)b * kLossAuxStride;
             ax[0] = (float)Pm; ax[1] = (float)Cm; ax[2] = (float)Lm; ax[3] = spd ? 0.f : 1.f;
         }
+#endif
     }
+#ifndef LC_STAMPS
     if (p.aux && tid < 36) p.aux[(size_t)b * kLossAuxStride + 4 + tid] = (float)S[tid];
+#endif
     if (p.d_pts2d == nullptr) return;  // forward only
 
+    LC_STAMP(9);
     // ---------------- reverse mode of the serial section ----------------
     // With h_j = S g_j:  S Phi_P S = sum cP_j h h^T (PsiP),  Psi = S Phi_C S = sum cC_j h h^T,  mu = S lambda = sum cL_j dl_j h_j,
     //   Hbar = -S Sbar S = -( PsiP + W + W^T + (mu sv^T + sv mu^T)/2 ),  W = Psi * (Mc S)
@@ -465,29 +493,28 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     const bool badP = sh.bad[0] != 0, badC = sh.bad[1] != 0;
     double psiP = 0;
     if (tid < 36) {
-        double fc = 0;
+        double fp = 0, fc = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const double cP = badP ? 0.0 : aP / (16.0 * sP[k]);
-            const double cC = badC ? 0.0 : aC / (16.0 * sC[k]);
+            double hh = 0;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double hh = sh.G[6 * (3 * k + d) + mi] * sh.G[6 * (3 * k + d) + mj];
-                psiP += cP * hh;
-                fc += cC * hh;
-            }
+            for (int d = 0; d < 3; ++d) hh += sh.G[6 * (3 * k + d) + mi] * sh.G[6 * (3 * k + d) + mj];
+            fp += sh.isq[k] * hh;
+            fc += sh.isq[8 + k] * hh;
         }
-        sh.Psi[tid] = fc;
+        psiP = badP ? 0.0 : fp * (aP * 0.0625);  // cP_k = aP / (16 sP_k)
+        sh.Psi[tid] = badC ? 0.0 : fc * (aC * 0.0625);
     } else if (tid < 42) {
         const int a = tid - 36;
         double l = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const double cL = sL[k] > 0 ? aC / (8.0 * sL[k]) : 0.0;
+            double hd = 0;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) l += cL * sh.dl[3 * k + d] * sh.G[6 * (3 * k + d) + a];
+            for (int d = 0; d < 3; ++d) hd += sh.dl[3 * k + d] * sh.G[6 * (3 * k + d) + a];
+            l += sh.isq[16 + k] * hd;
         }
-        sh.mu[a] = l;
+        sh.mu[a] = l * (aC * 0.125);  // cL_k = aC / (8 sL_k)
     }
     __syncthreads();
     if (tid < 36) sh.T[tid] = mm6_entry(sh.Psi, sh.SM, mi, mj);  // W
@@ -498,6 +525,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     }
     __syncthreads();
 
+    LC_STAMP(10);
     // ---------------- pass 4: per-point gradients ----------------
     // symmetric 6x6 forms from registers: packed upper triangles with the off-diagonals doubled
     double Hs[21], Ps[21], mu[6];
@@ -596,6 +624,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
             backward_point(pt, e, n);
         }
     }
+    LC_STAMP(11);
 }
 
 }  // namespace loss
