@@ -70,7 +70,7 @@ def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3):
         "config": {"workload": f"logits ({B},{S},{H},{W}) fp32, synthetic"},
         "roofline": {"bound": "hbm", "kernel": "lc_head_bwd_kernel", "achieved": by_b / (t_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": by_b / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "fwd": {"kernel": "lc_head_fwd_kernel", "achieved": by_f / (t_f * 1e-3) / 1e9,
+                     "fwd": {"kernel": "lc_head_fwd_rows_kernel", "achieved": by_f / (t_f * 1e-3) / 1e9,
                              "frac": by_f / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": t_f},
                      "bwd_ms": t_b, "algorithmic_bytes_per_sample": 3 * S * map_bytes},
     }

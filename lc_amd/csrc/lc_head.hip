@@ -123,6 +123,124 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_kernel(const HeadPar
     }
 }
 
+
+// ---- fast path: W = 4*LPR (64 or 128), H*W a multiple of 1024: marginals straight from registers -------------------
+// Thread t owns float4 #(t + 256 k): row = (t + 256k) / LPR, columns 4*(t % LPR)..+3 (the same four columns for every k).
+// A row lives in LPR consecutive lanes -> row sums by DPP (and one permlane16 swap when LPR = 32); a column lives in the
+// lanes with equal (lane % LPR) -> column sums by permlane swaps; only 4 x (W + rows) floats cross waves through LDS.
+template <int CTRL>
+__device__ __forceinline__ float dpp_sum_step(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
+    return x + __int_as_float(y);
+}
+__device__ __forceinline__ float row16_sum(float x) {  // all 16 lanes of a DPP row get the row total
+    x = dpp_sum_step<0xB1>(x);   // quad_perm [1,0,3,2]
+    x = dpp_sum_step<0x4E>(x);   // quad_perm [2,3,0,1]
+    x = dpp_sum_step<0x141>(x);  // row_half_mirror
+    x = dpp_sum_step<0x140>(x);  // row_mirror
+    return x;
+}
+__device__ __forceinline__ float swap16_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(x), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float swap32_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(x), __float_as_int(x), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_rows_kernel(const HeadParams p) {
+    constexpr int W = 4 * LPR, H = NV * kHeadThreads / LPR, HW = H * W;
+    constexpr int RPW = kWave / LPR;           // rows a wave covers per k
+    __shared__ float colp[4][W];               // per-wave column partials
+    __shared__ float py[H];
+    __shared__ float px[W];
+    __shared__ float redf[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t m = blockIdx.x;
+    const float4* in = reinterpret_cast<const float4*>(p.in + m * HW);
+    const bool is_prob = p.is_prob != 0;
+
+    float4 x[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) x[k] = in[tid + k * kHeadThreads];
+    float bmax = 0.f;
+    if (!is_prob) {
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lmax = fmaxf(fmaxf(lmax, fmaxf(x[k].x, x[k].y)), fmaxf(x[k].z, x[k].w));
+        lmax = wave_max(lmax);
+        if (lane == 0) redf[wave] = lmax;
+        __syncthreads();
+        bmax = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    }
+    float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rowsum[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float4 e = x[k];
+        if (!is_prob) {
+            e.x = __expf(e.x - bmax); e.y = __expf(e.y - bmax); e.z = __expf(e.z - bmax); e.w = __expf(e.w - bmax);
+        }
+        col.x += e.x; col.y += e.y; col.z += e.z; col.w += e.w;
+        float r = (e.x + e.y) + (e.z + e.w);
+        r = row16_sum(r);
+        if (LPR == 32) r = swap16_sum(r);
+        rowsum[k] = r;
+    }
+    // rows: lane (lane % LPR == 0) of each row group writes the un-normalised row sum
+    if ((lane % LPR) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) py[(tid + k * kHeadThreads) / LPR] = rowsum[k];
+    }
+    // columns: combine the lanes of this wave that hold the same four columns
+    if (LPR == 16) {
+        col.x = swap16_sum(col.x); col.y = swap16_sum(col.y); col.z = swap16_sum(col.z); col.w = swap16_sum(col.w);
+    }
+    col.x = swap32_sum(col.x); col.y = swap32_sum(col.y); col.z = swap32_sum(col.z); col.w = swap32_sum(col.w);
+    if (lane < LPR) *reinterpret_cast<float4*>(&colp[wave][4 * lane]) = col;
+    __syncthreads();
+    // px, total mass
+    float bsum = 0.f;
+    if (tid < W) {
+        const float c = (colp[0][tid] + colp[1][tid]) + (colp[2][tid] + colp[3][tid]);
+        px[tid] = c;
+        bsum = c;
+    }
+    if (wave < W / kWave) {  // the waves that hold px entries
+        bsum = wave_sum(bsum);
+        if (lane == 0) redf[4 + wave] = bsum;
+    }
+    __syncthreads();
+    bsum = W / kWave == 1 ? redf[4] : redf[4] + redf[5];
+    const float inv = is_prob ? 1.f : 1.f / bsum;
+    // softargmax_1d_cov (ptnet.py:85-97): wave 0 -> x from px, wave 1 -> y from py
+    if (wave < 2) {
+        const float* pr = wave == 0 ? px : py;
+        constexpr int nx = W, ny = H;
+        const int n = wave == 0 ? nx : ny;
+        float mu = 0.f;
+        for (int i = lane; i < n; i += kWave) mu += (float)i * (pr[i] * inv);
+        mu = wave_sum(mu);
+        float var = 0.f;
+        for (int i = lane; i < n; i += kWave) {
+            const float d = (float)i - mu;
+            var += d * d * (pr[i] * inv);
+        }
+        var = wave_sum(var);
+        if (lane == 0) {
+            p.mean[m * 2 + wave] = mu;
+            p.std[m * 2 + wave] = sqrtf(var + 1e-6f);
+            p.stats[m * 4 + 1 + wave] = var;
+            if (wave == 0) {
+                p.stats[m * 4] = is_prob ? bsum : bmax + __logf(bsum);
+                p.stats[m * 4 + 3] = 0.f;
+            }
+        }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwdParams p) {
     const int H = p.H, W = p.W, HW = H * W;
@@ -192,6 +310,14 @@ int launch_head_fwd(const HeadParams& p, hipStream_t stream) {
     int nv = (HW + kHeadThreads * vec - 1) / (kHeadThreads * vec);
     int nvp = 1;
     while (nvp < nv) nvp <<= 1;
+    if (vec4 && p.W == 64 && p.H == 64) {
+        hipLaunchKernelGGL((lc_head_fwd_rows_kernel<16, 4>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    if (vec4 && p.W == 128 && p.H == 128) {
+        hipLaunchKernelGGL((lc_head_fwd_rows_kernel<32, 16>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     const size_t smem = sizeof(float) * ((size_t)p.H * (p.W + 1) + p.W + p.H + 8);
     if (smem > 160 * 1024 || nvp > 32) return 3;  // map too large for the single-pass design
     return vec4 ? launch_fwd_nv<4>(p, stream, nvp, smem) : launch_fwd_nv<1>(p, stream, nvp, smem);
