@@ -92,6 +92,21 @@ int lc_softargmax2d_bwd_f32(const float *in, const float *mean, const float *std
                             const float *g_mean, const float *g_std, int M, int H, int W, int is_prob, float *g_in,
                             void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (2d) Dense-correspondence front end -- replaces the torch glue of losses.py:355-356 (joint softmax
+ *      over all 2*H*W weight logits x per-sample scale) + losses.py:142-161 dense_pnp_matching_from_xyz (strided
+ *      sub-sampling with phase (top,left), noc_scale multiply, (N,C) transposes).
+ *      xyz (B,3,H,W) wlogits (B,2,H,W) wscale (B) noc_scale (B,3)|NULL -> pts2d,inv_std (B,N,2) pts3d (B,N,3) lse (B)
+ *      with N = ceil((H-top)/sample) * ceil((W-left)/sample).  Backward: cotangents of inv_std / pts3d (either NULL)
+ *      -> d_xyz (B,3,H,W), d_wlogits (B,2,H,W), d_wscale (B) (any NULL to skip).
+ * ------------------------------------------------------------------------------------------------ */
+int lc_dense_frontend_fwd_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale, int B,
+                              int H, int W, int top, int left, int sample, float *pts2d, float *inv_std, float *pts3d,
+                              float *lse, void *stream);
+int lc_dense_frontend_bwd_f32(const float *wlogits, const float *wscale, const float *noc_scale, const float *lse,
+                              const float *g_inv_std, const float *g_pts3d, int B, int H, int W, int top, int left,
+                              int sample, float *d_xyz, float *d_wlogits, float *d_wscale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

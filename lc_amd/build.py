@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return SO_PATH
     os.makedirs(OUT_DIR, exist_ok=True)
     tmp = SO_PATH + ".tmp"
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
            *sources(), "-o", tmp]
     if verbose:
         print(" ".join(cmd))

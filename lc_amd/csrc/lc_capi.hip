@@ -145,6 +145,7 @@ int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pt
 
 }  // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 int lc_amd_version(void) { return LC_AMD_VERSION; }
@@ -250,4 +251,27 @@ int lc_softargmax2d_bwd_f32(const float* in, const float* mean, const float* std
     return lc::launch_head_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "head backward launch failed") : 0;
 }
 
+int lc_dense_frontend_fwd_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, int B, int H,
+                              int W, int top, int left, int sample, float* pts2d, float* inv_std, float* pts3d, float* lse,
+                              void* stream) {
+    if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!xyz || !wlogits || !wscale || !pts2d || !inv_std || !pts3d || !lse) return fail(1, "null pointer");
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    lc::DenseParams p{xyz, wlogits, wscale, noc_scale, pts2d, inv_std, pts3d, lse, B, H, W, N, top, left, sample};
+    return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
+}
+
+int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const float* noc_scale, const float* lse,
+                              const float* g_inv_std, const float* g_pts3d, int B, int H, int W, int top, int left, int sample,
+                              float* d_xyz, float* d_wlogits, float* d_wscale, void* stream) {
+    if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!wlogits || !wscale || !lse) return fail(1, "null pointer");
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    lc::DenseBwdParams p{wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, d_xyz, d_wlogits, d_wscale, B, H, W, N, top, left, sample};
+    return lc::launch_dense_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end backward launch failed") : 0;
+}
+
 }  // extern "C"
+#pragma GCC visibility pop

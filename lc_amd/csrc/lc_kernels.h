@@ -67,4 +67,31 @@ struct HeadBwdParams {
 };
 int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream);
 
+struct DenseParams {
+    const float* xyz;        // (B,3,H,W) network xyz head
+    const float* wlogits;    // (B,2,H,W) weight logits
+    const float* wscale;     // (B,) per-sample weight scale
+    const float* noc_scale;  // (B,3) or null
+    float* pts2d;            // (B,N,2)
+    float* inv_std;          // (B,N,2)
+    float* pts3d;            // (B,N,3)
+    float* lse;              // (B,) saved for backward
+    int B, H, W, N, top, left, sample;
+};
+int launch_dense_fwd(const DenseParams& p, hipStream_t stream);
+
+struct DenseBwdParams {
+    const float* wlogits;    // (B,2,H,W)
+    const float* wscale;     // (B,)
+    const float* noc_scale;  // (B,3) or null
+    const float* lse;        // (B,)
+    const float* g_inv_std;  // (B,N,2) or null
+    const float* g_pts3d;    // (B,N,3) or null
+    float* d_xyz;            // (B,3,H,W) or null
+    float* d_wlogits;        // (B,2,H,W) or null
+    float* d_wscale;         // (B,) or null
+    int B, H, W, N, top, left, sample;
+};
+int launch_dense_bwd(const DenseBwdParams& p, hipStream_t stream);
+
 }  // namespace lc

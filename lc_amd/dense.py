@@ -1,0 +1,80 @@
+"""Dense-correspondence front end: network output -> (pts2d, inv_std2d, pts3d) for Loss_cov_mixed / PnP.
+
+`dense_front_end` fuses what the reference does with ~10 torch ops between the dense head and the loss
+(`losses.py:355-356` joint softmax over all 2*H*W weight logits times the per-sample scale, `losses.py:142-161`
+`dense_pnp_matching_from_xyz`: strided sub-sampling with phase, noc_scale multiply, transposes) into one HIP launch
+forward and one backward.  Same random phase source (`np.random.randint`) so seeded runs line up with the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _n_points(H, W, top, left, sample):
+    return ((H - top + sample - 1) // sample) * ((W - left + sample - 1) // sample)
+
+
+def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample):
+    lib = _lib.load()
+    B, _, H, W = xyz.shape
+    N = _n_points(H, W, top, left, sample)
+    f = dict(device=xyz.device, dtype=torch.float32)
+    pts2d, inv_std, pts3d, lse = torch.empty(B, N, 2, **f), torch.empty(B, N, 2, **f), torch.empty(B, N, 3, **f), torch.empty(B, **f)
+    with torch.cuda.device(xyz.device):
+        rc = lib.lc_dense_frontend_fwd_f32(_lib.ptr(xyz), _lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), B, H, W, top, left,
+                                           sample, _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(pts3d), _lib.ptr(lse),
+                                           _lib.stream_ptr(xyz.device))
+    _lib.check(rc, "lc_dense_frontend_fwd_f32")
+    return pts2d, inv_std, pts3d, lse
+
+
+def _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, shape, top, left, sample, need):
+    lib = _lib.load()
+    B, H, W = shape
+    f = dict(device=wlogits.device, dtype=torch.float32)
+    d_xyz = torch.empty(B, 3, H, W, **f) if need[0] else None
+    d_wl = torch.empty(B, 2, H, W, **f) if need[1] else None
+    d_ws = torch.empty(B, **f) if need[2] else None
+    with torch.cuda.device(wlogits.device):
+        rc = lib.lc_dense_frontend_bwd_f32(_lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(lse), _lib.ptr(g_inv_std),
+                                           _lib.ptr(g_pts3d), B, H, W, top, left, sample, _lib.ptr(d_xyz), _lib.ptr(d_wl), _lib.ptr(d_ws),
+                                           _lib.stream_ptr(wlogits.device))
+    _lib.check(rc, "lc_dense_frontend_bwd_f32")
+    return d_xyz, d_wl, d_ws
+
+
+class _DenseFrontEndFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, wlogits, wscale, noc_scale, top, left, sample):
+        pts2d, inv_std, pts3d, lse = _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample)
+        ctx.save_for_backward(wlogits, wscale, noc_scale, lse)
+        ctx.cfg = (xyz.shape[0], xyz.shape[2], xyz.shape[3], top, left, sample)
+        ctx.mark_non_differentiable(pts2d)
+        return pts2d, inv_std, pts3d
+
+    @staticmethod
+    def backward(ctx, _g2, g_inv_std, g_pts3d):
+        wlogits, wscale, noc_scale, lse = ctx.saved_tensors
+        B, H, W, top, left, sample = ctx.cfg
+        need = ctx.needs_input_grad[:3]
+        g_inv_std = None if g_inv_std is None else g_inv_std.contiguous().to(torch.float32)
+        g_pts3d = None if g_pts3d is None else g_pts3d.contiguous().to(torch.float32)
+        d_xyz, d_wl, d_ws = _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, (B, H, W), top, left, sample, need)
+        return d_xyz, d_wl, d_ws, None, None, None, None
+
+
+def dense_front_end(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scale: Tensor, noc_scale: Tensor = None, sample: int = 2,
+                    top_left=None):
+    """xyz_noc (B,3,H,W), xyz_weight_logits (B,2,H,W), xyz_weights_scale (B,1,1,1) [or (B,)], noc_scale (B,3)|None
+    -> pts2d (B,N,2) pixel grid, inv_std2d (B,N,2), pts3d (B,N,3); differentiable w.r.t. the first three."""
+    top, left = np.random.randint(0, sample, size=2) if top_left is None else top_left  # losses.py:152
+    B = xyz_noc.shape[0]
+    xyz = _lib.require_hip_f32("xyz_noc", xyz_noc)
+    wl = _lib.require_hip_f32("xyz_weight_logits", xyz_weight_logits)
+    ws = _lib.require_hip_f32("xyz_weights_scale", xyz_weights_scale.reshape(B))
+    ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
+    return _DenseFrontEndFn.apply(xyz, wl, ws, ns, int(top), int(left), int(sample))

@@ -21,6 +21,7 @@ from torch import Tensor
 
 from . import transforms as xforms
 from .cov_mixed import Loss_cov_mixed
+from .dense import dense_front_end
 from .grad import NormClipper
 
 
@@ -154,12 +155,10 @@ class Loss_fn(nn.Module):
         if self.scale_grad_clipper is not None and xyz_weights_scale.requires_grad:
             xyz_weights_scale.register_hook(lambda grad: self.scale_grad_clipper.clip(grad))
 
-        # one softmax over all 2*H*W logits, times the per-sample scale (losses.py:355-356)
-        raw = xyz_weight_logits.reshape(xyz_weight_logits.shape[:-3] + (1, -1)).softmax(dim=-1)
-        xyz_weights = raw.reshape_as(xyz_weight_logits) * xyz_weights_scale
-
-        den_pts2d, den_inv_std2d, den_pts3d, _ = dense_pnp_matching_from_xyz(
-            out_dict["xyz_noc"], xyz_weights, gt_dict["msk_vis"], noc_scale, sample=cfg.get("dense_sample", 2))
+        # joint softmax over all 2*H*W logits x per-sample scale (losses.py:355-356) + strided sub-sampling with random
+        # phase (losses.py:142-161): one fused HIP launch each way (lc_amd/dense.py)
+        den_pts2d, den_inv_std2d, den_pts3d = dense_front_end(out_dict["xyz_noc"], xyz_weight_logits, xyz_weights_scale, noc_scale,
+                                                              sample=cfg.get("dense_sample", 2))
         den_valid_msk = torch.ones_like(den_pts3d[..., 0])
         if self.pts_grad_clipper is not None and den_pts3d.requires_grad:
             den_pts3d.register_hook(lambda grad: self.pts_grad_clipper.clip(grad))

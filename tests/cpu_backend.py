@@ -30,10 +30,19 @@ def _solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_ite
     return torch.from_numpy(st), torch.from_numpy(tr), torch.from_numpy(ret)
 
 
+def _dense_front_end(xyz_noc, wl, ws, noc_scale=None, sample=2, top_left=None):
+    from oracle import dense_oracle
+
+    top_left = tuple(np.random.randint(0, sample, size=2)) if top_left is None else top_left
+    return dense_oracle.dense_front_end(xyz_noc, wl, ws, noc_scale, sample, top_left)
+
+
 @pytest.fixture
 def oracle_backend(monkeypatch):
-    from lc_amd import _lib, cov_mixed
+    from lc_amd import _lib, cov_mixed, losses
     from lc_amd.pnp import pnp_ceres
+
+    monkeypatch.setattr(losses, "dense_front_end", _dense_front_end)
 
     monkeypatch.setattr(_lib, "require_hip_f32", lambda name, t: t.contiguous())
     monkeypatch.setattr(cov_mixed, "_launch_loss", _launch_loss)

@@ -62,28 +62,30 @@ DENSE_CFG = dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scal
                  w_loss_noc=1, w_loss_seg=1, w_loss_pose=0.05, seg_loss_type="L1")
 
 
-def run(Loss_fn_cls, kind, steps, dtype=torch.float32):
+def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None):
     """Shared by the generator (reference class) and the tests (lc_amd class): returns a flat record of the trajectory."""
     cfg = AttrDict(SPARSE_CFG if kind == "sparse" else DENSE_CFG)
     fn = Loss_fn_cls(cfg, AttrDict(), 0)
+    if device is not None:
+        fn = fn.to(device)
     rec = {}
     for i, step in enumerate(steps):
         gt, out = (sparse_inputs(seed=i) if kind == "sparse" else dense_inputs(seed=i))
-        gt = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in gt.items()}
-        leaves = {k: v.to(dtype).clone().requires_grad_(True) for k, v in out.items()}
+        gt = {k: (v.to(dtype) if v.is_floating_point() else v).to(device) for k, v in gt.items()}
+        leaves = {k: v.to(dtype).to(device).clone().requires_grad_(True) for k, v in out.items()}
         np.random.seed(1000 + i)  # random sub-sampling phase (losses.py:152)
         loss_dict, w_loss_dict = fn(gt, leaves, 0, step, 10)
         total = sum(w_loss_dict.values())
         grads = torch.autograd.grad(total, list(leaves.values()), allow_unused=True)
         for k, v in loss_dict.items():
-            rec[f"s{i}_loss_{k}"] = v.detach().double().numpy()
+            rec[f"s{i}_loss_{k}"] = v.detach().double().cpu().numpy()
         for k, v in w_loss_dict.items():
-            rec[f"s{i}_wloss_{k}"] = v.detach().double().numpy()
+            rec[f"s{i}_wloss_{k}"] = v.detach().double().cpu().numpy()
         for k, gk in zip(leaves, grads):
             if gk is not None:
-                rec[f"s{i}_grad_{k}"] = gk.double().numpy()
+                rec[f"s{i}_grad_{k}"] = gk.double().cpu().numpy()
         for k, v in fn.state_dict().items():
-            rec[f"s{i}_state_{k}"] = v.double().numpy()
+            rec[f"s{i}_state_{k}"] = v.double().cpu().numpy()
     rec["steps"] = np.asarray(steps)
     return rec
 
