@@ -107,6 +107,15 @@ int lc_dense_frontend_bwd_f32(const float *wlogits, const float *wscale, const f
                               const float *g_inv_std, const float *g_pts3d, int B, int H, int W, int top, int left,
                               int sample, float *d_xyz, float *d_wlogits, float *d_wscale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (2e) Pose-error metrics -- lib/utils/error6d.py:87-154 (add, adi, re, te) bundled as
+ *      lib/utils/evaluate.py:333-339 compute_pose_errors, batched: R_* (B,3,3) t_* (B,3); pts (P,3) model vertices;
+ *      pts_off/pts_cnt (B) select each pose's vertex range (both NULL: every pose uses pts[0:M]).
+ *      -> out (B,4) = adi, add, re [deg], te.  want_adi=0 skips the O(M^2) nearest-neighbour search.
+ * ------------------------------------------------------------------------------------------------ */
+int lc_pose_errors_f32(const float *R_est, const float *t_est, const float *R_gt, const float *t_gt, const float *pts,
+                       const int *pts_off, const int *pts_cnt, int B, int M, int want_adi, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

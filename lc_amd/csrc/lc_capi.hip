@@ -273,5 +273,15 @@ int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const f
     return lc::launch_dense_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end backward launch failed") : 0;
 }
 
+int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt, const float* t_gt, const float* pts,
+                       const int* pts_off, const int* pts_cnt, int B, int M, int want_adi, float* out, void* stream) {
+    if (B < 0 || M < 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!R_est || !t_est || !R_gt || !t_gt || !pts || !out) return fail(1, "null pointer");
+    if ((pts_off == nullptr) != (pts_cnt == nullptr)) return fail(1, "pts_off and pts_cnt go together");
+    lc::MetricsParams p{R_est, t_est, R_gt, t_gt, pts, pts_off, pts_cnt, out, B, M, want_adi};
+    return lc::launch_pose_errors(p, static_cast<hipStream_t>(stream)) ? fail(11, "pose-error kernel launch failed") : 0;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

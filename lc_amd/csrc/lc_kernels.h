@@ -67,6 +67,19 @@ struct HeadBwdParams {
 };
 int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream);
 
+struct MetricsParams {
+    const float* R_est;  // (B,3,3)
+    const float* t_est;  // (B,3)
+    const float* R_gt;   // (B,3,3)
+    const float* t_gt;   // (B,3)
+    const float* pts;    // (P,3) model vertices, all objects back to back
+    const int* pts_off;  // (B,) first vertex of the pose's object, or null (0)
+    const int* pts_cnt;  // (B,) vertex count of the pose's object, or null (M)
+    float* out;          // (B,4) adi, add, re [deg], te
+    int B, M, want_adi;
+};
+int launch_pose_errors(const MetricsParams& p, hipStream_t stream);
+
 struct DenseParams {
     const float* xyz;        // (B,3,H,W) network xyz head
     const float* wlogits;    // (B,2,H,W) weight logits

@@ -201,8 +201,35 @@ def gen_head():
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def gen_pose_errors():
+    """lib/utils/error6d.py (numpy/scipy only) on random pose pairs and a random vertex cloud."""
+    from lib.utils import error6d
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(0)
+    B, M = 12, 700
+    pts = (rng.random((M, 3)) * 2 - 1).astype(np.float32) * np.array(synth.EXTENT_MM, np.float32)
+    R_gt = Rotation.random(B, random_state=1).as_matrix().astype(np.float32)
+    dR = Rotation.from_rotvec(rng.normal(size=(B, 3)) * np.array([[0.0], [1e-4], [1e-3]] + [[0.05]] * (B - 3))).as_matrix()
+    R_est = (R_gt.astype(np.float64) @ dR).astype(np.float32)
+    t_gt = np.stack((rng.uniform(-50, 50, B), rng.uniform(-50, 50, B), rng.uniform(600, 1200, B)), -1).astype(np.float32)
+    t_est = (t_gt + rng.normal(size=(B, 3)) * np.array([[0.0], [1e-3], [0.1]] + [[3.0]] * (B - 3))).astype(np.float32)
+    out = {k: np.zeros(B) for k in ("adi", "add", "re", "te")}
+    for i in range(B):
+        args = [a.astype(np.float64) for a in (R_est[i], t_est[i].reshape(3, 1), R_gt[i], t_gt[i].reshape(3, 1))]
+        out["adi"][i] = error6d.adi(*args, pts.astype(np.float64))
+        out["add"][i] = error6d.add(*args, pts.astype(np.float64))
+        out["re"][i] = error6d.re(args[0], args[2])
+        out["te"][i] = error6d.te(args[1], args[3])
+    path = os.path.join(HERE, "pose_err_b12_m700.npz")
+    np.savez_compressed(path, in_R_est=R_est, in_t_est=t_est, in_R_gt=R_gt, in_t_gt=t_gt, in_pts=pts, **{"ref_" + k: v for k, v in out.items()})
+    print("pose errors:", {k: v[:4] for k, v in out.items()}, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["loss", "head"]
+    if "errors" in what:
+        gen_pose_errors()
     if "loss" in what:
         gen_loss()
     if "head" in what:
