@@ -108,6 +108,24 @@ int lc_dense_frontend_bwd_f32(const float *wlogits, const float *wscale, const f
                               int sample, float *d_xyz, float *d_wlogits, float *d_wscale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (2f) ZebraPose binary surface codes -- floatbits.py.  logits (B,C,H,W), C = n0+n1+n2 code bits
+ *      (x,y,z axes back to back, floatbits.py:35-48); black_background as floatbits.py:7-11.
+ *      lc_bits_decode_gt_*: floatbits.py:130-160 + :108-118 (training decode against the raw ground-truth bits gt_bits
+ *      (B,C,H,W) uint8 and the object mask gt_msk (B,H,W) uint8|NULL), evaluated on the strided pixel subset
+ *      (top,left,sample) of losses.py:163-184 -> noc (B,N,3); backward writes the full (B,C,H,W) logit gradient.
+ *      lc_bits_decode_f32: floatbits.py:194-223 + :162-180 (inference Gray decode) -> noc (B,H,W,3).
+ *      (2d) accepts xyz = pts3d = NULL for these heads (weights / pixel grid only).
+ * ------------------------------------------------------------------------------------------------ */
+int lc_bits_decode_gt_fwd_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk, int B, int C,
+                              int H, int W, int n0, int n1, int n2, int black_background, int top, int left, int sample,
+                              float *noc, void *stream);
+int lc_bits_decode_gt_bwd_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
+                              const float *g_noc, int B, int C, int H, int W, int n0, int n1, int n2, int black_background,
+                              int top, int left, int sample, float *d_logits, void *stream);
+int lc_bits_decode_f32(const float *logits, int B, int C, int H, int W, int n0, int n1, int n2, int black_background,
+                       float *noc, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (2e) Pose-error metrics -- lib/utils/error6d.py:87-154 (add, adi, re, te) bundled as
  *      lib/utils/evaluate.py:333-339 compute_pose_errors, batched: R_* (B,3,3) t_* (B,3); pts (P,3) model vertices;
  *      pts_off/pts_cnt (B) select each pose's vertex range (both NULL: every pose uses pts[0:M]).

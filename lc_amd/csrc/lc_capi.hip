@@ -256,7 +256,7 @@ int lc_dense_frontend_fwd_f32(const float* xyz, const float* wlogits, const floa
                               void* stream) {
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (B == 0) return 0;
-    if (!xyz || !wlogits || !wscale || !pts2d || !inv_std || !pts3d || !lse) return fail(1, "null pointer");
+    if (!wlogits || !wscale || !pts2d || !inv_std || !lse || (xyz != nullptr) != (pts3d != nullptr)) return fail(1, "null pointer");
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     lc::DenseParams p{xyz, wlogits, wscale, noc_scale, pts2d, inv_std, pts3d, lse, B, H, W, N, top, left, sample};
     return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
@@ -271,6 +271,45 @@ int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const f
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     lc::DenseBwdParams p{wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, d_xyz, d_wlogits, d_wscale, B, H, W, N, top, left, sample};
     return lc::launch_dense_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end backward launch failed") : 0;
+}
+
+static int bits_check(int B, int C, int H, int W, int n0, int n1, int n2, int top, int left, int sample) {
+    if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
+    if (n0 < 1 || n1 < 1 || n2 < 1 || n0 > 24 || n1 > 24 || n2 > 24 || n0 + n1 + n2 != C) return fail(1, "bad bit counts");
+    return 0;
+}
+
+int lc_bits_decode_gt_fwd_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, int B, int C, int H,
+                              int W, int n0, int n1, int n2, int black_background, int top, int left, int sample, float* noc,
+                              void* stream) {
+    if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
+    if (B == 0) return 0;
+    if (!logits || !gt_bits || !noc) return fail(1, "null pointer");
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    lc::BitsParams p{logits, gt_bits, gt_msk, nullptr, noc, nullptr, B, C, H, W, N, top, left, sample, {n0, n1, n2},
+                     black_background ? -1 : 1};
+    return lc::launch_bits_decode_gt_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
+}
+
+int lc_bits_decode_gt_bwd_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* g_noc,
+                              int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top, int left,
+                              int sample, float* d_logits, void* stream) {
+    if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
+    if (B == 0) return 0;
+    if (!logits || !gt_bits || !g_noc || !d_logits) return fail(1, "null pointer");
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    lc::BitsParams p{logits, gt_bits, gt_msk, g_noc, nullptr, d_logits, B, C, H, W, N, top, left, sample, {n0, n1, n2},
+                     black_background ? -1 : 1};
+    return lc::launch_bits_decode_gt_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode backward launch failed") : 0;
+}
+
+int lc_bits_decode_f32(const float* logits, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, float* noc,
+                       void* stream) {
+    if (int rc = bits_check(B, C, H, W, n0, n1, n2, 0, 0, 1)) return rc;
+    if (B == 0) return 0;
+    if (!logits || !noc) return fail(1, "null pointer");
+    lc::BitsParams p{logits, nullptr, nullptr, nullptr, noc, nullptr, B, C, H, W, H * W, 0, 0, 1, {n0, n1, n2}, black_background ? -1 : 1};
+    return lc::launch_bits_decode(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
 }
 
 int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt, const float* t_gt, const float* pts,

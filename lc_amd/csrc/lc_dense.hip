@@ -53,8 +53,10 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_fwd_kernel(const D
         *reinterpret_cast<float2*>(p.pts2d + (ob + n) * 2) = make_float2((float)x, (float)y);
         *reinterpret_cast<float2*>(p.inv_std + (ob + n) * 2) =
             make_float2(__expf(lg[px] - lse) * scale, __expf(lg[HW + px] - lse) * scale);
-        float* o = p.pts3d + (ob + n) * 3;
-        o[0] = xyz[px] * ns0; o[1] = xyz[HW + px] * ns1; o[2] = xyz[2 * HW + px] * ns2;
+        if (p.xyz) {  // binary-code heads decode their 3D points with lc_bits_decode_gt_* instead
+            float* o = p.pts3d + (ob + n) * 3;
+            o[0] = xyz[px] * ns0; o[1] = xyz[HW + px] * ns1; o[2] = xyz[2 * HW + px] * ns2;
+        }
     }
 }
 

@@ -67,6 +67,21 @@ struct HeadBwdParams {
 };
 int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream);
 
+struct BitsParams {
+    const float* logits;          // (B,C,H,W) code logits, C = bits[0]+bits[1]+bits[2]
+    const unsigned char* gt_bits; // (B,C,H,W) raw ground-truth bits (training decode) or null
+    const unsigned char* gt_msk;  // (B,H,W) object mask or null (all inside)
+    const float* g_out;           // (B,N,3) cotangent (backward) or null
+    float* out;                   // fwd: (B,N,3) normalised coordinates
+    float* d_logits;              // bwd: (B,C,H,W)
+    int B, C, H, W, N, top, left, sample;
+    int bits[3];
+    int black_factor;             // -1: black background (default), +1 otherwise
+};
+int launch_bits_decode_gt_fwd(const BitsParams& p, hipStream_t stream);
+int launch_bits_decode_gt_bwd(const BitsParams& p, hipStream_t stream);
+int launch_bits_decode(const BitsParams& p, hipStream_t stream);
+
 struct MetricsParams {
     const float* R_est;  // (B,3,3)
     const float* t_est;  // (B,3)

@@ -20,14 +20,15 @@ def _n_points(H, W, top, left, sample):
 
 def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample):
     lib = _lib.load()
-    B, _, H, W = xyz.shape
+    B, _, H, W = wlogits.shape
     N = _n_points(H, W, top, left, sample)
-    f = dict(device=xyz.device, dtype=torch.float32)
-    pts2d, inv_std, pts3d, lse = torch.empty(B, N, 2, **f), torch.empty(B, N, 2, **f), torch.empty(B, N, 3, **f), torch.empty(B, **f)
-    with torch.cuda.device(xyz.device):
+    f = dict(device=wlogits.device, dtype=torch.float32)
+    pts2d, inv_std, lse = torch.empty(B, N, 2, **f), torch.empty(B, N, 2, **f), torch.empty(B, **f)
+    pts3d = torch.empty(B, N, 3, **f) if xyz is not None else None
+    with torch.cuda.device(wlogits.device):
         rc = lib.lc_dense_frontend_fwd_f32(_lib.ptr(xyz), _lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), B, H, W, top, left,
                                            sample, _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(pts3d), _lib.ptr(lse),
-                                           _lib.stream_ptr(xyz.device))
+                                           _lib.stream_ptr(wlogits.device))
     _lib.check(rc, "lc_dense_frontend_fwd_f32")
     return pts2d, inv_std, pts3d, lse
 
@@ -52,15 +53,20 @@ class _DenseFrontEndFn(torch.autograd.Function):
     def forward(ctx, xyz, wlogits, wscale, noc_scale, top, left, sample):
         pts2d, inv_std, pts3d, lse = _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample)
         ctx.save_for_backward(wlogits, wscale, noc_scale, lse)
-        ctx.cfg = (xyz.shape[0], xyz.shape[2], xyz.shape[3], top, left, sample)
+        ctx.cfg = (wlogits.shape[0], wlogits.shape[2], wlogits.shape[3], top, left, sample)
         ctx.mark_non_differentiable(pts2d)
+        if pts3d is None:  # binary-code heads: no continuous xyz input
+            pts3d = wlogits.new_zeros(0)
+            ctx.mark_non_differentiable(pts3d)
         return pts2d, inv_std, pts3d
 
     @staticmethod
     def backward(ctx, _g2, g_inv_std, g_pts3d):
         wlogits, wscale, noc_scale, lse = ctx.saved_tensors
         B, H, W, top, left, sample = ctx.cfg
-        need = ctx.needs_input_grad[:3]
+        need = list(ctx.needs_input_grad[:3])
+        if g_pts3d is not None and g_pts3d.numel() == 0:
+            g_pts3d, need[0] = None, False
         g_inv_std = None if g_inv_std is None else g_inv_std.contiguous().to(torch.float32)
         g_pts3d = None if g_pts3d is None else g_pts3d.contiguous().to(torch.float32)
         d_xyz, d_wl, d_ws = _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, (B, H, W), top, left, sample, need)
@@ -72,9 +78,10 @@ def dense_front_end(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scal
     """xyz_noc (B,3,H,W), xyz_weight_logits (B,2,H,W), xyz_weights_scale (B,1,1,1) [or (B,)], noc_scale (B,3)|None
     -> pts2d (B,N,2) pixel grid, inv_std2d (B,N,2), pts3d (B,N,3); differentiable w.r.t. the first three."""
     top, left = np.random.randint(0, sample, size=2) if top_left is None else top_left  # losses.py:152
-    B = xyz_noc.shape[0]
-    xyz = _lib.require_hip_f32("xyz_noc", xyz_noc)
+    B = xyz_weight_logits.shape[0]
+    xyz = None if xyz_noc is None else _lib.require_hip_f32("xyz_noc", xyz_noc)
     wl = _lib.require_hip_f32("xyz_weight_logits", xyz_weight_logits)
     ws = _lib.require_hip_f32("xyz_weights_scale", xyz_weights_scale.reshape(B))
     ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
-    return _DenseFrontEndFn.apply(xyz, wl, ws, ns, int(top), int(left), int(sample))
+    pts2d, inv_std, pts3d = _DenseFrontEndFn.apply(xyz, wl, ws, ns, int(top), int(left), int(sample))
+    return pts2d, inv_std, (pts3d if xyz is not None else None)

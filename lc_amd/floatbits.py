@@ -1,0 +1,142 @@
+"""`floatbits.py` call surface (ZebraPose-style binary surface codes) on the HIP decode kernels.
+
+    nn_logits2noc_with_gt(logits, gt_raw_bits, bit_cnt, gt_msk)   <- floatbits.py:50-72  (training, differentiable)
+    nn_logits2noc(logits, bit_cnt)                                <- floatbits.py:35-48  (inference)
+    nn_noc2target(noc, bit_cnt)                                   <- floatbits.py:13-33  (label prep, no grad, plain torch)
+Tensors keep the network layout (B,C,H,W); outputs are (B,H,W,3) like the reference.  `nearest_lut` is not supported
+(no reference call site passes it)."""
+from __future__ import annotations
+
+import math
+from collections import abc
+from typing import List, Union
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+_black_background = True
+
+
+def set_black_background(black=True):
+    global _black_background
+    _black_background = black
+
+
+def _bits3(bit_cnt, C):
+    if isinstance(bit_cnt, abc.Sequence):
+        bits = [int(b) for b in bit_cnt]
+    else:
+        bits = [int(bit_cnt)] * 3
+    if len(bits) != 3 or sum(bits) != C:
+        raise ValueError(f"lc_amd.floatbits: bit_cnt {bit_cnt} does not match {C} code channels")
+    return bits
+
+
+def _as_u8(name, t):
+    if not t.is_cuda:
+        raise RuntimeError(f"lc_amd: {name} is on {t.device}; the HIP path needs tensors on the MI355X (there is no CPU fallback "
+                           f"in the product path)")
+    return (t != 0).to(torch.uint8).contiguous() if t.dtype != torch.uint8 else t.contiguous()
+
+
+def _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample):
+    lib = _lib.load()
+    B, C, H, W = logits.shape
+    N = ((H - top + sample - 1) // sample) * ((W - left + sample - 1) // sample)
+    noc = torch.empty(B, N, 3, device=logits.device, dtype=torch.float32)
+    with torch.cuda.device(logits.device):
+        rc = lib.lc_bits_decode_gt_fwd_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), B, C, H, W, *bits, int(_black_background),
+                                           top, left, sample, _lib.ptr(noc), _lib.stream_ptr(logits.device))
+    _lib.check(rc, "lc_bits_decode_gt_fwd_f32")
+    return noc
+
+
+def _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g_noc, bits, top, left, sample, black):
+    lib = _lib.load()
+    B, C, H, W = logits.shape
+    d = torch.empty_like(logits)
+    with torch.cuda.device(logits.device):
+        rc = lib.lc_bits_decode_gt_bwd_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(g_noc), B, C, H, W, *bits, int(black),
+                                           top, left, sample, _lib.ptr(d), _lib.stream_ptr(logits.device))
+    _lib.check(rc, "lc_bits_decode_gt_bwd_f32")
+    return d
+
+
+class _DecodeGtFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, gt_bits, gt_msk, bits, top, left, sample):
+        noc = _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample)
+        ctx.save_for_backward(logits, gt_bits, gt_msk)
+        ctx.cfg = (tuple(bits), top, left, sample, _black_background)
+        return noc
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, gt_bits, gt_msk = ctx.saved_tensors
+        bits, top, left, sample, black = ctx.cfg
+        d = _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g.contiguous().to(torch.float32), list(bits), top, left, sample, black)
+        return d, None, None, None, None, None, None
+
+
+def decode_with_gt_strided(logits: Tensor, gt_raw_bits: Tensor, bit_cnt, gt_msk: Tensor, sample: int = 1, top_left=(0, 0)) -> Tensor:
+    """(B,C,H,W) logits -> (B,N,3) normalised coordinates of the strided pixel subset (losses.py:163-184 order:
+    sub-sample first, decode second)."""
+    lg = _lib.require_hip_f32("logits", logits)
+    bits = _bits3(bit_cnt, lg.shape[1])
+    gb = _as_u8("gt_raw_bits", gt_raw_bits)
+    gm = None if gt_msk is None else _as_u8("gt_msk", gt_msk)
+    return _DecodeGtFn.apply(lg, gb, gm, bits, int(top_left[0]), int(top_left[1]), int(sample))
+
+
+def nn_logits2noc_with_gt(logits: Tensor, gt_raw_bits: Tensor, bit_cnt: Union[int, List[int]], gt_msk: Tensor) -> Tensor:
+    """floatbits.py:50-72: logits, gt_raw_bits (B,C,H,W), gt_msk (B,H,W) -> noc (B,H,W,3), differentiable w.r.t. logits."""
+    B, _, H, W = logits.shape
+    return decode_with_gt_strided(logits, gt_raw_bits, bit_cnt, gt_msk).reshape(B, H, W, 3)
+
+
+@torch.no_grad()
+def nn_logits2noc(logits: Tensor, bit_cnt: Union[int, List[int]], nearest_lut: Tensor = None) -> Tensor:
+    """floatbits.py:35-48 (inference decode): (B,C,H,W) -> (B,H,W,3)."""
+    if nearest_lut is not None:
+        raise NotImplementedError("lc_amd.floatbits: nearest_lut is not used by any reference call site")
+    lib = _lib.load()
+    lg = _lib.require_hip_f32("logits", logits)
+    B, C, H, W = lg.shape
+    bits = _bits3(bit_cnt, C)
+    noc = torch.empty(B, H, W, 3, device=lg.device, dtype=torch.float32)
+    with torch.cuda.device(lg.device):
+        rc = lib.lc_bits_decode_f32(_lib.ptr(lg), B, C, H, W, *bits, int(_black_background), _lib.ptr(noc), _lib.stream_ptr(lg.device))
+    _lib.check(rc, "lc_bits_decode_f32")
+    return noc
+
+
+@torch.no_grad()
+def mod_noc2bits_bb(numbers: Tensor, N: int, black_background=True):
+    """floatbits.py:77-97 (label prep): normalised coordinate (-1,1) -> Gray-coded bits + raw bits, (*,N) bool."""
+    max_num = 2 ** N - 1
+    ints = torch.clamp((numbers + 1) * (max_num * 0.5), 0, max_num).round().to(torch.int32)
+    mask = 2 ** torch.arange(N - 1, -1, -1, dtype=torch.int32, device=numbers.device)
+    bits = ints.unsqueeze(-1).bitwise_and(mask).bool()
+    mod_bits = bits.clone()
+    mod_bits[..., 1:] = mod_bits[..., 1:].logical_xor(bits[..., 0:-1])
+    if black_background:
+        mod_bits[..., 0:2] = mod_bits[..., 0:2].logical_not()
+    return mod_bits, bits
+
+
+@torch.no_grad()
+def nn_noc2target(noc: Tensor, bit_cnt: Union[int, List[int]]):
+    """floatbits.py:13-33: noc (B,H,W,3) -> (mod_bits, raw_bits), each (B,C,H,W) bool."""
+    bits = [int(b) for b in bit_cnt] if isinstance(bit_cnt, abc.Sequence) else [int(bit_cnt)] * 3
+    outs = [mod_noc2bits_bb(noc[..., a], n, _black_background) for a, n in enumerate(bits)]
+    mod = torch.cat([o[0] for o in outs], dim=-1).permute(0, 3, 1, 2)
+    raw = torch.cat([o[1] for o in outs], dim=-1).permute(0, 3, 1, 2)
+    return mod, raw
+
+
+def calc_bit_count(sizes, max_bits=7, min_bits=2):
+    """floatbits.py:259-263."""
+    max_size = max(sizes)
+    return [max(min_bits, round(max_bits + math.log2(size / max_size))) for size in sizes]

@@ -6,8 +6,8 @@ with the same arguments, return values and buffer names (`weight_grad_clipper.ma
 (one fused HIP launch); the surrounding warm-up blending, weight softmax, strided sub-sampling and Laplace keypoint NLL
 are cheap torch glue exactly as in `losses.py:142-161,261-386`.
 
-Not in this round (SURVEY.md 8f "next" row f3): the ZebraPose binary-code branch (`xyz_noc_bin`,
-`losses.py:163-184,196-216`), which needs `floatbits.py`; it raises NotImplementedError.
+The ZebraPose binary-code branch (`xyz_noc_bin`, `losses.py:163-184,196-216`) decodes through `lc_amd.floatbits`
+(HIP kernels).
 """
 from __future__ import annotations
 
@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from . import floatbits
 from . import transforms as xforms
 from .cov_mixed import Loss_cov_mixed
 from .dense import dense_front_end
@@ -27,11 +28,60 @@ from .grad import NormClipper
 
 def nn_out_to_xyz(nn_out: Tensor = None, noc_scale_xfd: Tensor = None, *, raw_bits_gt=None, noc_mask=None,
                   model_transform=None, bit_cnt=None, inference=False) -> Tensor:
-    """(B,3,H,W) continuous xyz head -> (B,H,W,3) in mm (`losses.py:17-47`, continuous branch)."""
-    if bit_cnt is not None:
-        raise NotImplementedError("lc_amd: binary-code (ZebraPose) outputs are a 'next' row (SURVEY 8f f3)")
-    assert model_transform is None, "Model transform not implemented for continuous xyz output"
-    return nn_out.permute(0, 2, 3, 1) * noc_scale_xfd[:, None, None, :]
+    """Network output -> (B,H,W,3) object coordinates in mm (`losses.py:17-47`): continuous xyz head (bit_cnt None) or
+    binary surface codes decoded with / without the ground-truth bits."""
+    if bit_cnt is None:
+        assert model_transform is None, "Model transform not implemented for continuous xyz output"
+        return nn_out.permute(0, 2, 3, 1) * noc_scale_xfd[:, None, None, :]
+    if not inference:
+        noc_xformed = floatbits.nn_logits2noc_with_gt(nn_out, raw_bits_gt, bit_cnt, noc_mask)
+    else:
+        noc_xformed = floatbits.nn_logits2noc(nn_out, bit_cnt)
+    xyz_xformed = noc_xformed * noc_scale_xfd[:, None, None, :]
+    if model_transform is None:
+        return xyz_xformed
+    return (xyz_xformed - model_transform[:, None, None, :3, 3]) @ model_transform[:, None, :3, :3]
+
+
+def dense_pnp_matching_from_noc_bin(noc_bin_out_logits: Tensor, noc_bin_gt_raw: Tensor, weights_out: Tensor, valid_msk_full: Tensor,
+                                    noc_mask: Tensor, noc_scale: Tensor, gt_dict: dict, sample=2, top_left=None):
+    """`losses.py:163-184`: strided sub-sampling of a binary-code head; the 3D points are decoded on the sampled pixels only."""
+    top, left = np.random.randint(0, sample, size=2) if top_left is None else top_left
+    uv_grid = xforms.gen_uv(weights_out.shape[-2:], weights_out.device)
+    pts2d = uv_grid[..., top::sample, left::sample, :].flatten(start_dim=-3, end_dim=-2)
+    inv_std2d = weights_out[..., top::sample, left::sample].flatten(start_dim=-2).mT
+    valid_msk = valid_msk_full[..., top::sample, left::sample].flatten(start_dim=-2)
+    pts3d = _decode_bin_points(noc_bin_out_logits, noc_bin_gt_raw, noc_mask, noc_scale, gt_dict, sample, (top, left))
+    return pts2d.expand_as(inv_std2d), inv_std2d, pts3d, valid_msk
+
+
+def _decode_bin_points(logits, raw_bits, noc_mask, noc_scale, gt_dict, sample, top_left):
+    noc = floatbits.decode_with_gt_strided(logits, raw_bits, gt_dict["bit_cnt"], noc_mask, sample=sample, top_left=top_left)  # (B,N,3)
+    xyz = noc * noc_scale.unsqueeze(-2)
+    T = gt_dict.get("model_transform", None)
+    if T is not None:
+        xyz = (xyz - T[:, None, :3, 3]) @ T[:, :3, :3]
+    return xyz
+
+
+class Loss_xyz_bin(nn.Module):
+    """`losses.py:196-216`: per-bit weighted BCE on the code logits with an EMA histogram of per-bit Hamming errors
+    (`histogram` buffer: rides in the checkpoint as `loss_fn.xyz_bin_loss_fn.histogram`)."""
+
+    def __init__(self, total_bit_cnt: int, momentum=0.05) -> None:
+        super().__init__()
+        self.register_buffer("histogram", torch.full((total_bit_cnt,), 0.5))
+        self.momentum = momentum
+
+    def forward(self, noc_xyz_bin_logits: Tensor, noc_xyz_bin_gt: Tensor, msk_vis_logits: Tensor):
+        msk_hard = msk_vis_logits > 0
+        hamm = (noc_xyz_bin_logits > 0).logical_xor(noc_xyz_bin_gt.to(torch.bool)).logical_and(msk_hard)
+        hist = hamm.sum([0, 2, 3]) / (msk_hard.sum() + 1)
+        self.histogram.mul_(1 - self.momentum).add_(hist * self.momentum)
+        hist_soft = torch.minimum(self.histogram, 0.51 - self.histogram)
+        bin_weights = (hist_soft * 3).softmax(dim=-1)
+        loss_raw = F.binary_cross_entropy_with_logits(noc_xyz_bin_logits * msk_hard, noc_xyz_bin_gt.float(), reduction="none")
+        return (loss_raw.mean([0, 2, 3]) * bin_weights).sum(-1).mean()
 
 
 def dense_pnp_matching_from_xyz(xyz_out: Tensor, weights_out: Tensor, valid_msk_full: Tensor, xyz_scale: Tensor, sample=2,
@@ -86,7 +136,7 @@ class Loss_fn(nn.Module):
         self.pts_grad_clipper = NormClipper(rel_thresh=2, group=group) if pose_cfg.get("clip_pts_grad", False) else None
         self.cfg_global = cfg_global
         if total_bit_cnt > 0:
-            raise NotImplementedError("lc_amd: binary-code (ZebraPose) loss is a 'next' row (SURVEY 8f f3)")
+            self.xyz_bin_loss_fn = Loss_xyz_bin(total_bit_cnt)
         seg_loss_type = cfg.get("seg_loss_type", "BCE")
         if seg_loss_type.lower() == "bce":
             self.seg_loss_fn = F.binary_cross_entropy_with_logits
@@ -109,8 +159,9 @@ class Loss_fn(nn.Module):
             return loss_dict, w_loss_dict
 
         # dense case, losses.py:281-316
-        if "xyz_noc_bin" in out_dict:
-            raise NotImplementedError("lc_amd: binary-code (ZebraPose) loss is a 'next' row (SURVEY 8f f3)")
+        if "xyz_noc_bin" in out_dict:  # zebra-pose structure (losses.py:289-291)
+            loss_dict["loss_noc_bin"] = self.xyz_bin_loss_fn(out_dict["xyz_noc_bin"], gt_dict["xyz_noc_bin_tgt"],
+                                                             out_dict["msk_vis_logits"])
         if "xyz_noc" in out_dict:
             noc_msked, noc_gt = out_dict["xyz_noc"] * msk_noc.unsqueeze(-3), gt_dict["xyz_noc_tgt"]
             loss_dict["loss_noc"] = F.l1_loss(noc_msked, noc_gt, reduction="mean")
@@ -144,7 +195,7 @@ class Loss_fn(nn.Module):
         return Loss_cov_mixed(K, pose_best, pts3d, pts2d, 1 / pts2d_std, None, bbox_3d=bbox_3d).mean()
 
     def dense_pose_loss(self, cfg, gt_dict, out_dict):
-        """`losses.py:336-386` (GDR-Net structure)."""
+        """`losses.py:336-386` (GDR-Net continuous-xyz structure or ZebraPose binary-code structure)."""
         noc_scale = gt_dict["noc_scale"]
         pose_best, K, bbox_3d = itemgetter("pose_best", "out_K", "bbox_3d")(gt_dict)
 
@@ -157,8 +208,16 @@ class Loss_fn(nn.Module):
 
         # joint softmax over all 2*H*W logits x per-sample scale (losses.py:355-356) + strided sub-sampling with random
         # phase (losses.py:142-161): one fused HIP launch each way (lc_amd/dense.py)
-        den_pts2d, den_inv_std2d, den_pts3d = dense_front_end(out_dict["xyz_noc"], xyz_weight_logits, xyz_weights_scale, noc_scale,
-                                                              sample=cfg.get("dense_sample", 2))
+        sample = cfg.get("dense_sample", 2)
+        assert ("xyz_noc" in out_dict) != ("xyz_noc_bin" in out_dict)  # either structure, not both (losses.py:360)
+        if "xyz_noc" in out_dict:
+            den_pts2d, den_inv_std2d, den_pts3d = dense_front_end(out_dict["xyz_noc"], xyz_weight_logits, xyz_weights_scale, noc_scale,
+                                                                  sample=sample)
+        else:
+            top_left = tuple(int(v) for v in np.random.randint(0, sample, size=2))  # losses.py:169
+            den_pts2d, den_inv_std2d, _ = dense_front_end(None, xyz_weight_logits, xyz_weights_scale, None, sample=sample, top_left=top_left)
+            den_pts3d = _decode_bin_points(out_dict["xyz_noc_bin"], gt_dict["xyz_noc_bin_raw"], gt_dict["msk_noc"], noc_scale, gt_dict,
+                                           sample, top_left)
         den_valid_msk = torch.ones_like(den_pts3d[..., 0])
         if self.pts_grad_clipper is not None and den_pts3d.requires_grad:
             den_pts3d.register_hook(lambda grad: self.pts_grad_clipper.clip(grad))

@@ -15,11 +15,13 @@ def dense_front_end(xyz_noc, weight_logits, weights_scale, noc_scale, sample, to
     top, left = top_left
     raw = weight_logits.reshape(weight_logits.shape[:-3] + (1, -1)).softmax(dim=-1)
     weights = raw.reshape_as(weight_logits) * weights_scale.reshape(-1, 1, 1, 1)
-    H, W = xyz_noc.shape[-2:]
-    uv = gen_uv(H, W, xyz_noc.dtype)
+    H, W = weight_logits.shape[-2:]
+    uv = gen_uv(H, W, weight_logits.dtype)
     pts2d = uv[top::sample, left::sample, :].flatten(0, 1)
     inv_std = weights[..., top::sample, left::sample].flatten(start_dim=-2).mT
-    pts3d = xyz_noc[..., top::sample, left::sample].flatten(start_dim=-2).mT
-    if noc_scale is not None:
-        pts3d = pts3d * noc_scale.unsqueeze(-2)
+    pts3d = None
+    if xyz_noc is not None:  # binary-code heads decode their points elsewhere (losses.py:163-184)
+        pts3d = xyz_noc[..., top::sample, left::sample].flatten(start_dim=-2).mT
+        if noc_scale is not None:
+            pts3d = pts3d * noc_scale.unsqueeze(-2)
     return pts2d.expand_as(inv_std), inv_std, pts3d

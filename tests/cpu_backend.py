@@ -37,12 +37,24 @@ def _dense_front_end(xyz_noc, wl, ws, noc_scale=None, sample=2, top_left=None):
     return dense_oracle.dense_front_end(xyz_noc, wl, ws, noc_scale, sample, top_left)
 
 
+def _decode_with_gt_strided(logits, gt_raw_bits, bit_cnt, gt_msk, sample=1, top_left=(0, 0)):
+    from oracle import floatbits_oracle
+
+    t, l = top_left
+    bits = list(bit_cnt) if isinstance(bit_cnt, (list, tuple)) else [bit_cnt] * 3
+    from lc_amd import floatbits
+    noc = floatbits_oracle.nn_logits2noc_with_gt(logits[..., t::sample, l::sample], gt_raw_bits[..., t::sample, l::sample], bits,
+                                                 gt_msk[..., t::sample, l::sample], black=floatbits._black_background)
+    return noc.flatten(1, 2)
+
+
 @pytest.fixture
 def oracle_backend(monkeypatch):
     from lc_amd import _lib, cov_mixed, losses
     from lc_amd.pnp import pnp_ceres
 
     monkeypatch.setattr(losses, "dense_front_end", _dense_front_end)
+    monkeypatch.setattr(losses.floatbits, "decode_with_gt_strided", _decode_with_gt_strided)
 
     monkeypatch.setattr(_lib, "require_hip_f32", lambda name, t: t.contiguous())
     monkeypatch.setattr(cov_mixed, "_launch_loss", _launch_loss)

@@ -226,8 +226,38 @@ def gen_pose_errors():
     print("pose errors:", {k: v[:4] for k, v in out.items()}, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_bits():
+    """floatbits.py (pure torch): target generation, training decode (+ logit gradient) and inference decode."""
+    import floatbits as fb
+
+    g = torch.Generator().manual_seed(0)
+    for name, (B, H, W, bits) in dict(b2_8x10_n655=(2, 8, 10, [6, 5, 5]), b2_16x16_n7=(2, 16, 16, 7)).items():
+        noc = torch.rand(B, H, W, 3, generator=g) * 2 - 1
+        mod_bits, raw_bits = fb.nn_noc2target(noc, bits)
+        # network logits: mostly agreeing with the target code, with errors at random bit positions
+        C = mod_bits.shape[1]
+        logits = (mod_bits.float() * 2 - 1) * (torch.rand(B, C, H, W, generator=g) * 4 + 0.2)
+        flip = torch.rand(B, C, H, W, generator=g) < 0.15
+        logits = torch.where(flip, -logits, logits)
+        msk = torch.rand(B, H, W, generator=g) > 0.25
+        ct = torch.randn(B, H, W, 3, generator=g)
+        rec = dict(in_noc=noc.numpy(), in_logits=logits.numpy(), in_raw_bits=raw_bits.numpy(), in_mod_bits=mod_bits.numpy(),
+                   in_msk=msk.numpy(), in_ct=ct.numpy(), bits=np.asarray(bits if isinstance(bits, list) else [bits] * 3))
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            lg = logits.to(dt).requires_grad_(True)
+            out = fb.nn_logits2noc_with_gt(lg, raw_bits, bits, msk)
+            (gl,) = torch.autograd.grad(out, lg, ct.to(dt))
+            inf = fb.nn_logits2noc(logits.to(dt), bits)
+            rec.update({f"{tag}_noc_gt": out.detach().numpy(), f"{tag}_g_logits": gl.numpy(), f"{tag}_noc_inf": inf.numpy()})
+        path = os.path.join(HERE, f"bits_{name}.npz")
+        np.savez_compressed(path, **rec)
+        print("bits", name, rec["f64_noc_gt"][0, 0, 0], rec["f64_noc_inf"][0, 0, 0], os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["loss", "head"]
+    if "bits" in what:
+        gen_bits()
     if "errors" in what:
         gen_pose_errors()
     if "loss" in what:

@@ -55,6 +55,31 @@ def dense_inputs(B=3, H=16, W=16, seed=0):
     return gt, out
 
 
+def bin_inputs(B=3, H=16, W=16, seed=0, bits=(6, 6, 5)):
+    """ZebraPose structure: binary surface codes instead of the continuous xyz head, with a model transform."""
+    from lc_amd import floatbits as fb
+
+    gt, out = dense_inputs(B, H, W, seed)
+    g = torch.Generator().manual_seed(seed + 50)
+    noc = (gt["xyz_noc_tgt"] / 1.0).permute(0, 2, 3, 1).clamp(-0.999, 0.999)  # (B,H,W,3) normalised target coordinates
+    mod_bits, raw_bits = fb.nn_noc2target(noc, list(bits))
+    C = sum(bits)
+    logits = (mod_bits.float() * 2 - 1) * (torch.rand(B, C, H, W, generator=g) * 3 + 0.2)
+    logits = torch.where(torch.rand(B, C, H, W, generator=g) < 0.12, -logits, logits)
+    ang = 0.3
+    T = torch.eye(4).repeat(B, 1, 1)
+    T[:, 0, 0] = T[:, 1, 1] = float(np.cos(ang))
+    T[:, 0, 1], T[:, 1, 0] = -float(np.sin(ang)), float(np.sin(ang))
+    T[:, :3, 3] = torch.tensor([1.5, -2.0, 0.5])
+    gt.pop("xyz_noc_tgt")
+    gt.update(xyz_noc_bin_tgt=mod_bits, xyz_noc_bin_raw=raw_bits, bit_cnt=list(bits), model_transform=T)
+    out.pop("xyz_noc")
+    out["xyz_noc_bin"] = logits
+    return gt, out
+
+
+BIN_CFG = dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, dense_sample=2, max_err_len=32), pose_loss_start_step=2,
+               pose_loss_start_epoch=0, loss_pose_nz_step=0, w_loss_noc_bin=1, w_loss_seg=1, w_loss_pose=0.05, seg_loss_type="L1")
 SPARSE_CFG = dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True), pose_loss_start_step=6, pose_loss_start_epoch=0,
                   loss_pose_nz_step=2, w_loss_kpts=1, w_loss_pose=0.7)
 DENSE_CFG = dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scale_grad=True, clip_pts_grad=True, dense_sample=2,
@@ -64,14 +89,14 @@ DENSE_CFG = dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scal
 
 def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None):
     """Shared by the generator (reference class) and the tests (lc_amd class): returns a flat record of the trajectory."""
-    cfg = AttrDict(SPARSE_CFG if kind == "sparse" else DENSE_CFG)
-    fn = Loss_fn_cls(cfg, AttrDict(), 0)
+    cfg = AttrDict({"sparse": SPARSE_CFG, "dense": DENSE_CFG, "bin": BIN_CFG}[kind])
+    fn = Loss_fn_cls(cfg, AttrDict(), 17 if kind == "bin" else 0)
     if device is not None:
         fn = fn.to(device)
     rec = {}
     for i, step in enumerate(steps):
-        gt, out = (sparse_inputs(seed=i) if kind == "sparse" else dense_inputs(seed=i))
-        gt = {k: (v.to(dtype) if v.is_floating_point() else v).to(device) for k, v in gt.items()}
+        gt, out = {"sparse": sparse_inputs, "dense": dense_inputs, "bin": bin_inputs}[kind](seed=i)
+        gt = {k: ((v.to(dtype) if v.is_floating_point() else v).to(device) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
         leaves = {k: v.to(dtype).to(device).clone().requires_grad_(True) for k, v in out.items()}
         np.random.seed(1000 + i)  # random sub-sampling phase (losses.py:152)
         loss_dict, w_loss_dict = fn(gt, leaves, 0, step, 10)
@@ -94,12 +119,12 @@ def gen_lossfn():
     sys.path.insert(0, os.environ.get("LC_REFERENCE", "/root/reference"))
     import losses as ref_losses
 
-    for kind, steps in (("sparse", [0, 2, 4, 6, 9]), ("dense", [0, 1, 2, 5])):
+    for kind, steps in (("sparse", [0, 2, 4, 6, 9]), ("dense", [0, 1, 2, 5]), ("bin", [0, 1, 3])):
         for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
             rec = run(ref_losses.Loss_fn, kind, steps, dt)
             path = os.path.join(HERE, f"lossfn_{kind}_{tag}.npz")
             np.savez_compressed(path, **rec)
-            print(kind, tag, {k: float(v) for k, v in rec.items() if "_loss_" in k and k.startswith("s0")}, os.path.getsize(path) // 1024, "KiB")
+            print(kind, tag, {k: float(v) for k, v in rec.items() if k.startswith("s0_loss_")}, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,51 @@
+"""GPU parity of the binary-code decode kernels against goldens from the reference's floatbits.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import golden_files, case_name, rel_err
+
+pytestmark = pytest.mark.gpu
+FILES = golden_files("bits_")
+
+
+@pytest.mark.parametrize("path", FILES, ids=[case_name(p, "bits_") for p in FILES])
+def test_bits_decode_vs_reference(path):
+    from lc_amd import floatbits as fb
+
+    z = np.load(path)
+    dev = torch.device("cuda:0")
+    bits = [int(b) for b in z["bits"]]
+    lg = torch.from_numpy(z["in_logits"]).to(dev).requires_grad_(True)
+    raw = torch.from_numpy(z["in_raw_bits"]).to(dev)
+    msk = torch.from_numpy(z["in_msk"]).to(dev)
+    out = fb.nn_logits2noc_with_gt(lg, raw, bits, msk)
+    (gl,) = torch.autograd.grad(out, lg, torch.from_numpy(z["in_ct"]).to(dev))
+    assert rel_err(out.detach().cpu(), z["f64_noc_gt"]) <= 2e-6
+    assert rel_err(gl.cpu(), z["f64_g_logits"]) <= 5e-6
+    inf = fb.nn_logits2noc(lg.detach(), bits)
+    assert rel_err(inf.cpu(), z["f64_noc_inf"]) <= 2e-6
+
+
+def test_bits_strided_subset_and_zlmo_shape():
+    """Sub-sample first, decode second (losses.py:163-184) on a 128x128 map with the zlmo bit budget."""
+    from lc_amd import floatbits as fb
+    from oracle import floatbits_oracle as orc
+
+    g = torch.Generator().manual_seed(2)
+    B, H, W, bits = 2, 128, 128, [7, 7, 6]
+    noc = torch.rand(B, H, W, 3, generator=g) * 2 - 1
+    mod, raw = fb.nn_noc2target(noc, bits)
+    lg = (mod.float() * 2 - 1) * (torch.rand(B, sum(bits), H, W, generator=g) * 3 + 0.1)
+    lg = torch.where(torch.rand(lg.shape, generator=g) < 0.1, -lg, lg)
+    msk = torch.rand(B, H, W, generator=g) > 0.2
+    dev = torch.device("cuda:0")
+    x = lg.to(dev).requires_grad_(True)
+    out = fb.decode_with_gt_strided(x, raw.to(dev), bits, msk.to(dev), sample=3, top_left=(1, 2))
+    x64 = lg.double().requires_grad_(True)
+    ref = orc.nn_logits2noc_with_gt(x64[..., 1::3, 2::3], raw[..., 1::3, 2::3], bits, msk[..., 1::3, 2::3]).flatten(1, 2)
+    assert out.shape == ref.shape and rel_err(out.detach().cpu(), ref.detach()) <= 2e-6
+    ct = torch.randn(out.shape, generator=g)
+    (gk,) = torch.autograd.grad(out, x, ct.to(dev))
+    (go,) = torch.autograd.grad(ref, x64, ct.double())
+    assert rel_err(gk.cpu(), go) <= 5e-6

@@ -1,4 +1,6 @@
 """GPU parity of the fused dense front end against the reference's op sequence (oracle/dense_oracle.py)."""
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -45,7 +47,7 @@ def test_dense_loss_fn_end_to_end_on_gpu():
     for k in z.files:
         if k == "steps":
             continue
-        if "_loss_" in k or "_wloss_" in k:
+        if re.match(r"s\d+_w?loss_", k):
             assert abs(float(rec[k]) - float(z[k])) <= 1e-4 * max(1.0, abs(float(z[k]))), k
         elif "_grad_" in k:
             assert rel_err(rec[k], z[k]) <= 2e-3, k
@@ -64,7 +66,27 @@ def test_sparse_loss_fn_end_to_end_on_gpu():
     for k in z.files:
         if k == "steps":
             continue
-        if "_loss_" in k or "_wloss_" in k:
+        if re.match(r"s\d+_w?loss_", k):
             assert abs(float(rec[k]) - float(z[k])) <= 1e-4 * max(1.0, abs(float(z[k]))), k
         else:
             assert rel_err(rec[k], z[k]) <= 2e-3, k
+
+
+def test_bin_loss_fn_end_to_end_on_gpu():
+    """ZebraPose structure: binary-code decode kernels + fused front end + fused loss vs the reference trajectory."""
+    import os
+    from lc_amd.losses import Loss_fn
+    from tests.golden.gen_golden_lossfn import run
+    from tests.util import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "lossfn_bin_f64.npz"))
+    rec = run(Loss_fn, "bin", list(z["steps"]), torch.float32, device=torch.device("cuda:0"))
+    for k in z.files:
+        if k == "steps":
+            continue
+        if re.match(r"s\d+_w?loss_", k):
+            assert abs(float(rec[k]) - float(z[k])) <= 1e-4 * max(1.0, abs(float(z[k]))), k
+        elif "_grad_" in k:
+            assert rel_err(rec[k], z[k]) <= 2e-3, k
+        else:
+            assert rel_err(rec[k], z[k]) <= 1e-3, k

@@ -78,7 +78,7 @@ def test_cer_solver_surface_on_oracle_backend(oracle_backend):
     assert torch.equal(st2, b["start"]) and not inv2["invalids"].any()
 
 
-@pytest.mark.parametrize("kind", ["sparse", "dense"])
+@pytest.mark.parametrize("kind", ["sparse", "dense", "bin"])
 def test_loss_fn_matches_reference_trajectory(oracle_backend, kind):
     """lc_amd.losses.Loss_fn (host logic) + oracle loss == the reference's Loss_fn over the warm-up ramp, incl. the
     NormClipper.max_norm buffer trajectory and the gradients on the network outputs."""
@@ -97,7 +97,7 @@ def test_loss_fn_matches_reference_trajectory(oracle_backend, kind):
     z32 = np.load(os.path.join(GOLDEN, f"lossfn_{kind}_f32.npz"))
     rec32 = run(Loss_fn, kind, list(z32["steps"]), torch.float32)
     for k in z32.files:
-        if "_loss_" in k or "_wloss_" in k:
+        if re.match(r"s\d+_w?loss_", k):
             assert abs(float(rec32[k]) - float(z32[k])) <= 1e-4 * max(1.0, abs(float(z32[k]))), k
 
 
@@ -109,8 +109,8 @@ def test_loss_fn_state_dict_keys_match_reference_checkpoints():
     assert list(fn.state_dict().keys()) == ["weight_grad_clipper.max_norm"]
     fn2 = Loss_fn(AttrDict(pose_loss_cfg=dict(clip_weight_grad=True, clip_scale_grad=True, clip_pts_grad=True)), AttrDict())
     assert set(fn2.state_dict()) == {"weight_grad_clipper.max_norm", "scale_grad_clipper.max_norm", "pts_grad_clipper.max_norm"}
-    with pytest.raises(NotImplementedError):
-        Loss_fn(AttrDict(pose_loss_cfg=dict()), AttrDict(), total_bit_cnt=16)
+    fn3 = Loss_fn(AttrDict(pose_loss_cfg=dict()), AttrDict(), total_bit_cnt=16)
+    assert set(fn3.state_dict()) == {"weight_grad_clipper.max_norm", "xyz_bin_loss_fn.histogram"}  # losses.py:199
 
 
 def test_dense_matching_shapes_and_phase():
