@@ -108,6 +108,18 @@ int lc_dense_frontend_bwd_f32(const float *wlogits, const float *wscale, const f
                               int sample, float *d_xyz, float *d_wlogits, float *d_wscale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (2g) PnP initialiser -- takes the place of lib/pnp/cv2_solver.py:69-88 (cv2.solvePnPRansac, EPnP,
+ *      iterationsCount=150) in front of the weighted solve: RANSAC over P3P minimal samples, one wavefront per pose,
+ *      `iterations` hypotheses rounded up to a multiple of 64.  Same zero-padded batch layout as (2a).
+ *      reproj_err in pixels (scalar, or per pose when reproj_err_per_pose != NULL, test.py:56-57,116-118).
+ *      -> states (B,7) w,x,y,z,tx,ty,tz; inlier_mask (B,Nmax) uint8; n_inliers (B); invalid (B) (1: fewer than 4 points
+ *      or no hypothesis with >= 4 inliers; states is then the identity pose like the reference's zero rvec/tvec).
+ * ------------------------------------------------------------------------------------------------ */
+int lc_pnp_ransac_init_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
+                           float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
+                           float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (2f) ZebraPose binary surface codes -- floatbits.py.  logits (B,C,H,W), C = n0+n1+n2 code bits
  *      (x,y,z axes back to back, floatbits.py:35-48); black_background as floatbits.py:7-11.
  *      lc_bits_decode_gt_*: floatbits.py:130-160 + :108-118 (training decode against the raw ground-truth bits gt_bits

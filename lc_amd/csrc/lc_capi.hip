@@ -273,6 +273,17 @@ int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const f
     return lc::launch_dense_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end backward launch failed") : 0;
 }
 
+int lc_pnp_ransac_init_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+                           float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
+                           unsigned char* inlier_mask, int* n_inliers, int* invalid, void* stream) {
+    if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
+    lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
+                       (iterations + 63) / 64, reproj_err, seed};
+    return lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream)) ? fail(11, "ransac kernel launch failed") : 0;
+}
+
 static int bits_check(int B, int C, int H, int W, int n0, int n1, int n2, int top, int left, int sample) {
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (n0 < 1 || n1 < 1 || n2 < 1 || n0 > 24 || n1 > 24 || n2 > 24 || n0 + n1 + n2 != C) return fail(1, "bad bit counts");

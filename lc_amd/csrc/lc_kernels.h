@@ -67,6 +67,22 @@ struct HeadBwdParams {
 };
 int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream);
 
+struct RansacParams {
+    const float* K;        // (B,3,3)
+    const float* pts3d;    // (B,Nmax,3)
+    const float* pts2d;    // (B,Nmax,2)
+    const int* counts;     // (B,) or null
+    const float* reproj_err_per_pose;  // (B,) or null (use reproj_err)
+    float* states;         // (B,7) out
+    unsigned char* inlier_mask;  // (B,Nmax) out
+    int* n_inliers;        // (B,) out
+    int* invalid;          // (B,) out
+    int B, Nmax, rounds;
+    float reproj_err;
+    unsigned seed;
+};
+int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);
+
 struct BitsParams {
     const float* logits;          // (B,C,H,W) code logits, C = bits[0]+bits[1]+bits[2]
     const unsigned char* gt_bits; // (B,C,H,W) raw ground-truth bits (training decode) or null

@@ -1,2 +1,2 @@
 """`lib.pnp` call surface: `cer_solver.solve` (torch-facing) and `pnp_ceres.solve` (marshaller)."""
-from . import cer_solver, pnp_ceres  # noqa: F401
+from . import cer_solver, pnp_ceres, gpu_solver  # noqa: F401

@@ -1,0 +1,66 @@
+"""GPU initialiser with the call surface of `lib.pnp.cv2_solver.solve` (`lib/pnp/cv2_solver.py:8-60`).
+
+    invalids, states, inliers = gpu_solver.solve(K, pts3d, pts2d, reprojectionError=2)
+
+RANSAC over P3P minimal samples (one wavefront per pose, >= 150 hypotheses like the reference's iterationsCount),
+optionally polished by a few unweighted LM iterations on the inliers (the role EPnP-on-inliers plays inside
+cv2.solvePnPRansac).  Everything stays on the device; `inliers` are per-pose index tensors like the reference returns.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from . import cer_solver, pnp_ceres
+
+
+def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True):
+    """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool."""
+    lib = _lib.load()
+    K = _lib.require_hip_f32("cam_mat", cam_mat)
+    X = _lib.require_hip_f32("coord_3d", coord_3d)
+    U = _lib.require_hip_f32("coord_2d", coord_2d)
+    B, N = X.shape[:2]
+    dev = X.device
+    counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
+    per_pose = None
+    if isinstance(reprojectionError, torch.Tensor):
+        per_pose = reprojectionError.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
+        reprojectionError = 0.0
+    states = torch.empty(B, 7, device=dev, dtype=torch.float32)
+    mask = torch.empty(B, N, device=dev, dtype=torch.uint8)
+    n_in = torch.empty(B, device=dev, dtype=torch.int32)
+    invalid = torch.empty(B, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        rc = lib.lc_pnp_ransac_init_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError),
+                                        _lib.ptr(per_pose), int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask),
+                                        _lib.ptr(n_in), _lib.ptr(invalid), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_ransac_init_f32")
+    inl = mask.bool()
+    bad = invalid.bool()
+    if refine:
+        w = inl.to(torch.float32).unsqueeze(-1).expand(B, N, 2).contiguous()  # unit information on inliers, zero elsewhere
+        st, _, ret = pnp_ceres.solve_device(K, X, U, w, states, counts, max_iter_count=20)
+        states = torch.where((ret != 0)[:, None] | bad[:, None], states, st)
+    return states, inl, bad
+
+
+def solve(cam_mat, coord_3d, coord_2d, *, reprojectionError=3.0, confidence=0.99, num_workers=1, **kwargs):
+    """`cv2_solver.solve` surface: tensors or per-pose lists -> (invalids, states, inliers) as tuples of per-pose items."""
+    single = not isinstance(coord_2d, (list, tuple)) and coord_2d.dim() == 2
+    if single:
+        cam_mat, coord_3d, coord_2d = cam_mat[None], coord_3d[None], coord_2d[None]
+    n_points = None
+    if isinstance(coord_3d, (list, tuple)):
+        n_points = [len(c) for c in coord_3d]
+        dev = coord_3d[0].device
+        cam_mat, coord_3d, coord_2d, n_points = cer_solver._batch_tensors(cam_mat, coord_3d, coord_2d, n_points, device=dev)
+    states, inl, bad = solve_device(cam_mat, coord_3d, coord_2d, n_points, reprojectionError=reprojectionError,
+                                    iterations=kwargs.get("iterationsCount", 150), seed=kwargs.get("seed", 0),
+                                    refine=kwargs.get("refine", True))
+    invalids = tuple(bool(v) for v in bad.tolist())
+    st = tuple(states.unbind(0))
+    inliers = tuple(torch.nonzero(m, as_tuple=False)[:, 0] if not b else m.new_zeros(0, dtype=torch.int64) for m, b in zip(inl, invalids))
+    if single:
+        return invalids[0], st[0], inliers[0]
+    return invalids, st, inliers
