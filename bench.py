@@ -54,9 +54,11 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
     for nt in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         one(nt)
-        t0 = time.perf_counter()
-        one(nt)
-        dt1 = time.perf_counter() - t0
+        dt1 = float("inf")
+        for _ in range(3):  # best of three: shared hosts are noisy
+            t0 = time.perf_counter()
+            one(nt)
+            dt1 = min(dt1, time.perf_counter() - t0)
         if best is None or dt1 < best[1]:
             best = (nt, dt1)
     cores = best[0]
