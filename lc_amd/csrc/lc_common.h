@@ -97,14 +97,97 @@ __device__ __forceinline__ int scatter16_base(int lane, int R) {
     return R * (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1));
 }
 
-// 1/x to full double precision without the IEEE division sequence (v_rcp_f64 + two Newton steps; x finite, non-zero,
-// normal -- every use below is a pivot, a depth or a norm that is checked separately)
+// 1/x without the IEEE division sequence: v_rcp_f64 (measured 4.5e-8 relative on gfx950, scripts/ubench/rcp_accuracy.cpp)
+// + one Newton step -> 2.2e-15.  x finite, non-zero, normal -- every use is a pivot, a depth or a norm that is checked
+// separately.  ~29 cycles for a lone wave against ~72 for `1.0 / x` (scripts/ubench/fp64_latency.cpp).
 __device__ __forceinline__ double fast_rcp(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-x, y, 1.0);
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, y, 1.0);
     return __builtin_fma(y, e, y);
+}
+
+// sqrt(x) and 1/sqrt(x) from v_rsq_f64 + one coupled Goldschmidt step (4e-15 relative; ~39 cycles against ~104 for sqrt()).
+// x >= 0; x == 0 gives sqrt 0 / rsqrt +inf.
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+    const double r0 = __builtin_amdgcn_rsq(x);
+    const double g = x * r0, h = 0.5 * r0;
+    const double rr = __builtin_fma(-h, g, 0.5);
+    const double g1 = __builtin_fma(g, rr, g), h1 = __builtin_fma(h, rr, h);
+    s = x == 0.0 ? 0.0 : g1;
+    rs = x == 0.0 ? r0 : 2.0 * h1;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    double s, rs;
+    fast_sqrt_rsqrt(x, s, rs);
+    return s;
+}
+
+// Sum of K doubles per lane over the 64 lanes of a ONE-WAVE workgroup, result in every lane, through LDS:
+// lane l stores v[k] at lds[k*66 + l] (row stride 66 doubles: conflict-free ds_write_b64 and ds_read_b128), lane l < 2K
+// sums half a row (32 doubles, sixteen 16-byte reads), the two halves meet by DPP, the K totals are re-read by all lanes.
+// Measured cheaper than the permlane/DPP reduce-scatter + broadcast for a lone wave (each 64-bit cross-lane exchange
+// costs 25-32 cycles, scripts/ubench/fp64_latency.cpp).  Needs K <= 32 and lds of K*66 + K doubles.
+template <int K>
+__device__ __forceinline__ void wave_sum_bcast_lds(double (&v)[K], double* lds, int lane) {
+    static_assert(K <= 32, "two reader lanes per value");
+    constexpr int LD = 66;
+    __syncthreads();  // the previous totals have been read
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[k * LD + lane] = v[k];
+    __syncthreads();
+    double s = 0;
+    if (lane < 2 * K) {
+        const double2* row = reinterpret_cast<const double2*>(lds + (lane >> 1) * LD + 32 * (lane & 1));
+        double2 a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = row[i];
+#pragma unroll
+        for (int st = 8; st >= 1; st >>= 1) {
+#pragma unroll
+            for (int i = 0; i < st; ++i) { a[i].x += a[i + st].x; a[i].y += a[i + st].y; }
+        }
+        s = a[0].x + a[0].y;
+    }
+    s += dpp_mov_f64<kDppQuadXor1>(s, s);
+    double* tot = lds + K * LD;
+    if (lane < 2 * K && (lane & 1) == 0) tot[lane >> 1] = s;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = tot[k];
+}
+
+// sin and cos of a rotation angle 0 <= x <~ 8 (angle-axis norms; the LM keeps them within a few pi): Cody-Waite reduction
+// by pi/2 into [-pi/4, pi/4] and the fdlibm minimax polynomials (|error| < 1 ulp on that interval).  About a third of the
+// instructions of the general sincos(), whose Payne-Hanek path for huge arguments is never needed here.
+__device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
+    if (!(x < 1.0e4)) {  // wave-uniform and never taken in practice: keep full-range correctness anyway
+        sincos(x, &s, &c);
+        return;
+    }
+    const double kf = __builtin_rint(x * 0.63661977236758134308);  // x * 2/pi
+    const int q = (int)kf;
+    double r = __builtin_fma(-kf, 1.57079632673412561417e+00, x);   // pi/2 split in three parts (fdlibm pio2_1, _2, _3)
+    r = __builtin_fma(-kf, 6.07710050650619224932e-11, r);
+    r = __builtin_fma(-kf, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    // sin(r) ~ r + r^3 (S1 + z (S2 + ... )),  cos(r) ~ 1 - z/2 + z^2 (C1 + z (C2 + ...))   (fdlibm k_sin.c / k_cos.c)
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(ps * z, r, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
+    const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
 }
 
 // index of (i,j), i<=j, in a packed upper-triangular 6x6 (21 entries, row-major)

@@ -9,9 +9,9 @@
 namespace lc {
 namespace {
 
-union FusedShared {
+union __attribute__((aligned(16))) FusedShared {
     loss::LossShared loss;
-    double bc[32];
+    double bc[pnp::kPnpLdsDoubles];
 };
 
 __global__ __launch_bounds__(64) void lc_pose_unit_kernel(const LossParams lp, const PnpParams pp) {

@@ -14,6 +14,7 @@
 //   loss = log P + (C + L) / (2 P)
 // and its hand-derived reverse mode (see DESIGN.md "LC-loss backward").
 #pragma once
+#include <type_traits>
 #include "lc_common.h"
 #include "lc_kernels.h"
 
@@ -287,9 +288,9 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     LC_STAMP(3);
     // ---------------- pass 3: accumulate H (21) | Mc (21) | v (6) ----------------
     double acc[48];
-#pragma unroll
-    for (int i = 0; i < 48; ++i) acc[i] = 0;
-    auto accumulate = [&](const Pt& pt, const double e[2]) {
+    // first == true: acc is written, not added to (a lane that owns one point needs no zero-fill and no extra add)
+    auto accumulate = [&](const Pt& pt, const double e[2], auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         const Proj pr = project(pc, pt.X);
         const PointJac pj = point_jac(pc, pt.X, pr);
         double w[2], cc[2];
@@ -298,21 +299,6 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
             cc[c] = huber(fabs(e[c]), dlt_e[c]);
             const double ds = sqrt(mwe[c] / (cc[c] + 1e-6));
             w[c] = huber(pt.s[c], ds);
-        }
-        // first-order part
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const double wc = w[c], w2c = w[c] * w[c] * cc[c], we = w[c] * e[c];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double wj = wc * pj.J[c][i], mj = w2c * pj.J[c][i];
-#pragma unroll
-                for (int j = i; j < 6; ++j) {
-                    acc[tri6(i, j)] += wj * pj.J[c][j];
-                    acc[21 + tri6(i, j)] += mj * pj.J[c][j];
-                }
-                acc[42 + i] += we * pj.J[c][i];
-            }
         }
         // second-order part  sum_c w_c r_c Hess(r_c)  (pnp_auto.py:59-83; exact 2nd derivative, see oracle)
         const double rho0 = pc.K[0] * w[0] * pj.r[0] + pc.K[3] * w[1] * pj.r[1];
@@ -332,25 +318,39 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 #pragma unroll
         for (int l = 0; l < 3; ++l) pi[l] = pc.R[l] * pv[0] + pc.R[3 + l] * pv[1] + pc.R[6 + l] * pv[2];
         const double piX = pi[0] * pt.X[0] + pi[1] * pt.X[1] + pi[2] * pt.X[2];
+        const double m0 = w[0] * w[0] * cc[0], m1 = w[1] * w[1] * cc[1], we0 = w[0] * e[0], we1 = w[1] * e[1];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
+            const double wj0 = w[0] * pj.J[0][i], wj1 = w[1] * pj.J[1][i], mj0 = m0 * pj.J[0][i], mj1 = m1 * pj.J[1][i];
 #pragma unroll
             for (int j = i; j < 6; ++j) {
-                double h = t2[i] * tq[j] + tq[i] * t2[j];
+                double h = t2[i] * tq[j] + tq[i] * t2[j];  // compile-time zeros of t2 fold away
                 if (i < 3 && j < 3) h += 0.5 * (pi[i] * pt.X[j] + pt.X[i] * pi[j]) - (i == j ? piX : 0.0);
-                acc[tri6(i, j)] += h;
+                const double hv = __builtin_fma(wj1, pj.J[1][j], __builtin_fma(wj0, pj.J[0][j], h));
+                const double mv = __builtin_fma(mj1, pj.J[1][j], mj0 * pj.J[0][j]);
+                acc[tri6(i, j)] = FIRST ? hv : acc[tri6(i, j)] + hv;
+                acc[21 + tri6(i, j)] = FIRST ? mv : acc[21 + tri6(i, j)] + mv;
             }
+            const double vv = __builtin_fma(we1, pj.J[1][i], we0 * pj.J[0][i]);
+            acc[42 + i] = FIRST ? vv : acc[42 + i] + vv;
         }
     };
     if constexpr (REG) {
-        if (active) accumulate(rp, re);
+        if (active) {
+            accumulate(rp, re, std::true_type{});
+        } else {
+#pragma unroll
+            for (int i = 0; i < 48; ++i) acc[i] = 0;
+        }
     } else {
+#pragma unroll
+        for (int i = 0; i < 48; ++i) acc[i] = 0;
         for (int n = tid; n < N; n += nthr) {
             const Pt pt = load_pt(p, base, n);
             const Proj pr = project(pc, pt.X);
             double e[2];
             clamp_err(pt.u, pr.proj, max_len, e);
-            accumulate(pt, e);
+            accumulate(pt, e, std::false_type{});
         }
     }
     LC_STAMP(4);

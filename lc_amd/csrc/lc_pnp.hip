@@ -6,7 +6,7 @@ namespace {
 
 template <bool REG>
 __global__ __launch_bounds__(64) void lc_pnp_lm_kernel(const PnpParams p) {
-    __shared__ double bc[32];
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles];
     pnp::solve_pose<REG>(p, blockIdx.x, threadIdx.x, bc);
 }
 

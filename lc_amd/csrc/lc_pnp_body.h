@@ -21,8 +21,34 @@
 #include "lc_common.h"
 #include "lc_kernels.h"
 
+// Diagnostic build only (-DLC_STAMPS, scripts/diag_stamps.py): per-phase s_memtime sums, written to p.result_tr's
+// neighbour buffer p.iters (reinterpreted) which nothing else reads in that build.  Never defined in the shipped library.
+#ifdef LC_STAMPS
+#define LC_PSTAMP_DECL unsigned long long pst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0_ = 0, pt1_ = 0
+#define LC_PSTAMP_BEGIN()                                                                 \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt0_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#define LC_PSTAMP(i)                                                                      \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt1_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        pst_[i] += pt1_ - pt0_;                                                           \
+        pt0_ = pt1_;                                                                      \
+    } while (0)
+#else
+#define LC_PSTAMP_DECL
+#define LC_PSTAMP_BEGIN() do {} while (0)
+#define LC_PSTAMP(i) do {} while (0)
+#endif
+
 namespace lc {
 namespace pnp {
+
+constexpr int kPnpLdsDoubles = 28 * 66 + 28;  // wave_sum_bcast_lds<28>
 
 struct Point {
     double X[3];
@@ -41,10 +67,11 @@ __device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
     const double x = aa[0], y = aa[1], z = aa[2];
     const double th2 = x * x + y * y + z * z;
     const bool small = !(th2 > DBL_EPSILON);  // ceres/rotation.h AngleAxisRotatePoint: pt + aa x pt, derivative -[pt]x
-    const double th = sqrt(th2);
+    double th, ith;
+    fast_sqrt_rsqrt(th2, th, ith);
     double s, c;
-    sincos(th, &s, &c);
-    const double ith = fast_rcp(th), ith2 = ith * ith;
+    sincos_small(th, s, c);
+    const double ith2 = ith * ith;
     const double A = small ? 1.0 : s * ith;
     const double B = small ? 0.0 : (1.0 - c) * ith2;
     const double C = small ? 0.0 : (th - s) * ith2 * ith;
@@ -62,8 +89,10 @@ __device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
 
 // adds one correspondence's contribution to acc = [J^T J upper (21) | J^T r (6) | r^T r | pad]
 // (columns of J pre-multiplied by the Jacobi scaling sc: acc holds Js^T Js and Js^T r directly)
+// FIRST: acc is written (not added to) -- saves zero-filling 32 accumulators and one add per entry when a lane owns one point.
+template <bool FIRST>
 __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt, const double t[3], const double k[6],
-                                                 const double (&sc)[6], double (&acc)[32]) {
+                                                 const double (&sc)[6], double (&acc)[28]) {
     double q[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) q[d] = rt.R[3 * d] * pt.X[0] + rt.R[3 * d + 1] * pt.X[1] + rt.R[3 * d + 2] * pt.X[2] + t[d];
@@ -95,10 +124,15 @@ __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt,
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = i; j < 6; ++j) acc[tri6(i, j)] += J[0][i] * J[0][j] + J[1][i] * J[1][j];
-        acc[21 + i] += J[0][i] * r[0] + J[1][i] * r[1];
+        for (int j = i; j < 6; ++j) {
+            const double v = __builtin_fma(J[0][i], J[0][j], J[1][i] * J[1][j]);
+            acc[tri6(i, j)] = FIRST ? v : acc[tri6(i, j)] + v;
+        }
+        const double gi = __builtin_fma(J[0][i], r[0], J[1][i] * r[1]);
+        acc[21 + i] = FIRST ? gi : acc[21 + i] + gi;
     }
-    acc[27] += r[0] * r[0] + r[1] * r[1];
+    const double ss = __builtin_fma(r[0], r[0], r[1] * r[1]);
+    acc[27] = FIRST ? ss : acc[27] + ss;
 }
 
 // solve (A + diag(dg)) y = rhs for symmetric A (packed upper 21) by LDL^T; false if a pivot is not positive/finite
@@ -166,13 +200,15 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
     double m = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) m += v[j] * v[j];
-    return sqrt(m);
+    return fast_sqrt(m);
 }
 
-// One pose per wavefront (64 threads). bc: 32 doubles of LDS owned by this wavefront.
+// One pose per wavefront (64 threads). bc: kPnpLdsDoubles doubles of LDS owned by this wavefront.
 // REG: Nmax <= 64, each lane keeps its correspondence in registers across the whole solve.
 template <bool REG>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
+    LC_PSTAMP_DECL;
+    LC_PSTAMP_BEGIN();
     const int n = p.counts ? p.counts[b] : p.Nmax;
     const float* st_in = (p.start ? p.start : p.states) + 7 * (size_t)b;
     if (n < 3) {  // ceres.cpp:84-91
@@ -205,7 +241,8 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         x[0] = q1 * kk; x[1] = q2 * kk; x[2] = q3 * kk;
         x[3] = st_in[4]; x[4] = st_in[5]; x[5] = st_in[6];
     }
-    Point rp;
+    LC_PSTAMP(0);
+    Point rp = {{0.0, 0.0, 1.0}, 0.0, 0.0, 0.0, 0.0, 0.0};  // harmless dummy for lanes without a correspondence
     const bool active = lane < n;
     if constexpr (REG) {
         if (active) rp = load_point(p, base, lane, cam);
@@ -213,34 +250,36 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
 
     // full evaluation at xe with column scaling sc: H = Js^T Js (21), g = Js^T r (6), cost; false when anything is non-finite
     auto evaluate = [&](const double (&xe)[6], const double (&sc)[6], double (&H)[21], double (&g)[6], double& cost) -> bool {
+        LC_PSTAMP(1);
         Rot rt;
         make_rot(xe, rt);
+        LC_PSTAMP(2);
         const double t[3] = {xe[3], xe[4], xe[5]};
-        double acc[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) acc[i] = 0;
+        double acc[28];
         if constexpr (REG) {
-            if (active) accumulate_point(rp, rt, t, cam, sc, acc);
+            accumulate_point<true>(rp, rt, t, cam, sc, acc);  // inactive lanes hold a dummy point; zeroed below
+            if (!active) {
+#pragma unroll
+                for (int i = 0; i < 28; ++i) acc[i] = 0;
+            }
         } else {
-            for (int i = lane; i < n; i += kWave) accumulate_point(load_point(p, base, i, cam), rt, t, cam, sc, acc);
-        }
-        wave_reduce_scatter16<32>(acc, lane);
-        __syncthreads();  // one-wave workgroup: orders this wave's LDS reads of the previous broadcast before the writes
-        if ((lane & 3) == 0) {
-            const int bs = scatter16_base(lane, 2);
-            bc[bs] = acc[0];
-            bc[bs + 1] = acc[1];
-        }
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 21; ++i) H[i] = bc[i];
+            for (int i = 0; i < 28; ++i) acc[i] = 0;
+            for (int i = lane; i < n; i += kWave) accumulate_point<false>(load_point(p, base, i, cam), rt, t, cam, sc, acc);
+        }
+        LC_PSTAMP(3);
+        wave_sum_bcast_lds<28>(acc, bc, lane);
+        LC_PSTAMP(4);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g[i] = bc[21 + i];
-        const double ss = bc[27];
+        for (int i = 0; i < 21; ++i) H[i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = acc[21 + i];
+        const double ss = acc[27];
         cost = 0.5 * ss;
         double chk = ss;  // every term is >= 0: the sum is finite iff all residuals and Jacobian entries are
 #pragma unroll
         for (int i = 0; i < 6; ++i) chk += H[tri6(i, i)];
+        LC_PSTAMP(5);
         return chk <= DBL_MAX;
     };
 
@@ -286,14 +325,11 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         for (int i = 0; i < 6; ++i) dg[i] = fmin(fmax(H[tri6(i, i)], 1e-6), 1e32) * inv_radius;
         bool step_ok = ldlt_solve6(H, dg, g, y);
         // model_cost_change = y.g - y^T H y / 2 with (H + D) y = g  =>  (y.g + sum d_i y_i^2) / 2   (step = -y)
-        double mcc = 0, ysum = 0;
+        double mcc = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            mcc += y[i] * (g[i] + dg[i] * y[i]);
-            ysum += fabs(y[i]);
-        }
+        for (int i = 0; i < 6; ++i) mcc += y[i] * (g[i] + dg[i] * y[i]);
         mcc *= 0.5;
-        step_ok = step_ok && (ysum <= DBL_MAX) && (mcc > 0.0);
+        step_ok = step_ok && (mcc > 0.0) && (mcc <= DBL_MAX);  // a non-finite y makes mcc non-finite
         if (!step_ok) {  // HandleInvalidStep
             if (++n_invalid >= 5) { failed = true; break; }
             radius /= dfac; dfac *= 2.0;
@@ -304,8 +340,10 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
 #pragma unroll
         for (int j = 0; j < 6; ++j) { delta[j] = -y[j] * scale[j]; xc[j] = x[j] + delta[j]; }
         const double step_norm = norm6(delta);
-        double Hc[21], gc[6], cost_c;
-        const bool cand_ok = evaluate(xc, scale, Hc, gc, cost_c);
+        // the candidate's H, g overwrite the current ones (an accepted step then needs no copy and no second Jacobian);
+        // a rejected step -- rare -- restores them by re-evaluating at x
+        double cost_c;
+        const bool cand_ok = evaluate(xc, scale, H, g, cost_c);
         if (!cand_ok) cost_c = DBL_MAX;
         if (step_norm <= ptol * (xnorm + ptol)) { converged = true; break; }  // ParameterToleranceReached
         const double cost_change = cost - cost_c;
@@ -313,9 +351,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         const double rel = cost_change * fast_rcp(mcc);
         if (rel > 1e-3) {  // HandleSuccessfulStep
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { x[j] = xc[j]; g[j] = gc[j]; }
-#pragma unroll
-            for (int j = 0; j < 21; ++j) H[j] = Hc[j];
+            for (int j = 0; j < 6; ++j) x[j] = xc[j];
             cost = cost_c;
             xnorm = norm6(x);
             gmax = grad_max(g);
@@ -324,14 +360,26 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             dfac = 2.0;
         } else {
             radius /= dfac; dfac *= 2.0;
+            double cost_again;
+            if (!evaluate(x, scale, H, g, cost_again)) { failed = true; break; }
         }
     }
+    LC_PSTAMP(1);
+#ifdef LC_STAMPS
+    if (lane == 0 && p.iters) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.iters) + 8 * (size_t)b;
+        for (int i = 0; i < 6; ++i) o[i] = pst_[i];
+        o[6] = iter;
+    }
+#endif
     const bool invalid = failed || !converged;
     if (invalid && p.start && lane < 7) p.states[7 * (size_t)b + lane] = st_in[lane];
     if (lane == 0) {
         p.rets[b] = invalid ? 1 : 0;
         p.result_tr[b] = (float)radius;
+#ifndef LC_STAMPS
         if (p.iters) p.iters[b] = iter;
+#endif
         if (!invalid) {  // ceres.cpp:131-144: AngleAxisToQuaternion, write back in place
             float* st = p.states + 7 * (size_t)b;
             const double t2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];

@@ -11,7 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/liblc_amd_diag.so"
-srcs = [os.path.join(ROOT, "lc_amd", "csrc", f) for f in ("lc_capi.hip", "lc_fused.hip", "lc_head.hip", "lc_loss.hip", "lc_pnp.hip")]
+import glob
+srcs = sorted(glob.glob(os.path.join(ROOT, "lc_amd", "csrc", "*.hip")))
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLC_STAMPS", *srcs, "-o", so])
 os.environ["LC_AMD_LIB"] = so
 from lc_amd import synth  # noqa: E402
@@ -31,3 +32,20 @@ tot = st[:, 11] - st[:, 0]
 print(f"total cycles/workgroup: median {np.median(tot):.0f}  (min {tot.min()}, max {tot.max()})")
 for i in range(11):
     print(f"  {names[i + 1]:22s} {np.median(d[:, i]):8.0f}  {100 * np.median(d[:, i]) / np.median(tot):5.1f} %")
+
+# ---- PnP LM kernel: phase sums over the whole solve ----
+lib = __import__("lc_amd._lib", fromlist=["x"]).load()
+from lc_amd import _lib  # noqa: E402
+states = torch.empty_like(b["start"]); tr = torch.empty(B, device=dev); ret = torch.empty(B, device=dev, dtype=torch.int32)
+stamps = torch.zeros(B, 16, device=dev, dtype=torch.int32)  # 8 x uint64 per pose
+P = _lib.ptr
+for rep in range(3):
+    rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), None, P(b["start"]), P(states), P(tr), P(ret),
+                           P(stamps), B, N, 50, 1e-6, None)
+    torch.cuda.synchronize()
+ps = stamps.cpu().numpy().view(np.uint64).reshape(B, 8).astype(np.int64)
+iters = ps[:, 6]
+tot = ps[:, :6].sum(1)
+print(f"\nPnP: total cycles/wave median {np.median(tot):.0f}; LM iterations mean {iters.mean():.2f} (min {iters.min()}, max {iters.max()})")
+for i, nm in enumerate(["prologue (loads, quat->aa)", "LM algebra (solve, tests)", "make_rot (sincos)", "accumulate J^T J", "reduce-scatter 32", "LDS broadcast"]):
+    print(f"  {nm:28s} {np.median(ps[:, i]):8.0f}  {100 * np.median(ps[:, i]) / np.median(tot):5.1f} %   per evaluation {np.median(ps[:, i] / (iters + 1)):7.0f}")
