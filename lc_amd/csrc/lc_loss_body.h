@@ -87,7 +87,7 @@ __device__ __forceinline__ Proj project(const PoseConst& pc, const double X[3]) 
 // clamp_error (cov_mixed.py:16-24): cap the 2-vector length at max_len, identity gradient
 __device__ __forceinline__ void clamp_err(const double u[2], const double proj[2], double max_len, double e[2]) {
     const double e0 = u[0] - proj[0], e1 = u[1] - proj[1];
-    const double len = sqrt(e0 * e0 + e1 * e1) + 1e-6;
+    const double len = fast_sqrt(e0 * e0 + e1 * e1) + 1e-6;
     // f = (len - max)/len > 0  <=>  len > max (len >= 1e-6 > 0);  e = err - f err
     const double f = len > max_len ? (len - max_len) * fast_rcp(len) : 0.0;
     e[0] = e0 - f * e0;
@@ -212,9 +212,10 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 #pragma unroll
         for (int i = 0; i < 9; ++i) pc.K[i] = Kp[i];
         const double q[4] = {ps[0], ps[1], ps[2], ps[3]};
-        pc.rho = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-        quat_matrix(q, 2.0 / pc.rho, pc.R);
-        quat_matrix(q, 2.0 / (pc.rho * pc.rho), pc.Rt);
+        double irho;
+        fast_sqrt_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3], pc.rho, irho);
+        quat_matrix(q, 2.0 * irho, pc.R);
+        quat_matrix(q, 2.0 * irho * irho, pc.Rt);
         pc.t[0] = ps[4]; pc.t[1] = ps[5]; pc.t[2] = ps[6];
     }
     if (tid < 2) sh.bad[tid] = 0;
@@ -255,7 +256,8 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     }
     block_allreduce_small<3>(s1, sh.small, lane, wave, nw);
     const double vcnt = p.valid ? s1[2] : (double)N;
-    const double dlt_e[2] = {s1[0] / vcnt * rel_thresh, s1[1] / vcnt * rel_thresh};  // Huber knee of |e|
+    const double ivcnt = fast_rcp(vcnt);  // vcnt == 0 (no valid point) gives NaN like the reference's 0/0
+    const double dlt_e[2] = {s1[0] * ivcnt * rel_thresh, s1[1] * ivcnt * rel_thresh};  // Huber knee of |e|
 
     LC_STAMP(2);
     // ---------------- pass 2: c, mean(s^2 c) (cov_mixed.py:32-36) ----------------
@@ -283,7 +285,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         }
     }
     block_allreduce_small<2>(s2, sh.small, lane, wave, nw);
-    const double mwe[2] = {s2[0] / vcnt * w_e_thresh, s2[1] / vcnt * w_e_thresh};
+    const double mwe[2] = {s2[0] * ivcnt * w_e_thresh, s2[1] * ivcnt * w_e_thresh};
 
     LC_STAMP(3);
     // ---------------- pass 3: accumulate H (21) | Mc (21) | v (6) ----------------
@@ -297,7 +299,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             cc[c] = huber(fabs(e[c]), dlt_e[c]);
-            const double ds = sqrt(mwe[c] / (cc[c] + 1e-6));
+            const double ds = fast_sqrt(mwe[c] * fast_rcp(cc[c] + 1e-6));
             w[c] = huber(pt.s[c], ds);
         }
         // second-order part  sum_c w_c r_c Hess(r_c)  (pnp_auto.py:59-83; exact 2nd derivative, see oracle)
@@ -446,11 +448,10 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         const int q = tid >> 3, k = tid & 7;
         const double* src = q == 0 ? sh.pd : (q == 1 ? sh.cd : sh.dl);
         const double a0 = src[3 * k], a1 = src[3 * k + 1], a2 = src[3 * k + 2];
-        double val;
-        if (q == 2) val = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-        else val = sqrt(sh.bad[q] ? 1.0 : a0 + a1 + a2);
+        double val, ival;
+        fast_sqrt_rsqrt(q == 2 ? a0 * a0 + a1 * a1 + a2 * a2 : (sh.bad[q] ? 1.0 : a0 + a1 + a2), val, ival);
         sh.sq[tid] = val;
-        sh.isq[tid] = val > 0 ? 1.0 / val : 0.0;  // norm backward at 0 is 0 (torch.linalg.vector_norm)
+        sh.isq[tid] = val > 0 ? ival : 0.0;  // norm backward at 0 is 0 (torch.linalg.vector_norm)
     } else if (tid < 30) {
         const int a = tid - 24;
         double acc2 = 0;
@@ -467,7 +468,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         Pm += sP[k]; Cm += sC[k]; Lm += sL[k];
     }
     Pm *= 0.125; Cm *= 0.125; Lm *= 0.125;
-    const double iP = 1.0 / Pm;
+    const double iP = fast_rcp(Pm);
     const double loss = log(Pm) + 0.5 * (Cm + Lm) * iP;
     const double gout = p.grad_out ? (double)p.grad_out[b] : 1.0;
     if (tid == 0) {
@@ -547,7 +548,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             cc[c] = huber(fabs(e[c]), dlt_e[c]);
-            dsk[c] = sqrt(mwe[c] / (cc[c] + 1e-6));
+            dsk[c] = fast_sqrt(mwe[c] * fast_rcp(cc[c] + 1e-6));
             w[c] = huber(pt.s[c], dsk[c]);
         }
         // h2 = Hbar * t2 with t2 = (M0[2,:], 0, 0, 1);  q3 = Hbar_ww X - tr(Hbar_ww) X   (Hs off-diagonals are doubled)
@@ -601,7 +602,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         if (p.d_pts3d) {
             // err = u - proj: dX = -(d proj/d X)^T ge, d proj_a/dX = (KR[a,:] - zpass * proj_a KR[2,:]) / zc
             double gx[3];
-            const double izc = 1.0 / pr.zc;
+            const double izc = fast_rcp(pr.zc);  // zc >= 0.1
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 const double kr0 = pc.K[0] * pc.R[l] + pc.K[1] * pc.R[3 + l] + pc.K[2] * pc.R[6 + l];
