@@ -138,11 +138,17 @@ __device__ __forceinline__ void wave_sum_bcast_lds(double (&v)[K], double* lds, 
     double s = 0;
     if (lane < 2 * K) {
         const double2* row = reinterpret_cast<const double2*>(lds + (lane >> 1) * LD + 32 * (lane & 1));
-        double2 a[16];
+        double2 a[8];  // two batches of eight 16-byte reads: keeps the register peak (and so the occupancy) down
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = row[i];
+        for (int i = 0; i < 8; ++i) a[i] = row[i];
 #pragma unroll
-        for (int st = 8; st >= 1; st >>= 1) {
+        for (int i = 0; i < 8; ++i) {
+            const double2 t = row[8 + i];
+            a[i].x += t.x;
+            a[i].y += t.y;
+        }
+#pragma unroll
+        for (int st = 4; st >= 1; st >>= 1) {
 #pragma unroll
             for (int i = 0; i < st; ++i) { a[i].x += a[i + st].x; a[i].y += a[i + st].y; }
         }

@@ -14,7 +14,8 @@ union __attribute__((aligned(16))) FusedShared {
     double bc[pnp::kPnpLdsDoubles];
 };
 
-__global__ __launch_bounds__(64) void lc_pose_unit_kernel(const LossParams lp, const PnpParams pp) {
+template <int WPS>  // see lc_pnp.hip: 1 = latency build for small grids, 2 = occupancy build for large ones
+__global__ __launch_bounds__(64, WPS) void lc_pose_unit_kernel(const LossParams lp, const PnpParams pp) {
     __shared__ FusedShared sh;
     if ((int)blockIdx.x < pp.B)
         pnp::solve_pose<true>(pp, blockIdx.x, threadIdx.x, sh.bc);
@@ -28,7 +29,10 @@ int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stre
     if (lp.N > 64 || pp.Nmax > 64 || lp.N <= 0) return 3;
     const int blocks = (lp.B > 0 ? lp.B : 0) + (pp.B > 0 ? pp.B : 0);
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(lc_pose_unit_kernel, dim3(blocks), dim3(64), 0, stream, lp, pp);
+    if (blocks > kLatencyGridMax)
+        hipLaunchKernelGGL(lc_pose_unit_kernel<2>, dim3(blocks), dim3(64), 0, stream, lp, pp);
+    else
+        hipLaunchKernelGGL(lc_pose_unit_kernel<1>, dim3(blocks), dim3(64), 0, stream, lp, pp);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

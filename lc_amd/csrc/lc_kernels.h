@@ -4,7 +4,10 @@
 
 namespace lc {
 
-constexpr int kLossAuxStride = 40;  // P, C, L, not_spd, Hinv[36]
+constexpr int kLossAuxStride = 40;
+// up to this many one-wave workgroups use the register-rich 'latency' build (1 wave/SIMD, no spills); beyond it the
+// 2-waves/SIMD build wins (measured: B = 768 -> 19 us, B = 1024 -> 57 us with the latency build vs 19.5 us with the other)
+constexpr int kLatencyGridMax = 768;  // P, C, L, not_spd, Hinv[36]
 
 struct LossParams {
     const float* K;         // (B,3,3)
