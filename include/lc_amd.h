@@ -77,6 +77,13 @@ int lc_pose_unit_f32(const float *K, const float *pose, const float *pts3d, cons
                      const float *pnp_sqrt_diag, const float *pnp_start, float *pnp_states, float *pnp_result_tr,
                      int *pnp_rets, int pnp_max_iter, float pnp_function_tolerance, void *stream);
 
+/* same with the cov_2d switch of cov_mixed.py:111,125-130 (covariance of the PROJECTED bbox corners; no reference call site
+ * enables it, losses.py:333,383) */
+int lc_cov_loss2_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,
+                             const float *inv_std, const float *valid, const float *bbox_3d, const float *grad_out,
+                             int B, int N, float max_err_len, float rel_thresh, float w_e_thresh, int cov_2d, float *loss,
+                             float *d_pts2d, float *d_inv_std, float *d_pts3d, float *aux, void *stream);
+
 /* dst[b, :] = scale[b] * src[b, :]  for up to three (B,row_len) tensors in one launch (autograd's chain-rule step) */
 int lc_scale_rows_f32(const float *scale, int B, const float *src0, float *dst0, int len0, const float *src1, float *dst1,
                       int len1, const float *src2, float *dst2, int len2, void *stream);

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "pnp_ceres_f32_omp": (None, [_FP, _FP, _FP, _FP, _FP, _I, c_int, c_float, c_int, _F, _I, c_int, c_int]),
     "lc_pnp_lm_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p]),
     "lc_cov_loss_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 6),
+    "lc_cov_loss2_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float, c_int] + [c_void_p] * 6),
     "lc_pose_unit_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 9 +
                          [c_int, c_float, c_void_p]),
     "lc_scale_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -13,7 +13,7 @@ from . import _lib
 
 
 def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_len, rel_thresh, w_e_thresh,
-                 want_grads: bool, want_pts3d: bool, want_aux: bool = False):
+                 want_grads: bool, want_pts3d: bool, want_aux: bool = False, cov_2d: bool = False):
     """One fused launch.  Returns loss (B,), d_pts2d, d_inv_std, d_pts3d, aux (None where not requested)."""
     lib = _lib.load()
     B, N = pts3d.shape[0], pts3d.shape[1]
@@ -23,11 +23,11 @@ def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_
     d_x = torch.empty_like(pts3d) if (want_grads and want_pts3d) else None
     aux = torch.empty(B, 40, device=pts3d.device, dtype=torch.float32) if want_aux else None
     with torch.cuda.device(pts3d.device):
-        rc = lib.lc_cov_loss_fwd_bwd_f32(
+        rc = lib.lc_cov_loss2_fwd_bwd_f32(
             _lib.ptr(K), _lib.ptr(pose), _lib.ptr(pts3d), _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(valid), _lib.ptr(bbox),
-            _lib.ptr(grad_out), B, N, float(max_err_len), float(rel_thresh), float(w_e_thresh), _lib.ptr(loss), _lib.ptr(d_u),
+            _lib.ptr(grad_out), B, N, float(max_err_len), float(rel_thresh), float(w_e_thresh), int(cov_2d), _lib.ptr(loss), _lib.ptr(d_u),
             _lib.ptr(d_s), _lib.ptr(d_x), _lib.ptr(aux), _lib.stream_ptr(pts3d.device))
-    _lib.check(rc, "lc_cov_loss_fwd_bwd_f32")
+    _lib.check(rc, "lc_cov_loss2_fwd_bwd_f32")
     return loss, d_u, d_s, d_x, aux
 
 
@@ -46,11 +46,11 @@ def _launch_scale(scale, srcs):
 
 class _LossCovMixedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, K, pose, pts3d, pts2d, inv_std, valid, bbox, max_err_len, rel_thresh, w_e_thresh):
+    def forward(ctx, K, pose, pts3d, pts2d, inv_std, valid, bbox, max_err_len, rel_thresh, w_e_thresh, cov_2d=False):
         need = ctx.needs_input_grad
         want_grads = need[2] or need[3] or need[4]
         loss, d_u, d_s, d_x, _ = _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, None, max_err_len, rel_thresh,
-                                              w_e_thresh, want_grads, need[2])
+                                              w_e_thresh, want_grads, need[2], cov_2d=cov_2d)
         ctx.have = (d_x is not None, want_grads)
         saved = [t for t in (d_x, d_u, d_s) if t is not None]
         ctx.save_for_backward(*saved)
@@ -60,27 +60,25 @@ class _LossCovMixedFn(torch.autograd.Function):
     def backward(ctx, gout):
         have_x, have = ctx.have
         if not have:
-            return (None,) * 10
+            return (None,) * 11
         saved = list(ctx.saved_tensors)
         d_x = saved.pop(0) if have_x else None
         d_u, d_s = saved
         gout = gout.contiguous().to(torch.float32)
         g_x, g_u, g_s = _launch_scale(gout, [d_x, d_u, d_s])
-        return None, None, g_x, g_u, g_s, None, None, None, None, None
+        return None, None, g_x, g_u, g_s, None, None, None, None, None, None
 
 
 def Loss_cov_mixed(K_out: Tensor, pose_gt: Tensor, pts3d: Tensor, pts2d_out: Tensor, inv_std2d: Tensor, valid_factor: Tensor,
                    **kwargs) -> Tensor:
     """Drop-in for `lib.cov_mixed.Loss_cov_mixed` (cov_mixed.py:100-150).
 
-    kwargs: bbox_3d (required), max_err_len=32, rel_thresh=3, w_e_thresh=4, cov_2d=False (the 2D variant is never
-    enabled by any reference call site -- losses.py:333,383 -- and is not implemented).
+    kwargs: bbox_3d (required), max_err_len=32, rel_thresh=3, w_e_thresh=4, cov_2d=False (covariance of the projected
+    bbox corners instead of the 3D ones, cov_mixed.py:125-130; no reference call site enables it -- losses.py:333,383).
     Gradients flow to pts2d_out, inv_std2d and pts3d; K_out / pose_gt / bbox_3d are treated as constants, as every
     reference caller passes ground-truth (non-differentiable) tensors there.
     """
     bbox_3d = kwargs["bbox_3d"]
-    if kwargs.get("cov_2d", False):
-        raise NotImplementedError("lc_amd: cov_2d=True is not used by any reference call site and is not implemented")
     for name, t in (("K_out", K_out), ("pose_gt", pose_gt), ("bbox_3d", bbox_3d)):
         if t.requires_grad:
             raise NotImplementedError(f"lc_amd: gradient w.r.t. {name} is not provided by the fused kernel")
@@ -95,11 +93,11 @@ def Loss_cov_mixed(K_out: Tensor, pose_gt: Tensor, pts3d: Tensor, pts2d_out: Ten
         valid = _lib.require_hip_f32("valid_factor", valid_factor.to(torch.float32).expand(B, N))
     return _LossCovMixedFn.apply(args["K_out"], args["pose_gt"], args["pts3d"], args["pts2d_out"], args["inv_std2d"], valid,
                                  args["bbox_3d"], kwargs.get("max_err_len", 32), kwargs.get("rel_thresh", 3),
-                                 kwargs.get("w_e_thresh", 4))
+                                 kwargs.get("w_e_thresh", 4), bool(kwargs.get("cov_2d", False)))
 
 
 def loss_cov_mixed_fused(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out=None, want_pts3d=True, want_aux=False,
-                         max_err_len=32, rel_thresh=3, w_e_thresh=4):
+                         max_err_len=32, rel_thresh=3, w_e_thresh=4, cov_2d=False):
     """Non-autograd entry: loss AND input gradients for a known cotangent in ONE launch (bench / training loops that
     know d(total)/d(loss_b) up front, e.g. 1/B for `.mean()`).  Returns (loss, d_pts2d, d_inv_std, d_pts3d, aux)."""
     ts = [_lib.require_hip_f32(n, t) for n, t in (("K", K), ("pose", pose), ("pts3d", pts3d), ("pts2d", pts2d),
@@ -107,4 +105,4 @@ def loss_cov_mixed_fused(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_ou
     valid = None if valid is None else _lib.require_hip_f32("valid", valid)
     grad_out = None if grad_out is None else _lib.require_hip_f32("grad_out", grad_out)
     return _launch_loss(ts[0], ts[1], ts[2], ts[3], ts[4], valid, ts[5], grad_out, max_err_len, rel_thresh, w_e_thresh,
-                        True, want_pts3d, want_aux)
+                        True, want_pts3d, want_aux, cov_2d=cov_2d)

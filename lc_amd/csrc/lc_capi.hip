@@ -187,13 +187,21 @@ int lc_cov_loss_fwd_bwd_f32(const float* K, const float* pose, const float* pts3
                             const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
                             float rel_thresh, float w_e_thresh, float* loss, float* d_pts2d, float* d_inv_std, float* d_pts3d,
                             float* aux, void* stream) {
+    return lc_cov_loss2_fwd_bwd_f32(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, B, N, max_err_len, rel_thresh,
+                                    w_e_thresh, 0, loss, d_pts2d, d_inv_std, d_pts3d, aux, stream);
+}
+
+int lc_cov_loss2_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
+                             const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
+                             float rel_thresh, float w_e_thresh, int cov_2d, float* loss, float* d_pts2d, float* d_inv_std,
+                             float* d_pts3d, float* aux, void* stream) {
     if (B < 0 || N <= 0) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss) return fail(1, "null pointer");
     if ((d_pts2d == nullptr) != (d_inv_std == nullptr)) return fail(1, "d_pts2d and d_inv_std must both be given or both be NULL");
     if (d_pts3d && !d_pts2d) return fail(1, "d_pts3d needs d_pts2d/d_inv_std");
     lc::LossParams p{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, aux,
-                     B, N, max_err_len, rel_thresh, w_e_thresh};
+                     B, N, max_err_len, rel_thresh, w_e_thresh, cov_2d ? 1 : 0};
     if (lc::launch_cov_loss(p, static_cast<hipStream_t>(stream))) return fail(11, "loss kernel launch failed");
     return 0;
 }
@@ -210,7 +218,7 @@ int lc_pose_unit_f32(const float* K, const float* pose, const float* pts3d, cons
         !pnp_start || !pnp_states || !pnp_result_tr || !pnp_rets)
         return fail(1, "null pointer");
     lc::LossParams lp{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, nullptr,
-                      B, N, max_err_len, rel_thresh, w_e_thresh};
+                      B, N, max_err_len, rel_thresh, w_e_thresh, 0};
     lc::PnpParams pp{K, pts2d, pts3d, nullptr, pnp_sqrt_diag, nullptr, pnp_start == pnp_states ? nullptr : pnp_start, pnp_states,
                      pnp_result_tr, pnp_rets, nullptr, B, N, pnp_max_iter, pnp_function_tolerance};
     if (lc::launch_pose_unit(lp, pp, static_cast<hipStream_t>(stream))) return fail(11, "pose-unit kernel launch failed");

@@ -25,6 +25,7 @@ struct LossParams {
     float* aux;             // (B,kLossAuxStride) or null
     int B, N;
     float max_err_len, rel_thresh, w_e_thresh;
+    int cov_2d;  // 0: 3D bbox-corner covariance (every reference call site); 1: projected corners (cov_mixed.py:125-127)
 };
 int launch_cov_loss(const LossParams& p, hipStream_t stream);
 

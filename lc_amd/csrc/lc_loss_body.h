@@ -197,7 +197,8 @@ __device__ __forceinline__ Pt load_pt(const LossParams& p, size_t base, int n) {
 
 // REG: the block has at least N threads, each point's raw inputs and clamped error stay in registers.
 // !REG: block-stride over points; raw inputs are re-read (L1/L2 hits) and e re-derived in every pass.
-template <bool REG>
+// COV2D: covariance of the projected bbox corners (cov_mixed.py:125-127) instead of the 3D ones (every reference call site).
+template <bool REG, bool COV2D = false>
 __device__ __forceinline__ void sample(const LossParams& p, const int b, LossShared& sh) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
@@ -221,8 +222,10 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     if (tid < 2) sh.bad[tid] = 0;
     // bbox corner of this lane's Jacobian row, fetched now so its HBM latency hides under passes 1-3
     double bbx = 0, bby = 0, bbz = 0;
-    if (tid < 24) {
-        const float* bb = p.bbox + ((size_t)b * 8 + tid / 3) * 3;
+    constexpr int gdim = COV2D ? 2 : 3;  // rows per bbox corner: projected (u,v) or transformed (x,y,z)   (cov_mixed.py:125-130)
+    constexpr int grows = 8 * gdim;
+    if (tid < grows) {
+        const float* bb = p.bbox + ((size_t)b * 8 + tid / gdim) * 3;
         bbx = bb[0]; bby = bb[1]; bbz = bb[2];
     }
 
@@ -408,31 +411,56 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     // step A: lanes 0..23 own one row g_j = [ -rho (Rt[d,:] x b_k) | e_d ] of the bbox Jacobian (jac_update2alter,
     // cov_mixed.py:42-65):  h_j = S g_j;  diag(G S G^T)_j = g.h;  diag(G S Mc S G^T)_j = h^T Mc h;  (G S v)_j = h.v
     // lanes 28..63 form McS = Mc * S meanwhile.
-    if (tid < 24) {
-        const int d = tid % 3;
-        // static selects (a runtime-indexed pc.Rt[3*d] would push the whole PoseConst to scratch)
-        const double r0 = d == 0 ? pc.Rt[0] : (d == 1 ? pc.Rt[3] : pc.Rt[6]);
-        const double r1 = d == 0 ? pc.Rt[1] : (d == 1 ? pc.Rt[4] : pc.Rt[7]);
-        const double r2 = d == 0 ? pc.Rt[2] : (d == 1 ? pc.Rt[5] : pc.Rt[8]);
-        const double g0 = -pc.rho * (r1 * bbz - r2 * bby);
-        const double g1 = -pc.rho * (r2 * bbx - r0 * bbz);
-        const double g2 = -pc.rho * (r0 * bby - r1 * bbx);
-        double h[6];
+    if (tid < grows) {
+        double h[6], pd;
+        if constexpr (!COV2D) {  // xform_3d (cov_mixed.py:73-75): rows g = [ -rho (Rt[d,:] x b) | e_d ]
+            const int d = tid % 3;
+            // static selects (a runtime-indexed pc.Rt[3*d] would push the whole PoseConst to scratch)
+            const double r0 = d == 0 ? pc.Rt[0] : (d == 1 ? pc.Rt[3] : pc.Rt[6]);
+            const double r1 = d == 0 ? pc.Rt[1] : (d == 1 ? pc.Rt[4] : pc.Rt[7]);
+            const double r2 = d == 0 ? pc.Rt[2] : (d == 1 ? pc.Rt[5] : pc.Rt[8]);
+            const double g0 = -pc.rho * (r1 * bbz - r2 * bby);
+            const double g1 = -pc.rho * (r2 * bbx - r0 * bbz);
+            const double g2 = -pc.rho * (r0 * bby - r1 * bbx);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            h[i] = S[6 * i] * g0 + S[6 * i + 1] * g1 + S[6 * i + 2] * g2 + S[6 * i + 3 + d];  // g[3+d] = 1
-            sh.G[6 * tid + i] = h[i];  // G holds the rows h_j
+            for (int i = 0; i < 6; ++i) h[i] = S[6 * i] * g0 + S[6 * i + 1] * g1 + S[6 * i + 2] * g2 + S[6 * i + 3 + d];  // g[3+d] = 1
+            pd = g0 * h[0] + g1 * h[1] + g2 * h[2] + (d == 0 ? h[3] : (d == 1 ? h[4] : h[5]));
+        } else {  // xform_2d (cov_mixed.py:78-80): project_apply of the corner, chained with the 3D rows above
+            const int a = tid % 2;
+            const double bX[3] = {bbx, bby, bbz};
+            const Proj pr = project(pc, bX);
+            const double izc = fast_rcp(pr.zc);
+            double pa[3], g[6];  // d proj_a / d Xc = (K[a,:] - zpass proj_a K[2,:]) / zc
+#pragma unroll
+            for (int l = 0; l < 3; ++l) pa[l] = ((a == 0 ? pc.K[l] : pc.K[3 + l]) - pr.zpass * pr.proj[a] * pc.K[6 + l]) * izc;
+            // sum_d pa[d] * (-rho (Rt[d,:] x b)) = -rho ((pa^T Rt) x b)
+            const double v0 = pa[0] * pc.Rt[0] + pa[1] * pc.Rt[3] + pa[2] * pc.Rt[6];
+            const double v1 = pa[0] * pc.Rt[1] + pa[1] * pc.Rt[4] + pa[2] * pc.Rt[7];
+            const double v2 = pa[0] * pc.Rt[2] + pa[1] * pc.Rt[5] + pa[2] * pc.Rt[8];
+            g[0] = -pc.rho * (v1 * bbz - v2 * bby);
+            g[1] = -pc.rho * (v2 * bbx - v0 * bbz);
+            g[2] = -pc.rho * (v0 * bby - v1 * bbx);
+            g[3] = pa[0]; g[4] = pa[1]; g[5] = pa[2];
+            pd = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double acc2 = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc2 += S[6 * i + k] * g[k];
+                h[i] = acc2;
+                pd += g[i] * acc2;
+            }
         }
-        const double pd = g0 * h[0] + g1 * h[1] + g2 * h[2] + (d == 0 ? h[3] : (d == 1 ? h[4] : h[5]));
         double dl = 0, cd = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
+            sh.G[6 * tid + i] = h[i];  // G holds the rows h_j
             dl += h[i] * vp[i];
 #pragma unroll
             for (int j = i; j < 6; ++j) cd += (i == j ? 1.0 : 2.0) * Mp[tri6(i, j)] * (h[i] * h[j]);
         }
         sh.pd[tid] = pd; sh.cd[tid] = cd; sh.dl[tid] = dl;
-        if (!(pd > 0)) sh.bad[0] = 1;  // loss_cov_3d 'good' (cov_mixed.py:83-89)
+        if (!(pd > 0)) sh.bad[0] = 1;  // loss_cov_3d / loss_cov_2d 'good' (cov_mixed.py:83-97)
         if (!(cd > 0)) sh.bad[1] = 1;
     } else if (tid >= 28 && tid < 64) {
         const int e = tid - 28, a = e / 6, c = e % 6;
@@ -447,7 +475,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     if (tid < 24) {
         const int q = tid >> 3, k = tid & 7;
         const double* src = q == 0 ? sh.pd : (q == 1 ? sh.cd : sh.dl);
-        const double a0 = src[3 * k], a1 = src[3 * k + 1], a2 = src[3 * k + 2];
+        const double a0 = src[gdim * k], a1 = src[gdim * k + 1], a2 = COV2D ? 0.0 : src[gdim * k + (COV2D ? 1 : 2)];
         double val, ival;
         fast_sqrt_rsqrt(q == 2 ? a0 * a0 + a1 * a1 + a2 * a2 : (sh.bad[q] ? 1.0 : a0 + a1 + a2), val, ival);
         sh.sq[tid] = val;
@@ -499,7 +527,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         for (int k = 0; k < 8; ++k) {
             double hh = 0;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) hh += sh.G[6 * (3 * k + d) + mi] * sh.G[6 * (3 * k + d) + mj];
+            for (int d = 0; d < gdim; ++d) hh += sh.G[6 * (gdim * k + d) + mi] * sh.G[6 * (gdim * k + d) + mj];
             fp += sh.isq[k] * hh;
             fc += sh.isq[8 + k] * hh;
         }
@@ -512,7 +540,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         for (int k = 0; k < 8; ++k) {
             double hd = 0;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) hd += sh.dl[3 * k + d] * sh.G[6 * (3 * k + d) + a];
+            for (int d = 0; d < gdim; ++d) hd += sh.dl[gdim * k + d] * sh.G[6 * (gdim * k + d) + a];
             l += sh.isq[16 + k] * hd;
         }
         sh.mu[a] = l * (aC * 0.125);  // cL_k = aC / (8 sL_k)

@@ -117,18 +117,31 @@ def bbox_jacobian(R_true: Tensor, rho: Tensor, bbox: Tensor) -> Tensor:
     return torch.cat((rot, eye3), -1).reshape(B, 24, 6)
 
 
-def loss_cov_3d(diag: Tensor) -> Tensor:
-    """`lib/cov_mixed.py:83-89`."""
+def loss_cov_3d(diag: Tensor, dim: int = 3) -> Tensor:
+    """`lib/cov_mixed.py:83-89` (dim=3) and `loss_cov_2d` `:91-97` (dim=2)."""
     B = len(diag)
     good = (diag > 0).all(dim=-1, keepdim=True)
-    pw = diag.reshape(B, -1, 3)
+    pw = diag.reshape(B, -1, dim)
     return torch.where(good, pw.sum(-1), 1).sqrt().mean(-1)
 
 
+def bbox_jacobian_2d(K: Tensor, R: Tensor, t: Tensor, R_true: Tensor, rho: Tensor, bbox: Tensor) -> Tensor:
+    """`jac_update2alter` with `xform_2d` (cov_mixed.py:78-80): d(project_apply(K, R b + t))/d(delta) at 0, (B,16,6)."""
+    B = bbox.shape[0]
+    G3 = bbox_jacobian(R_true, rho, bbox).reshape(B, 8, 3, 6)
+    Xc = bbox @ R.mT + t[:, None, :]
+    xf = Xc @ K.mT
+    zpass = (xf[..., 2:3] >= 0.1).to(K.dtype)
+    zc = xf[..., 2:3].clamp(min=0.1)
+    proj = xf[..., :2] / zc
+    Pa = (K[:, None, :2, :] - zpass[..., None] * proj[..., None] * K[:, None, 2:3, :]) / zc[..., None]  # (B,8,2,3)
+    return (Pa @ G3).reshape(B, 16, 6)
+
+
 def loss_cov_mixed(K: Tensor, pose: Tensor, pts3d: Tensor, pts2d: Tensor, inv_std: Tensor,
-                   valid: Tensor | None, *, bbox_3d: Tensor, max_err_len=32, rel_thresh=3, w_e_thresh=4,
+                   valid: Tensor | None, *, bbox_3d: Tensor, max_err_len=32, rel_thresh=3, w_e_thresh=4, cov_2d=False,
                    return_intermediates: bool = False):
-    """Closed form of `lib/cov_mixed.py:100-150` (cov_2d=False branch, the only one any caller uses)."""
+    """Closed form of `lib/cov_mixed.py:100-150` (cov_2d=False is the branch every caller uses)."""
     R, R_true, rho = quaternion_to_matrix(pose[..., :4])
     t = pose[..., 4:7]
     proj = project_apply(K, pts3d, R, t)
@@ -165,16 +178,20 @@ def loss_cov_mixed(K: Tensor, pose: Tensor, pts3d: Tensor, pts2d: Tensor, inv_st
     S = torch.cholesky_inverse(L)  # prior_update_cov (pnp_auto.py:107)
     A = torch.einsum('bkj,bncj,bnc->bknc', S, J, w).flatten(-2)  # (B,6,2N)  = H^-1 J^T W
 
-    G = bbox_jacobian(R_true.detach(), rho.detach(), bbox_3d)
+    gdim = 2 if cov_2d else 3
+    if cov_2d:
+        G = bbox_jacobian_2d(K.detach(), R.detach(), t.detach(), R_true.detach(), rho.detach(), bbox_3d)
+    else:
+        G = bbox_jacobian(R_true.detach(), rho.detach(), bbox_3d)
     prior_diag = ((G @ S) * G).sum(-1)  # transformed_cov_from_jac (:68-70)
-    prior_error = loss_cov_3d(prior_diag)
+    prior_error = loss_cov_3d(prior_diag, gdim)
     cc = c.flatten(-2)
     half = (A * cc.unsqueeze(-2)) @ A.mT * 0.5
     U = half + half.mT
     cov_diag = ((G @ U) * G).sum(-1)
-    cov_err = loss_cov_3d(cov_diag)
+    cov_err = loss_cov_3d(cov_diag, gdim)
     dlt = (G @ (A @ e.detach().flatten(-2).unsqueeze(-1))).squeeze(-1)
-    lin = torch.linalg.vector_norm(dlt.reshape(dlt.shape[:-1] + (8, 3)), dim=-1).mean(-1)
+    lin = torch.linalg.vector_norm(dlt.reshape(dlt.shape[:-1] + (8, gdim)), dim=-1).mean(-1)
     loss = prior_error.log() + 0.5 * (cov_err + lin) / prior_error
     if return_intermediates:
         return loss, dict(w=w, c=c, Hinv=S, A=A, G=G, e=e, info=info,

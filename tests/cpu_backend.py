@@ -8,11 +8,11 @@ from oracle import lc_loss_oracle, pnp_oracle
 
 
 def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_len, rel_thresh, w_e_thresh, want_grads, want_pts3d,
-                 want_aux=False):
+                 want_aux=False, cov_2d=False):
     with torch.enable_grad():  # we are called from inside autograd.Function.forward (grad mode off)
         loss, du, ds, dx = lc_loss_oracle.loss_and_grads(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out=grad_out,
                                                          want_pts3d=want_pts3d, max_err_len=max_err_len, rel_thresh=rel_thresh,
-                                                         w_e_thresh=w_e_thresh)
+                                                         w_e_thresh=w_e_thresh, cov_2d=cov_2d)
     if not want_grads:
         du = ds = dx = None
     return loss, du, ds, dx, None

@@ -104,6 +104,10 @@ def loss_cases():
     b["pose"][:, :4] *= torch.tensor([[1.3], [0.8], [1.0]], dtype=torch.float64)
     cases["nonunit_quat_B3_N16"] = dict(b, valid=None, want_pts3d=True)
 
+    # covariance of the projected bbox corners (cov_2d=True; no call site uses it, cov_mixed.py:125-127)
+    b = synth.make_batch(4, 16, seed=13, dtype=torch.float64)
+    cases["cov2d_B4_N16"] = dict(b, valid=None, want_pts3d=True, kwargs=dict(cov_2d=True))
+
     # noise-free (err == 0): linear_err norm at 0, c == 0
     b = synth.make_batch(2, 16, seed=12, dtype=torch.float64, outlier_frac=0.0, noise_px=0.0)
     cases["noisefree_B2_N16"] = dict(b, valid=None)
@@ -137,7 +141,10 @@ def run_reference_loss(case, dtype):
         ec = cov_mixed.clamp_error(err, kwargs.get("max_err_len", 32))
         w, c = cov_mixed.robust_weights_cov(s.detach(), ec, valid)
         A, Hinv = pnp_auto.weighted_pnp_jac_wrt_pts2d(proj, pose, K, X.detach(), w, with_cov=True)
-        G = cov_mixed.jac_update2alter(pose, lambda st: cov_mixed.xform_3d(st, bbox))
+        if kwargs.get("cov_2d", False):
+            G = cov_mixed.jac_update2alter(pose, lambda st: cov_mixed.xform_2d(st, K, bbox))
+        else:
+            G = cov_mixed.jac_update2alter(pose, lambda st: cov_mixed.xform_3d(st, bbox))
     out.update(w=w.detach(), c=c.detach(), Hinv=Hinv.detach(), A=A.detach().flatten(-2), G=G.detach(), e=ec.detach())
     return {k: v.numpy() for k, v in out.items()}
 
