@@ -174,8 +174,8 @@ int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const 
                   const int* counts, const float* start, float* states, float* result_tr, int* rets, int* iters, int B, int Nmax,
                   int max_iter, float function_tolerance, void* stream) {
     if (B < 0 || Nmax < 0) return fail(1, "negative size");
-    if ((sqrtL == nullptr) == (sqrt_diag == nullptr)) return fail(1, "exactly one of sqrtL / sqrt_diag must be given");
     if (B == 0) return 0;
+    if ((sqrtL == nullptr) == (sqrt_diag == nullptr)) return fail(1, "exactly one of sqrtL / sqrt_diag must be given");
     if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
     lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
                     B, Nmax, max_iter, function_tolerance};

@@ -104,6 +104,16 @@ def loss_cases():
     b["pose"][:, :4] *= torch.tensor([[1.3], [0.8], [1.0]], dtype=torch.float64)
     cases["nonunit_quat_B3_N16"] = dict(b, valid=None, want_pts3d=True)
 
+    # general last row of K: project_apply uses the full 3x3 matrix, residual_with_jac6d only K[:2] -> residual != 0
+    b = synth.make_batch(3, 16, seed=14, dtype=torch.float64)
+    b["K"][:, 2] = torch.tensor([1e-4, -2e-4, 1.05], dtype=torch.float64)
+    cases["fullK_B3_N16"] = dict(b, valid=None, want_pts3d=True)
+
+    # minimal problem (N=3: six residual rows for six pose parameters).  N=2 is NOT a fixture: H is then rank-deficient and
+    # the reference's own fp32 and fp64 paths disagree on whether cholesky_ex flags it (round-off decides: 16.98 vs 21.59)
+    b = synth.make_batch(3, 3, seed=15, dtype=torch.float64)
+    cases["n3_B3_N3"] = dict(b, valid=None)
+
     # covariance of the projected bbox corners (cov_2d=True; no call site uses it, cov_mixed.py:125-127)
     b = synth.make_batch(4, 16, seed=13, dtype=torch.float64)
     cases["cov2d_B4_N16"] = dict(b, valid=None, want_pts3d=True, kwargs=dict(cov_2d=True))
