@@ -122,22 +122,27 @@ __device__ __forceinline__ double fast_sqrt(double x) {
     return s;
 }
 
-// Sum of K doubles per lane over the 64 lanes of a ONE-WAVE workgroup, result in every lane, through LDS:
-// lane l stores v[k] at lds[k*66 + l] (row stride 66 doubles: conflict-free ds_write_b64 and ds_read_b128), lane l < 2K
-// sums half a row (32 doubles, sixteen 16-byte reads), the two halves meet by DPP, the K totals are re-read by all lanes.
-// Measured cheaper than the permlane/DPP reduce-scatter + broadcast for a lone wave (each 64-bit cross-lane exchange
-// costs 25-32 cycles, scripts/ubench/fp64_latency.cpp).  Needs K <= 32 and lds of K*66 + K doubles.
-template <int K>
-__device__ __forceinline__ void wave_sum_bcast_lds(double (&v)[K], double* lds, int lane) {
-    static_assert(K <= 32, "two reader lanes per value");
-    constexpr int LD = 66;
+// Sum of K doubles per thread over the 64*NW threads of a workgroup, result in every thread, through LDS.
+// Thread t stores v[k] at lds[k*LD + t + 2*(t/32)] (32-double segments padded by 16 bytes, LD = 68*NW doubles: conflict-free
+// ds_write_b64 and ds_read_b128); thread r < K*S (S = 2*NW segments per row) sums one segment with eight + eight 16-byte
+// reads, the S partial sums of a row meet by DPP (S consecutive, S-aligned lanes), the K totals are re-read by all threads.
+// Measured cheaper than the permlane/DPP reduce-scatter + broadcast for a lone wave (each 64-bit cross-lane exchange costs
+// 25-32 cycles, scripts/ubench/fp64_latency.cpp).  Needs K <= 32, NW in {1, 4} and K*68*NW + K doubles of LDS.
+template <int NW>
+constexpr int sum_bcast_lds_doubles(int K) { return K * 68 * NW + K; }
+
+template <int K, int NW>
+__device__ __forceinline__ void block_sum_bcast_lds(double (&v)[K], double* lds, int tid) {
+    static_assert(K <= 32 && (NW == 1 || NW == 4), "unsupported shape");
+    constexpr int LD = 68 * NW, S = 2 * NW;
     __syncthreads();  // the previous totals have been read
+    const int pos = tid + 2 * (tid >> 5);
 #pragma unroll
-    for (int k = 0; k < K; ++k) lds[k * LD + lane] = v[k];
+    for (int k = 0; k < K; ++k) lds[k * LD + pos] = v[k];
     __syncthreads();
     double s = 0;
-    if (lane < 2 * K) {
-        const double2* row = reinterpret_cast<const double2*>(lds + (lane >> 1) * LD + 32 * (lane & 1));
+    if (tid < K * S) {
+        const double2* row = reinterpret_cast<const double2*>(lds + (tid / S) * LD + 34 * (tid % S));
         double2 a[8];  // two batches of eight 16-byte reads: keeps the register peak (and so the occupancy) down
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = row[i];
@@ -155,8 +160,12 @@ __device__ __forceinline__ void wave_sum_bcast_lds(double (&v)[K], double* lds, 
         s = a[0].x + a[0].y;
     }
     s += dpp_mov_f64<kDppQuadXor1>(s, s);
+    if constexpr (NW == 4) {
+        s += dpp_mov_f64<kDppQuadXor2>(s, s);
+        s += dpp_mov_f64<kDppHalfMirror>(s, s);
+    }
     double* tot = lds + K * LD;
-    if (lane < 2 * K && (lane & 1) == 0) tot[lane >> 1] = s;
+    if (tid < K * S && (tid % S) == 0) tot[tid / S] = s;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = tot[k];

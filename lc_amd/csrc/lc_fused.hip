@@ -11,14 +11,14 @@ namespace {
 
 union __attribute__((aligned(16))) FusedShared {
     loss::LossShared loss;
-    double bc[pnp::kPnpLdsDoubles];
+    double bc[pnp::kPnpLdsDoubles<1>];
 };
 
 template <int WPS>  // see lc_pnp.hip: 1 = latency build for small grids, 2 = occupancy build for large ones
 __global__ __launch_bounds__(64, WPS) void lc_pose_unit_kernel(const LossParams lp, const PnpParams pp) {
     __shared__ FusedShared sh;
     if ((int)blockIdx.x < pp.B)
-        pnp::solve_pose<true>(pp, blockIdx.x, threadIdx.x, sh.bc);
+        pnp::solve_pose<true, 1>(pp, blockIdx.x, threadIdx.x, sh.bc);
     else
         loss::sample<true>(lp, (int)blockIdx.x - pp.B, sh.loss);
 }

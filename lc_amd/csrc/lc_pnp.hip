@@ -8,8 +8,15 @@ namespace {
 // idle anyway, spilling would only lengthen the lone wave), 2 for large grids (+43 % throughput at B = 16384).
 template <bool REG, int WPS>
 __global__ __launch_bounds__(64, WPS) void lc_pnp_lm_kernel(const PnpParams p) {
-    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles];
-    pnp::solve_pose<REG>(p, blockIdx.x, threadIdx.x, bc);
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<1>];
+    pnp::solve_pose<REG, 1>(p, blockIdx.x, threadIdx.x, bc);
+}
+
+// four wavefronts per pose for N > 64 (dense heads, ragged inference batches)
+template <bool REG>
+__global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) {
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
+    pnp::solve_pose<REG, 4>(p, blockIdx.x, threadIdx.x, bc);
 }
 
 }  // namespace
@@ -20,9 +27,10 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     if (p.Nmax <= 64) {
         if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 2>), dim3(p.B), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);
+    } else if (p.Nmax <= 256) {
+        hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);
     } else {
-        if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<false, 2>), dim3(p.B), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL((lc_pnp_lm_kernel<false, 1>), dim3(p.B), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<false>, dim3(p.B), dim3(256), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

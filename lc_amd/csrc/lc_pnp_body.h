@@ -48,7 +48,8 @@
 namespace lc {
 namespace pnp {
 
-constexpr int kPnpLdsDoubles = 28 * 66 + 28;  // wave_sum_bcast_lds<28>
+template <int NW>
+constexpr int kPnpLdsDoubles = sum_bcast_lds_doubles<NW>(28);  // block_sum_bcast_lds<28, NW>
 
 struct Point {
     double X[3];
@@ -203,10 +204,13 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
     return fast_sqrt(m);
 }
 
-// One pose per wavefront (64 threads). bc: kPnpLdsDoubles doubles of LDS owned by this wavefront.
-// REG: Nmax <= 64, each lane keeps its correspondence in registers across the whole solve.
-template <bool REG>
+// One pose per workgroup of NW wavefronts (NW = 1: N <= 64, the metric's shape; NW = 4: larger N, e.g. the dense heads'
+// N = 1024..1849, where four waves cut the per-evaluation point loop by four; the wave-uniform LM algebra is simply
+// replicated in every wave).  bc: kPnpLdsDoubles<NW> doubles of LDS.
+// REG: Nmax <= 64*NW, each thread keeps its correspondence in registers across the whole solve.
+template <bool REG, int NW = 1>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
+    constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
     LC_PSTAMP_DECL;
     LC_PSTAMP_BEGIN();
     const int n = p.counts ? p.counts[b] : p.Nmax;
@@ -265,10 +269,10 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         } else {
 #pragma unroll
             for (int i = 0; i < 28; ++i) acc[i] = 0;
-            for (int i = lane; i < n; i += kWave) accumulate_point<false>(load_point(p, base, i, cam), rt, t, cam, sc, acc);
+            for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point(p, base, i, cam), rt, t, cam, sc, acc);
         }
         LC_PSTAMP(3);
-        wave_sum_bcast_lds<28>(acc, bc, lane);
+        block_sum_bcast_lds<28, NW>(acc, bc, lane);
         LC_PSTAMP(4);
 #pragma unroll
         for (int i = 0; i < 21; ++i) H[i] = acc[i];
