@@ -204,6 +204,19 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / reps
 
+    def kernel_percentiles_us(fn, reps=200):
+        """p10 / median / p90 of individually event-timed launches (SURVEY.md 8d timing protocol)."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        fn()
+        torch.cuda.synchronize(dev)
+        for e0, e1 in evs:
+            e0.record()
+            fn()
+            e1.record()
+        torch.cuda.synchronize(dev)
+        ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+        return [ts[reps // 10], ts[reps // 2], ts[(9 * reps) // 10]]
+
     if rank == 0:
         t_loss = kernel_ms(launch_loss)
         t_pnp = kernel_ms(launch_pnp)
@@ -214,6 +227,7 @@ def main():
             t_unit = kernel_ms(step_fused)
             dom = ("lc_pose_unit_kernel", t_unit, by_loss + by_pnp)
             kernel_us["lc_pose_unit_kernel"] = t_unit * 1e3
+            kernel_us["lc_pose_unit_kernel_p10_p50_p90"] = kernel_percentiles_us(step_fused)
         achieved = dom[2] * B / (dom[1] * 1e-3) / 1e9
         out = {
             "metric": "poses/sec (cov-loss fwd+bwd + weighted PnP), B=256 N=64",

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""End-to-end training step around the HIP hot path (BASELINE configs[2]/[3] plumbing, synthetic data):
+
+    backbone (ResNet-34-style encoder + 3-stage up-sampling decoder, plain PyTorch-ROCm: MIOpen/hipBLASLt own the conv GEMMs)
+      -> keypoint logits (B,S,64,64) -> lc_amd.ptnet.sparse_head   (fused spatial softmax + soft-argmax, HIP)
+      -> lc_amd.losses.Loss_fn (Laplace keypoint NLL + LC loss via the fused HIP kernel, warm-up blend)
+      -> backward -> gradient all-reduce over RCCL (DistributedDataParallel) -> Adam step
+
+    python examples/train_sparse_ddp.py --steps 20                       # one GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_sparse_ddp.py --steps 20
+
+The backbone is NOT part of the hot path this repo re-implements; it is here so that the drop-in
+surface can be exercised exactly as `train.py:23-80` uses it.  Random-init weights, synthetic crops and poses.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lc_amd import synth  # noqa: E402
+from lc_amd.config import AttrDict  # noqa: E402
+from lc_amd.losses import Loss_fn  # noqa: E402
+from lc_amd.ptnet import sparse_head  # noqa: E402
+
+
+class Block(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.c1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.b1 = nn.BatchNorm2d(cout)
+        self.c2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.b2 = nn.BatchNorm2d(cout)
+        self.down = None
+        if stride != 1 or cin != cout:
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu(self.b1(self.c1(x)))
+        y = self.b2(self.c2(y))
+        return F.relu(y + (x if self.down is None else self.down(x)))
+
+
+class KeypointNet(nn.Module):
+    """34-layer residual encoder ([3,4,6,3] basic blocks) + three x2 up-sampling stages: 256x256 crop -> (S,64,64) logits."""
+
+    def __init__(self, sparse_cnt=64, width=64, layers=(3, 4, 6, 3)):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(3, width, 7, 2, 3, bias=False), nn.BatchNorm2d(width), nn.ReLU(inplace=True),
+                                  nn.MaxPool2d(3, 2, 1))
+        chans = [width, width * 2, width * 4, width * 8]
+        blocks, cin = [], width
+        for i, (c, n) in enumerate(zip(chans, layers)):
+            for j in range(n):
+                blocks.append(Block(cin, c, 2 if (j == 0 and i > 0) else 1))
+                cin = c
+        self.encoder = nn.Sequential(*blocks)
+        ups, c = [], cin
+        for _ in range(3):
+            ups += [nn.ConvTranspose2d(c, 256, 3, 2, 1, output_padding=1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+                    nn.Conv2d(256, 256, 3, 1, 1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True)]
+            c = 256
+        self.decoder = nn.Sequential(*ups)
+        self.head = nn.Conv2d(256, sparse_cnt, 1)
+
+    def forward(self, rgb):
+        return self.head(self.decoder(self.encoder(self.stem(rgb))))  # (B,S,64,64) for a 256x256 input
+
+
+def synthetic_blob(B, S, dev, seed):
+    """A batch of the reference's blob shape (dataset.py:451-489) with random crops and consistent pose labels."""
+    b = synth.make_batch(B, S, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    blob = dict(rgb_in=torch.rand(B, 3, 256, 256, generator=g), pose_best=b["pose"], out_K=b["K"], pts3d=b["pts3d"], bbox_3d=b["bbox_3d"],
+                msk_noc=torch.ones(B, 64, 64, dtype=torch.bool), msk_vis=torch.ones(B, 64, 64))
+    return {k: v.to(dev) for k, v in blob.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs/gsplmo.yaml: 32)")
+    ap.add_argument("--sparse-cnt", type=int, default=64)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--bf16", action="store_true", default=True)
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    torch.manual_seed(0)
+    model = KeypointNet(args.sparse_cnt, args.width).to(dev).to(memory_format=torch.channels_last)
+    cfg = AttrDict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True), pose_loss_start_step=4, pose_loss_start_epoch=0,
+                   w_loss_kpts=1, w_loss_pose=0.7)
+    loss_fn = Loss_fn(cfg, AttrDict()).to(dev)
+    model.loss_fn = loss_fn  # train.py:31: rides in the checkpoint
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    times = []
+    for step in range(args.steps):
+        blob = synthetic_blob(args.batch, args.sparse_cnt, dev, seed=1000 * rank + step)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
+            logits = net(blob["rgb_in"].contiguous(memory_format=torch.channels_last))
+        out = sparse_head(logits.float())  # fused HIP head, fp32 (ptnet.py:59-66)
+        loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
+        loss = sum(w_loss_dict.values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize(dev)
+        times.append(time.perf_counter() - t0)
+        if rank == 0:
+            print(f"step {step:3d}  loss {float(loss):9.4f}  kpts {float(loss_dict['loss_kpts']):8.4f}  pose {float(loss_dict['loss_pose']):8.4f}"
+                  f"  {times[-1] * 1e3:7.1f} ms")
+    if rank == 0 and len(times) > 3:
+        t = sorted(times[2:])[len(times[2:]) // 2]
+        print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), bf16 backbone, fp32/fp64 LC loss")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
