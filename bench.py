@@ -33,6 +33,22 @@ def algorithmic_bytes(N: int, want_pts3d: bool):
     return loss, pnp
 
 
+def pmc_traffic(kernel: str, B: int, N: int):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/<round>/pmc_traffic.json, produced by
+    scripts/profile_r01.sh on the default workload); None for other workloads or when no profile is committed."""
+    if (B, N) != (256, 64):
+        return None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f)).get(kernel)
+            if d:
+                return d["bytes_per_launch"]
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(B, N, seed, budget_s=15.0):
     """The oracle (CPU restatement of the reference path) timed on this host: torch closed-form LC loss fwd+bwd on all
     cores + the C/OpenMP LM solve on all cores, over a bounded number of B-sized batches."""
@@ -246,7 +262,7 @@ def main():
                        "global_batch": B * world, "n_points": N, "sharding": f"poses over {world} rank(s), no data-path collective",
                        "launch": args.launch},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom[0], B, N),
                          "note": "latency/VALU-bound by construction (5 KB working set per pose, one wave per pose): see DESIGN.md",
                          "kernel_us": kernel_us,
                          "algorithmic_bytes_per_pose": {"loss": by_loss, "pnp": by_pnp}},

@@ -44,3 +44,24 @@ for sub, title in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("p
             for c, v in d.items():
                 print(f"| {k} | {c} | {len(v)} | {sum(v) / len(v):.4g} |")
         print()
+
+
+# machine-readable HBM traffic per launch for bench.py's roofline.traffic (bytes; FETCH_SIZE/WRITE_SIZE are in KB)
+import json
+traffic = {}
+for sub, key in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("head_pmc_fetch", "fetch"), ("head_pmc_write", "write")):
+    for f in find(f"{sub}/**/*counter_collection.csv"):
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            if k.startswith("lc_"):
+                traffic.setdefault(k, {})[key + "_kb_raw"] = sum(v) / len(v)
+for k, d in traffic.items():
+    wide = k.startswith("lc_head")  # 16 B/lane streaming reads: gfx950 FETCH_SIZE counts half the bytes (MI355X_MICROARCH.md, HBM)
+    d["fetch_correction"] = 2.0 if wide else 1.0
+    d["bytes_per_launch"] = (d.get("fetch_kb_raw", 0.0) * d["fetch_correction"] + d.get("write_kb_raw", 0.0)) * 1024
+    d["note"] = ("FETCH_SIZE x2 (gfx950 correction for 16 B/lane streams)" if wide else
+                 "raw counters; 8-12 B/lane accesses are uncalibrated on gfx950 (MI355X_MICROARCH.md, HBM)")
+json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
