@@ -205,6 +205,10 @@ __device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
     c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// A condition that is the same in every lane, as a SCALAR: lets hipcc branch with s_cbranch instead of saving/masking EXEC
+// around code the whole wave takes or skips together (the LM loop's tests on wave-uniform doubles).
+__device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
 // index of (i,j), i<=j, in a packed upper-triangular 6x6 (21 entries, row-major)
 __host__ __device__ constexpr int tri6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 

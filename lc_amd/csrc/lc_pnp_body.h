@@ -317,10 +317,10 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     int iter = 0, n_invalid = 0;
     bool converged = false;
 
-    while (!failed && !converged) {
+    while (uniform(!failed && !converged)) {
         // FinalizeIterationAndCheckIfMinimizerCanContinue
         if (iter >= p.max_iter) break;
-        if (gmax <= gtol || radius <= 1e-32) { converged = true; break; }
+        if (uniform(gmax <= gtol || radius <= 1e-32)) { converged = true; break; }
         ++iter;
         // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system
         double dg[6], y[6];
@@ -334,7 +334,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         for (int i = 0; i < 6; ++i) mcc += y[i] * (g[i] + dg[i] * y[i]);
         mcc *= 0.5;
         step_ok = step_ok && (mcc > 0.0) && (mcc <= DBL_MAX);  // a non-finite y makes mcc non-finite
-        if (!step_ok) {  // HandleInvalidStep
+        if (uniform(!step_ok)) {  // HandleInvalidStep
             if (++n_invalid >= 5) { failed = true; break; }
             radius /= dfac; dfac *= 2.0;
             continue;
@@ -349,11 +349,11 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         double cost_c;
         const bool cand_ok = evaluate(xc, scale, H, g, cost_c);
         if (!cand_ok) cost_c = DBL_MAX;
-        if (step_norm <= ptol * (xnorm + ptol)) { converged = true; break; }  // ParameterToleranceReached
+        if (uniform(step_norm <= ptol * (xnorm + ptol))) { converged = true; break; }  // ParameterToleranceReached
         const double cost_change = cost - cost_c;
-        if (fabs(cost_change) <= ftol * cost) { converged = true; break; }    // FunctionToleranceReached
+        if (uniform(fabs(cost_change) <= ftol * cost)) { converged = true; break; }    // FunctionToleranceReached
         const double rel = cost_change * fast_rcp(mcc);
-        if (rel > 1e-3) {  // HandleSuccessfulStep
+        if (uniform(rel > 1e-3)) {  // HandleSuccessfulStep
 #pragma unroll
             for (int j = 0; j < 6; ++j) x[j] = xc[j];
             cost = cost_c;
