@@ -40,9 +40,9 @@ struct LossShared {
     double red[16][48];   // cross-wave partials of the 48-value reduction
     double small[16][4];  // cross-wave partials of the small reductions
     double A0[36];          // S = H^-1
-    double SM[36], sv[6];   // Mc*S, S*v
-    double G[24 * 6], pd[24], cd[24], dl[24], sq[24], isq[24];  // G: rows h_j = S g_j
-    double T[36];           // W = Psi * Mc * S
+    double sv[6];           // S*v
+    double2 HM[24 * 6] __attribute__((aligned(16)));  // per bbox-Jacobian row j: pairs (h_j[a], m_j[a]), h_j = S g_j, m_j = S Mc h_j
+    double pd[24], cd[24], dl[24], sq[24], isq[24];
     double Hbar[36], Psi[36], mu[6];
     int bad[4];  // [0],[1]: a non-positive diagonal in loss_cov_3d (P, C); [2]: H not SPD
 };
@@ -409,28 +409,26 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     LC_STAMP(6);
     const double* S = sh.A0;
     // step A: lanes 0..23 own one row g_j = [ -rho (Rt[d,:] x b_k) | e_d ] of the bbox Jacobian (jac_update2alter,
-    // cov_mixed.py:42-65):  h_j = S g_j;  diag(G S G^T)_j = g.h;  diag(G S Mc S G^T)_j = h^T Mc h;  (G S v)_j = h.v
-    // lanes 28..63 form McS = Mc * S meanwhile.
+    // cov_mixed.py:42-65):  h_j = S g_j;  diag(G S G^T)_j = g.h;  n_j = Mc h_j;  diag(G S Mc S G^T)_j = h.n;
+    // (G S v)_j = h.v;  m_j = S n_j (so that Psi*Mc*S = sum cC_j h_j m_j^T in the reverse section).
     if (tid < grows) {
-        double h[6], pd;
+        double g[6];
         if constexpr (!COV2D) {  // xform_3d (cov_mixed.py:73-75): rows g = [ -rho (Rt[d,:] x b) | e_d ]
             const int d = tid % 3;
             // static selects (a runtime-indexed pc.Rt[3*d] would push the whole PoseConst to scratch)
             const double r0 = d == 0 ? pc.Rt[0] : (d == 1 ? pc.Rt[3] : pc.Rt[6]);
             const double r1 = d == 0 ? pc.Rt[1] : (d == 1 ? pc.Rt[4] : pc.Rt[7]);
             const double r2 = d == 0 ? pc.Rt[2] : (d == 1 ? pc.Rt[5] : pc.Rt[8]);
-            const double g0 = -pc.rho * (r1 * bbz - r2 * bby);
-            const double g1 = -pc.rho * (r2 * bbx - r0 * bbz);
-            const double g2 = -pc.rho * (r0 * bby - r1 * bbx);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) h[i] = S[6 * i] * g0 + S[6 * i + 1] * g1 + S[6 * i + 2] * g2 + S[6 * i + 3 + d];  // g[3+d] = 1
-            pd = g0 * h[0] + g1 * h[1] + g2 * h[2] + (d == 0 ? h[3] : (d == 1 ? h[4] : h[5]));
+            g[0] = -pc.rho * (r1 * bbz - r2 * bby);
+            g[1] = -pc.rho * (r2 * bbx - r0 * bbz);
+            g[2] = -pc.rho * (r0 * bby - r1 * bbx);
+            g[3] = d == 0 ? 1.0 : 0.0; g[4] = d == 1 ? 1.0 : 0.0; g[5] = d == 2 ? 1.0 : 0.0;
         } else {  // xform_2d (cov_mixed.py:78-80): project_apply of the corner, chained with the 3D rows above
             const int a = tid % 2;
             const double bX[3] = {bbx, bby, bbz};
             const Proj pr = project(pc, bX);
             const double izc = fast_rcp(pr.zc);
-            double pa[3], g[6];  // d proj_a / d Xc = (K[a,:] - zpass proj_a K[2,:]) / zc
+            double pa[3];  // d proj_a / d Xc = (K[a,:] - zpass proj_a K[2,:]) / zc
 #pragma unroll
             for (int l = 0; l < 3; ++l) pa[l] = ((a == 0 ? pc.K[l] : pc.K[3 + l]) - pr.zpass * pr.proj[a] * pc.K[6 + l]) * izc;
             // sum_d pa[d] * (-rho (Rt[d,:] x b)) = -rho ((pa^T Rt) x b)
@@ -441,33 +439,38 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
             g[1] = -pc.rho * (v2 * bbx - v0 * bbz);
             g[2] = -pc.rho * (v0 * bby - v1 * bbx);
             g[3] = pa[0]; g[4] = pa[1]; g[5] = pa[2];
-            pd = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                double acc2 = 0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) acc2 += S[6 * i + k] * g[k];
-                h[i] = acc2;
-                pd += g[i] * acc2;
-            }
         }
-        double dl = 0, cd = 0;
+        double Sr[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) Sr[i] = S[i];
+        double h[6], nn[6], pd = 0, dl = 0, cd = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            sh.G[6 * tid + i] = h[i];  // G holds the rows h_j
-            dl += h[i] * vp[i];
+            double a2 = Sr[6 * i] * g[0];
 #pragma unroll
-            for (int j = i; j < 6; ++j) cd += (i == j ? 1.0 : 2.0) * Mp[tri6(i, j)] * (h[i] * h[j]);
+            for (int k = 1; k < 6; ++k) a2 = __builtin_fma(Sr[6 * i + k], g[k], a2);
+            h[i] = a2;
+            pd = __builtin_fma(g[i], a2, pd);
+            dl = __builtin_fma(a2, vp[i], dl);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double a2 = Mp[tri6(0, i)] * h[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) a2 = __builtin_fma(Mp[i <= k ? tri6(i, k) : tri6(k, i)], h[k], a2);
+            nn[i] = a2;
+            cd = __builtin_fma(h[i], a2, cd);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double a2 = Sr[6 * i] * nn[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) a2 = __builtin_fma(Sr[6 * i + k], nn[k], a2);
+            sh.HM[6 * tid + i] = make_double2(h[i], a2);
         }
         sh.pd[tid] = pd; sh.cd[tid] = cd; sh.dl[tid] = dl;
         if (!(pd > 0)) sh.bad[0] = 1;  // loss_cov_3d / loss_cov_2d 'good' (cov_mixed.py:83-97)
         if (!(cd > 0)) sh.bad[1] = 1;
-    } else if (tid >= 28 && tid < 64) {
-        const int e = tid - 28, a = e / 6, c = e % 6;
-        double acc2 = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc2 += Mp[a <= k ? tri6(a, k) : tri6(k, a)] * S[6 * k + c];
-        sh.SM[e] = acc2;  // McS
     }
     __syncthreads();
     LC_STAMP(7);
@@ -515,42 +518,40 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 
     LC_STAMP(9);
     // ---------------- reverse mode of the serial section ----------------
-    // With h_j = S g_j:  S Phi_P S = sum cP_j h h^T (PsiP),  Psi = S Phi_C S = sum cC_j h h^T,  mu = S lambda = sum cL_j dl_j h_j,
-    //   Hbar = -S Sbar S = -( PsiP + W + W^T + (mu sv^T + sv mu^T)/2 ),  W = Psi * (Mc S)
+    // With h_j = S g_j, m_j = S Mc h_j:  S Phi_P S = sum cP_j h h^T (PsiP),  Psi = S Phi_C S = sum cC_j h h^T,
+    //   W = Psi Mc S = sum cC_j h m^T,  mu = S lambda = sum cL_j dl_j h_j,
+    //   Hbar = -S Sbar S = -( PsiP + W + W^T + (mu sv^T + sv mu^T)/2 );  lane (a,b) forms its own entry of every term.
     const double aP = gout * (iP - 0.5 * (Cm + Lm) * iP * iP);
     const double aC = gout * 0.5 * iP;  // = dloss/dC = dloss/dL
     const bool badP = sh.bad[0] != 0, badC = sh.bad[1] != 0;
-    double psiP = 0;
     if (tid < 36) {
-        double fp = 0, fc = 0;
+        double fp = 0, fc = 0, fw = 0, la = 0, lb = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            double hh = 0;
+            double hh = 0, ww = 0, da = 0, db = 0;
 #pragma unroll
-            for (int d = 0; d < gdim; ++d) hh += sh.G[6 * (gdim * k + d) + mi] * sh.G[6 * (gdim * k + d) + mj];
-            fp += sh.isq[k] * hh;
-            fc += sh.isq[8 + k] * hh;
+            for (int d = 0; d < gdim; ++d) {
+                const int j = gdim * k + d;
+                const double2 xa = sh.HM[6 * j + mi], xb = sh.HM[6 * j + mj];
+                const double dlj = sh.dl[j];
+                hh = __builtin_fma(xa.x, xb.x, hh);
+                ww = __builtin_fma(xa.x, xb.y, __builtin_fma(xb.x, xa.y, ww));  // W[a][b] + W[b][a]
+                da = __builtin_fma(dlj, xa.x, da);
+                db = __builtin_fma(dlj, xb.x, db);
+            }
+            fp = __builtin_fma(sh.isq[k], hh, fp);
+            fc = __builtin_fma(sh.isq[8 + k], hh, fc);
+            fw = __builtin_fma(sh.isq[8 + k], ww, fw);
+            la = __builtin_fma(sh.isq[16 + k], da, la);
+            lb = __builtin_fma(sh.isq[16 + k], db, lb);
         }
-        psiP = badP ? 0.0 : fp * (aP * 0.0625);  // cP_k = aP / (16 sP_k)
-        sh.Psi[tid] = badC ? 0.0 : fc * (aC * 0.0625);
-    } else if (tid < 42) {
-        const int a = tid - 36;
-        double l = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            double hd = 0;
-#pragma unroll
-            for (int d = 0; d < gdim; ++d) hd += sh.dl[gdim * k + d] * sh.G[6 * (gdim * k + d) + a];
-            l += sh.isq[16 + k] * hd;
-        }
-        sh.mu[a] = l * (aC * 0.125);  // cL_k = aC / (8 sL_k)
-    }
-    __syncthreads();
-    if (tid < 36) sh.T[tid] = mm6_entry(sh.Psi, sh.SM, mi, mj);  // W
-    __syncthreads();
-    if (tid < 36) {
-        const double hb = -(psiP + sh.T[tid] + sh.T[6 * mj + mi] + 0.5 * (sh.mu[mi] * sh.sv[mj] + sh.sv[mi] * sh.mu[mj]));
+        const double psiP = badP ? 0.0 : fp * (aP * 0.0625);  // cP_k = aP / (16 sP_k)
+        const double cC = badC ? 0.0 : aC * 0.0625;           // cC_k = aC / (16 sC_k)
+        const double mua = la * (aC * 0.125), mub = lb * (aC * 0.125);  // cL_k = aC / (8 sL_k)
+        const double hb = -(psiP + cC * fw + 0.5 * (mua * sh.sv[mj] + sh.sv[mi] * mub));
+        sh.Psi[tid] = cC * fc;
         sh.Hbar[tid] = spd ? hb : 0.0;
+        if (mj == 0) sh.mu[mi] = mua;
     }
     __syncthreads();
 
