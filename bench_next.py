@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Measurement of the SURVEY.md 8f "next" rows (f1 dense front end, f2 RANSAC initialiser, f3 ZebraPose codes, f4 pose-error
+metrics) and of the wide (N > 64) PnP on one MI355X.  Not the headline (bench.py is): one JSON line per kernel with the
+event-timed launch duration and the algorithmic bytes it moves, priced against the 8 TB/s HBM peak where the kernel is a
+streaming one; the compute-shaped ones (RANSAC, ADI nearest neighbour, LM) carry a note instead of a meaningful fraction."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def ev(fn, dev, reps, warm=3):
+    """Median over `reps` launches of the event-bracketed duration (a median, because a one-off host stall of tens of ms --
+    allocator or runtime housekeeping -- otherwise lands inside a back-to-back window; rocprofv3's per-kernel average in
+    profiles/ is the authoritative figure)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize(dev)
+    d = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    return d[len(d) // 2] * 1e3  # us
+
+
+def line(name, us, nbytes, units, unit_name, note=None, **cfg):
+    gbs = nbytes / (us * 1e-6) / 1e9
+    rec = {"kernel": name, "us": round(us, 2), "units_per_s": units / (us * 1e-6), "unit": unit_name + "/s",
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes": nbytes}, "config": cfg}
+    if note:
+        rec["roofline"]["note"] = note
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=30)
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X")
+    dev = torch.device("cuda:0")
+    from lc_amd import _lib, dense, floatbits, metrics, synth
+    from lc_amd.pnp import gpu_solver, pnp_ceres
+
+    lib = _lib.load()
+    P, st = _lib.ptr, _lib.stream_ptr(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+
+    # ---- f1: dense front end, (B,3,128,128) maps, stride-2 sub-sampling -> N = 4096 points per sample ----
+    B, H, W, sample = 64, 128, 128, 2
+    xyz = torch.randn(B, 3, H, W, generator=g).to(dev)
+    wl = torch.randn(B, 2, H, W, generator=g).to(dev)
+    ws = torch.rand(B, generator=g).to(dev) + 0.5
+    ns = torch.rand(B, 3, generator=g).to(dev) + 0.5
+    N = (H // sample) * (W // sample)
+    out = dense._launch_fwd(xyz, wl, ws, ns, 0, 0, sample)
+    us = ev(lambda: dense._launch_fwd(xyz, wl, ws, ns, 0, 0, sample), dev, a.reps)
+    # the joint softmax normaliser reads every weight logit (2 maps), the strided subset of xyz is gathered, N*(2+2+3) floats out
+    by = B * (2 * H * W * 4 + 3 * N * 4 + 7 * N * 4)
+    line("lc_dense_frontend_fwd_kernel", us, by, B, "samples", B=B, H=H, W=W, sample=sample)
+    lse = out[3]
+    if True:
+        gi = torch.randn(B, N, 2, generator=g).to(dev)
+        gp = torch.randn(B, N, 3, generator=g).to(dev)
+        need = (True, True, True)
+        us = ev(lambda: dense._launch_bwd(wl, ws, ns, lse, gi, gp, (B, H, W), 0, 0, sample, need), dev, a.reps)
+        by = B * (2 * H * W * 4 + 5 * N * 4 + 5 * H * W * 4)  # re-read logits + grads in, dense (zero-filled) d_xyz + d_wlogits out
+        line("lc_dense_frontend_bwd_kernel", us, by, B, "samples", B=B, H=H, W=W, sample=sample)
+
+    # ---- f3: ZebraPose codes: 3x7-bit logits over 128x128 ----
+    C, bits = 21, 7
+    lg = torch.randn(B, C, H, W, generator=g).to(dev)
+    gb = (torch.rand(B, C, H, W, generator=g) > 0.5).to(torch.uint8).to(dev)
+    gm = (torch.rand(B, H, W, generator=g) > 0.3).to(torch.uint8).to(dev)
+    us = ev(lambda: floatbits.nn_logits2noc(lg, bits), dev, a.reps)
+    line("lc_bits_decode_kernel", us, B * H * W * (C * 4 + 12), B, "samples", B=B, C=C, H=H, W=W)
+    b3 = floatbits._bits3(bits, C)
+    us = ev(lambda: floatbits._launch_decode_gt(lg, gb, gm, b3, 0, 0, 1), dev, a.reps)
+    line("lc_bits_decode_gt_fwd_kernel", us, B * H * W * (C * 4 + C + 1 + 12), B, "samples", B=B, C=C, H=H, W=W)
+    gn = torch.randn(B, H * W, 3, generator=g).to(dev)
+    us = ev(lambda: floatbits._launch_decode_gt_bwd(lg, gb, gm, gn, b3, 0, 0, 1, True), dev, a.reps)
+    line("lc_bits_decode_gt_bwd_kernel", us, B * H * W * (2 * C * 4 + C + 1 + 12), B, "samples", B=B, C=C, H=H, W=W)
+
+    # ---- f4: pose errors over a test set: 1024 poses x 2048 model points (ADI is an all-pairs nearest neighbour) ----
+    Bp, M = 1024, 2048
+    bt = synth.make_batch(Bp, 8, seed=1)
+    from lc_amd.transforms import quaternion_rep_to_RT
+    Rg, tg = quaternion_rep_to_RT(bt["pose"].to(dev))
+    Re, te = quaternion_rep_to_RT(bt["start"].to(dev))
+    pts = (torch.rand(M, 3, generator=g) - 0.5).to(dev) * 0.2
+    us = ev(lambda: metrics.compute_pose_errors(Re, te, Rg, tg, pts), dev, max(3, a.reps // 5))
+    line("lc_pose_errors_kernel (add+adi)", us, Bp * (24 * 4 + 16) + M * 12, Bp, "poses",
+         note="compute-shaped: %.1f G point-pair distances/s (3 fma + min each)" % (Bp * M * M / (us * 1e-6) / 1e9), B=Bp, M=M)
+    us = ev(lambda: metrics.compute_pose_errors(Re, te, Rg, tg, pts, want_adi=False), dev, a.reps)
+    line("lc_pose_errors_kernel (add only)", us, Bp * (24 * 4 + 16) + M * 12, Bp, "poses", B=Bp, M=M)
+
+    # ---- f2: RANSAC initialiser ----
+    for (Br, Nr) in ((256, 64), (256, 1024)):
+        bt = synth.make_batch(Br, Nr, seed=2, outlier_frac=0.2)
+        K, X, U = bt["K"].to(dev), bt["pts3d"].to(dev), bt["pts2d"].to(dev)
+        us = ev(lambda: gpu_solver.solve_device(K, X, U, reprojectionError=3.0, refine=False), dev, a.reps)
+        line("lc_pnp_ransac_kernel", us, Br * (Nr * 21 + 36 + 40), Br, "poses",
+             note="compute-shaped: 150 P3P hypotheses x N reprojections per pose (%.1f G reprojections/s)" % (Br * 150 * Nr / (us * 1e-6) / 1e9),
+             B=Br, N=Nr, hypotheses=150)
+
+    # ---- wide PnP (dense heads): N = 1024 and 1849 ----
+    for Nw in (1024, 1849):
+        bt = synth.make_batch(256, Nw, seed=3)
+        K, X, U, Wt, S0 = (bt[k].to(dev) for k in ("K", "pts3d", "pts2d", "inv_std", "start"))
+        us = ev(lambda: pnp_ceres.solve_device(K, X, U, Wt, S0), dev, a.reps)
+        line("lc_pnp_lm_wide_kernel", us, 256 * (Nw * 28 + 36 + 28 + 36), 256, "poses",
+             note="latency/VALU-bound LM iterations (see DESIGN.md 4.2)", B=256, N=Nw)
+
+
+if __name__ == "__main__":
+    main()

@@ -152,7 +152,6 @@ __device__ __forceinline__ float swap32_sum(float x) {
 template <int LPR, int NV>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_rows_kernel(const HeadParams p) {
     constexpr int W = 4 * LPR, H = NV * kHeadThreads / LPR, HW = H * W;
-    constexpr int RPW = kWave / LPR;           // rows a wave covers per k
     __shared__ float colp[4][W];               // per-wave column partials
     __shared__ float py[H];
     __shared__ float px[W];
