@@ -4,7 +4,10 @@
 // ~15 elementwise ops + gather/scatter over (B,H,W,3,bits)) and floatbits.py:194-223 (mod_logits2float_bb: Gray-code
 // decode used at inference), including the /(max/2)-1 normalisation of floatbits.py:108-118,162-180 and the strided
 // sub-sampling of losses.py:163-184.  Works directly on the network layout (B,C,H,W), C = n0+n1+n2 code bits, one thread
-// per (sampled) pixel: channel reads are coalesced across the pixels of a row; nothing is permuted or materialised.
+// per four consecutive pixels of a row (float4 / uchar4 channel reads, float4 stores; one pixel per thread when the row
+// length or the sub-sampling stride does not allow it); nothing is permuted or materialised.
+#include <cstdint>
+
 #include "lc_common.h"
 #include "lc_kernels.h"
 
@@ -19,19 +22,16 @@ struct AxisDecode {
     float dval;    // d val / d logit[idx]
 };
 
-// floatbits.py:130-160 for one axis of one pixel
-__device__ __forceinline__ AxisDecode decode_with_gt(const float* lg, const unsigned char* gt, size_t stride, int n, bool in_msk,
-                                                     int black_factor) {
-    float out_val = 0.f, correct = 0.f;
-    int idx = n - 1;
-    bool found = false;
-    float x_idx = 0.f, sgn_idx = 1.f;
-    bool prev = false;
-    for (int k = 0; k < n; ++k) {
-        const bool b = gt[k * stride] != 0;
+// floatbits.py:130-160 for one axis of one pixel, fed one code bit (channel) at a time, MSB first
+struct AxisState {
+    float out_val = 0.f, correct = 0.f, x_idx = 0.f, sgn_idx = 1.f;
+    int idx = 0;
+    bool found = false, prev = false;
+
+    __device__ __forceinline__ void push(int k, int n, float logit, bool b, int black_factor) {
         float sgn = (k >= 1 && prev) ? -1.f : 1.f;   // logits_msk[1:] = -1 where the previous gt bit is set
         if (k < 2) sgn *= (float)black_factor;       // logits_msk[0:2] *= black_factor
-        const float x = lg[k * stride] * sgn;
+        const float x = logit * sgn;
         const bool pred = x > 0.f;
         const float w = (float)(1 << (n - 1 - k));
         out_val += pred ? w : 0.f;
@@ -44,105 +44,223 @@ __device__ __forceinline__ AxisDecode decode_with_gt(const float* lg, const unsi
         }
         prev = b;
     }
-    AxisDecode o;
-    const float w = (float)(1 << (n - 1 - idx));
-    const float s = 1.f / (1.f + __expf(-x_idx));
-    if (in_msk) {
-        o.val = correct + s * w;
-        o.idx = idx;
-        o.dval = w * s * (1.f - s) * sgn_idx;
+    __device__ __forceinline__ AxisDecode finish(int n, bool in_msk) const {
+        AxisDecode o;
+        const float w = (float)(1 << (n - 1 - idx));
+        const float s = 1.f / (1.f + __expf(-x_idx));
+        if (in_msk) {
+            o.val = correct + s * w;
+            o.idx = idx;
+            o.dval = w * s * (1.f - s) * sgn_idx;
+        } else {
+            o.val = out_val;
+            o.idx = -1;
+            o.dval = 0.f;
+        }
+        return o;
+    }
+};
+
+// V consecutive pixels of one row per thread: float4 / uchar4 channel reads when V == 4
+template <int V>
+__device__ __forceinline__ void load_px(const float* lg, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(lg);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
-        o.val = out_val;
-        o.idx = -1;
-        o.dval = 0.f;
+        v[0] = lg[0];
     }
-    return o;
+}
+template <int V>
+__device__ __forceinline__ void load_px(const unsigned char* g, bool (&v)[V]) {
+    if constexpr (V == 4) {
+        const uchar4 t = *reinterpret_cast<const uchar4*>(g);
+        v[0] = t.x != 0; v[1] = t.y != 0; v[2] = t.z != 0; v[3] = t.w != 0;
+    } else {
+        v[0] = g[0] != 0;
+    }
+}
+template <int V>
+__device__ __forceinline__ void store_px(float* o, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    else o[0] = v[0];
 }
 
-// floatbits.py:194-223 for one axis of one pixel
-__device__ __forceinline__ float decode_gray(const float* lg, size_t stride, int n, bool black) {
-    unsigned code = 0;
-    float last = 0.f;
+template <int V>
+__device__ __forceinline__ void decode_axis_gt(const float* lg, const unsigned char* gt, size_t stride, int n, int black_factor,
+                                               AxisState (&st)[V]) {
     for (int k = 0; k < n; ++k) {
-        last = lg[k * stride];
-        bool bit = last > 0.f;
-        if (black && k < 2) bit = !bit;
-        code = (code << 1) | (bit ? 1u : 0u);
+        float x[V];
+        bool bt[V];
+        load_px<V>(lg + k * stride, x);
+        load_px<V>(gt + k * stride, bt);
+#pragma unroll
+        for (int v = 0; v < V; ++v) st[v].push(k, n, x[v], bt[v], black_factor);
     }
-    unsigned v = code;  // inverse Gray code (the reference's lut[src] = dst with src = dst ^ (dst >> 1))
-    for (unsigned sh = 1; sh < 32; sh <<= 1) v ^= v >> sh;
-    const float lsb_factor = (v & 2u) ? -1.f : 1.f;
-    return (float)(v & ~1u) + 1.f / (1.f + __expf(-last * lsb_factor));
 }
 
+// floatbits.py:194-223 for one axis of V pixels
+template <int V>
+__device__ __forceinline__ void decode_gray(const float* lg, size_t stride, int n, bool black, float (&out)[V]) {
+    unsigned code[V];
+    float last[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) code[v] = 0;
+    for (int k = 0; k < n; ++k) {
+        load_px<V>(lg + k * stride, last);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            bool bit = last[v] > 0.f;
+            if (black && k < 2) bit = !bit;
+            code[v] = (code[v] << 1) | (bit ? 1u : 0u);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        unsigned g = code[v];  // inverse Gray code (the reference's lut[src] = dst with src = dst ^ (dst >> 1))
+        for (unsigned sh = 1; sh < 32; sh <<= 1) g ^= g >> sh;
+        const float lsb_factor = (g & 2u) ? -1.f : 1.f;
+        out[v] = (float)(g & ~1u) + 1.f / (1.f + __expf(-last[v] * lsb_factor));
+    }
+}
+
+// forward of the training decode.  V == 4 needs sample == 1 (the pixel subset is the whole map), W % 4 == 0
+template <int V>
 __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_fwd_kernel(const BitsParams p) {
     const int Wn = (p.W - p.left + p.sample - 1) / p.sample;
     const size_t HW = (size_t)p.H * p.W;
-    const size_t total = (size_t)p.B * p.N;
+    const size_t total = (size_t)p.B * p.N / V;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads) {
-        const int b = (int)(i / p.N), n = (int)(i % p.N);
+        const size_t i0 = i * V;
+        const int b = (int)(i0 / p.N), n = (int)(i0 % p.N);
         const int y = p.top + (n / Wn) * p.sample, x = p.left + (n % Wn) * p.sample;
         const size_t px = (size_t)y * p.W + x;
-        const bool in_msk = p.gt_msk ? p.gt_msk[(size_t)b * HW + px] != 0 : true;
+        bool in_msk[V];
+        if (p.gt_msk) {
+            load_px<V>(p.gt_msk + (size_t)b * HW + px, in_msk);
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) in_msk[v] = true;
+        }
+        float res[V][3];
         int c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
             const size_t base = ((size_t)b * p.C + c0) * HW + px;
-            const AxisDecode d = decode_with_gt(p.logits + base, p.gt_bits + base, HW, nb, in_msk, p.black_factor);
-            p.out[i * 3 + a] = d.val / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
+            AxisState st[V];
+            decode_axis_gt<V>(p.logits + base, p.gt_bits + base, HW, nb, p.black_factor, st);
+#pragma unroll
+            for (int v = 0; v < V; ++v) res[v][a] = st[v].finish(nb, in_msk[v]).val / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
+        }
+        float* o = p.out + i0 * 3;
+        if constexpr (V == 4) {  // 12 contiguous floats
+            *reinterpret_cast<float4*>(o) = make_float4(res[0][0], res[0][1], res[0][2], res[1][0]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(res[1][1], res[1][2], res[2][0], res[2][1]);
+            *reinterpret_cast<float4*>(o + 8) = make_float4(res[2][2], res[3][0], res[3][1], res[3][2]);
+        } else {
+            o[0] = res[0][0]; o[1] = res[0][1]; o[2] = res[0][2];
         }
     }
 }
 
+// backward: one thread per V pixels of the FULL map: writes every channel (zeros where no gradient arrives)
+template <int V>
 __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const BitsParams p) {
-    // one thread per pixel of the FULL map: writes every channel (zeros where no gradient arrives)
     const int Wn = (p.W - p.left + p.sample - 1) / p.sample;
     const size_t HW = (size_t)p.H * p.W;
-    const size_t total = (size_t)p.B * HW;
+    const size_t total = (size_t)p.B * HW / V;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads) {
-        const int b = (int)(i / HW);
-        const size_t px = i % HW;
-        const int y = (int)(px / p.W), x = (int)(px % p.W);
-        const int dy = y - p.top, dx = x - p.left;
-        const bool hit = dy >= 0 && dx >= 0 && (dy % p.sample) == 0 && (dx % p.sample) == 0;
-        const bool in_msk = p.gt_msk ? p.gt_msk[(size_t)b * HW + px] != 0 : true;
-        const size_t n = hit ? (size_t)(dy / p.sample) * Wn + dx / p.sample : 0;
+        const size_t i0 = i * V;
+        const int b = (int)(i0 / HW);
+        const size_t px = i0 % HW;
+        const int y = (int)(px / p.W), x0 = (int)(px % p.W);
+        const int dy = y - p.top;
+        const bool row_hit = dy >= 0 && (dy % p.sample) == 0;
+        bool live[V], any = false;
+        size_t n[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) live[v] = false;
+        if (row_hit) {
+            if (p.gt_msk) {
+                load_px<V>(p.gt_msk + (size_t)b * HW + px, live);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) live[v] = true;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int dx = x0 + v - p.left;
+            live[v] = row_hit && live[v] && dx >= 0 && (dx % p.sample) == 0;
+            n[v] = live[v] ? (size_t)(dy / p.sample) * Wn + dx / p.sample : 0;
+            any = any || live[v];
+        }
         int c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
             const size_t base = ((size_t)b * p.C + c0) * HW + px;
-            int idx = -1;
-            float g = 0.f;
-            if (hit && in_msk) {
-                const AxisDecode d = decode_with_gt(p.logits + base, p.gt_bits + base, HW, nb, true, p.black_factor);
-                idx = d.idx;
-                g = p.g_out[((size_t)b * p.N + n) * 3 + a] * d.dval / ((float)((1 << nb) - 1) * 0.5f);
+            int idx[V];
+            float g[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { idx[v] = -1; g[v] = 0.f; }
+            if (any) {
+                AxisState st[V];
+                decode_axis_gt<V>(p.logits + base, p.gt_bits + base, HW, nb, p.black_factor, st);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    if (live[v]) {
+                        const AxisDecode d = st[v].finish(nb, true);
+                        idx[v] = d.idx;
+                        g[v] = p.g_out[((size_t)b * p.N + n[v]) * 3 + a] * d.dval / ((float)((1 << nb) - 1) * 0.5f);
+                    }
+                }
             }
-            for (int k = 0; k < nb; ++k) p.d_logits[base + k * HW] = (k == idx) ? g : 0.f;
+            for (int k = 0; k < nb; ++k) {
+                float o[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) o[v] = (k == idx[v]) ? g[v] : 0.f;
+                store_px<V>(p.d_logits + base + k * HW, o);
+            }
             c0 += nb;
         }
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(kThreads) void lc_bits_decode_kernel(const BitsParams p) {
     const size_t HW = (size_t)p.H * p.W;
-    const size_t total = (size_t)p.B * HW;
+    const size_t total = (size_t)p.B * HW / V;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads) {
-        const int b = (int)(i / HW);
-        const size_t px = i % HW;
+        const size_t i0 = i * V;
+        const int b = (int)(i0 / HW);
+        const size_t px = i0 % HW;
+        float res[V][3];
         int c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
-            const float v = decode_gray(p.logits + ((size_t)b * p.C + c0) * HW + px, HW, nb, p.black_factor < 0);
-            p.out[i * 3 + a] = v / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
+            float val[V];
+            decode_gray<V>(p.logits + ((size_t)b * p.C + c0) * HW + px, HW, nb, p.black_factor < 0, val);
+#pragma unroll
+            for (int v = 0; v < V; ++v) res[v][a] = val[v] / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
+        }
+        float* o = p.out + i0 * 3;
+        if constexpr (V == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(res[0][0], res[0][1], res[0][2], res[1][0]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(res[1][1], res[1][2], res[2][0], res[2][1]);
+            *reinterpret_cast<float4*>(o + 8) = make_float4(res[2][2], res[3][0], res[3][1], res[3][2]);
+        } else {
+            o[0] = res[0][0]; o[1] = res[0][1]; o[2] = res[0][2];
         }
     }
 }
+
+bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+bool aligned4(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; }
 
 int grid_for(size_t total) {
     size_t g = (total + kThreads - 1) / kThreads;
@@ -153,17 +271,23 @@ int grid_for(size_t total) {
 
 int launch_bits_decode_gt_fwd(const BitsParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.N <= 0) return 0;
-    hipLaunchKernelGGL(lc_bits_decode_gt_fwd_kernel, dim3(grid_for((size_t)p.B * p.N)), dim3(kThreads), 0, stream, p);
+    const bool vec = p.sample == 1 && p.top == 0 && p.left == 0 && p.W % 4 == 0 && aligned16(p.logits) && aligned16(p.out) && aligned4(p.gt_bits) && aligned4(p.gt_msk);
+    if (vec) hipLaunchKernelGGL(lc_bits_decode_gt_fwd_kernel<4>, dim3(grid_for((size_t)p.B * p.N / 4)), dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL(lc_bits_decode_gt_fwd_kernel<1>, dim3(grid_for((size_t)p.B * p.N)), dim3(kThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 int launch_bits_decode_gt_bwd(const BitsParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
-    hipLaunchKernelGGL(lc_bits_decode_gt_bwd_kernel, dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p);
+    const bool vec = p.W % 4 == 0 && aligned16(p.logits) && aligned16(p.d_logits) && aligned4(p.gt_bits) && aligned4(p.gt_msk);
+    if (vec) hipLaunchKernelGGL(lc_bits_decode_gt_bwd_kernel<4>, dim3(grid_for((size_t)p.B * p.H * p.W / 4)), dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL(lc_bits_decode_gt_bwd_kernel<1>, dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 int launch_bits_decode(const BitsParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
-    hipLaunchKernelGGL(lc_bits_decode_kernel, dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p);
+    const bool vec = p.W % 4 == 0 && aligned16(p.logits) && aligned16(p.out);
+    if (vec) hipLaunchKernelGGL(lc_bits_decode_kernel<4>, dim3(grid_for((size_t)p.B * p.H * p.W / 4)), dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL(lc_bits_decode_kernel<1>, dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -222,17 +222,21 @@ __device__ void mat_to_quat(const double R[9], float q[4]) {
 
 constexpr int kMaxLdsPts = 2048;
 
-__global__ __launch_bounds__(64) void lc_pnp_ransac_kernel(const RansacParams p) {
+constexpr int kRansacMaxWaves = 4;  // hypothesis rounds of 64 run on separate wavefronts of the pose's workgroup
+
+__global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(const RansacParams p) {
     __shared__ float sx[kMaxLdsPts * 3];   // 3D points
     __shared__ float su[kMaxLdsPts * 2];   // normalised image coordinates K^-1 (u,v,1)
-    __shared__ double best_pose[12];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ double best_pose[kRansacMaxWaves][12];
+    __shared__ int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
+    __shared__ float wv_err[kRansacMaxWaves];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
     const size_t base = (size_t)b * p.Nmax;
     unsigned char* mask = p.inlier_mask + base;
-    for (int i = lane; i < p.Nmax; i += kWave) mask[i] = 0;
+    for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
     if (n < 4) {  // cv2.solvePnPRansac needs >= 4 (EPnP: 5 model points); flagged invalid like a failed call (cv2_solver.py:74-80)
-        if (lane == 0) {
+        if (tid == 0) {
             float* st = p.states + 7 * (size_t)b;
             st[0] = 1; st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0;
             p.invalid[b] = 1;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(64) void lc_pnp_ransac_kernel(const RansacParams p)
     const double k0 = Kp[0], k1 = Kp[1], k2 = Kp[2], k3 = Kp[3], k4 = Kp[4], k5 = Kp[5];
     const double idet = 1.0 / (k0 * k4 - k1 * k3);
     const int nl = min(n, kMaxLdsPts);  // hypotheses are scored on the first kMaxLdsPts points (dense heads: N <= 1849)
-    for (int i = lane; i < nl; i += kWave) {
+    for (int i = tid; i < nl; i += nthr) {
         sx[3 * i] = p.pts3d[(base + i) * 3]; sx[3 * i + 1] = p.pts3d[(base + i) * 3 + 1]; sx[3 * i + 2] = p.pts3d[(base + i) * 3 + 2];
         const double du = (double)p.pts2d[(base + i) * 2] - k2, dv = (double)p.pts2d[(base + i) * 2 + 1] - k5;
         su[2 * i] = (float)((k4 * du - k1 * dv) * idet);
@@ -257,10 +261,10 @@ __global__ __launch_bounds__(64) void lc_pnp_ransac_kernel(const RansacParams p)
     const float thr = thr_px * (float)sqrt(fabs(idet));
     const float thr2 = thr * thr;
 
-    int best_cnt = -1;
+    int best_cnt = -1, best_hyp = 0;
     float best_err = INFINITY;
     Pose best;
-    for (int round = 0; round < p.rounds; ++round) {
+    for (int round = wave; round < p.rounds; round += nwaves) {  // hypothesis id = round*64 + lane, whatever the wave count
         // minimal sample: 3 distinct indices + a 4th to disambiguate the up-to-4 P3P solutions
         unsigned h = hash_u32(p.seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)(round * kWave + lane)));
         int idx[4];
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(64) void lc_pnp_ransac_kernel(const RansacParams p)
             for (int i = 0; i < nl; ++i) {
                 const float X = sx[3 * i], Y = sx[3 * i + 1], Z = sx[3 * i + 2];
                 const float cz = R[6] * X + R[7] * Y + R[8] * Z + t[2];
-                const float icz = 1.f / cz;
+                const float icz = __builtin_amdgcn_rcpf(cz);  // 1 ulp: scoring only
                 const float ex = (R[0] * X + R[1] * Y + R[2] * Z + t[0]) * icz - su[2 * i];
                 const float ey = (R[3] * X + R[4] * Y + R[5] * Z + t[1]) * icz - su[2 * i + 1];
                 const float e = ex * ex + ey * ey;
@@ -319,33 +323,38 @@ __global__ __launch_bounds__(64) void lc_pnp_ransac_kernel(const RansacParams p)
             }
         }
         if (cnt > best_cnt || (cnt == best_cnt && err < best_err)) {
-            best_cnt = cnt; best_err = err;
+            best_cnt = cnt; best_err = err; best_hyp = round * kWave + lane;
             if (pick >= 0) best = sols[pick];
         }
     }
-    // wave arg-max over lanes: (count, -err, lane)
-    int win_cnt = best_cnt;
+    // arg-max over lanes, then over the waves: (count, -err, -hypothesis id)
+    int win_cnt = best_cnt, win_hyp = best_hyp;
     float win_err = best_err;
-    int win_lane = lane;
+    auto better = [](int oc, float oe, int oh, int c, float e, int h) { return oc > c || (oc == c && (oe < e || (oe == e && oh < h))); };
     for (int m = 32; m >= 1; m >>= 1) {
-        const int oc = __shfl_xor(win_cnt, m, kWave);
+        const int oc = __shfl_xor(win_cnt, m, kWave), oh = __shfl_xor(win_hyp, m, kWave);
         const float oe = __shfl_xor(win_err, m, kWave);
-        const int ol = __shfl_xor(win_lane, m, kWave);
-        const bool take = oc > win_cnt || (oc == win_cnt && (oe < win_err || (oe == win_err && ol < win_lane)));
-        if (take) { win_cnt = oc; win_err = oe; win_lane = ol; }
+        if (better(oc, oe, oh, win_cnt, win_err, win_hyp)) { win_cnt = oc; win_err = oe; win_hyp = oh; }
     }
-    if (lane == win_lane && win_cnt >= 0) {
-        for (int k = 0; k < 9; ++k) best_pose[k] = best.R[k];
-        for (int k = 0; k < 3; ++k) best_pose[9 + k] = best.t[k];
+    if (best_hyp == win_hyp && best_cnt == win_cnt && win_cnt >= 0) {
+        for (int k = 0; k < 9; ++k) best_pose[wave][k] = best.R[k];
+        for (int k = 0; k < 3; ++k) best_pose[wave][9 + k] = best.t[k];
     }
+    if (lane == 0) { wv_cnt[wave] = win_cnt; wv_err[wave] = win_err; wv_hyp[wave] = win_hyp; }
     __syncthreads();
+    int ww = 0;
+    win_cnt = wv_cnt[0]; win_err = wv_err[0]; win_hyp = wv_hyp[0];
+    for (int w = 1; w < nwaves; ++w) {
+        if (better(wv_cnt[w], wv_err[w], wv_hyp[w], win_cnt, win_err, win_hyp)) { win_cnt = wv_cnt[w]; win_err = wv_err[w]; win_hyp = wv_hyp[w]; ww = w; }
+    }
+    const double* bp = best_pose[ww];
     const bool ok = win_cnt >= 4;
     if (ok) {  // inlier mask of the winner over ALL n points
         float R[9], t[3];
-        for (int k = 0; k < 9; ++k) R[k] = (float)best_pose[k];
-        for (int k = 0; k < 3; ++k) t[k] = (float)best_pose[9 + k];
+        for (int k = 0; k < 9; ++k) R[k] = (float)bp[k];
+        for (int k = 0; k < 3; ++k) t[k] = (float)bp[9 + k];
         int total = 0;
-        for (int i = lane; i < n; i += kWave) {
+        for (int i = tid; i < n; i += nthr) {
             const float X = p.pts3d[(base + i) * 3], Y = p.pts3d[(base + i) * 3 + 1], Z = p.pts3d[(base + i) * 3 + 2];
             const double du = (double)p.pts2d[(base + i) * 2] - k2, dv = (double)p.pts2d[(base + i) * 2 + 1] - k5;
             const float ux = (float)((k4 * du - k1 * dv) * idet), uy = (float)((-k3 * du + k0 * dv) * idet);
@@ -356,13 +365,20 @@ __global__ __launch_bounds__(64) void lc_pnp_ransac_kernel(const RansacParams p)
             total += in ? 1 : 0;
         }
         for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m, kWave);
-        if (lane == 0) p.n_inliers[b] = total;
+        __syncthreads();  // wv_cnt was read by every thread above
+        if (lane == 0) wv_cnt[wave] = total;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < nwaves; ++w) tot += wv_cnt[w];
+            p.n_inliers[b] = tot;
+        }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         float* st = p.states + 7 * (size_t)b;
         if (ok) {
-            mat_to_quat(best_pose, st);
-            st[4] = (float)best_pose[9]; st[5] = (float)best_pose[10]; st[6] = (float)best_pose[11];
+            mat_to_quat(bp, st);
+            st[4] = (float)bp[9]; st[5] = (float)bp[10]; st[6] = (float)bp[11];
         } else {
             st[0] = 1; st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0;
             p.n_inliers[b] = 0;
@@ -375,7 +391,8 @@ __global__ __launch_bounds__(64) void lc_pnp_ransac_kernel(const RansacParams p)
 
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
-    hipLaunchKernelGGL(lc_pnp_ransac_kernel, dim3(p.B), dim3(64), 0, stream, p);
+    const int waves = p.rounds < kRansacMaxWaves ? (p.rounds < 1 ? 1 : p.rounds) : kRansacMaxWaves;
+    hipLaunchKernelGGL(lc_pnp_ransac_kernel, dim3(p.B), dim3(64 * waves), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -49,3 +49,31 @@ def test_bits_strided_subset_and_zlmo_shape():
     (gk,) = torch.autograd.grad(out, x, ct.to(dev))
     (go,) = torch.autograd.grad(ref, x64, ct.double())
     assert rel_err(gk.cpu(), go) <= 5e-6
+
+
+@pytest.mark.parametrize("H,W,sample,tl", [(6, 10, 1, (0, 0)), (5, 7, 2, (1, 0)), (8, 12, 1, (0, 0)), (8, 12, 2, (0, 1))])
+def test_bits_odd_widths_take_the_scalar_path(H, W, sample, tl):
+    """Row lengths that are not a multiple of four (one pixel per thread) and the float4 path agree with the oracle."""
+    from lc_amd import floatbits as fb
+    from oracle import floatbits_oracle as orc
+
+    g = torch.Generator().manual_seed(H * 100 + W)
+    B, bits = 3, [5, 4, 3]
+    noc = torch.rand(B, H, W, 3, generator=g) * 2 - 1
+    mod, raw = fb.nn_noc2target(noc, bits)
+    lg = (mod.float() * 2 - 1) * (torch.rand(B, sum(bits), H, W, generator=g) * 3 + 0.1)
+    lg = torch.where(torch.rand(lg.shape, generator=g) < 0.15, -lg, lg)
+    msk = torch.rand(B, H, W, generator=g) > 0.3
+    dev = torch.device("cuda:0")
+    x = lg.to(dev).requires_grad_(True)
+    out = fb.decode_with_gt_strided(x, raw.to(dev), bits, msk.to(dev), sample=sample, top_left=tl)
+    x64 = lg.double().requires_grad_(True)
+    sl = (Ellipsis, slice(tl[0], None, sample), slice(tl[1], None, sample))
+    ref = orc.nn_logits2noc_with_gt(x64[sl], raw[sl], bits, msk[sl]).flatten(1, 2)
+    assert out.shape == ref.shape and rel_err(out.detach().cpu(), ref.detach()) <= 2e-6
+    ct = torch.randn(out.shape, generator=g)
+    (gk,) = torch.autograd.grad(out, x, ct.to(dev))
+    (go,) = torch.autograd.grad(ref, x64, ct.double())
+    assert rel_err(gk.cpu(), go) <= 5e-6
+    inf = fb.nn_logits2noc(lg.to(dev), bits)
+    assert rel_err(inf.cpu(), orc.nn_logits2noc(lg.double(), bits)) <= 2e-6
