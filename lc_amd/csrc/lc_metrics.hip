@@ -2,7 +2,11 @@
 // (estimate, ground truth) pose pairs -- lib/utils/error6d.py:87-154 (add, adi, re, te) as evaluate.py:333-339
 // compute_pose_errors bundles them; replaces trimesh/cKDTree + multiprocessing.Pool(6) (evaluate.py:193-210).
 // One workgroup per pose.  ADI's nearest-neighbour search is brute force over LDS tiles of the estimated-pose vertices
-// (fp32 distances, fp64 means): M^2/256 fused-multiply-adds per thread, no tree build, no host round trip.
+// (fp32 distances, fp64 means), no tree build, no host round trip.  The pair loop is the only hot part (M^2 pairs per
+// pose) and is VALU-bound, so it is shaped for the packed fp32 pipe: a thread holds four gt-pose queries in registers and
+// walks the tile two est-pose vertices at a time (SoA pairs in LDS, one broadcast ds_read_b64 per coordinate), so the
+// three differences, the square and the two FMAs are v_pk_* instructions on (vertex j, vertex j+1) and the running
+// minimum is one v_min3_f32: 3.5 VALU instructions per point pair instead of 7.
 #include "lc_common.h"
 #include "lc_kernels.h"
 
@@ -10,7 +14,9 @@ namespace lc {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTile = 1024;
+constexpr int kTile = 1024;   // est-pose vertices per LDS tile
+constexpr int kQ = 4;         // gt-pose queries per thread
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
     double a[1] = {v};
@@ -22,7 +28,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 __global__ __launch_bounds__(kThreads) void lc_pose_errors_kernel(const MetricsParams p) {
-    __shared__ float4 tile[kTile];
+    __shared__ v2f tx[kTile / 2], ty[kTile / 2], tz[kTile / 2];  // vertex pairs (j, j+1), one array per coordinate
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int off = p.pts_off ? p.pts_off[b] : 0, M = p.pts_cnt ? p.pts_cnt[b] : p.M;
@@ -51,40 +57,53 @@ __global__ __launch_bounds__(kThreads) void lc_pose_errors_kernel(const MetricsP
     // ADI (error6d.py:104-125): mean over gt-pose vertices of the distance to the nearest est-pose vertex
     double adi_sum = 0;
     if (p.want_adi) {
-        for (int i0 = 0; i0 < M; i0 += kThreads) {  // every thread stays in the loop: the tile loads are collective
-            const int i = i0 + tid;
-            const bool act = i < M;
-            float gx = 0, gy = 0, gz = 0;
-            if (act) {
-                const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-                gx = Rg[0] * x + Rg[1] * y + Rg[2] * z + tg[0];
-                gy = Rg[3] * x + Rg[4] * y + Rg[5] * z + tg[1];
-                gz = Rg[6] * x + Rg[7] * y + Rg[8] * z + tg[2];
+        for (int i0 = 0; i0 < M; i0 += kThreads * kQ) {  // every thread stays in the loop: the tile loads are collective
+            float gx[kQ], gy[kQ], gz[kQ], best[kQ];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                const int i = i0 + q * kThreads + tid;
+                gx[q] = gy[q] = gz[q] = 0.f;
+                best[q] = INFINITY;
+                if (i < M) {
+                    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+                    gx[q] = Rg[0] * x + Rg[1] * y + Rg[2] * z + tg[0];
+                    gy[q] = Rg[3] * x + Rg[4] * y + Rg[5] * z + tg[1];
+                    gz[q] = Rg[6] * x + Rg[7] * y + Rg[8] * z + tg[2];
+                }
             }
-            float best = INFINITY;
             for (int j0 = 0; j0 < M; j0 += kTile) {
                 __syncthreads();
                 for (int j = tid; j < kTile; j += kThreads) {
                     const int jj = j0 + j;
-                    float4 e = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+                    float ex = 1e30f, ey = 1e30f, ez = 1e30f;  // padding: distance^2 overflows to +inf, never the minimum
                     if (jj < M) {
                         const float x = pts[3 * jj], y = pts[3 * jj + 1], z = pts[3 * jj + 2];
-                        e.x = Re[0] * x + Re[1] * y + Re[2] * z + te[0];
-                        e.y = Re[3] * x + Re[4] * y + Re[5] * z + te[1];
-                        e.z = Re[6] * x + Re[7] * y + Re[8] * z + te[2];
+                        ex = Re[0] * x + Re[1] * y + Re[2] * z + te[0];
+                        ey = Re[3] * x + Re[4] * y + Re[5] * z + te[1];
+                        ez = Re[6] * x + Re[7] * y + Re[8] * z + te[2];
                     }
-                    tile[j] = e;
+                    reinterpret_cast<float*>(tx)[j] = ex;
+                    reinterpret_cast<float*>(ty)[j] = ey;
+                    reinterpret_cast<float*>(tz)[j] = ez;
                 }
                 __syncthreads();
-                const int nj = min(kTile, M - j0);
-#pragma unroll 8
-                for (int j = 0; j < nj; ++j) {
-                    const float4 e = tile[j];
-                    const float dx = e.x - gx, dy = e.y - gy, dz = e.z - gz;
-                    best = fminf(best, fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+                const int npair = (min(kTile, M - j0) + 1) >> 1;
+#pragma unroll 4
+                for (int jp = 0; jp < npair; ++jp) {
+                    const v2f ex = tx[jp], ey = ty[jp], ez = tz[jp];
+#pragma unroll
+                    for (int q = 0; q < kQ; ++q) {
+                        const v2f dx = ex - gx[q], dy = ey - gy[q], dz = ez - gz[q];
+                        v2f d = dz * dz;
+                        d = __builtin_elementwise_fma(dy, dy, d);
+                        d = __builtin_elementwise_fma(dx, dx, d);
+                        best[q] = fminf(fminf(best[q], d.x), d.y);
+                    }
                 }
             }
-            if (act) adi_sum += sqrt((double)best);
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+                if (i0 + q * kThreads + tid < M) adi_sum += sqrt((double)best[q]);
         }
         adi_sum = block_sum(adi_sum, red);
     }
