@@ -118,6 +118,15 @@ def main():
              note="compute-shaped: 150 P3P hypotheses x N reprojections per pose (%.1f G reprojections/s)" % (Br * 150 * Nr / (us * 1e-6) / 1e9),
              B=Br, N=Nr, hypotheses=150)
 
+    # ---- LC loss on the dense heads' shapes (training step of the dense configs): N = 1024 / 4096 points per sample ----
+    from lc_amd import cov_mixed
+    for (Bl, Nl) in ((32, 1024), (64, 1024), (64, 4096), (256, 1024)):
+        bt = synth.make_batch(Bl, Nl, seed=4)
+        K, pose, X, U, Wt, bb = (bt[k].to(dev) for k in ("K", "pose", "pts3d", "pts2d", "inv_std", "bbox_3d"))
+        us = ev(lambda: cov_mixed._launch_loss(K, pose, X, U, Wt, None, bb, None, 32.0, 0.3, 8.0, True, True), dev, a.reps)
+        line("lc_cov_loss_kernel (dense shape, fwd+bwd incl. d_pts3d)", us, Bl * (Nl * (28 + 28) + 36 + 28 + 96 + 4), Bl, "samples",
+             note="%.1f M points/s" % (Bl * Nl / us), B=Bl, N=Nl)
+
     # ---- wide PnP (dense heads): N = 1024 and 1849 ----
     for Nw in (1024, 1849):
         bt = synth.make_batch(256, Nw, seed=3)
