@@ -23,6 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "poses/sec (cov-loss fwd+bwd + weighted PnP), B=256 N=64, 1/2/4/8 MI355X"  # BASELINE.json:metric
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -49,6 +50,16 @@ def pmc_traffic(kernel: str, B: int, N: int):
     return None
 
 
+def host_cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(B, N, seed, budget_s=15.0):
     """The oracle (CPU restatement of the reference path) timed on this host: torch closed-form LC loss fwd+bwd on all
     cores + the C/OpenMP LM solve on all cores, over a bounded number of B-sized batches."""
@@ -66,8 +77,9 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
         pnp_oracle.solve_batched(npb["start"], npb["K"], npb["pts2d"], npb["pts3d"], L, num_threads=nt)
 
     # B=256 poses of ~5 KB each do not scale to hundreds of host threads: pick the fastest of a few thread counts
-    best = None
-    for nt in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
+    # (1 and 4 threads are reported too: BASELINE.md 3.3 -- 4 = the reference's num_workers, test.py:62,127)
+    best, by_threads = None, {}
+    for nt in sorted({min(avail, c) for c in (1, 4, 8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         one(nt)
         dt1 = float("inf")
@@ -75,6 +87,7 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
             t0 = time.perf_counter()
             one(nt)
             dt1 = min(dt1, time.perf_counter() - t0)
+        by_threads[str(nt)] = B / dt1
         if best is None or dt1 < best[1]:
             best = (nt, dt1)
     cores = best[0]
@@ -90,7 +103,8 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s or n >= 2000:
             break
     dt = time.perf_counter() - t0
-    return dict(value=B * n / dt, unit="poses/s", cores=cores, kind="port", host_cores_available=avail,
+    return dict(value=B * n / dt, unit="poses/s", cores=cores, kind="port", host_cores_available=avail, host_cpu=host_cpu_model(),
+                poses_per_s_by_threads=by_threads,
                 sample=f"{n} batches of B={B} N={N} (oracle: torch-CPU closed-form loss fwd+bwd + C/OpenMP LM, "
                        f"{cores} threads = fastest of 4..64), {dt:.1f} s")
 
@@ -106,6 +120,7 @@ def main():
                     help="fused (default): loss and PnP workgroups share ONE grid (lc_pose_unit_f32); eager: two launches on "
                          "one stream; eager2: LM solve forked onto a second stream; graph*: the same step replayed as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-head", action="store_true", help="skip the keypoint-head measurement attached as out['head']")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -246,7 +261,7 @@ def main():
             kernel_us["lc_pose_unit_kernel_p10_p50_p90"] = kernel_percentiles_us(step_fused)
         achieved = dom[2] * B / (dom[1] * 1e-3) / 1e9
         out = {
-            "metric": "poses/sec (cov-loss fwd+bwd + weighted PnP), B=256 N=64",
+            "metric": METRIC,
             "value": B * world * args.steps / elapsed,
             "unit": "poses/s",
             "n_gpus": world,
@@ -267,6 +282,11 @@ def main():
                          "kernel_us": kernel_us,
                          "algorithmic_bytes_per_pose": {"loss": by_loss, "pnp": by_pnp}},
         }
+        if world == 1 and not args.no_head:
+            # the third kernel family of the path (keypoint head), HBM-bound; its own line: bench_head.py
+            from bench_head import measure_head
+            h = measure_head(dev, steps=10, warmup=2)
+            out["head"] = {"metric": h["metric"], "value": h["value"], "unit": h["unit"], "config": h["config"], "roofline": h["roofline"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, N, seed=rank, budget_s=args.cpu_budget)
         print(json.dumps(out))

@@ -153,6 +153,24 @@ int lc_bits_decode_f32(const float *logits, int B, int C, int H, int W, int n0, 
 int lc_pose_errors_f32(const float *R_est, const float *t_est, const float *R_gt, const float *t_gt, const float *pts,
                        const int *pts_off, const int *pts_cnt, int B, int M, int want_adi, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (2f) Test-time point selection of the dense heads (second half) -- test.py:39-45 quantile_msk,
+ *      test.py:94-113 dense_point_select = mask | quantile | quantile_in_mask + the per-sample nonzero()/list/np.random
+ *      padding, batched and compacted on the device.  Inputs are the dense front end's (B,N,.) rows (valid prefix
+ *      in_counts[b], NULL = N; in_index (B,N) = source index of each entry for a second-stage selection, NULL = identity).
+ *        mode 0: keep mask != 0                       (mask required: segmentation or RANSAC inliers)
+ *        mode 1: keep w >= torch.quantile(w, q)       with w = inv_std[:,0] + inv_std[:,1]
+ *        mode 2: q_b = 1 - (1-q) * mean(mask);  keep (w*mask >= torch.quantile(w*mask, q_b)) & mask
+ *      Survivors are written in source order to the front of out_* (B,N,.); out_weights = inv_std, squared when
+ *      square_weights (the inverse covariance lc_pnp_lm_f32 takes as sqrt_diag^2 -- pass 0 to keep inv_std);
+ *      counts[b] = survivors, padded to min_count with seeded pseudo-random source indices when fewer survive
+ *      (np.random.choice in the reference).  out_index may be NULL.
+ * ------------------------------------------------------------------------------------------------ */
+int lc_dense_select_f32(const float *pts2d, const float *inv_std, const float *pts3d, const unsigned char *mask,
+                        const int *in_counts, const int *in_index, int B, int N, int mode, double quantile,
+                        int square_weights, int min_count, unsigned seed, float *out_pts2d, float *out_weights,
+                        float *out_pts3d, int *out_index, int *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -341,5 +341,21 @@ int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt
     return lc::launch_pose_errors(p, static_cast<hipStream_t>(stream)) ? fail(11, "pose-error kernel launch failed") : 0;
 }
 
+int lc_dense_select_f32(const float* pts2d, const float* inv_std, const float* pts3d, const unsigned char* mask,
+                        const int* in_counts, const int* in_index, int B, int N, int mode, double quantile, int square_weights,
+                        int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d, int* out_index,
+                        int* counts, void* stream) {
+    if (B < 0 || N <= 0 || mode < 0 || mode > 2 || min_count < 0 || min_count > N) return fail(1, "bad size or mode");
+    if (mode != 0 && !(quantile >= 0.0 && quantile <= 1.0)) return fail(1, "quantile outside [0,1]");
+    if (B == 0) return 0;
+    if (!pts2d || !inv_std || !pts3d || !out_pts2d || !out_weights || !out_pts3d || !counts) return fail(1, "null pointer");
+    if (mode != 1 && !mask) return fail(1, "modes 0 (mask) and 2 (quantile_in_mask) need a mask");
+    lc::SelectParams p{pts2d, inv_std, pts3d, mask, in_counts, in_index, out_pts2d, out_weights, out_pts3d, out_index, counts,
+                       B, N, mode, (float)quantile, (float)(1.0 - quantile), square_weights, min_count, seed};
+    const int rc = lc::launch_dense_select(p, static_cast<hipStream_t>(stream));
+    if (rc == 3) return fail(1, "more than 32768 points per sample do not fit the LDS sort");
+    return rc ? fail(11, "dense select launch failed") : 0;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -142,4 +142,24 @@ struct DenseBwdParams {
 };
 int launch_dense_bwd(const DenseBwdParams& p, hipStream_t stream);
 
+struct SelectParams {
+    const float* pts2d;         // (B,N,2)
+    const float* inv_std;       // (B,N,2) weights
+    const float* pts3d;         // (B,N,3)
+    const unsigned char* mask;  // (B,N) segmentation / inlier mask (modes 0 and 2), else null
+    const int* in_counts;       // (B,) valid prefix of each input row, or null (N)
+    const int* in_index;        // (B,N) source index of each input entry (second-stage selection), or null (identity)
+    float* o_pts2d;             // (B,N,2) compacted
+    float* o_w;                 // (B,N,2) compacted weights (squared when `square`)
+    float* o_pts3d;             // (B,N,3) compacted
+    int* o_index;               // (B,N) source indices of the survivors, or null
+    int* counts;                // (B,)
+    int B, N;
+    int mode;                   // 0 mask, 1 quantile, 2 quantile_in_mask (test.py:94-104)
+    float quantile, one_minus_q;
+    int square, min_count;
+    unsigned seed;
+};
+int launch_dense_select(const SelectParams& p, hipStream_t stream);
+
 }  // namespace lc

@@ -1,0 +1,152 @@
+// Test-time point selection for the dense heads (second half): per-sample mask / weight-quantile
+// selection of the dense correspondences and their COMPACTION into padded per-sample lists + counts, on the device.
+//
+// Replaces test.py:39-45 (quantile_msk: torch.quantile over the summed weights), test.py:94-106 (the three
+// dense_point_select modes, one nonzero() per sample = one host sync per sample, ragged Python lists, np.random padding)
+// and the re-batching of those lists in cer_solver.py:67-87.  One workgroup per sample:
+//   1. weight_i = inv_std[i,0] + inv_std[i,1]  (x seg_i in mode 2)
+//   2. modes 1/2: bitonic sort of the weights in LDS, threshold = torch.quantile's linear interpolation between the two
+//      order statistics around q*(n-1)  (mode 2: q_b = 1 - (1-q) * mean(seg), test.py:102-103)
+//   3. keep_i = seg_i | weight_i >= thr | (weight_i >= thr) & seg_i
+//   4. order-preserving compaction (wave ballots + prefix over the waves) of pts2d, weights (optionally squared: the
+//      inverse covariance the solver takes, test.py:92), pts3d and the source indices; count per sample
+//   5. fewer than min_count survivors (and more than min_count candidates): pad with pseudo-random source indices, the
+//      role np.random.choice plays in test.py:108-113 (seeded hash instead of the host RNG)
+// The outputs feed lc_pnp_ransac_init_f32 / lc_pnp_lm_f32 directly through their `counts` argument.
+#include <cfloat>
+
+#include "lc_common.h"
+#include "lc_kernels.h"
+
+namespace lc {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+
+__device__ __forceinline__ unsigned hash_u32(unsigned x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// torch.lerp (aten/src/ATen/native/Lerp.h): the form that is exact at both ends
+__device__ __forceinline__ float torch_lerp(float a, float b, float w) {
+    return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.f - w);
+}
+
+__global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectParams p) {
+    extern __shared__ float srt[];  // P floats (modes 1, 2)
+    __shared__ int wave_cnt[kWaves];
+    __shared__ int s_seg;
+    __shared__ float s_thr;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(p.in_counts ? p.in_counts[b] : p.N, p.N);
+    const size_t base = (size_t)b * p.N;
+    const float* ws = p.inv_std + base * 2;
+    const unsigned char* seg = p.mask ? p.mask + base : nullptr;
+    auto weight = [&](int i) {
+        const float2 s = *reinterpret_cast<const float2*>(ws + 2 * i);
+        return (p.mode == 2 && !seg[i]) ? 0.f : s.x + s.y;  // mode 2: (inv_std * seg).sum(-1)
+    };
+    if (tid == 0) { s_seg = 0; s_thr = -FLT_MAX; }
+    __syncthreads();
+    if (p.mode != 0 && n > 0) {
+        int P = 1;
+        while (P < n) P <<= 1;
+        int segc = 0;
+        for (int i = tid; i < P; i += kThreads) {
+            srt[i] = i < n ? weight(i) : FLT_MAX;
+            if (p.mode == 2 && i < n && seg[i]) ++segc;
+        }
+        if (p.mode == 2) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) segc += __shfl_xor(segc, m, kWave);
+            if (lane == 0) atomicAdd(&s_seg, segc);
+        }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j >= 1; j >>= 1) {
+                for (int t = tid; t < (P >> 1); t += kThreads) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+                    const int l = i | j;
+                    const bool up = (i & k) == 0;
+                    const float a = srt[i], c = srt[l];
+                    if ((a > c) == up) { srt[i] = c; srt[l] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            float q = p.quantile;
+            if (p.mode == 2) q = 1.f - p.one_minus_q * ((float)s_seg / (float)n);  // test.py:102-103, fp32 like the tensor op
+            q = fminf(fmaxf(q, 0.f), 1.f);
+            const float rank = q * (float)(n - 1);
+            const float lo = floorf(rank), hi = ceilf(rank);
+            s_thr = torch_lerp(srt[(int)lo], srt[min((int)hi, n - 1)], rank - lo);
+        }
+        __syncthreads();
+    }
+    const float thr = s_thr;
+    const size_t ob = base;
+    int running = 0;  // survivors in the chunks before this one (same value in every thread)
+    for (int i0 = 0; i0 < n; i0 += kThreads) {
+        const int i = i0 + tid;
+        bool keep = false;
+        if (i < n) {
+            if (p.mode == 0) keep = seg[i] != 0;
+            else keep = weight(i) >= thr && (p.mode == 1 || seg[i] != 0);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = running, tot = running;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            if (w < wave) off += wave_cnt[w];
+            tot += wave_cnt[w];
+        }
+        if (keep) {
+            const int o = off + before;
+            const float2 s = *reinterpret_cast<const float2*>(ws + 2 * i);
+            *reinterpret_cast<float2*>(p.o_pts2d + (ob + o) * 2) = *reinterpret_cast<const float2*>(p.pts2d + (base + i) * 2);
+            *reinterpret_cast<float2*>(p.o_w + (ob + o) * 2) = p.square ? make_float2(s.x * s.x, s.y * s.y) : s;
+            const float* X = p.pts3d + (base + i) * 3;
+            float* oX = p.o_pts3d + (ob + o) * 3;
+            oX[0] = X[0]; oX[1] = X[1]; oX[2] = X[2];
+            if (p.o_index) p.o_index[ob + o] = p.in_index ? p.in_index[base + i] : i;
+        }
+        running = tot;
+        __syncthreads();  // wave_cnt is rewritten by the next chunk
+    }
+    int total = running;
+    if (total < p.min_count && n > p.min_count) {  // test.py:108-113
+        for (int k = total + tid; k < p.min_count; k += kThreads) {
+            const int i = (int)(hash_u32(p.seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)k)) % (unsigned)n);
+            const float2 s = *reinterpret_cast<const float2*>(ws + 2 * i);
+            *reinterpret_cast<float2*>(p.o_pts2d + (ob + k) * 2) = *reinterpret_cast<const float2*>(p.pts2d + (base + i) * 2);
+            *reinterpret_cast<float2*>(p.o_w + (ob + k) * 2) = p.square ? make_float2(s.x * s.x, s.y * s.y) : s;
+            for (int d = 0; d < 3; ++d) p.o_pts3d[(ob + k) * 3 + d] = p.pts3d[(base + i) * 3 + d];
+            if (p.o_index) p.o_index[ob + k] = p.in_index ? p.in_index[base + i] : i;
+        }
+        total = p.min_count;
+    }
+    if (tid == 0) p.counts[b] = total;
+}
+
+}  // namespace
+
+int launch_dense_select(const SelectParams& p, hipStream_t stream) {
+    if (p.B <= 0) return 0;
+    int P = 1;
+    while (P < p.N) P <<= 1;
+    const size_t lds = p.mode == 0 ? 0 : (size_t)P * sizeof(float);
+    if (lds > 128 * 1024) return 3;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lc_dense_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return 2;
+    hipLaunchKernelGGL(lc_dense_select_kernel, dim3(p.B), dim3(kThreads), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace lc

@@ -85,3 +85,40 @@ def dense_front_end(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scal
     ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
     pts2d, inv_std, pts3d = _DenseFrontEndFn.apply(xyz, wl, ws, ns, int(top), int(left), int(sample))
     return pts2d, inv_std, (pts3d if xyz is not None else None)
+
+
+SELECT_MODES = {"mask": 0, "quantile": 1, "quantile_in_mask": 2}
+
+
+@torch.no_grad()
+def dense_select(pts2d: Tensor, inv_std2d: Tensor, pts3d: Tensor, mode: str, *, mask: Tensor = None, quantile: float = 0.0,
+                 counts: Tensor = None, index: Tensor = None, square_weights: bool = True, min_count: int = 4, seed: int = 0):
+    """Test-time point selection (`test.py:39-45,94-113`) as ONE launch: (B,N,.) rows -> survivors compacted to the front of
+    padded (B,N,.) rows + `counts` (B,) int32 + their source indices (B,N) int32.  No host synchronisation, no ragged lists:
+    the results go straight into `gpu_solver.solve_device(..., n_points=counts)` / `cer_solver.solve(..., n_points=counts)`.
+
+    mode: 'mask' (keep mask), 'quantile' (keep summed weight >= per-sample quantile), 'quantile_in_mask' (the quantile is
+    rescaled by the visible fraction and applied inside the mask).  `counts`/`index` describe an already compacted input
+    (second-stage selection, e.g. by the RANSAC inlier mask).  Returns (pts2d, weights, pts3d, counts, index);
+    weights = inv_std2d**2 when `square_weights` (the solver's inverse covariance, `test.py:92`)."""
+    lib = _lib.load()
+    U = _lib.require_hip_f32("pts2d", pts2d)
+    S = _lib.require_hip_f32("inv_std2d", inv_std2d)
+    X = _lib.require_hip_f32("pts3d", pts3d)
+    B, N = U.shape[:2]
+    dev = U.device
+    m = None
+    if mask is not None:
+        m = mask.to(device=dev).reshape(B, N)
+        m = (m if m.dtype == torch.uint8 else (m != 0).to(torch.uint8)).contiguous()
+    cnt_in = None if counts is None else counts.to(device=dev, dtype=torch.int32).contiguous()
+    idx_in = None if index is None else index.to(device=dev, dtype=torch.int32).contiguous()
+    o_u, o_w, o_x = torch.empty_like(U), torch.empty_like(S), torch.empty_like(X)
+    o_i = torch.empty(B, N, device=dev, dtype=torch.int32)
+    o_c = torch.empty(B, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        rc = lib.lc_dense_select_f32(_lib.ptr(U), _lib.ptr(S), _lib.ptr(X), _lib.ptr(m), _lib.ptr(cnt_in), _lib.ptr(idx_in), B, N,
+                                     SELECT_MODES[mode], float(quantile), int(square_weights), int(min_count), int(seed) & 0xFFFFFFFF,
+                                     _lib.ptr(o_u), _lib.ptr(o_w), _lib.ptr(o_x), _lib.ptr(o_i), _lib.ptr(o_c), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_dense_select_f32")
+    return o_u, o_w, o_x, o_c, o_i

@@ -1,81 +1,79 @@
 """`lib.pnp.cer_solver.solve` call surface (`lib/pnp/cer_solver.py:6-53`): torch-facing weighted PnP.
 
-Same arguments, defaults, return value `(invalid_dict, states)` and fallback rule (invalid -> `start`) as the
-reference; the device->host->Ceres->device trip of the reference (pnp_ceres.py:50-67, cer_solver.py:46-47) is gone:
-ragged lists are zero-padded ON the device and solved by one kernel launch.
+Same arguments, defaults and return value as the reference -- `(invalid_dict, states)` with the keys 'solver_invalids'
+and 'invalids', failed solves falling back to `start` -- but device-first: whatever arrives (batched tensors, or the
+ragged per-job lists `test.py` builds) becomes one padded device batch + a device `n_points` vector and is solved by ONE
+kernel launch; the reference's device -> host -> Ceres -> device trip (pnp_ceres.py:50-67, cer_solver.py:46-47) and its
+per-job Python padding loop (cer_solver.py:67-87) do not exist here.
 """
 from __future__ import annotations
 
 import torch
 from torch import Tensor
+from torch.nn.utils.rnn import pad_sequence
 
 from . import pnp_ceres
+
+
+def _is_ragged(x) -> bool:
+    return isinstance(x, (list, tuple))
+
+
+def _pad(rows, device) -> Tensor:
+    """Per-job tensors of different lengths -> one zero-padded (B, Nmax, ...) batch; per-job scalars/vectors -> (B, ...)."""
+    if isinstance(rows, Tensor):
+        return rows.to(device)
+    first = rows[0]
+    if not isinstance(first, Tensor):
+        return torch.as_tensor(rows, device=device)
+    rows = [r.to(device) for r in rows]
+    if all(r.shape == first.shape for r in rows):
+        return torch.stack(rows)
+    return pad_sequence(rows, batch_first=True)
+
+
+def _batch_tensors(*groups, device=None):
+    """Batched view of every argument of a ragged call (the role of cer_solver.py:67-87); None stays None."""
+    return [None if g is None else _pad(g, device) for g in groups]
+
+
+def _information_factor(pts2d: Tensor, icovs: Tensor) -> Tensor:
+    """What the kernel weighs residuals with: sqrt of a diagonal inverse covariance (B,N,2), or the lower Cholesky factor
+    of a full one (B,N,2,2) -- cer_solver.py:33-38."""
+    if icovs.dim() == pts2d.dim():
+        return icovs.sqrt()
+    return torch.linalg.cholesky_ex(icovs).L
+
+
+@torch.no_grad()
+def _weighted_solve(cam_mat, pts3d, pts2d, icovs, start, n_points, max_iter_count, num_workers, kwargs):
+    states, _radius, flags = pnp_ceres.solve(cam_mat, pts3d, pts2d, _information_factor(pts2d, icovs), start, n_points,
+                                             max_iter_count=max_iter_count, num_workers=num_workers, **kwargs)
+    return states, flags
 
 
 def solve(cam_mat, pts3d, pts2d, icovs, start, n_points=None, *, optimal_start=False, max_iter_count=50, num_workers=1,
           filter_input_nan=False, **kwargs):
     dev = pts3d[0].device
-    if isinstance(pts3d, (list, tuple)):
+    if _is_ragged(pts3d):
         if n_points is None:
-            n_points = [len(p3d) for p3d in pts3d]
+            n_points = [len(p) for p in pts3d]
         cam_mat, pts3d, pts2d, icovs, start, n_points = _batch_tensors(cam_mat, pts3d, pts2d, icovs, start, n_points, device=dev)
+    elif _is_ragged(start):
+        start = _pad(start, dev)
     if filter_input_nan:
-        cam_mat, pts3d, pts2d, icovs, start, n_points = (
-            torch.nan_to_num(t) if t is not None else None for t in (cam_mat, pts3d, pts2d, icovs, start, n_points))
-    invalid_dict = dict()
-
+        cam_mat, pts3d, pts2d, icovs, start = (torch.nan_to_num(t) for t in (cam_mat, pts3d, pts2d, icovs, start))
     start = start.detach()
+
+    invalid_dict = {}
     if optimal_start:
-        solutions = start
+        states = start
+        invalids = torch.zeros(start.shape[:-1], dtype=torch.bool, device=start.device)
     else:
-        with torch.no_grad():
-            if len(pts2d.shape) == len(icovs.shape):  # (*, N, 2): diagonal information -> pass the diagonal factor only
-                icovs_sqrtL = icovs.sqrt()
-            else:  # (*, N, 2, 2)
-                icovs_sqrtL = torch.linalg.cholesky_ex(icovs)[0]
-            opt_states, trust_regions, solver_invalids = pnp_ceres.solve(
-                cam_mat, pts3d, pts2d, icovs_sqrtL, start, n_points, max_iter_count=max_iter_count, num_workers=num_workers,
-                **kwargs)
-        solutions = opt_states.to(dev, non_blocking=True)
-        invalid_dict["solver_invalids"] = solver_invalids.to(device=dev, dtype=torch.bool, non_blocking=True)
-
-    states = solutions
-    invalid_dict, invalids = _combine_invalids(invalid_dict, states)
-    states = torch.where(invalids[..., None], start.to(states.device), states)
-    return invalid_dict, states
-
-
-def _combine_invalids(invalid_dict, states):
-    if not invalid_dict:
-        shape = (len(states),) if isinstance(states, list) else states.shape[:-1]
-        invalids = torch.zeros(shape, dtype=torch.bool, device=states[0].device)
-        return dict(invalids=invalids), invalids
-    invalids = torch.stack(tuple(invalid_dict.values())).any(dim=0)
+        states, flags = _weighted_solve(cam_mat, pts3d, pts2d, icovs, start, n_points, max_iter_count, num_workers, kwargs)
+        states = states.to(dev)
+        invalids = flags.to(device=dev, dtype=torch.bool)
+        invalid_dict["solver_invalids"] = invalids
+        states = torch.where(invalids[..., None], start.to(states.device), states)
     invalid_dict["invalids"] = invalids
-    return invalid_dict, invalids
-
-
-def _batch_tensors(*tensor_lsts, device=None):
-    """Zero-pad ragged per-job lists into batches (cer_solver.py:67-87)."""
-    batched_all = []
-    for tensor_lst in tensor_lsts:
-        if tensor_lst is None:
-            batched_all.append(None)
-            continue
-        if isinstance(tensor_lst, Tensor):  # already batched (e.g. cam_mat, pts2d given as tensors next to list pts3d)
-            batched_all.append(tensor_lst)
-            continue
-        sample = tensor_lst[0]
-        if isinstance(sample, Tensor):
-            max_shape = max(t.shape[:1] for t in tensor_lst)
-            batched = sample.new_zeros((len(tensor_lst),) + max_shape + sample.shape[1:])
-            if len(batched.shape) > 1:
-                for i, t in enumerate(tensor_lst):
-                    batched[i, :len(t)] = t
-            else:
-                for i, t in enumerate(tensor_lst):
-                    batched[i] = t
-        else:
-            batched = torch.tensor(tensor_lst, device=device)
-        batched_all.append(batched)
-    return batched_all
+    return invalid_dict, states

@@ -45,17 +45,15 @@ def test_product_path_has_no_cpu_fallback():
         _lib.require_hip_f32("x", [1, 2, 3])
 
 
-def test_batch_tensors_and_invalid_combination():
-    from lc_amd.pnp.cer_solver import _batch_tensors, _combine_invalids
+def test_ragged_jobs_become_one_padded_batch():
+    from lc_amd.pnp.cer_solver import _batch_tensors
 
     a = [torch.ones(3, 2), torch.ones(5, 2) * 2, torch.ones(1, 2) * 3]
-    (bt, cnt, none) = _batch_tensors(a, [3, 5, 1], None)
-    assert bt.shape == (3, 5, 2) and none is None and cnt.tolist() == [3, 5, 1]
+    (bt, cnt, none, same) = _batch_tensors(a, [3, 5, 1], None, [torch.zeros(7), torch.ones(7), torch.zeros(7)])
+    assert bt.shape == (3, 5, 2) and none is None and cnt.tolist() == [3, 5, 1] and same.shape == (3, 7)
     assert bt[0, 3:].abs().sum() == 0 and bt[2, 1:].abs().sum() == 0 and (bt[1] == 2).all()
-    d, inv = _combine_invalids({}, torch.zeros(4, 7))
-    assert inv.shape == (4,) and not inv.any() and set(d) == {"invalids"}
-    d, inv = _combine_invalids({"a": torch.tensor([True, False]), "b": torch.tensor([False, False])}, torch.zeros(2, 7))
-    assert inv.tolist() == [True, False]
+    already = torch.rand(3, 4, 2)
+    assert _batch_tensors(already)[0] is already or torch.equal(_batch_tensors(already)[0], already)
 
 
 def test_cer_solver_surface_on_oracle_backend(oracle_backend):
