@@ -80,6 +80,15 @@ def main():
         by = B * (2 * H * W * 4 + 5 * N * 4 + 5 * H * W * 4)  # re-read logits + grads in, dense (zero-filled) d_xyz + d_wlogits out
         line("lc_dense_frontend_bwd_kernel", us, by, B, "samples", B=B, H=H, W=W, sample=sample)
 
+    # ---- f1 (test-time half): point selection + compaction of the N = 4096 dense correspondences ----
+    pts2d_d, inv_std_d, pts3d_d, _ = out
+    seg = (torch.rand(B, N, generator=g) > 0.4).to(torch.uint8).to(dev)
+    for mode in ("mask", "quantile", "quantile_in_mask"):
+        us = ev(lambda: dense.dense_select(pts2d_d, inv_std_d, pts3d_d, mode, mask=seg, quantile=0.7), dev, a.reps)
+        line("lc_dense_select_kernel (%s)" % mode, us, B * N * (28 + 1) + B * int(N * 0.5) * 32, B, "samples",
+             note="one workgroup per sample; quantile modes sort N weights in LDS (bitonic, %d compare-exchange stages)"
+                  % (12 * 13 // 2), B=B, N=N, mode=mode)
+
     # ---- f3: ZebraPose codes: 3x7-bit logits over 128x128 ----
     C, bits = 21, 7
     lg = torch.randn(B, C, H, W, generator=g).to(dev)

@@ -21,7 +21,7 @@
 namespace lc {
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / kWave;
 
 __device__ __forceinline__ unsigned hash_u32(unsigned x) {
