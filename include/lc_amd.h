@@ -154,6 +154,14 @@ int lc_pose_errors_f32(const float *R_est, const float *t_est, const float *R_gt
                        const int *pts_off, const int *pts_cnt, int B, int M, int want_adi, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (2g) Keypoint NLL of the sparse heads -- losses.py:318-326 sparse_kpt_loss: per-sample
+ *      nll[b] = sum_{n,c} ( log std + |pts2d - project_apply(K, pts3d, R(q), t)| / std )   (the caller divides by B*N*2)
+ *      and, when the pointers are non-NULL, d nll[b]/d pts2d and d nll[b]/d std (B,N,2) for a unit cotangent.
+ * ------------------------------------------------------------------------------------------------ */
+int lc_kpt_nll_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,
+                           const float *pts2d_std, int B, int N, float *nll, float *d_pts2d, float *d_std, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (2f) Test-time point selection of the dense heads (second half) -- test.py:39-45 quantile_msk,
  *      test.py:94-113 dense_point_select = mask | quantile | quantile_in_mask + the per-sample nonzero()/list/np.random
  *      padding, batched and compacted on the device.  Inputs are the dense front end's (B,N,.) rows (valid prefix

@@ -341,6 +341,15 @@ int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt
     return lc::launch_pose_errors(p, static_cast<hipStream_t>(stream)) ? fail(11, "pose-error kernel launch failed") : 0;
 }
 
+int lc_kpt_nll_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* pts2d_std, int B,
+                           int N, float* nll, float* d_pts2d, float* d_std, void* stream) {
+    if (B < 0 || N <= 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!K || !pose || !pts3d || !pts2d || !pts2d_std || !nll) return fail(1, "null pointer");
+    lc::KptParams p{K, pose, pts3d, pts2d, pts2d_std, nll, d_pts2d, d_std, B, N};
+    return lc::launch_kpt_nll(p, static_cast<hipStream_t>(stream)) ? fail(11, "keypoint NLL launch failed") : 0;
+}
+
 int lc_dense_select_f32(const float* pts2d, const float* inv_std, const float* pts3d, const unsigned char* mask,
                         const int* in_counts, const int* in_index, int B, int N, int mode, double quantile, int square_weights,
                         int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d, int* out_index,

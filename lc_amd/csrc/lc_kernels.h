@@ -142,6 +142,19 @@ struct DenseBwdParams {
 };
 int launch_dense_bwd(const DenseBwdParams& p, hipStream_t stream);
 
+struct KptParams {
+    const float* K;      // (B,3,3)
+    const float* pose;   // (B,7) wxyz + xyz
+    const float* pts3d;  // (B,N,3)
+    const float* pts2d;  // (B,N,2)
+    const float* std;    // (B,N,2) predicted sigma
+    float* nll;          // (B,) sum over the sample's N*2 terms
+    float* d_pts2d;      // (B,N,2) d nll[b] / d pts2d, or null
+    float* d_std;        // (B,N,2) d nll[b] / d sigma, or null
+    int B, N;
+};
+int launch_kpt_nll(const KptParams& p, hipStream_t stream);
+
 struct SelectParams {
     const float* pts2d;         // (B,N,2)
     const float* inv_std;       // (B,N,2) weights

@@ -1,0 +1,57 @@
+"""Laplace keypoint NLL of the sparse heads (`losses.py:318-326`) as one fused HIP launch.
+
+    loss_kpts = kpt_nll_mean(K, pose_best, pts3d, pts2d, pts2d_std)        # scalar, differentiable w.r.t. pts2d / pts2d_std
+
+The launch returns the per-sample sums together with the unit-cotangent gradients (they cost nothing extra: the projection
+error is already in registers); backward only rescales them.  Replaces ~25 small torch ops and their autograd twins.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _launch_kpt(K, pose, pts3d, pts2d, std, want_grads: bool):
+    lib = _lib.load()
+    B, N = pts2d.shape[0], pts2d.shape[1]
+    nll = torch.empty(B, device=pts2d.device, dtype=torch.float32)
+    d_u = torch.empty_like(pts2d) if want_grads else None
+    d_s = torch.empty_like(std) if want_grads else None
+    with torch.cuda.device(pts2d.device):
+        rc = lib.lc_kpt_nll_fwd_bwd_f32(_lib.ptr(K), _lib.ptr(pose), _lib.ptr(pts3d), _lib.ptr(pts2d), _lib.ptr(std), B, N, _lib.ptr(nll),
+                                        _lib.ptr(d_u), _lib.ptr(d_s), _lib.stream_ptr(pts2d.device))
+    _lib.check(rc, "lc_kpt_nll_fwd_bwd_f32")
+    return nll, d_u, d_s
+
+
+class _KptNllFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, K, pose, pts3d, pts2d, std):
+        need = ctx.needs_input_grad
+        if need[0] or need[1] or need[2]:
+            raise NotImplementedError("lc_amd.kpt: gradients w.r.t. K / pose / pts3d are not produced (ground-truth inputs, losses.py:321)")
+        nll, d_u, d_s = _launch_kpt(K, pose, pts3d, pts2d, std, need[3] or need[4])
+        ctx.save_for_backward(*[t for t in (d_u, d_s) if t is not None])
+        ctx.count = pts2d.numel()
+        return nll.sum() / ctx.count
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.saved_tensors:
+            return None, None, None, None, None
+        d_u, d_s = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        w = g / ctx.count
+        return None, None, None, (d_u * w if need[3] else None), (d_s * w if need[4] else None)
+
+
+def kpt_nll_mean(K: Tensor, pose: Tensor, pts3d: Tensor, pts2d: Tensor, pts2d_std: Tensor) -> Tensor:
+    """mean over (B,N,2) of log(std) + |pts2d - proj| / std."""
+    B, N = pts2d.shape[:2]
+    args = [_lib.require_hip_f32(n, t) for n, t in (("out_K", K), ("pose_best", pose), ("pts3d", pts3d), ("pts2d", pts2d),
+                                                   ("pts2d_std", pts2d_std))]
+    if args[0].shape != (B, 3, 3) or args[1].shape != (B, 7) or args[2].shape != (B, N, 3) or args[4].shape != (B, N, 2):
+        raise ValueError("kpt_nll_mean: K (B,3,3), pose (B,7), pts3d (B,N,3), pts2d / pts2d_std (B,N,2) expected")
+    return _KptNllFn.apply(*args)

@@ -3,8 +3,8 @@
 Keeps the names `train.py:31,58-59` / `test.py:12` use -- `Loss_fn`, `dense_pnp_matching_from_xyz`, `nn_out_to_xyz` --
 with the same arguments, return values and buffer names (`weight_grad_clipper.max_norm`), so a checkpointed
 `model.loss_fn` loads strictly.  The pose term goes through `lc_amd.cov_mixed.Loss_cov_mixed`
-(one fused HIP launch); the surrounding warm-up blending, weight softmax, strided sub-sampling and Laplace keypoint NLL
-are cheap torch glue exactly as in `losses.py:142-161,261-386`.
+(one fused HIP launch), the Laplace keypoint NLL through `lc_amd.kpt` (one launch), the weight softmax + strided sub-sampling
+through `lc_amd.dense` (one launch each way); what remains of `losses.py:261-386` here is the warm-up blending and the dicts.
 
 The ZebraPose binary-code branch (`xyz_noc_bin`, `losses.py:163-184,196-216`) decodes through `lc_amd.floatbits`
 (HIP kernels).
@@ -24,6 +24,7 @@ from . import transforms as xforms
 from .cov_mixed import Loss_cov_mixed
 from .dense import dense_front_end
 from .grad import NormClipper
+from .kpt import kpt_nll_mean
 
 
 def nn_out_to_xyz(nn_out: Tensor = None, noc_scale_xfd: Tensor = None, *, raw_bits_gt=None, noc_mask=None,
@@ -181,12 +182,10 @@ class Loss_fn(nn.Module):
         return loss_dict, w_loss_dict
 
     def sparse_kpt_loss(self, cfg, gt_dict, out_dict):
-        """Laplace NLL of the keypoints, mean(log sigma + |u - proj|/sigma) (`losses.py:318-326`)."""
+        """Laplace NLL of the keypoints, mean(log sigma + |u - proj|/sigma) (`losses.py:318-326`): one fused launch."""
         pts2d, pts2d_std = itemgetter("pts2d", "pts2d_std")(out_dict)
         pose_best, K, pts3d = itemgetter("pose_best", "out_K", "pts3d")(gt_dict)
-        pts2d_proj = xforms.project_apply(K, pts3d, *xforms.quaternion_rep_to_RT(pose_best))
-        err = (pts2d - pts2d_proj).abs()
-        return (torch.log(pts2d_std) + err / pts2d_std).mean()
+        return kpt_nll_mean(K, pose_best, pts3d, pts2d, pts2d_std)
 
     def sparse_pose_loss(self, cfg, gt_dict, out_dict):
         """`losses.py:329-334`."""

@@ -18,6 +18,14 @@ def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_
     return loss, du, ds, dx, None
 
 
+def _launch_kpt(K, pose, pts3d, pts2d, std, want_grads):
+    from oracle import kpt_oracle
+
+    with torch.enable_grad():
+        nll, du, ds = kpt_oracle.nll_and_grads(K, pose, pts3d, pts2d, std)
+    return nll, (du if want_grads else None), (ds if want_grads else None)
+
+
 def _launch_scale(scale, srcs):
     return [None if s is None else s * scale.view(-1, *([1] * (s.dim() - 1))) for s in srcs]
 
@@ -50,7 +58,7 @@ def _decode_with_gt_strided(logits, gt_raw_bits, bit_cnt, gt_msk, sample=1, top_
 
 @pytest.fixture
 def oracle_backend(monkeypatch):
-    from lc_amd import _lib, cov_mixed, losses
+    from lc_amd import _lib, cov_mixed, kpt, losses
     from lc_amd.pnp import pnp_ceres
 
     monkeypatch.setattr(losses, "dense_front_end", _dense_front_end)
@@ -59,6 +67,7 @@ def oracle_backend(monkeypatch):
     monkeypatch.setattr(_lib, "require_hip_f32", lambda name, t: t.contiguous())
     monkeypatch.setattr(cov_mixed, "_launch_loss", _launch_loss)
     monkeypatch.setattr(cov_mixed, "_launch_scale", _launch_scale)
+    monkeypatch.setattr(kpt, "_launch_kpt", _launch_kpt)
     monkeypatch.setattr(pnp_ceres, "solve_device", _solve_device)
     orig_solve = pnp_ceres.solve
 

@@ -18,13 +18,14 @@ def _free_port():
 
 def _patch_backend(monkeypatch=None):
     """What the `oracle_backend` fixture does; without pytest's monkeypatch in the spawned children."""
-    from lc_amd import _lib, cov_mixed
+    from lc_amd import _lib, cov_mixed, kpt
     from tests import cpu_backend
 
     setter = monkeypatch.setattr if monkeypatch is not None else setattr
     setter(_lib, "require_hip_f32", lambda name, t: t.contiguous())
     setter(cov_mixed, "_launch_loss", cpu_backend._launch_loss)
     setter(cov_mixed, "_launch_scale", cpu_backend._launch_scale)
+    setter(kpt, "_launch_kpt", cpu_backend._launch_kpt)
 
 
 def _model_and_batch(B, N, dtype=torch.float64):
