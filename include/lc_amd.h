@@ -154,6 +154,23 @@ int lc_pose_errors_f32(const float *R_est, const float *t_est, const float *R_gt
                        const int *pts_off, const int *pts_cnt, int B, int M, int want_adi, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (2h) EMA-adaptive gradient-norm clipping -- lib/utils/grad.py:5-30 (NormClipper.clip) + :33-83 (clip_norm), the
+ *      backward hook of the dense heads (losses.py:343-352,378-381), without host synchronisation:
+ *        lc_sqnorm_f32            sq (device float) = [sq +] sum x^2.  partials: LC_SQNORM_BLOCKS doubles of workspace,
+ *                                 ticket: one zero-initialised unsigned (left at zero); both owned by the caller.
+ *        [all-reduce sq over the data-parallel group when the batch is sharded]
+ *        lc_norm_clip_apply_f32   norm = sqrt(sq);  limit = state_in <= 0 ? initial_max_norm : state_in;
+ *                                 out = grad * min(limit / (norm + 1e-6), 1);
+ *                                 state_out = state_in <= 0 ? norm*scale
+ *                                           : state_in*(1-momentum) + momentum*scale*min(norm, state_in*scale)
+ *                                 (state_out / norm_out may be NULL: scale a further tensor of the same hook call).
+ * ------------------------------------------------------------------------------------------------ */
+#define LC_SQNORM_BLOCKS 512
+int lc_sqnorm_f32(const float *x, long long n, double *partials, unsigned *ticket, float *sq, int accumulate, void *stream);
+int lc_norm_clip_apply_f32(const float *grad, long long n, const float *sq, const float *state_in, float initial_max_norm,
+                           float scale, double momentum, float *out, float *state_out, float *norm_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (2g) Keypoint NLL of the sparse heads -- losses.py:318-326 sparse_kpt_loss: per-sample
  *      nll[b] = sum_{n,c} ( log std + |pts2d - project_apply(K, pts3d, R(q), t)| / std )   (the caller divides by B*N*2)
  *      and, when the pointers are non-NULL, d nll[b]/d pts2d and d nll[b]/d std (B,N,2) for a unit cotangent.

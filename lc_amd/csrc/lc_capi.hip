@@ -8,6 +8,8 @@
 
 #include "../../include/lc_amd.h"
 #include "lc_common.h"
+#include <cstdint>
+
 #include "lc_kernels.h"
 
 namespace {
@@ -339,6 +341,27 @@ int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt
     if ((pts_off == nullptr) != (pts_cnt == nullptr)) return fail(1, "pts_off and pts_cnt go together");
     lc::MetricsParams p{R_est, t_est, R_gt, t_gt, pts, pts_off, pts_cnt, out, B, M, want_adi};
     return lc::launch_pose_errors(p, static_cast<hipStream_t>(stream)) ? fail(11, "pose-error kernel launch failed") : 0;
+}
+
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+int lc_sqnorm_f32(const float* x, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, void* stream) {
+    if (n < 0) return fail(1, "bad size");
+    if (!partials || !ticket || !sq || (n > 0 && !x)) return fail(1, "null pointer");
+    lc::ClipParams p{};
+    p.x = x; p.n = n; p.vec = aligned16(x); p.partials = partials; p.ticket = ticket; p.sq = sq; p.accumulate = accumulate;
+    return lc::launch_sqnorm(p, static_cast<hipStream_t>(stream)) ? fail(11, "sqnorm launch failed") : 0;
+}
+
+int lc_norm_clip_apply_f32(const float* grad, long long n, const float* sq, const float* state_in, float initial_max_norm, float scale,
+                           double momentum, float* out, float* state_out, float* norm_out, void* stream) {
+    if (n < 0) return fail(1, "bad size");
+    if (!sq || !state_in || (n > 0 && (!grad || !out))) return fail(1, "null pointer");
+    lc::ClipParams p{};
+    p.x = grad; p.n = n; p.vec = aligned16(grad) && aligned16(out); p.sq = const_cast<float*>(sq); p.state_in = state_in;
+    p.initial_max_norm = initial_max_norm; p.scale = scale; p.keep = (float)(1.0 - momentum); p.gain = (float)(momentum * (double)scale);
+    p.out = out; p.state_out = state_out; p.norm_out = norm_out;
+    return lc::launch_clip_apply(p, static_cast<hipStream_t>(stream)) ? fail(11, "clip launch failed") : 0;
 }
 
 int lc_kpt_nll_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* pts2d_std, int B,

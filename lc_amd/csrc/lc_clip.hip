@@ -1,0 +1,95 @@
+// EMA-adaptive global-norm gradient clipping (lib/utils/grad.py:5-30 NormClipper + :33-83 clip_norm), the backward hook the
+// dense heads hang on their weight logits / weight scale / 3D points (losses.py:245-247,343-352,378-381).
+// The reference spends ~15 small torch launches per hook call (norm, add, div, clamp, mul, the EMA update); here:
+//   lc_sqnorm_kernel      sum of squares of the gradient -> one device float (deterministic: per-block partials in a
+//                         fixed order, summed by the last block to arrive)
+//   [ all-reduce of that float over the process group when the batch is sharded: SURVEY.md 8e ]
+//   lc_clip_apply_kernel  coefficient + scaling of the gradient + the EMA state update, all from device scalars
+// No host synchronisation: the reference's `self.start and self.max_norm <= 0` test is evaluated on the device.
+#include "lc_common.h"
+#include "lc_kernels.h"
+
+namespace lc {
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    double a[1] = {v};
+    wave_allreduce<1>(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a[0];
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(kThreads) void lc_sqnorm_kernel(const ClipParams p) {
+    __shared__ double red[4];
+    __shared__ bool last;
+    const long long tid = (long long)blockIdx.x * kThreads + threadIdx.x, stride = (long long)gridDim.x * kThreads;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const long long n4 = p.vec ? p.n >> 2 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(p.x);
+    for (long long i = tid; i < n4; i += stride) {
+        const float4 v = x4[i];
+        a0 = fmaf(v.x, v.x, a0); a1 = fmaf(v.y, v.y, a1); a2 = fmaf(v.z, v.z, a2); a3 = fmaf(v.w, v.w, a3);
+    }
+    for (long long i = (n4 << 2) + tid; i < p.n; i += stride) a0 = fmaf(p.x[i], p.x[i], a0);
+    const double part = block_sum_d(((double)a0 + (double)a1) + ((double)a2 + (double)a3), red);
+    if (threadIdx.x == 0) {
+        p.partials[blockIdx.x] = part;
+        __threadfence();
+        last = atomicAdd(p.ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double s = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads) s += p.partials[i];
+    s = block_sum_d(s, red);
+    if (threadIdx.x == 0) {
+        *p.sq = (p.accumulate ? *p.sq : 0.f) + (float)s;
+        *p.ticket = 0;  // ready for the next call on this stream
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void lc_clip_apply_kernel(const ClipParams p) {
+    const float norm = sqrtf(*p.sq);
+    const float state = *p.state_in;
+    const bool fresh = state <= 0.f;  // grad.py:20: no running maximum yet
+    const float limit = fresh ? p.initial_max_norm : state;
+    const float coef = fminf(limit / (norm + 1e-6f), 1.f);  // grad.py:76-80
+    const long long tid = (long long)blockIdx.x * kThreads + threadIdx.x, stride = (long long)gridDim.x * kThreads;
+    const long long n4 = p.vec ? p.n >> 2 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(p.x);
+    float4* o4 = reinterpret_cast<float4*>(p.out);
+    for (long long i = tid; i < n4; i += stride) {
+        const float4 v = x4[i];
+        o4[i] = make_float4(v.x * coef, v.y * coef, v.z * coef, v.w * coef);
+    }
+    for (long long i = (n4 << 2) + tid; i < p.n; i += stride) p.out[i] = p.x[i] * coef;
+    if (tid == 0 && p.state_out) {
+        // grad.py:22 / :26-27 in the reference's fp32 operation order
+        *p.state_out = fresh ? norm * p.scale : state * p.keep + p.gain * fminf(norm, state * p.scale);
+        if (p.norm_out) *p.norm_out = norm;
+    }
+}
+
+int grid_for(long long n) {
+    long long g = (n + (long long)kThreads * 8 - 1) / ((long long)kThreads * 8);
+    return (int)(g < 1 ? 1 : (g > kClipMaxBlocks ? kClipMaxBlocks : g));
+}
+
+}  // namespace
+
+int launch_sqnorm(const ClipParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(lc_sqnorm_kernel, dim3(grid_for(p.n)), dim3(kThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_clip_apply(const ClipParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(lc_clip_apply_kernel, dim3(grid_for(p.n)), dim3(kThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace lc

@@ -142,6 +142,26 @@ struct DenseBwdParams {
 };
 int launch_dense_bwd(const DenseBwdParams& p, hipStream_t stream);
 
+constexpr int kClipMaxBlocks = 512;  // length of the caller-provided `partials` workspace of lc_sqnorm_f32
+struct ClipParams {
+    const float* x;      // gradient
+    long long n;
+    int vec;             // x (and out) 16-byte aligned: float4 stream
+    // lc_sqnorm
+    double* partials;    // (kClipMaxBlocks,) workspace
+    unsigned* ticket;    // zero-initialised counter, left at zero
+    float* sq;           // device scalar: sum of squares (accumulated into when `accumulate`)
+    int accumulate;
+    // lc_clip_apply
+    const float* state_in;   // max_norm before the call (<= 0: not started)
+    float initial_max_norm, scale, keep, gain;  // keep = 1 - momentum, gain = momentum * scale
+    float* out;
+    float* state_out;    // max_norm after the call, or null (do not update)
+    float* norm_out;     // total norm, or null
+};
+int launch_sqnorm(const ClipParams& p, hipStream_t stream);
+int launch_clip_apply(const ClipParams& p, hipStream_t stream);
+
 struct KptParams {
     const float* K;      // (B,3,3)
     const float* pose;   // (B,7) wxyz + xyz

@@ -1,33 +1,56 @@
-"""`lib.utils.grad.NormClipper` (`lib/utils/grad.py:5-30`): EMA-adaptive global-norm clipping used as a backward hook
-on the weight logits (`losses.py:245-247,343-352`).  Buffer name `max_norm` is kept so checkpoints load strictly.
+"""`lib.utils.grad.NormClipper` call surface (`lib/utils/grad.py:5-30`): EMA-adaptive global-norm clipping, hung as a backward
+hook on the dense heads' weight logits / scale / points (`losses.py:245-247,343-352,378-381`).  The buffer name `max_norm`
+is kept so checkpoints load strictly.
 
-Under batch sharding the norm must be taken over the WHOLE batch gradient (grad.py:66-68): pass a process group and
-the squared norm is all-reduced (one float over RCCL) before the clip coefficient is formed.
+Two launches per hook call and no host synchronisation (`lc_amd/csrc/lc_clip.hip`): sum of squares -> device scalar, then
+coefficient + scaling + the EMA update of `max_norm` from device scalars.  The reference's `start` flag only exists to
+skip a device->host read of `max_norm <= 0`; with the test evaluated on the device it has no role (`max_norm` stays
+positive once it has been set, so "not started" and "max_norm <= 0" coincide).
+
+Under batch sharding the norm must be taken over the WHOLE batch gradient (grad.py:66-68): pass a process group and the
+squared norm is all-reduced (one float over RCCL) between the two launches.
 """
 from __future__ import annotations
 
 import torch
 from torch import Tensor
 
+from . import _lib
 
-def clip_norm(grads, max_norm, norm_type: float = 2.0, group=None):
-    if isinstance(grads, Tensor):
-        grads = [grads]
-    norm_type = float(norm_type)
-    if len(grads) == 0:
-        return torch.tensor(0.0), []
-    if norm_type != 2.0:
-        raise NotImplementedError("lc_amd NormClipper: only the 2-norm the reference uses is implemented")
-    sq = torch.stack([p.detach().pow(2).sum() for p in grads]).sum()
-    if group is not None:
-        import torch.distributed as dist
+_SQNORM_BLOCKS = 512  # LC_SQNORM_BLOCKS (include/lc_amd.h)
 
-        dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)
-    total_norm = sq.sqrt()
-    clip_coef = max_norm / (total_norm + 1e-6)
-    clip_coef_clamped = torch.clamp(clip_coef, max=1.0)
-    clipped = [p.mul(clip_coef_clamped.to(p.device)) for p in grads]
-    return total_norm, clipped
+
+def _launch_sqnorm(grads, workspace):
+    """Sum of squares over all tensors of the hook call -> float32 device scalar."""
+    lib = _lib.load()
+    dev = grads[0].device
+    partials, ticket = workspace
+    sq = torch.empty((), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        for i, g in enumerate(grads):
+            rc = lib.lc_sqnorm_f32(_lib.ptr(g), g.numel(), _lib.ptr(partials), _lib.ptr(ticket), _lib.ptr(sq), int(i > 0), _lib.stream_ptr(dev))
+            _lib.check(rc, "lc_sqnorm_f32")
+    return sq
+
+
+def _launch_apply(grads, sq, state, initial_max_norm, scale, momentum):
+    """-> (clipped tensors, new max_norm, total norm); the state update rides on the last tensor's launch."""
+    lib = _lib.load()
+    dev = grads[0].device
+    state = state.to(torch.float32)
+    new_state = torch.empty((), device=dev, dtype=torch.float32)
+    norm = torch.empty((), device=dev, dtype=torch.float32)
+    outs = []
+    with torch.cuda.device(dev):
+        for i, g in enumerate(grads):
+            o = torch.empty_like(g)
+            last = i == len(grads) - 1
+            rc = lib.lc_norm_clip_apply_f32(_lib.ptr(g), g.numel(), _lib.ptr(sq), _lib.ptr(state), float(initial_max_norm), float(scale),
+                                            float(momentum), _lib.ptr(o), _lib.ptr(new_state) if last else None,
+                                            _lib.ptr(norm) if last else None, _lib.stream_ptr(dev))
+            _lib.check(rc, "lc_norm_clip_apply_f32")
+            outs.append(o)
+    return outs, new_state, norm
 
 
 class NormClipper(torch.nn.Module):
@@ -38,20 +61,33 @@ class NormClipper(torch.nn.Module):
         self.momentum = momentum
         self.scale = 1 + rel_thresh
         self.last_norm = 0
-        self.start = True
         self.group = group
+        self._workspace = {}
+
+    def _ws(self, dev):
+        if dev not in self._workspace:
+            self._workspace[dev] = (torch.empty(_SQNORM_BLOCKS, device=dev, dtype=torch.float64),
+                                    torch.zeros(1, device=dev, dtype=torch.int32))
+        return self._workspace[dev]
 
     def forward(self, grads, norm_type=2):
         return self.clip(grads, norm_type)
 
+    @torch.no_grad()
     def clip(self, grads, norm_type=2):
-        if self.start and self.max_norm <= 0:
-            new_norm, clipped = clip_norm(grads, self.initial_max_norm, norm_type=norm_type, group=self.group)
-            self.max_norm = new_norm * self.scale
-        else:
-            self.start = False
-            new_norm, clipped = clip_norm(grads, self.max_norm, norm_type=norm_type, group=self.group)
-            self.max_norm = self.max_norm * (1 - self.momentum) \
-                + self.momentum * self.scale * new_norm.clamp_max(self.max_norm * self.scale)
-        self.last_norm = new_norm
-        return clipped[0] if isinstance(grads, Tensor) else clipped
+        if float(norm_type) != 2.0:
+            raise NotImplementedError("lc_amd NormClipper: only the 2-norm the reference uses is implemented")
+        single = isinstance(grads, Tensor)
+        tensors = [grads] if single else list(grads)
+        if not tensors:
+            return tensors
+        tensors = [_lib.require_hip_f32("grad", g) for g in tensors]
+        dev = tensors[0].device
+        sq = _launch_sqnorm(tensors, self._ws(dev))
+        if self.group is not None:
+            import torch.distributed as dist
+
+            dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+        state = self.max_norm.to(device=dev)
+        clipped, self.max_norm, self.last_norm = _launch_apply(tensors, sq, state, self.initial_max_norm, self.scale, self.momentum)
+        return clipped[0] if single else clipped

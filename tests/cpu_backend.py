@@ -26,6 +26,18 @@ def _launch_kpt(K, pose, pts3d, pts2d, std, want_grads):
     return nll, (du if want_grads else None), (ds if want_grads else None)
 
 
+def _launch_sqnorm(grads, workspace):
+    from oracle import grad_oracle
+
+    return grad_oracle.sum_of_squares(grads)
+
+
+def _launch_apply(grads, sq, state, initial_max_norm, scale, momentum):
+    from oracle import grad_oracle
+
+    return grad_oracle.apply(grads, sq, state.to(sq.dtype), initial_max_norm, scale, momentum)
+
+
 def _launch_scale(scale, srcs):
     return [None if s is None else s * scale.view(-1, *([1] * (s.dim() - 1))) for s in srcs]
 
@@ -58,7 +70,7 @@ def _decode_with_gt_strided(logits, gt_raw_bits, bit_cnt, gt_msk, sample=1, top_
 
 @pytest.fixture
 def oracle_backend(monkeypatch):
-    from lc_amd import _lib, cov_mixed, kpt, losses
+    from lc_amd import _lib, cov_mixed, grad, kpt, losses
     from lc_amd.pnp import pnp_ceres
 
     monkeypatch.setattr(losses, "dense_front_end", _dense_front_end)
@@ -68,6 +80,9 @@ def oracle_backend(monkeypatch):
     monkeypatch.setattr(cov_mixed, "_launch_loss", _launch_loss)
     monkeypatch.setattr(cov_mixed, "_launch_scale", _launch_scale)
     monkeypatch.setattr(kpt, "_launch_kpt", _launch_kpt)
+    monkeypatch.setattr(grad, "_launch_sqnorm", _launch_sqnorm)
+    monkeypatch.setattr(grad, "_launch_apply", _launch_apply)
+    monkeypatch.setattr(grad.NormClipper, "_ws", lambda self, dev: None)
     monkeypatch.setattr(pnp_ceres, "solve_device", _solve_device)
     orig_solve = pnp_ceres.solve
 
