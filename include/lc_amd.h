@@ -9,6 +9,9 @@
  * Plain pointers and sizes only; no torch types.  All `float*`/`int*` of the device API are DEVICE pointers,
  * `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream.
  * Return value: 0 on success, non-zero on error (lc_amd_last_error() gives the text).
+ * Alignment: rows of two floats (pts2d, inv_std / sqrt_diag / std and their gradients) must be 8-byte aligned, 2x2 factors
+ * (sqrtL) and maps whose width is a multiple of four 16-byte aligned -- true for every contiguous batch and every row
+ * slice of one; a misaligned pointer is rejected (error 1), never read through a narrower fallback silently.
  */
 #ifndef LC_AMD_H
 #define LC_AMD_H

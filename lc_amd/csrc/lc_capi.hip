@@ -147,6 +147,18 @@ int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pt
 
 }  // namespace
 
+// Pointers the kernels access with 8-byte (float2 rows: pts2d, inv_std, their gradients) or 16-byte (float4: 2x2 factors, head
+// and code maps) vector instructions.  Row slices of contiguous batches always satisfy this; an arbitrary element offset may not.
+template <typename... P>
+static bool misaligned(size_t bytes, P... ptrs) {
+    const void* v[] = {static_cast<const void*>(ptrs)...};
+    for (const void* q : v)
+        if (q && (reinterpret_cast<uintptr_t>(q) & (bytes - 1))) return true;
+    return false;
+}
+#define LC_REQUIRE_ALIGNED(bytes, ...) \
+    if (misaligned(bytes, __VA_ARGS__)) return fail(1, "pointer not " #bytes "-byte aligned (" #__VA_ARGS__ ")")
+
 #pragma GCC visibility push(default)
 extern "C" {
 
@@ -179,6 +191,8 @@ int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const 
     if (B == 0) return 0;
     if ((sqrtL == nullptr) == (sqrt_diag == nullptr)) return fail(1, "exactly one of sqrtL / sqrt_diag must be given");
     if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, sqrt_diag);
+    LC_REQUIRE_ALIGNED(16, sqrtL);
     lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
                     B, Nmax, max_iter, function_tolerance};
     if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
@@ -202,6 +216,7 @@ int lc_cov_loss2_fwd_bwd_f32(const float* K, const float* pose, const float* pts
     if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss) return fail(1, "null pointer");
     if ((d_pts2d == nullptr) != (d_inv_std == nullptr)) return fail(1, "d_pts2d and d_inv_std must both be given or both be NULL");
     if (d_pts3d && !d_pts2d) return fail(1, "d_pts3d needs d_pts2d/d_inv_std");
+    LC_REQUIRE_ALIGNED(8, pts2d, inv_std, d_pts2d, d_inv_std);
     lc::LossParams p{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, aux,
                      B, N, max_err_len, rel_thresh, w_e_thresh, cov_2d ? 1 : 0};
     if (lc::launch_cov_loss(p, static_cast<hipStream_t>(stream))) return fail(11, "loss kernel launch failed");
@@ -219,6 +234,7 @@ int lc_pose_unit_f32(const float* K, const float* pose, const float* pts3d, cons
     if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss || !d_pts2d || !d_inv_std || !pnp_sqrt_diag ||
         !pnp_start || !pnp_states || !pnp_result_tr || !pnp_rets)
         return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, inv_std, d_pts2d, d_inv_std, pnp_sqrt_diag);
     lc::LossParams lp{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, nullptr,
                       B, N, max_err_len, rel_thresh, w_e_thresh, 0};
     lc::PnpParams pp{K, pts2d, pts3d, nullptr, pnp_sqrt_diag, nullptr, pnp_start == pnp_states ? nullptr : pnp_start, pnp_states,
@@ -246,6 +262,7 @@ int lc_softargmax2d_fwd_f32(const float* in, int M, int H, int W, int is_prob, f
     if (M < 0 || H <= 0 || W <= 0) return fail(1, "bad size");
     if (M == 0) return 0;
     if (!in || !mean || !std || !stats) return fail(1, "null pointer");
+    if (W % 4 == 0) LC_REQUIRE_ALIGNED(16, in);
     lc::HeadParams p{in, mean, std, stats, M, H, W, is_prob};
     const int rc = lc::launch_head_fwd(p, static_cast<hipStream_t>(stream));
     if (rc == 3) return fail(3, "map too large for the single-pass soft-argmax kernel");
@@ -257,6 +274,7 @@ int lc_softargmax2d_bwd_f32(const float* in, const float* mean, const float* std
     if (M < 0 || H <= 0 || W <= 0) return fail(1, "bad size");
     if (M == 0) return 0;
     if (!in || !mean || !std || !stats || !g_mean || !g_std || !g_in) return fail(1, "null pointer");
+    if (W % 4 == 0) LC_REQUIRE_ALIGNED(16, in, g_in);
     lc::HeadBwdParams p{in, mean, std, stats, g_mean, g_std, g_in, M, H, W, is_prob};
     return lc::launch_head_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "head backward launch failed") : 0;
 }
@@ -267,6 +285,7 @@ int lc_dense_frontend_fwd_f32(const float* xyz, const float* wlogits, const floa
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!wlogits || !wscale || !pts2d || !inv_std || !lse || (xyz != nullptr) != (pts3d != nullptr)) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, inv_std);
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     lc::DenseParams p{xyz, wlogits, wscale, noc_scale, pts2d, inv_std, pts3d, lse, B, H, W, N, top, left, sample};
     return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
@@ -278,6 +297,7 @@ int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const f
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!wlogits || !wscale || !lse) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, g_inv_std);
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     lc::DenseBwdParams p{wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, d_xyz, d_wlogits, d_wscale, B, H, W, N, top, left, sample};
     return lc::launch_dense_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end backward launch failed") : 0;
@@ -343,13 +363,11 @@ int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt
     return lc::launch_pose_errors(p, static_cast<hipStream_t>(stream)) ? fail(11, "pose-error kernel launch failed") : 0;
 }
 
-static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
-
 int lc_sqnorm_f32(const float* x, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, void* stream) {
     if (n < 0) return fail(1, "bad size");
     if (!partials || !ticket || !sq || (n > 0 && !x)) return fail(1, "null pointer");
     lc::ClipParams p{};
-    p.x = x; p.n = n; p.vec = aligned16(x); p.partials = partials; p.ticket = ticket; p.sq = sq; p.accumulate = accumulate;
+    p.x = x; p.n = n; p.vec = !misaligned(16, x); p.partials = partials; p.ticket = ticket; p.sq = sq; p.accumulate = accumulate;
     return lc::launch_sqnorm(p, static_cast<hipStream_t>(stream)) ? fail(11, "sqnorm launch failed") : 0;
 }
 
@@ -358,7 +376,7 @@ int lc_norm_clip_apply_f32(const float* grad, long long n, const float* sq, cons
     if (n < 0) return fail(1, "bad size");
     if (!sq || !state_in || (n > 0 && (!grad || !out))) return fail(1, "null pointer");
     lc::ClipParams p{};
-    p.x = grad; p.n = n; p.vec = aligned16(grad) && aligned16(out); p.sq = const_cast<float*>(sq); p.state_in = state_in;
+    p.x = grad; p.n = n; p.vec = !misaligned(16, grad, out); p.sq = const_cast<float*>(sq); p.state_in = state_in;
     p.initial_max_norm = initial_max_norm; p.scale = scale; p.keep = (float)(1.0 - momentum); p.gain = (float)(momentum * (double)scale);
     p.out = out; p.state_out = state_out; p.norm_out = norm_out;
     return lc::launch_clip_apply(p, static_cast<hipStream_t>(stream)) ? fail(11, "clip launch failed") : 0;
@@ -369,6 +387,7 @@ int lc_kpt_nll_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d
     if (B < 0 || N <= 0) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!K || !pose || !pts3d || !pts2d || !pts2d_std || !nll) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, pts2d_std, d_pts2d, d_std);
     lc::KptParams p{K, pose, pts3d, pts2d, pts2d_std, nll, d_pts2d, d_std, B, N};
     return lc::launch_kpt_nll(p, static_cast<hipStream_t>(stream)) ? fail(11, "keypoint NLL launch failed") : 0;
 }
@@ -381,6 +400,7 @@ int lc_dense_select_f32(const float* pts2d, const float* inv_std, const float* p
     if (mode != 0 && !(quantile >= 0.0 && quantile <= 1.0)) return fail(1, "quantile outside [0,1]");
     if (B == 0) return 0;
     if (!pts2d || !inv_std || !pts3d || !out_pts2d || !out_weights || !out_pts3d || !counts) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, inv_std, out_pts2d, out_weights);
     if (mode != 1 && !mask) return fail(1, "modes 0 (mask) and 2 (quantile_in_mask) need a mask");
     lc::SelectParams p{pts2d, inv_std, pts3d, mask, in_counts, in_index, out_pts2d, out_weights, out_pts3d, out_index, counts,
                        B, N, mode, (float)quantile, (float)(1.0 - quantile), square_weights, min_count, seed};

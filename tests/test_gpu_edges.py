@@ -137,3 +137,19 @@ def test_pnp_dense_sizes_vs_oracle():
                                          counts=counts.numpy())
     np.testing.assert_array_equal(ret.cpu().numpy(), ro)
     assert np.abs(st.cpu().numpy()[:, :4] - so[:, :4]).max() <= 1e-4
+
+
+def test_misaligned_pointers_are_rejected():
+    """The C ABI refuses a float2-row pointer at an odd element offset instead of faulting in a vector load."""
+    from lc_amd import _lib, synth
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(2, 8, seed=0).items()}
+    flat = torch.zeros(2 * 8 * 2 + 1, device=dev)
+    odd = flat[1:]  # 4-byte offset: not 8-byte aligned
+    st, tr, ret = torch.empty_like(b["start"]), torch.empty(2, device=dev), torch.empty(2, device=dev, dtype=torch.int32)
+    P = _lib.ptr
+    rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(odd), None, P(b["inv_std"]), None, P(b["start"]), P(st), P(tr), P(ret), None, 2, 8,
+                           50, 1e-6, _lib.stream_ptr(dev))
+    assert rc == 1 and b"aligned" in lib.lc_amd_last_error()
