@@ -1,6 +1,7 @@
 // C ABI of liblc_amd.so (declared in include/lc_amd.h): argument checking, the host shim that gives the
 // reference's `pnp_ceres_f32_omp` symbol a GPU body, and the tiny row-scale kernel used by autograd's chain rule.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -42,11 +43,14 @@ __global__ void lc_scale_rows_kernel(const float* __restrict__ scale, int B, con
     }
 }
 
+constexpr size_t kZeroCopyMaxPoints = 4096 * 64;  // measured equal-or-better up to here (scripts/ubench/host_abi_rate.py)
+
 // Workspace of the host shim (pinned staging + device buffers), grown on demand and reused across calls.
 struct PnpHostWorkspace {
     std::mutex mu;
     size_t cap_jobs = 0, cap_pts = 0;
     char* host = nullptr;
+    char* host_dev = nullptr;  // device-side address of the pinned staging buffer (zero-copy route)
     char* dev = nullptr;
     size_t bytes = 0;
     hipStream_t stream = nullptr;
@@ -74,7 +78,8 @@ struct PnpHostWorkspace {
         if (dev) (void)hipFree(dev);
         host = dev = nullptr;
         cap_jobs = cap_pts = 0;
-        LC_HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&host), need, hipHostMallocDefault));
+        LC_HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&host), need, hipHostMallocMapped));
+        LC_HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), host, 0));
         LC_HIP_OK(hipMalloc(reinterpret_cast<void**>(&dev), need));
         bytes = need;
         cap_jobs = nb;
@@ -115,9 +120,13 @@ int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pt
         hC[i] = ptCnts[i];
         std::memcpy(hS + 7 * (size_t)i, init_states[i], 7 * sizeof(float));
     }
-    char* d = g_ws.dev;
+    // Small batches: the kernel reads the pinned staging buffer and writes its results there directly over PCIe (no copy
+    // commands: two API calls and their DMA set-up cost more than the ~2 KB/pose they move); large ones: one H2D, one D2H.
+    static const int zc_env = [] { const char* e = std::getenv("LC_AMD_HOST_ZEROCOPY"); return e ? std::atoi(e) : -1; }();
+    const bool zero_copy = zc_env >= 0 ? zc_env != 0 : (size_t)B * P <= kZeroCopyMaxPoints;
+    char* d = zero_copy ? g_ws.host_dev : g_ws.dev;
     hipStream_t st = g_ws.stream;
-    LC_HIP_OK(hipMemcpyAsync(d, h, off[6], hipMemcpyHostToDevice, st));  // everything up to and including states
+    if (!zero_copy) LC_HIP_OK(hipMemcpyAsync(d, h, off[6], hipMemcpyHostToDevice, st));  // everything up to and including states
     lc::PnpParams p{};
     p.K = reinterpret_cast<float*>(d + off[0]);
     p.pts3d = reinterpret_cast<float*>(d + off[1]);
@@ -132,7 +141,7 @@ int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pt
     p.iters = nullptr;
     p.B = B; p.Nmax = (int)P; p.max_iter = maxIterCnt; p.ftol = ftol;
     if (lc::launch_pnp_lm(p, st)) return fail(11, "pnp kernel launch failed");
-    LC_HIP_OK(hipMemcpyAsync(h + off[5], d + off[5], used - off[5], hipMemcpyDeviceToHost, st));
+    if (!zero_copy) LC_HIP_OK(hipMemcpyAsync(h + off[5], d + off[5], used - off[5], hipMemcpyDeviceToHost, st));
     LC_HIP_OK(hipStreamSynchronize(st));
     const float* oS = reinterpret_cast<float*>(h + off[5]);
     const float* oT = reinterpret_cast<float*>(h + off[6]);
