@@ -13,6 +13,7 @@ batched LM solve; the two are independent, so by default their workgroups share 
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -116,7 +117,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="poses per GPU per step")
     ap.add_argument("--npts", type=int, default=64)
-    ap.add_argument("--launch", default="fused", choices=["fused", "eager", "eager2", "graph", "graph2", "graph_fused"],
+    ap.add_argument("--slots", type=int, default=4, help="--launch streams: independent batches in flight (own buffers, own stream)")
+    ap.add_argument("--launch", default="fused", choices=["fused", "eager", "eager2", "graph", "graph2", "graph_fused", "streams"],
                     help="fused (default): loss and PnP workgroups share ONE grid (lc_pose_unit_f32); eager: two launches on "
                          "one stream; eager2: LM solve forked onto a second stream; graph*: the same step replayed as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,9 +188,32 @@ def main():
                                   P(states), P(tr), P(ret), 50, 1e-6, _lib.stream_ptr(dev))
         assert rc == 0
 
+    # --launch streams (NOT the default, reported separately in DESIGN.md): `slots` independent B-sized batches in flight, each
+    # with its own inputs, outputs and stream -- the serving-side picture (independent requests), where a 512-workgroup step
+    # leaves most of the chip idle.  A step is still one fused launch over one batch; steps of different slots overlap.
+    slot_state = []
+    if args.launch == "streams":
+        for s_i in range(args.slots):
+            bb = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=1000 * (rank + 1) + s_i).items()}
+            outs = dict(loss=torch.empty(B, device=dev), d_u=torch.empty_like(bb["pts2d"]), d_s=torch.empty_like(bb["inv_std"]),
+                        d_x=torch.empty_like(bb["pts3d"]), states=torch.empty_like(bb["start"]), tr=torch.empty(B, device=dev),
+                        ret=torch.empty(B, device=dev, dtype=torch.int32), sd=bb["inv_std"].contiguous())
+            slot_state.append((bb, outs, torch.cuda.Stream(dev)))
+        torch.cuda.synchronize(dev)
+    slot_i = [0]
+
+    def step_streams():
+        bb, o, stream = slot_state[slot_i[0] % len(slot_state)]
+        slot_i[0] += 1
+        rc = lib.lc_pose_unit_f32(P(bb["K"]), P(bb["pose"]), P(bb["pts3d"]), P(bb["pts2d"]), P(bb["inv_std"]), None, P(bb["bbox_3d"]),
+                                  P(go), B, N, 32.0, 3.0, 4.0, P(o["loss"]), P(o["d_u"]), P(o["d_s"]), P(o["d_x"]), P(o["sd"]),
+                                  P(bb["start"]), P(o["states"]), P(o["tr"]), P(o["ret"]), 50, 1e-6, ctypes.c_void_p(stream.cuda_stream))
+        assert rc == 0
+
     if args.launch == "fused" and N > 64:
         args.launch = "eager"
-    step_eager = {"eager": step_serial, "graph": step_serial, "fused": step_fused, "graph_fused": step_fused}.get(args.launch, step_forked)
+    step_eager = {"eager": step_serial, "graph": step_serial, "fused": step_fused, "graph_fused": step_fused,
+                  "streams": step_streams}.get(args.launch, step_forked)
     graph = None
     if args.launch.startswith("graph"):
         warm = torch.cuda.Stream(dev)
@@ -221,7 +246,10 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert int(ret.sum().item()) == 0 and bool(torch.isfinite(loss).all())
+    if args.launch == "streams":
+        assert all(int(o["ret"].sum().item()) == 0 and bool(torch.isfinite(o["loss"]).all()) for _, o, _ in slot_state)
+    else:
+        assert int(ret.sum().item()) == 0 and bool(torch.isfinite(loss).all())
 
     # per-kernel launch duration with events on the launch stream (torch's current stream == the kernels' stream)
     def kernel_ms(fn, reps=200):
@@ -275,7 +303,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic B={B} N={N} 2D-3D correspondences per GPU, HIP weighted-PnP + cov-loss",
                        "global_batch": B * world, "n_points": N, "sharding": f"poses over {world} rank(s), no data-path collective",
-                       "launch": args.launch},
+                       "launch": args.launch, **({"slots_in_flight": args.slots} if args.launch == "streams" else {})},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom[0], B, N),
                          "note": "latency/VALU-bound by construction (5 KB working set per pose, one wave per pose): see DESIGN.md",
