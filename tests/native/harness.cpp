@@ -1,4 +1,6 @@
-// Standalone C-ABI harness (no torch): exercises every entry point of liblc_amd.so with small synthetic inputs.
+// Standalone C-ABI harness (no torch, no Python): what a C/C++ maintainer of the reference links against.  Calls the entry
+// points of liblc_amd.so on small synthetic inputs and CHECKS the answers (exit code = number of failed checks);
+// tests/test_gpu_native_harness.py builds and runs it on the GPU box.
 // Build: hipcc --offload-arch=gfx950 -O2 tests/native/harness.cpp -Llc_amd/_C -llc_amd -Wl,-rpath,$PWD/lc_amd/_C -o /tmp/harness
 #include <hip/hip_runtime.h>
 
@@ -26,6 +28,15 @@ T* to_dev(const std::vector<T>& v) {
     CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return d;
 }
+
+static int g_failed = 0;
+#define EXPECT(cond)                                                         \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            ++g_failed;                                                      \
+        }                                                                    \
+    } while (0)
 
 int main(int argc, char** argv) {
     const int B = 4, N = 64;
@@ -80,6 +91,8 @@ int main(int argc, char** argv) {
         float hm[2], hs[2];
         CK(hipMemcpy(hm, mean, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, sd, 8, hipMemcpyDeviceToHost));
         std::printf("head rc=%d/%d mean=(%.3f,%.3f) std=(%.3f,%.3f)\n", rc, rc2, hm[0], hm[1], hs[0], hs[1]);
+        EXPECT(rc == 0 && rc2 == 0);
+        EXPECT(std::fabs(hm[0] - 42.f) < 2.f && std::fabs(hm[1] - 17.f) < 2.f);  // the e^12 bump at (x=42, y=17) dominates the map
     }
     if (all || std::string(which) == "pnp") {
         float* tr; int* ret; int* it;
@@ -91,6 +104,23 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(hr.data(), ret, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hi.data(), it, B * 4, hipMemcpyDeviceToHost));
         for (int b = 0; b < B; ++b)
             std::printf("pnp rc=%d job %d ret=%d iters=%d tr=%g  tz=%.4f (gt %.4f)\n", rc, b, hr[b], hi[b], htr[b], st[b * 7 + 6], pose[b * 7 + 6]);
+        EXPECT(rc == 0);
+        for (int b = 0; b < B; ++b) EXPECT(hr[b] == 0 && hi[b] >= 1 && std::fabs(st[b * 7 + 6] - pose[b * 7 + 6]) < 20.f);  // +-1 px of noise at f = 250, z = 800
+
+        // the reference's own entry point: host arrays of pointers in, states updated in place (lib/pnp/cxx/ext.h:2-15)
+        std::vector<float> hst(start), L(B * N * 4, 0.f), rtr(B, -1.f);
+        for (int i = 0; i < B * N; ++i) { L[4 * i] = s[2 * i]; L[4 * i + 3] = s[2 * i + 1]; }
+        std::vector<float*> pS(B), pK(B), pU(B), pX(B), pL(B);
+        std::vector<int> cnt(B, N), flags(B, -1);
+        for (int b = 0; b < B; ++b) { pS[b] = &hst[b * 7]; pK[b] = &K[b * 9]; pU[b] = &u[b * N * 2]; pX[b] = &X[b * N * 3]; pL[b] = &L[b * N * 4]; }
+        cnt[B - 1] = 2;  // too few points: flagged, state untouched, trust region 1 (ceres.cpp:84-91)
+        pnp_ceres_f32_omp(pS.data(), pK.data(), pU.data(), pX.data(), pL.data(), cnt.data(), 50, 1e-6f, 0, rtr.data(), flags.data(), B, 2);
+        for (int b = 0; b < B - 1; ++b) {
+            EXPECT(flags[b] == 0);
+            for (int i = 0; i < 7; ++i) EXPECT(std::fabs(hst[b * 7 + i] - st[b * 7 + i]) < 1e-4f * (i < 4 ? 1.f : 1000.f));  // same as the device route
+        }
+        EXPECT(flags[B - 1] == 1 && rtr[B - 1] == 1.f && hst[(B - 1) * 7 + 6] == start[(B - 1) * 7 + 6]);
+        std::printf("host abi: flags %d %d %d %d\n", flags[0], flags[1], flags[2], flags[3]);
     }
     if (all || std::string(which) == "loss") {
         float *loss, *du, *ds, *dx, *aux;
@@ -101,7 +131,54 @@ int main(int argc, char** argv) {
         std::vector<float> hl(B), hdu(4);
         CK(hipMemcpy(hl.data(), loss, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdu.data(), du, 16, hipMemcpyDeviceToHost));
         std::printf("loss rc=%d loss=(%.5f %.5f %.5f %.5f) du0=(%g %g)\n", rc, hl[0], hl[1], hl[2], hl[3], hdu[0], hdu[1]);
+        EXPECT(rc == 0);
+        for (int b = 0; b < B; ++b) EXPECT(std::isfinite(hl[b]) && hl[b] > -20.f && hl[b] < 20.f);
+        EXPECT(std::isfinite(hdu[0]) && hdu[0] != 0.f);
+        // error path: an 8-byte row pointer at a 4-byte offset is refused with a message, nothing is launched
+        rc = lc_cov_loss_fwd_bwd_f32(dK, dP, dX, dU + 1, dS, nullptr, dB, nullptr, B, N - 1, 32.f, 3.f, 4.f, loss, du, ds, dx, aux, nullptr);
+        EXPECT(rc != 0 && std::string(lc_amd_last_error()).find("aligned") != std::string::npos);
     }
-    std::printf("harness done\n");
-    return 0;
+    if (all || std::string(which) == "glue") {
+        // keypoint NLL (losses.py:318-326): per-sample sums + gradients
+        float *nll, *gu, *gs2;
+        CK(hipMalloc(&nll, B * 4)); CK(hipMalloc(&gu, B * N * 8)); CK(hipMalloc(&gs2, B * N * 8));
+        int rc = lc_kpt_nll_fwd_bwd_f32(dK, dP, dX, dU, dS, B, N, nll, gu, gs2, nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<float> hn(B);
+        CK(hipMemcpy(hn.data(), nll, B * 4, hipMemcpyDeviceToHost));
+        EXPECT(rc == 0);
+        for (int b = 0; b < B; ++b) EXPECT(std::isfinite(hn[b]));
+        // gradient clipping (grad.py:5-83): first call clips to initial_max_norm and starts the running maximum
+        const long long n = (long long)B * N * 2;
+        double* partials; unsigned* ticket; float *sq, *state, *state2, *norm, *out;
+        CK(hipMalloc(&partials, LC_SQNORM_BLOCKS * 8)); CK(hipMalloc(&ticket, 4)); CK(hipMemset(ticket, 0, 4));
+        CK(hipMalloc(&sq, 4)); CK(hipMalloc(&state2, 4)); CK(hipMalloc(&norm, 4)); CK(hipMalloc(&out, n * 4));
+        state = to_dev(std::vector<float>(1, -1.f));
+        rc = lc_sqnorm_f32(dU, n, partials, ticket, sq, 0, nullptr);
+        int rc2 = lc_norm_clip_apply_f32(dU, n, sq, state, 100.f, 1.7f, 0.1, out, state2, norm, nullptr);
+        CK(hipDeviceSynchronize());
+        float hsq, hs2, hnorm, ho;
+        CK(hipMemcpy(&hsq, sq, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hs2, state2, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&hnorm, norm, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ho, out, 4, hipMemcpyDeviceToHost));
+        double ref = 0;
+        for (float v : u) ref += (double)v * v;
+        EXPECT(rc == 0 && rc2 == 0);
+        EXPECT(std::fabs(hsq - ref) < 1e-5 * ref && std::fabs(hnorm - std::sqrt(ref)) < 1e-5 * std::sqrt(ref));
+        EXPECT(std::fabs(hs2 - 1.7f * hnorm) < 1e-4f * hs2);
+        EXPECT(std::fabs(ho - u[0] * std::fmin(100.0 / (std::sqrt(ref) + 1e-6), 1.0)) < 1e-5f * std::fabs(u[0]) + 1e-7f);
+        std::printf("glue: nll0=%.4f norm=%.3f max_norm=%.3f\n", hn[0], hnorm, hs2);
+        // dense point selection (test.py:39-45,94-113): median split keeps half of the points, in source order
+        float *ou, *ow, *ox; int *oi, *oc;
+        CK(hipMalloc(&ou, B * N * 8)); CK(hipMalloc(&ow, B * N * 8)); CK(hipMalloc(&ox, B * N * 12)); CK(hipMalloc(&oi, B * N * 4)); CK(hipMalloc(&oc, B * 4));
+        rc = lc_dense_select_f32(dU, dS, dX, nullptr, nullptr, nullptr, B, N, 1, 0.5, 1, 4, 0u, ou, ow, ox, oi, oc, nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<int> hc(B), hidx(N);
+        CK(hipMemcpy(hc.data(), oc, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hidx.data(), oi, N * 4, hipMemcpyDeviceToHost));
+        EXPECT(rc == 0);
+        for (int b = 0; b < B; ++b) EXPECT(hc[b] == N / 2);
+        for (int i = 1; i < hc[0]; ++i) EXPECT(hidx[i] > hidx[i - 1]);
+        std::printf("select: counts %d %d %d %d\n", hc[0], hc[1], hc[2], hc[3]);
+    }
+    std::printf("harness done, %d check(s) failed\n", g_failed);
+    return g_failed;
 }
