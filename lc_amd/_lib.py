@@ -78,12 +78,16 @@ def check(rc: int, what: str):
 
 
 def require_hip_f32(name: str, t: torch.Tensor) -> torch.Tensor:
-    """The kernels take contiguous float32 device tensors -- anything else is an error, never a silent fallback."""
+    """The kernels take contiguous float32 device tensors.  Half-precision network outputs (fp16 / bf16 heads under mixed
+    precision: BASELINE.json configs 3 and 5) are up-cast here, differentiably, so the loss itself always runs at the
+    reference's fp32 I/O precision; anything else (CPU tensors, float64, integers) is an error, never a silent fallback."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"lc_amd: {name} must be a torch.Tensor, got {type(t)}")
     if not t.is_cuda:
         raise RuntimeError(f"lc_amd: {name} is on {t.device}; the HIP path needs tensors on the MI355X "
                            f"(there is no CPU fallback in the product path)")
+    if t.dtype in (torch.float16, torch.bfloat16):
+        t = t.float()
     if t.dtype != torch.float32:
         raise TypeError(f"lc_amd: {name} must be float32 (reference I/O precision), got {t.dtype}")
     return t.contiguous()

@@ -153,3 +153,24 @@ def test_misaligned_pointers_are_rejected():
     rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(odd), None, P(b["inv_std"]), None, P(b["start"]), P(st), P(tr), P(ret), None, 2, 8,
                            50, 1e-6, _lib.stream_ptr(dev))
     assert rc == 1 and b"aligned" in lib.lc_amd_last_error()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_precision_network_outputs_are_upcast(dtype):
+    """bf16 / fp16 heads (mixed-precision training): same loss as fp32 on the rounded values, gradients return in the head's dtype."""
+    from lc_amd import synth
+    from lc_amd.cov_mixed import Loss_cov_mixed
+
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(4, 32, seed=5).items()}
+    u16 = b["pts2d"].to(dtype).requires_grad_(True)
+    s16 = b["inv_std"].to(dtype).requires_grad_(True)
+    l16 = Loss_cov_mixed(b["K"], b["pose"], b["pts3d"], u16, s16, None, bbox_3d=b["bbox_3d"])
+    gu16, gs16 = torch.autograd.grad(l16.sum(), (u16, s16))
+    u32 = u16.detach().float().requires_grad_(True)
+    s32 = s16.detach().float().requires_grad_(True)
+    l32 = Loss_cov_mixed(b["K"], b["pose"], b["pts3d"], u32, s32, None, bbox_3d=b["bbox_3d"])
+    gu32, gs32 = torch.autograd.grad(l32.sum(), (u32, s32))
+    assert l16.dtype == torch.float32 and torch.equal(l16, l32)
+    assert gu16.dtype == dtype and gs16.dtype == dtype
+    assert torch.equal(gu16, gu32.to(dtype)) and torch.equal(gs16, gs32.to(dtype))
