@@ -17,14 +17,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
-def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3):
+def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3, dtype="f32"):
     from lc_amd import _lib
 
     lib = _lib.load()
     P = _lib.ptr
     g = torch.Generator(device="cpu").manual_seed(0)
     M = B * S
-    logits = torch.randn(M, H, W, generator=g).to(dev)  # synthetic logits of the repo's shape (values do not change traffic)
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    code, esz = _lib.MAP_DTYPES[tdt], torch.empty((), dtype=tdt).element_size()
+    logits = torch.randn(M, H, W, generator=g).to(tdt).to(dev)  # synthetic logits of the repo's shape (values do not change traffic)
     mean = torch.empty(M, 2, device=dev)
     std = torch.empty(M, 2, device=dev)
     stats = torch.empty(M, 4, device=dev)
@@ -34,10 +36,10 @@ def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3):
     st = _lib.stream_ptr(dev)
 
     def fwd():
-        assert lib.lc_softargmax2d_fwd_f32(P(logits), M, H, W, 0, P(mean), P(std), P(stats), st) == 0
+        assert lib.lc_softargmax2d_fwd(P(logits), code, M, H, W, 0, P(mean), P(std), P(stats), st) == 0
 
     def bwd():
-        assert lib.lc_softargmax2d_bwd_f32(P(logits), P(mean), P(std), P(stats), P(g_mean), P(g_std), M, H, W, 0, P(g_in), st) == 0
+        assert lib.lc_softargmax2d_bwd(P(logits), code, P(mean), P(std), P(stats), P(g_mean), P(g_std), M, H, W, 0, P(g_in), st) == 0
 
     def step():
         fwd()
@@ -62,15 +64,16 @@ def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3):
         return e0.elapsed_time(e1) / reps
 
     t_f, t_b = ev(fwd), ev(bwd)
-    map_bytes = H * W * 4
+    map_bytes = H * W * esz
     by_f, by_b = M * map_bytes, 2 * M * map_bytes
     return {
         "metric": "keypoint-head samples/sec (spatial softmax + soft-argmax fwd+bwd)",
         "value": B * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3,
-        "config": {"workload": f"logits ({B},{S},{H},{W}) fp32, synthetic"},
+        "dtype": dtype,
+        "config": {"workload": f"logits ({B},{S},{H},{W}) {dtype}, synthetic"},
         "roofline": {"bound": "hbm", "kernel": "lc_head_bwd_kernel", "achieved": by_b / (t_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": by_b / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "fwd": {"kernel": "lc_head_fwd_rows_kernel", "achieved": by_f / (t_f * 1e-3) / 1e9,
+                     "fwd": {"kernel": "lc_head_fwd_wave64_kernel" if (H, W) == (64, 64) else "lc_head_fwd_rows_kernel", "achieved": by_f / (t_f * 1e-3) / 1e9,
                              "frac": by_f / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": t_f},
                      "bwd_ms": t_b, "algorithmic_bytes_per_sample": 3 * S * map_bytes},
     }
@@ -81,7 +84,8 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"], help="element type of the logits and their gradient")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X")
-    print(json.dumps(measure_head(torch.device("cuda:0"), B=a.batch, steps=a.steps, warmup=a.warmup)))
+    print(json.dumps(measure_head(torch.device("cuda:0"), B=a.batch, steps=a.steps, warmup=a.warmup, dtype=a.dtype)))

@@ -101,6 +101,17 @@ int lc_softargmax2d_fwd_f32(const float *in, int M, int H, int W, int is_prob, f
 int lc_softargmax2d_bwd_f32(const float *in, const float *mean, const float *std, const float *stats,
                             const float *g_mean, const float *g_std, int M, int H, int W, int is_prob, float *g_in,
                             void *stream);
+/* The same pair for maps in the element type a mixed-precision backbone emits (BASELINE.json configs 3, 5): `in` and `g_in`
+ * are (M,H,W) of `dtype`; statistics, mean/std and their cotangents stay fp32, arithmetic is fp32, the gradient is rounded
+ * to nearest even into the map's type.  16-bit maps halve the HBM bytes of this bandwidth-bound pair. */
+#define LC_F32 0
+#define LC_F16 1
+#define LC_BF16 2
+int lc_softargmax2d_fwd(const void *in, int dtype, int M, int H, int W, int is_prob, float *mean, float *std, float *stats,
+                        void *stream);
+int lc_softargmax2d_bwd(const void *in, int dtype, const float *mean, const float *std, const float *stats,
+                        const float *g_mean, const float *g_std, int M, int H, int W, int is_prob, void *g_in,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2d) Dense-correspondence front end -- replaces the torch glue of losses.py:355-356 (joint softmax

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "lc_dense_select_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, ctypes.c_double, c_int, c_int, ctypes.c_uint] + [c_void_p] * 6),
     "lc_softargmax2d_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lc_softargmax2d_bwd_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lc_softargmax2d_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lc_softargmax2d_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -90,6 +92,21 @@ def require_hip_f32(name: str, t: torch.Tensor) -> torch.Tensor:
         t = t.float()
     if t.dtype != torch.float32:
         raise TypeError(f"lc_amd: {name} must be float32 (reference I/O precision), got {t.dtype}")
+    return t.contiguous()
+
+
+MAP_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}  # LC_F32 / LC_F16 / LC_BF16 (include/lc_amd.h)
+
+
+def require_hip_map(name: str, t: torch.Tensor) -> torch.Tensor:
+    """(…,H,W) maps of the keypoint head: fp32, fp16 or bf16 device tensors are consumed in their own type (no up-cast copy)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"lc_amd: {name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"lc_amd: {name} is on {t.device}; the HIP path needs tensors on the MI355X "
+                           f"(there is no CPU fallback in the product path)")
+    if t.dtype not in MAP_DTYPES:
+        raise TypeError(f"lc_amd: {name} must be float32, float16 or bfloat16, got {t.dtype}")
     return t.contiguous()
 
 

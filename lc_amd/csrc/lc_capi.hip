@@ -267,25 +267,45 @@ int lc_scale_rows_f32(const float* scale, int B, const float* src0, float* dst0,
     return hipGetLastError() == hipSuccess ? 0 : fail(11, "scale kernel launch failed");
 }
 
-int lc_softargmax2d_fwd_f32(const float* in, int M, int H, int W, int is_prob, float* mean, float* std, float* stats, void* stream) {
+static int head_fwd(const void* in, int dtype, int M, int H, int W, int is_prob, float* mean, float* std, float* stats, void* stream) {
     if (M < 0 || H <= 0 || W <= 0) return fail(1, "bad size");
+    if (dtype < 0 || dtype > 2) return fail(1, "dtype must be LC_F32, LC_F16 or LC_BF16");
     if (M == 0) return 0;
     if (!in || !mean || !std || !stats) return fail(1, "null pointer");
-    if (W % 4 == 0) LC_REQUIRE_ALIGNED(16, in);
-    lc::HeadParams p{in, mean, std, stats, M, H, W, is_prob};
+    if (misaligned(dtype == 0 ? 4 : 2, in)) return fail(1, "map pointer not aligned to its element type");
+    lc::HeadParams p{in, mean, std, stats, M, H, W, is_prob, dtype};
     const int rc = lc::launch_head_fwd(p, static_cast<hipStream_t>(stream));
     if (rc == 3) return fail(3, "map too large for the single-pass soft-argmax kernel");
     return rc ? fail(11, "head kernel launch failed") : 0;
 }
 
-int lc_softargmax2d_bwd_f32(const float* in, const float* mean, const float* std, const float* stats, const float* g_mean,
-                            const float* g_std, int M, int H, int W, int is_prob, float* g_in, void* stream) {
+static int head_bwd(const void* in, int dtype, const float* mean, const float* std, const float* stats, const float* g_mean,
+                    const float* g_std, int M, int H, int W, int is_prob, void* g_in, void* stream) {
     if (M < 0 || H <= 0 || W <= 0) return fail(1, "bad size");
+    if (dtype < 0 || dtype > 2) return fail(1, "dtype must be LC_F32, LC_F16 or LC_BF16");
     if (M == 0) return 0;
     if (!in || !mean || !std || !stats || !g_mean || !g_std || !g_in) return fail(1, "null pointer");
-    if (W % 4 == 0) LC_REQUIRE_ALIGNED(16, in, g_in);
-    lc::HeadBwdParams p{in, mean, std, stats, g_mean, g_std, g_in, M, H, W, is_prob};
+    if (misaligned(dtype == 0 ? 4 : 2, in, g_in)) return fail(1, "map pointer not aligned to its element type");
+    lc::HeadBwdParams p{in, mean, std, stats, g_mean, g_std, g_in, M, H, W, is_prob, dtype};
     return lc::launch_head_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "head backward launch failed") : 0;
+}
+
+int lc_softargmax2d_fwd_f32(const float* in, int M, int H, int W, int is_prob, float* mean, float* std, float* stats, void* stream) {
+    return head_fwd(in, 0, M, H, W, is_prob, mean, std, stats, stream);
+}
+
+int lc_softargmax2d_bwd_f32(const float* in, const float* mean, const float* std, const float* stats, const float* g_mean,
+                            const float* g_std, int M, int H, int W, int is_prob, float* g_in, void* stream) {
+    return head_bwd(in, 0, mean, std, stats, g_mean, g_std, M, H, W, is_prob, g_in, stream);
+}
+
+int lc_softargmax2d_fwd(const void* in, int dtype, int M, int H, int W, int is_prob, float* mean, float* std, float* stats, void* stream) {
+    return head_fwd(in, dtype, M, H, W, is_prob, mean, std, stats, stream);
+}
+
+int lc_softargmax2d_bwd(const void* in, int dtype, const float* mean, const float* std, const float* stats, const float* g_mean,
+                        const float* g_std, int M, int H, int W, int is_prob, void* g_in, void* stream) {
+    return head_bwd(in, dtype, mean, std, stats, g_mean, g_std, M, H, W, is_prob, g_in, stream);
 }
 
 int lc_dense_frontend_fwd_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, int B, int H,

@@ -6,6 +6,8 @@
 // 4 floats (+4 saved statistics).  Backward is a pure streaming kernel: with lse, mean and variance saved,
 //   d/dlogit[h,w] = p[h,w] * (qx[w] + qy[h] - <p,q>),  qx[w] = g_mx w + g_vx (w-mx)^2,  <p,q> = g_mx mx + g_vx vx + (y terms)
 // so the map is read once and the gradient written once: 3 x H x W x 4 bytes per map fwd+bwd in total.
+#include <cstdint>
+
 #include "lc_common.h"
 #include "lc_kernels.h"
 
@@ -13,6 +15,37 @@ namespace lc {
 namespace {
 
 constexpr int kHeadThreads = 256;
+
+// Element types of the maps: fp32 (the reference's precision) and the 16-bit types a mixed-precision backbone emits
+// (BASELINE.json configs 3 and 5).  Arithmetic is fp32 for all of them; 16-bit maps halve the HBM bytes of this
+// bandwidth-bound kernel pair and the gradient is written back in the map's own type (round to nearest even).
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<_Float16> { using type = uint2; };
+template <> struct Vec4<__bf16> { using type = uint2; };
+
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* q) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const float4*>(q);
+    } else {
+        const uint2 r = *reinterpret_cast<const uint2*>(q);
+        T h[4];
+        __builtin_memcpy(h, &r, 8);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* q, float4 v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(q) = v;
+    } else {
+        const T h[4] = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+        uint2 r;
+        __builtin_memcpy(&r, h, 8);
+        *reinterpret_cast<uint2*>(q) = r;
+    }
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -26,7 +59,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // NV: vectors per thread, VEC: 4 (float4, needs W % 4 == 0) or 1
-template <int NV, int VEC>
+template <typename T, int NV, int VEC>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_kernel(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, W = p.W, HW = H * W, ld = W + 1;
@@ -36,7 +69,7 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_kernel(const HeadPar
     float* redf = py + H;                 // [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t m = blockIdx.x;
-    const float* in = p.in + m * HW;
+    const T* in = static_cast<const T*>(p.in) + m * HW;
 
     float x[NV * VEC];
     float lmax = -INFINITY;
@@ -45,10 +78,10 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_kernel(const HeadPar
         const int e = (tid + k * kHeadThreads) * VEC;
         if (e < HW) {
             if constexpr (VEC == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(in + e);
+                const float4 v = load4<T>(in + e);
                 x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
             } else {
-                x[k] = in[e];
+                x[k] = (float)in[e];
             }
         } else {
 #pragma unroll
@@ -149,7 +182,7 @@ __device__ __forceinline__ float swap32_sum(float x) {
     return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 
-template <int LPR, int NV>
+template <typename T, int LPR, int NV>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_rows_kernel(const HeadParams p) {
     constexpr int W = 4 * LPR, H = NV * kHeadThreads / LPR, HW = H * W;
     __shared__ float colp[4][W];               // per-wave column partials
@@ -158,12 +191,12 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_rows_kernel(const He
     __shared__ float redf[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t m = blockIdx.x;
-    const float4* in = reinterpret_cast<const float4*>(p.in + m * HW);
+    const T* in = static_cast<const T*>(p.in) + m * HW;
     const bool is_prob = p.is_prob != 0;
 
     float4 x[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) x[k] = in[tid + k * kHeadThreads];
+    for (int k = 0; k < NV; ++k) x[k] = load4<T>(in + 4 * (tid + k * kHeadThreads));
     float bmax = 0.f;
     if (!is_prob) {
         float lmax = -INFINITY;
@@ -240,12 +273,111 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_rows_kernel(const He
     }
 }
 
-template <int VEC>
+// ---- 64x64 maps (the sparse heads' shape): ONE WAVEFRONT PER MAP, no LDS, no barrier ---------------------------------
+// Lane l = (row group g = l/8, column group c = l%8).  For k = 0..7 the wave reads 512 contiguous elements: lane l takes the
+// eight elements 512k + 8l .. +7 = row 8k+g, columns 8c..8c+7 (16 or 32 contiguous bytes per lane, all 8-16 loads of the lane in
+// flight at once).  Row sums reduce over the 8 lanes of a row group (DPP), column sums over the 8 row groups (DPP row_ror 8,
+// permlane16/32 swaps); means and centred variances come from those marginals exactly as ptnet.py:85-97 forms them.
+template <int CTRL>
+__device__ __forceinline__ float dpp_max_step(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
+    return fmaxf(x, __int_as_float(y));
+}
+__device__ __forceinline__ float group8_sum(float x) {  // over lanes differing in bits 0..2
+    x = dpp_sum_step<0xB1>(x);   // quad_perm [1,0,3,2]  (xor 1)
+    x = dpp_sum_step<0x4E>(x);   // quad_perm [2,3,0,1]  (xor 2)
+    x = dpp_sum_step<0x141>(x);  // row_half_mirror      (pairs the two quads of an 8-lane half row)
+    return x;
+}
+__device__ __forceinline__ float across_groups_sum(float x) {  // over lanes differing in bits 3..5
+    x = dpp_sum_step<0x128>(x);  // row_ror 8  (xor 8 within a 16-lane row)
+    x = swap16_sum(x);
+    x = swap32_sum(x);
+    return x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const HeadParams p) {
+    constexpr int S = 64, HW = S * S;
+    const int lane = threadIdx.x & 63;
+    const size_t m = (size_t)blockIdx.x * (kHeadThreads / kWave) + (threadIdx.x >> 6);
+    if (m >= (size_t)p.M) return;
+    const T* in = static_cast<const T*>(p.in) + m * HW + 8 * lane;
+    const bool is_prob = p.is_prob != 0;
+    const int g = lane >> 3, c = lane & 7;
+
+    float x[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 a = load4<T>(in + 512 * k), b = load4<T>(in + 512 * k + 4);
+        x[k][0] = a.x; x[k][1] = a.y; x[k][2] = a.z; x[k][3] = a.w;
+        x[k][4] = b.x; x[k][5] = b.y; x[k][6] = b.z; x[k][7] = b.w;
+    }
+    float bmax = 0.f;
+    if (!is_prob) {
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lmax = fmaxf(lmax, x[k][j]);
+        bmax = wave_max(lmax);
+    }
+    float col[8], row[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) col[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e = is_prob ? x[k][j] : __expf(x[k][j] - bmax);
+            col[j] += e;
+            r += e;
+        }
+        row[k] = group8_sum(r);  // un-normalised mass of row 8k+g, in all 8 lanes of the group
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        col[j] = across_groups_sum(col[j]);  // un-normalised mass of column 8c+j, in every row group
+        tot += col[j];
+    }
+    const float bsum = group8_sum(tot);
+    const float inv = is_prob ? 1.f : 1.f / bsum;
+    // softargmax_1d_cov (ptnet.py:85-97) on the two marginals
+    float mx = 0.f, my = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx += (float)(8 * c + j) * (col[j] * inv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) my += (float)(8 * k + g) * (row[k] * inv);
+    mx = group8_sum(mx);
+    my = across_groups_sum(my);
+    float vx = 0.f, vy = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float d = (float)(8 * c + j) - mx;
+        vx += d * d * (col[j] * inv);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float d = (float)(8 * k + g) - my;
+        vy += d * d * (row[k] * inv);
+    }
+    vx = group8_sum(vx);
+    vy = across_groups_sum(vy);
+    if (lane == 0) {
+        *reinterpret_cast<float2*>(p.mean + m * 2) = make_float2(mx, my);
+        *reinterpret_cast<float2*>(p.std + m * 2) = make_float2(sqrtf(vx + 1e-6f), sqrtf(vy + 1e-6f));
+        *reinterpret_cast<float4*>(p.stats + m * 4) = make_float4(is_prob ? bsum : bmax + __logf(bsum), vx, vy, 0.f);
+    }
+}
+
+template <typename T, int VEC>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwdParams p) {
     const int H = p.H, W = p.W, HW = H * W;
     const size_t m = blockIdx.x;
-    const float* in = p.in + m * HW;
-    float* out = p.g_in + m * HW;
+    const T* in = static_cast<const T*>(p.in) + m * HW;
+    T* out = static_cast<T*>(p.g_in) + m * HW;
     const float mx = p.mean[m * 2], my = p.mean[m * 2 + 1];
     const float sx = p.std[m * 2], sy = p.std[m * 2 + 1];
     const float s0 = p.stats[m * 4], vx = p.stats[m * 4 + 1], vy = p.stats[m * 4 + 2];
@@ -262,10 +394,10 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwd
         const float qy = gmy * (float)h + gvy * dy * dy + ey * (float)h;
         float xin[VEC], g[VEC];
         if constexpr (VEC == 4) {
-            const float4 v = *reinterpret_cast<const float4*>(in + e);
+            const float4 v = load4<T>(in + e);
             xin[0] = v.x; xin[1] = v.y; xin[2] = v.z; xin[3] = v.w;
         } else {
-            xin[0] = in[e];
+            xin[0] = (float)in[e];
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -275,21 +407,21 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwd
             g[j] = is_prob ? q : __expf(xin[j] - s0) * (q - cdot);
         }
         if constexpr (VEC == 4) {
-            *reinterpret_cast<float4*>(out + e) = make_float4(g[0], g[1], g[2], g[3]);
+            store4<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
         } else {
-            out[e] = g[0];
+            out[e] = (T)g[0];
         }
     }
 }
 
-template <int VEC>
+template <typename T, int VEC>
 int launch_fwd_nv(const HeadParams& p, hipStream_t stream, int nv, size_t smem) {
 #define LC_HEAD_CASE(NVV)                                                                                       \
     case NVV:                                                                                                   \
         if (smem > 48 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lc_head_fwd_kernel<NVV, VEC>),             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lc_head_fwd_kernel<T, NVV, VEC>),          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                   \
-        hipLaunchKernelGGL((lc_head_fwd_kernel<NVV, VEC>), dim3(p.M), dim3(kHeadThreads), smem, stream, p);      \
+        hipLaunchKernelGGL((lc_head_fwd_kernel<T, NVV, VEC>), dim3(p.M), dim3(kHeadThreads), smem, stream, p);   \
         break;
     switch (nv) {
         LC_HEAD_CASE(1) LC_HEAD_CASE(2) LC_HEAD_CASE(4) LC_HEAD_CASE(8) LC_HEAD_CASE(16) LC_HEAD_CASE(32)
@@ -299,37 +431,66 @@ int launch_fwd_nv(const HeadParams& p, hipStream_t stream, int nv, size_t smem) 
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-}  // namespace
-
-int launch_head_fwd(const HeadParams& p, hipStream_t stream) {
-    if (p.M <= 0) return 0;
+template <typename T>
+int launch_head_fwd_t(const HeadParams& p, hipStream_t stream) {
     const int HW = p.H * p.W;
-    const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
+    const uintptr_t vec_mask = 4 * sizeof(T) - 1;  // four elements per access: 16 bytes (fp32) or 8 bytes (16-bit maps)
+    const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & vec_mask) == 0);
     const int vec = vec4 ? 4 : 1;
     int nv = (HW + kHeadThreads * vec - 1) / (kHeadThreads * vec);
     int nvp = 1;
     while (nvp < nv) nvp <<= 1;
+    const bool out8 = ((reinterpret_cast<uintptr_t>(p.mean) | reinterpret_cast<uintptr_t>(p.std)) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.stats) & 15) == 0;
+    if (vec4 && out8 && p.W == 64 && p.H == 64) {
+        const int waves = kHeadThreads / kWave;
+        hipLaunchKernelGGL(lc_head_fwd_wave64_kernel<T>, dim3((p.M + waves - 1) / waves), dim3(kHeadThreads), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     if (vec4 && p.W == 64 && p.H == 64) {
-        hipLaunchKernelGGL((lc_head_fwd_rows_kernel<16, 4>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+        hipLaunchKernelGGL((lc_head_fwd_rows_kernel<T, 16, 4>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     if (vec4 && p.W == 128 && p.H == 128) {
-        hipLaunchKernelGGL((lc_head_fwd_rows_kernel<32, 16>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+        hipLaunchKernelGGL((lc_head_fwd_rows_kernel<T, 32, 16>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     const size_t smem = sizeof(float) * ((size_t)p.H * (p.W + 1) + p.W + p.H + 8);
     if (smem > 160 * 1024 || nvp > 32) return 3;  // map too large for the single-pass design
-    return vec4 ? launch_fwd_nv<4>(p, stream, nvp, smem) : launch_fwd_nv<1>(p, stream, nvp, smem);
+    return vec4 ? launch_fwd_nv<T, 4>(p, stream, nvp, smem) : launch_fwd_nv<T, 1>(p, stream, nvp, smem);
+}
+
+template <typename T>
+int launch_head_bwd_t(const HeadBwdParams& p, hipStream_t stream) {
+    const uintptr_t vec_mask = 4 * sizeof(T) - 1;
+    const bool vec4 = (p.W % 4 == 0) && (((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.g_in)) & vec_mask) == 0);
+    if (vec4)
+        hipLaunchKernelGGL((lc_head_bwd_kernel<T, 4>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+    else
+        hipLaunchKernelGGL((lc_head_bwd_kernel<T, 1>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace
+
+int launch_head_fwd(const HeadParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    switch (p.dtype) {
+        case kHeadF32: return launch_head_fwd_t<float>(p, stream);
+        case kHeadF16: return launch_head_fwd_t<_Float16>(p, stream);
+        case kHeadBF16: return launch_head_fwd_t<__bf16>(p, stream);
+        default: return 4;
+    }
 }
 
 int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
-    const bool vec4 = (p.W % 4 == 0) && (((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.g_in)) & 15) == 0);
-    if (vec4)
-        hipLaunchKernelGGL(lc_head_bwd_kernel<4>, dim3(p.M), dim3(kHeadThreads), 0, stream, p);
-    else
-        hipLaunchKernelGGL(lc_head_bwd_kernel<1>, dim3(p.M), dim3(kHeadThreads), 0, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
+    switch (p.dtype) {
+        case kHeadF32: return launch_head_bwd_t<float>(p, stream);
+        case kHeadF16: return launch_head_bwd_t<_Float16>(p, stream);
+        case kHeadBF16: return launch_head_bwd_t<__bf16>(p, stream);
+        default: return 4;
+    }
 }
 
 }  // namespace lc

@@ -48,26 +48,30 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream);
 // both of the above in one grid (N <= 64 only; returns 3 otherwise)
 int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stream);
 
+enum HeadDtype { kHeadF32 = 0, kHeadF16 = 1, kHeadBF16 = 2 };  // element type of the (M,H,W) maps (input and its gradient)
+
 struct HeadParams {
-    const float* in;      // (M,H,W) logits (or probabilities when is_prob)
+    const void* in;       // (M,H,W) logits (or probabilities when is_prob), element type `dtype`
     float* mean;          // (M,2) x,y
     float* std;           // (M,2)
     float* stats;         // (M,4): lse (or sum p), var_x, var_y, unused -- saved for backward
     int M, H, W;
     int is_prob;
+    int dtype;
 };
 int launch_head_fwd(const HeadParams& p, hipStream_t stream);
 
 struct HeadBwdParams {
-    const float* in;       // (M,H,W)
+    const void* in;        // (M,H,W), element type `dtype`
     const float* mean;     // (M,2)
     const float* std;      // (M,2)
     const float* stats;    // (M,4)
     const float* g_mean;   // (M,2)
     const float* g_std;    // (M,2)
-    float* g_in;           // (M,H,W)
+    void* g_in;            // (M,H,W), element type `dtype`
     int M, H, W;
     int is_prob;
+    int dtype;
 };
 int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream);
 

@@ -20,9 +20,9 @@ def _fwd(x: Tensor, is_prob: bool):
     std = torch.empty_like(mean)
     stats = torch.empty(x.shape[:-2] + (4,), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        rc = lib.lc_softargmax2d_fwd_f32(_lib.ptr(x), M, H, W, int(is_prob), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(stats),
-                                         _lib.stream_ptr(x.device))
-    _lib.check(rc, "lc_softargmax2d_fwd_f32")
+        rc = lib.lc_softargmax2d_fwd(_lib.ptr(x), _lib.MAP_DTYPES[x.dtype], M, H, W, int(is_prob), _lib.ptr(mean), _lib.ptr(std),
+                                     _lib.ptr(stats), _lib.stream_ptr(x.device))
+    _lib.check(rc, "lc_softargmax2d_fwd")
     return mean, std, stats
 
 
@@ -45,9 +45,10 @@ class _SoftArgmax2dFn(torch.autograd.Function):
         g_std = torch.zeros_like(std) if g_std is None else g_std.contiguous().to(torch.float32)
         g_in = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            rc = lib.lc_softargmax2d_bwd_f32(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(stats), _lib.ptr(g_mean),
-                                             _lib.ptr(g_std), M, H, W, int(ctx.is_prob), _lib.ptr(g_in), _lib.stream_ptr(x.device))
-        _lib.check(rc, "lc_softargmax2d_bwd_f32")
+            rc = lib.lc_softargmax2d_bwd(_lib.ptr(x), _lib.MAP_DTYPES[x.dtype], _lib.ptr(mean), _lib.ptr(std), _lib.ptr(stats),
+                                         _lib.ptr(g_mean), _lib.ptr(g_std), M, H, W, int(ctx.is_prob), _lib.ptr(g_in),
+                                         _lib.stream_ptr(x.device))
+        _lib.check(rc, "lc_softargmax2d_bwd")
         return g_in, None
 
 
@@ -58,14 +59,14 @@ def _clamp_std(std: Tensor) -> Tensor:
 
 def softargmax_2d_std(prob2d: Tensor, clamp_std: bool = False):
     """`ptnet.softargmax_2d_std` (ptnet.py:100-115): prob2d (*,H,W) -> mean (*,2) [x,y], std (*,2)."""
-    x = _lib.require_hip_f32("prob2d", prob2d)
+    x = _lib.require_hip_map("prob2d", prob2d)
     mean, std, _ = _SoftArgmax2dFn.apply(x, True)
     return mean, (_clamp_std(std) if clamp_std else std)
 
 
 def spatial_softargmax_2d_std(logits: Tensor, clamp_std: bool = False):
     """Fused `kpt_logits.flatten(-2).softmax(-1).reshape_as(kpt_logits)` + `softargmax_2d_std` (ptnet.py:61)."""
-    x = _lib.require_hip_f32("kpt_logits", logits)
+    x = _lib.require_hip_map("kpt_logits", logits)
     mean, std, _ = _SoftArgmax2dFn.apply(x, False)
     return mean, (_clamp_std(std) if clamp_std else std)
 

@@ -72,3 +72,32 @@ def test_head_full_size_properties():
     m3, s3 = spatial_softargmax_2d_std(spike)
     assert torch.allclose(m3, torch.tensor([42.0, 17.0], device=dev).expand(4, 1, 2), atol=1e-4)
     assert (s3 - 1e-3).abs().max().item() <= 1e-4  # sqrt(0 + 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 5, 64, 64), (2, 3, 128, 128), (2, 2, 24, 40), (2, 2, 7, 9)])
+def test_head_16bit_maps_match_the_fp32_kernel_on_the_same_values(dtype, shape):
+    """16-bit maps are consumed natively: statistics identical to the fp32 kernel on the up-cast values, gradient = the
+    fp32 gradient rounded to nearest even into the map's type (fast 64x64 / 128x128 paths, float4-able and scalar shapes)."""
+    from lc_amd.ptnet import spatial_softargmax_2d_std, softargmax_2d_std
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    lg16 = (torch.randn(shape, generator=g) * 3).to(dtype).to(dev).requires_grad_(True)
+    lg32 = lg16.detach().float().requires_grad_(True)
+    ct_m, ct_s = torch.randn(shape[:2] + (2,), generator=g).to(dev), torch.randn(shape[:2] + (2,), generator=g).to(dev)
+    m16, s16 = spatial_softargmax_2d_std(lg16)
+    m32, s32 = spatial_softargmax_2d_std(lg32)
+    assert m16.dtype == torch.float32 and torch.equal(m16, m32) and torch.equal(s16, s32)
+    (g16,) = torch.autograd.grad((m16 * ct_m).sum() + (s16 * ct_s).sum(), lg16)
+    (g32,) = torch.autograd.grad((m32 * ct_m).sum() + (s32 * ct_s).sum(), lg32)
+    assert g16.dtype == dtype and torch.equal(g16, g32.to(dtype))
+    # probability input (ptnet.softargmax_2d_std itself)
+    p16 = lg16.detach().float().flatten(-2).softmax(-1).reshape(shape).to(dtype).requires_grad_(True)
+    p32 = p16.detach().float().requires_grad_(True)
+    a16, b16 = softargmax_2d_std(p16)
+    a32, b32 = softargmax_2d_std(p32)
+    assert torch.equal(a16, a32) and torch.equal(b16, b32)
+    (h16,) = torch.autograd.grad((a16 * ct_m).sum() + (b16 * ct_s).sum(), p16)
+    (h32,) = torch.autograd.grad((a32 * ct_m).sum() + (b32 * ct_s).sum(), p32)
+    assert torch.equal(h16, h32.to(dtype))
