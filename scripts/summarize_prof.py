@@ -14,7 +14,7 @@ def find(pattern):
 
 
 def short(name):
-    for key in ("lc_pose_unit_kernel", "lc_cov_loss_kernel", "lc_pnp_lm_kernel", "lc_head_fwd_rows_kernel", "lc_head_fwd_kernel", "lc_head_bwd_kernel",
+    for key in ("lc_pose_unit_kernel", "lc_cov_loss_kernel", "lc_pnp_lm_kernel", "lc_head_fwd_wave64_kernel", "lc_head_fwd_rows_kernel", "lc_head_fwd_kernel", "lc_head_bwd_kernel",
                 "lc_scale_rows_kernel", "lc_dense"):
         if key in name:
             return key
