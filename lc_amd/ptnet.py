@@ -1,6 +1,7 @@
 """Sparse keypoint head of `ptnet.py` on the fused HIP soft-argmax kernels.
 
   softargmax_2d_std(prob2d, clamp_std=False)   -- same function as `ptnet.py:100-115` (input: probabilities)
+  softargmax_1d_cov(prob1d)                    -- `ptnet.py:85-97`
   spatial_softargmax_2d_std(logits)            -- `ptnet.py:59-66` fused: flatten -> softmax -> soft-argmax in one pass
   sparse_head(kpt_logits)                      -- the out_dict the sparse branch of `ptnet.forward` returns
 """
@@ -55,6 +56,13 @@ class _SoftArgmax2dFn(torch.autograd.Function):
 def _clamp_std(std: Tensor) -> Tensor:
     small_std = std < 1
     return torch.where(small_std, torch.exp((std - 1) * small_std), std)  # ptnet.py:112-114
+
+
+def softargmax_1d_cov(prob1d: Tensor):
+    """`ptnet.softargmax_1d_cov` (ptnet.py:85-97): prob1d (*,N) -> mean (*,), cov (*,) -- the 2D kernel on a one-row map."""
+    x = _lib.require_hip_map("prob1d", prob1d).unsqueeze(-2)
+    mean, std, _ = _SoftArgmax2dFn.apply(x, True)
+    return mean[..., 0], std[..., 0] ** 2 - 1e-6
 
 
 def softargmax_2d_std(prob2d: Tensor, clamp_std: bool = False):

@@ -101,3 +101,22 @@ def test_head_16bit_maps_match_the_fp32_kernel_on_the_same_values(dtype, shape):
     (h16,) = torch.autograd.grad((a16 * ct_m).sum() + (b16 * ct_s).sum(), p16)
     (h32,) = torch.autograd.grad((a32 * ct_m).sum() + (b32 * ct_s).sum(), p32)
     assert torch.equal(h16, h32.to(dtype))
+
+
+def test_softargmax_1d_cov_matches_the_reference_formula():
+    """ptnet.py:85-97 restated in fp64: mean = sum i p_i, cov = sum (i - mean)^2 p_i; forward and gradient."""
+    from lc_amd.ptnet import softargmax_1d_cov
+
+    g = torch.Generator().manual_seed(3)
+    p = torch.rand(5, 7, 37, generator=g).softmax(-1)
+    x = p.to("cuda:0").requires_grad_(True)
+    m, c = softargmax_1d_cov(x)
+    ct = torch.randn(5, 7, 2, generator=g)
+    (gx,) = torch.autograd.grad((m * ct[..., 0].to(x.device)).sum() + (c * ct[..., 1].to(x.device)).sum(), x)
+    p64 = p.double().requires_grad_(True)
+    idx = torch.arange(37, dtype=torch.float64)
+    m64 = (p64 * idx).sum(-1)
+    c64 = (p64 * (idx - m64[..., None]) ** 2).sum(-1)
+    (g64,) = torch.autograd.grad((m64 * ct[..., 0].double()).sum() + (c64 * ct[..., 1].double()).sum(), p64)
+    assert m.shape == (5, 7) and (m.cpu().double() - m64).abs().max() <= 1e-5 and (c.cpu().double() - c64).abs().max() <= 1e-4
+    assert (gx.cpu().double() - g64).abs().max() <= 1e-3 * g64.abs().max()
