@@ -136,6 +136,29 @@ def main():
         line("lc_cov_loss_kernel (dense shape, fwd+bwd incl. d_pts3d)", us, Bl * (Nl * (28 + 28) + 36 + 28 + 96 + 4), Bl, "samples",
              note="%.1f M points/s" % (Bl * Nl / us), B=Bl, N=Nl)
 
+    # ---- test-time driver end to end (test.py:67-136): network outputs -> poses, every stage on the device ----
+    import time
+    from lc_amd.config import AttrDict
+    from lc_amd.inference import solve_pnp
+    from tests.golden.gen_golden_lossfn import dense_inputs
+    gt_d, out_d = dense_inputs(B=64, H=64, W=64, seed=3)
+    out_d["xyz_weight_logits"] = out_d["xyz_weight_logits"] + 3 * gt_d["msk_vis"][:, None]
+    out_d["msk_vis_logits"] = (gt_d["msk_vis"][:, None] * 2 - 1) * 4
+    gt_d = {k: v.to(dev) for k, v in gt_d.items()}
+    out_d = {k: v.to(dev) for k, v in out_d.items()}
+    cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
+    for _ in range(3):
+        solve_pnp(cfg, out_d, gt_d)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        solve_pnp(cfg, out_d, gt_d)
+    torch.cuda.synchronize(dev)
+    us = (time.perf_counter() - t0) / a.reps * 1e6
+    line("inference.solve_pnp_dense (front end + select + RANSAC + 2 weighted solves + inlier re-selection)", us,
+         64 * 6 * 64 * 64 * 4, 64, "objects", note="wall clock per call incl. Python; no host synchronisation inside the pipeline",
+         B=64, H=64, W=64, N=1024, select="quantile_in_mask")
+
     # ---- wide PnP (dense heads): N = 1024 and 1849 ----
     for Nw in (1024, 1849):
         bt = synth.make_batch(256, Nw, seed=3)
