@@ -90,3 +90,46 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     if "weighted" in wanted:
         out["weighted"] = _weighted(K, x, u, icov, start, counts)
     return out
+
+
+class GraphedSolvePnP:
+    """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of ~40 short
+    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 355 us
+    eager -> ~200 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
+
+        solver = GraphedSolvePnP(cfg, out_dict, gt_dict)      # example inputs fix the shapes; captured on a side stream
+        poses = solver(out_dict, gt_dict)                     # copies the tensors into the static buffers, replays
+
+    Every tensor entry of the two dicts is treated as an input; non-tensor entries (bit counts, ...) are frozen at capture.
+    """
+
+    def __init__(self, cfg, out_dict, gt_dict, warmup: int = 2):
+        self.cfg = cfg
+        self._out = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in out_dict.items()}
+        self._gt = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in gt_dict.items()}
+        dev = next(v.device for v in self._out.values() if isinstance(v, Tensor))
+        if dev.type != "cuda":
+            raise RuntimeError("lc_amd: GraphedSolvePnP needs tensors on the MI355X (there is no CPU fallback in the product path)")
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up off the capture: module loading, allocator pools, LDS attributes
+            for _ in range(max(1, warmup)):
+                solve_pnp(cfg, self._out, self._gt)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._res = solve_pnp(cfg, self._out, self._gt)
+
+    @torch.no_grad()
+    def __call__(self, out_dict, gt_dict):
+        for static, new in ((self._out, out_dict), (self._gt, gt_dict)):
+            for k, buf in static.items():
+                if isinstance(buf, Tensor):
+                    src = new[k]
+                    if src.shape != buf.shape:
+                        raise ValueError(f"GraphedSolvePnP: {k} has shape {tuple(src.shape)}, captured with {tuple(buf.shape)}")
+                    if src.data_ptr() != buf.data_ptr():
+                        buf.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return {k: v.clone() for k, v in self._res.items()}

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Is the dense test-time pipeline hipGraph-capturable, and what does a replay cost next to the eager call?"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from lc_amd.config import AttrDict  # noqa: E402
+from lc_amd.inference import solve_pnp  # noqa: E402
+from tests.golden.gen_golden_lossfn import dense_inputs  # noqa: E402
+
+dev = torch.device("cuda:0")
+gt, out = dense_inputs(B=64, H=64, W=64, seed=3)
+out["xyz_weight_logits"] = out["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
+out["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
+gt = {k: v.to(dev) for k, v in gt.items()}
+out = {k: v.to(dev) for k, v in out.items()}
+cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
+
+
+def timeit(fn, n=100):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+eager = solve_pnp(cfg, out, gt)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        solve_pnp(cfg, out, gt)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    res = solve_pnp(cfg, out, gt)
+graph.replay()
+torch.cuda.synchronize()
+same = all(torch.equal(res[k], eager[k]) for k in eager)
+print(f"captured: results equal to eager: {same}")
+print(f"eager  {timeit(lambda: solve_pnp(cfg, out, gt)):7.1f} us per call (64 objects)")
+print(f"replay {timeit(graph.replay):7.1f} us per call")

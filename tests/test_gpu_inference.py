@@ -48,3 +48,30 @@ def test_dense_inference_pipeline(select):
     for key in ("weighted", "weighted-filtered"):
         dq, dt = pose_err(res[key].cpu().numpy(), gt["pose_best"].cpu().numpy())
         assert dq.max() < 0.05 and dt.max() < 0.05, (key, dq, dt)
+
+
+def test_graphed_dense_pipeline_replays_on_new_inputs():
+    """The sync-free pipeline is hipGraph-capturable: a replay on NEW inputs equals the eager call on those inputs."""
+    from lc_amd.config import AttrDict
+    from lc_amd.inference import GraphedSolvePnP, solve_pnp
+    from tests.golden.gen_golden_lossfn import dense_inputs
+
+    dev = torch.device("cuda:0")
+
+    def inputs(seed):
+        gt, out = dense_inputs(B=4, H=32, W=32, seed=seed)
+        out["xyz_weight_logits"] = out["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
+        out["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
+        return {k: v.to(dev) for k, v in gt.items()}, {k: v.to(dev) for k, v in out.items()}
+
+    cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["ransac", "weighted", "weighted_filtered"])
+    gt0, out0 = inputs(3)
+    solver = GraphedSolvePnP(cfg, out0, gt0)
+    for seed in (3, 4, 5):
+        gt, out = inputs(seed)
+        got, ref = solver(out, gt), solve_pnp(cfg, out, gt)
+        assert list(got) == list(ref)
+        assert all(torch.equal(got[k], ref[k]) for k in ref)
+    with pytest.raises(ValueError):
+        bad = dict(out, xyz_noc=out["xyz_noc"][:2])
+        solver(bad, gt)
