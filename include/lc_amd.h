@@ -172,6 +172,9 @@ int lc_pose_errors_f32(const float *R_est, const float *t_est, const float *R_gt
  *      backward hook of the dense heads (losses.py:343-352,378-381), without host synchronisation:
  *        lc_sqnorm_f32            sq (device float) = [sq +] sum x^2.  partials: LC_SQNORM_BLOCKS doubles of workspace,
  *                                 ticket: one zero-initialised unsigned (left at zero); both owned by the caller.
+ *                                 state/state_snapshot (both or neither): *state_snapshot = *state, so that the apply step
+ *                                 can take state_in = state_snapshot and state_out = state, i.e. update the running
+ *                                 maximum IN PLACE (fixed addresses: the pair can be replayed inside a hipGraph).
  *        [all-reduce sq over the data-parallel group when the batch is sharded]
  *        lc_norm_clip_apply_f32   norm = sqrt(sq);  limit = state_in <= 0 ? initial_max_norm : state_in;
  *                                 out = grad * min(limit / (norm + 1e-6), 1);
@@ -180,7 +183,8 @@ int lc_pose_errors_f32(const float *R_est, const float *t_est, const float *R_gt
  *                                 (state_out / norm_out may be NULL: scale a further tensor of the same hook call).
  * ------------------------------------------------------------------------------------------------ */
 #define LC_SQNORM_BLOCKS 512
-int lc_sqnorm_f32(const float *x, long long n, double *partials, unsigned *ticket, float *sq, int accumulate, void *stream);
+int lc_sqnorm_f32(const float *x, long long n, double *partials, unsigned *ticket, float *sq, int accumulate,
+                  const float *state, float *state_snapshot, void *stream);
 int lc_norm_clip_apply_f32(const float *grad, long long n, const float *sq, const float *state_in, float initial_max_norm,
                            float scale, double momentum, float *out, float *state_out, float *norm_out, void *stream);
 

@@ -392,11 +392,14 @@ int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt
     return lc::launch_pose_errors(p, static_cast<hipStream_t>(stream)) ? fail(11, "pose-error kernel launch failed") : 0;
 }
 
-int lc_sqnorm_f32(const float* x, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, void* stream) {
+int lc_sqnorm_f32(const float* x, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, const float* state,
+                  float* state_snapshot, void* stream) {
     if (n < 0) return fail(1, "bad size");
     if (!partials || !ticket || !sq || (n > 0 && !x)) return fail(1, "null pointer");
+    if ((state == nullptr) != (state_snapshot == nullptr)) return fail(1, "state and state_snapshot go together");
     lc::ClipParams p{};
     p.x = x; p.n = n; p.vec = !misaligned(16, x); p.partials = partials; p.ticket = ticket; p.sq = sq; p.accumulate = accumulate;
+    p.state_in = state; p.state_snapshot = state_snapshot;
     return lc::launch_sqnorm(p, static_cast<hipStream_t>(stream)) ? fail(11, "sqnorm launch failed") : 0;
 }
 

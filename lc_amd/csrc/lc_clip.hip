@@ -2,7 +2,8 @@
 // dense heads hang on their weight logits / weight scale / 3D points (losses.py:245-247,343-352,378-381).
 // The reference spends ~15 small torch launches per hook call (norm, add, div, clamp, mul, the EMA update); here:
 //   lc_sqnorm_kernel      sum of squares of the gradient -> one device float (deterministic: per-block partials in a
-//                         fixed order, summed by the last block to arrive)
+//                         fixed order, summed by the last block to arrive), which also snapshots max_norm so that the
+//                         second kernel can overwrite it IN PLACE (static addresses: the pair replays inside a hipGraph)
 //   [ all-reduce of that float over the process group when the batch is sharded: SURVEY.md 8e ]
 //   lc_clip_apply_kernel  coefficient + scaling of the gradient + the EMA state update, all from device scalars
 // No host synchronisation: the reference's `self.start and self.max_norm <= 0` test is evaluated on the device.
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(kThreads) void lc_sqnorm_kernel(const ClipParams p)
     s = block_sum_d(s, red);
     if (threadIdx.x == 0) {
         *p.sq = (p.accumulate ? *p.sq : 0.f) + (float)s;
+        if (p.state_snapshot) *p.state_snapshot = *p.state_in;  // lets lc_clip_apply update the state in place (hipGraph-safe)
         *p.ticket = 0;  // ready for the next call on this stream
     }
 }

@@ -156,6 +156,7 @@ struct ClipParams {
     unsigned* ticket;    // zero-initialised counter, left at zero
     float* sq;           // device scalar: sum of squares (accumulated into when `accumulate`)
     int accumulate;
+    float* state_snapshot;   // optional: receives *state_in (the running maximum before this hook call)
     // lc_clip_apply
     const float* state_in;   // max_norm before the call (<= 0: not started)
     float initial_max_norm, scale, keep, gain;  // keep = 1 - momentum, gain = momentum * scale

@@ -3,7 +3,8 @@ hook on the dense heads' weight logits / scale / points (`losses.py:245-247,343-
 is kept so checkpoints load strictly.
 
 Two launches per hook call and no host synchronisation (`lc_amd/csrc/lc_clip.hip`): sum of squares -> device scalar, then
-coefficient + scaling + the EMA update of `max_norm` from device scalars.  The reference's `start` flag only exists to
+coefficient + scaling + the EMA update of `max_norm` from device scalars.  `max_norm` is updated IN PLACE (the first launch
+snapshots it), so the addresses are fixed and a step containing the hook can be replayed as a hipGraph.  The reference's `start` flag only exists to
 skip a device->host read of `max_norm <= 0`; with the test evaluated on the device it has no role (`max_norm` stays
 positive once it has been set, so "not started" and "max_norm <= 0" coincide).
 
@@ -20,37 +21,39 @@ from . import _lib
 _SQNORM_BLOCKS = 512  # LC_SQNORM_BLOCKS (include/lc_amd.h)
 
 
-def _launch_sqnorm(grads, workspace):
-    """Sum of squares over all tensors of the hook call -> float32 device scalar."""
+def _launch_sqnorm(grads, workspace, state):
+    """Sum of squares over all tensors of the hook call -> float32 device scalar; also snapshots `state` (the running
+    maximum before this call) into the workspace so that `_launch_apply` may overwrite `state` in place."""
     lib = _lib.load()
     dev = grads[0].device
-    partials, ticket = workspace
+    partials, ticket, snap = workspace
     sq = torch.empty((), device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
         for i, g in enumerate(grads):
-            rc = lib.lc_sqnorm_f32(_lib.ptr(g), g.numel(), _lib.ptr(partials), _lib.ptr(ticket), _lib.ptr(sq), int(i > 0), _lib.stream_ptr(dev))
+            last = i == len(grads) - 1
+            rc = lib.lc_sqnorm_f32(_lib.ptr(g), g.numel(), _lib.ptr(partials), _lib.ptr(ticket), _lib.ptr(sq), int(i > 0),
+                                   _lib.ptr(state) if last else None, _lib.ptr(snap) if last else None, _lib.stream_ptr(dev))
             _lib.check(rc, "lc_sqnorm_f32")
-    return sq
+    return sq, snap
 
 
-def _launch_apply(grads, sq, state, initial_max_norm, scale, momentum):
-    """-> (clipped tensors, new max_norm, total norm); the state update rides on the last tensor's launch."""
+def _launch_apply(grads, sq, state_before, state, initial_max_norm, scale, momentum):
+    """-> (clipped tensors, total norm).  `state` (float32 device scalar) is updated IN PLACE from `state_before` (its
+    snapshot): fixed addresses, so the two launches can be replayed inside a hipGraph; the update rides on the last tensor."""
     lib = _lib.load()
     dev = grads[0].device
-    state = state.to(torch.float32)
-    new_state = torch.empty((), device=dev, dtype=torch.float32)
     norm = torch.empty((), device=dev, dtype=torch.float32)
     outs = []
     with torch.cuda.device(dev):
         for i, g in enumerate(grads):
             o = torch.empty_like(g)
             last = i == len(grads) - 1
-            rc = lib.lc_norm_clip_apply_f32(_lib.ptr(g), g.numel(), _lib.ptr(sq), _lib.ptr(state), float(initial_max_norm), float(scale),
-                                            float(momentum), _lib.ptr(o), _lib.ptr(new_state) if last else None,
+            rc = lib.lc_norm_clip_apply_f32(_lib.ptr(g), g.numel(), _lib.ptr(sq), _lib.ptr(state_before), float(initial_max_norm),
+                                            float(scale), float(momentum), _lib.ptr(o), _lib.ptr(state) if last else None,
                                             _lib.ptr(norm) if last else None, _lib.stream_ptr(dev))
             _lib.check(rc, "lc_norm_clip_apply_f32")
             outs.append(o)
-    return outs, new_state, norm
+    return outs, norm
 
 
 class NormClipper(torch.nn.Module):
@@ -67,7 +70,7 @@ class NormClipper(torch.nn.Module):
     def _ws(self, dev):
         if dev not in self._workspace:
             self._workspace[dev] = (torch.empty(_SQNORM_BLOCKS, device=dev, dtype=torch.float64),
-                                    torch.zeros(1, device=dev, dtype=torch.int32))
+                                    torch.zeros(1, device=dev, dtype=torch.int32), torch.empty((), device=dev, dtype=torch.float32))
         return self._workspace[dev]
 
     def forward(self, grads, norm_type=2):
@@ -83,11 +86,12 @@ class NormClipper(torch.nn.Module):
             return tensors
         tensors = [_lib.require_hip_f32("grad", g) for g in tensors]
         dev = tensors[0].device
-        sq = _launch_sqnorm(tensors, self._ws(dev))
+        if self.max_norm.device != dev:  # module left on the CPU: the state follows the gradients (once)
+            self.max_norm = self.max_norm.to(device=dev)
+        sq, before = _launch_sqnorm(tensors, self._ws(dev), self.max_norm)
         if self.group is not None:
             import torch.distributed as dist
 
             dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
-        state = self.max_norm.to(device=dev)
-        clipped, self.max_norm, self.last_norm = _launch_apply(tensors, sq, state, self.initial_max_norm, self.scale, self.momentum)
+        clipped, self.last_norm = _launch_apply(tensors, sq, before, self.max_norm, self.initial_max_norm, self.scale, self.momentum)
         return clipped[0] if single else clipped

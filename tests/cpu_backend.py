@@ -26,16 +26,20 @@ def _launch_kpt(K, pose, pts3d, pts2d, std, want_grads):
     return nll, (du if want_grads else None), (ds if want_grads else None)
 
 
-def _launch_sqnorm(grads, workspace):
+def _launch_sqnorm(grads, workspace, state):
     from oracle import grad_oracle
 
-    return grad_oracle.sum_of_squares(grads)
+    return grad_oracle.sum_of_squares(grads), state.detach().clone()
 
 
-def _launch_apply(grads, sq, state, initial_max_norm, scale, momentum):
+def _launch_apply(grads, sq, state_before, state, initial_max_norm, scale, momentum):
     from oracle import grad_oracle
 
-    return grad_oracle.apply(grads, sq, state.to(sq.dtype), initial_max_norm, scale, momentum)
+    outs, new_state, norm = grad_oracle.apply(grads, sq, state_before.to(sq.dtype), initial_max_norm, scale, momentum)
+    if state.dtype != new_state.dtype:  # the tests also run the host logic in fp64
+        state.data = state.data.to(new_state.dtype)
+    state.copy_(new_state)
+    return outs, norm
 
 
 def _launch_scale(scale, srcs):

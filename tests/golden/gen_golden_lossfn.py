@@ -110,7 +110,7 @@ def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None):
             if gk is not None:
                 rec[f"s{i}_grad_{k}"] = gk.double().cpu().numpy()
         for k, v in fn.state_dict().items():
-            rec[f"s{i}_state_{k}"] = v.double().cpu().numpy()
+            rec[f"s{i}_state_{k}"] = v.detach().double().cpu().numpy().copy()  # copy: the state may be updated in place
     rec["steps"] = np.asarray(steps)
     return rec
 

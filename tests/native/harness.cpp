@@ -154,7 +154,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&partials, LC_SQNORM_BLOCKS * 8)); CK(hipMalloc(&ticket, 4)); CK(hipMemset(ticket, 0, 4));
         CK(hipMalloc(&sq, 4)); CK(hipMalloc(&state2, 4)); CK(hipMalloc(&norm, 4)); CK(hipMalloc(&out, n * 4));
         state = to_dev(std::vector<float>(1, -1.f));
-        rc = lc_sqnorm_f32(dU, n, partials, ticket, sq, 0, nullptr);
+        rc = lc_sqnorm_f32(dU, n, partials, ticket, sq, 0, nullptr, nullptr, nullptr);
         int rc2 = lc_norm_clip_apply_f32(dU, n, sq, state, 100.f, 1.7f, 0.1, out, state2, norm, nullptr);
         CK(hipDeviceSynchronize());
         float hsq, hs2, hnorm, ho;

@@ -58,3 +58,34 @@ def test_clipper_rejects_other_norms_and_cpu_tensors():
         clip.clip(torch.ones(4, device=DEV), norm_type=float("inf"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         clip.clip(torch.ones(4))
+
+
+def test_clipper_state_recurrence_survives_hipgraph_replay():
+    """max_norm is updated in place (fixed addresses): replaying a captured hook call advances the EMA exactly like eager calls."""
+    from lc_amd.grad import NormClipper
+
+    g = torch.Generator().manual_seed(1)
+    grads = [(torch.randn(4, 2, 16, 16, generator=g) * s).to(DEV) for s in (1.0, 5.0, 0.3, 20.0, 1.0)]
+    eager = NormClipper().to(DEV)
+    ref_out, ref_state = [], []
+    for x in grads:
+        ref_out.append(eager.clip(x).clone())
+        ref_state.append(eager.max_norm.item())
+
+    graphed = NormClipper().to(DEV)
+    static_in = grads[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed._ws(static_in.device)  # workspace allocated outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = graphed.clip(static_in)
+    graphed.max_norm.fill_(-1.0)  # the capture itself does not execute: start the recurrence from scratch
+    for x, o, st in zip(grads, ref_out, ref_state):
+        static_in.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_out, o) and graphed.max_norm.item() == st
