@@ -1,36 +1,89 @@
 """hipGraph replay of the launch-bound pieces around the kernels (MI355X guideline: capture launch-bound inner loops).
 
-The sparse heads' `Loss_fn` step is ~25 short launches forward + backward for < 20 us of kernel time, i.e. bound by the host's
-launch rate; captured with `torch.cuda.make_graphed_callables` it replays as two graphs (forward, backward):
-B=256, N=64 on one MI355X: 338 us eager -> 103 us graphed, loss and gradients bit-identical (`scripts/ubench/graph_lossfn.py`).
-The test-time counterpart is `lc_amd.inference.GraphedSolvePnP`.
+A `Loss_fn` step is 25-75 short launches forward + backward for < 0.25 ms of kernel time, i.e. bound by the host's launch
+rate.  `GraphedLoss` captures it with `torch.cuda.make_graphed_callables` (one forward and one backward graph per
+configuration) and replays it: sparse heads, B=256 N=64 on one MI355X: 338 us eager -> 103 us graphed, loss values and
+gradients bit-identical (`scripts/ubench/graph_lossfn.py`).  The test-time counterpart is `lc_amd.inference.GraphedSolvePnP`.
+
+What makes the step capturable: no host synchronisation anywhere in the path, the `NormClipper` hooks keep their running
+maximum at a fixed address (updated in place, `lc_amd/grad.py`), and the two host-side sources of variation are handled
+outside the graph -- the dense heads' random sub-sampling phase (`np.random.randint`, `losses.py:152`) is drawn per call and
+selects one of `dense_sample**2` lazily captured graphs; the warm-up blending factor (`losses.py:272-276`, a Python float) is
+frozen at its value for the `step` given at construction, so capture after the ramp (or build a new `GraphedLoss` when it moves).
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
+from torch import Tensor
 
+from .grad import NormClipper
 from .inference import GraphedSolvePnP  # noqa: F401  (re-exported)
 
 
-def graphed_sparse_loss(loss_fn, gt_dict: dict, out_dict: dict, epoch: int, step: int, steps_per_epoch: int):
-    """Capture `loss_fn(gt_dict, out_dict, epoch, step, steps_per_epoch)` of the sparse branch for the shapes of the example dicts.
+class GraphedLoss:
+    """`loss_fn(gt_dict, out_dict, epoch, step, steps_per_epoch)` replayed as hipGraphs for the shapes of the example dicts.
 
-    Returns `f(pts2d, pts2d_std, out_K, pose_best, pts3d, bbox_3d) -> (total, loss_kpts, loss_pose)`; `total` is the weighted sum
-    the training loop back-propagates (`sum(w_loss_dict.values())`), differentiable w.r.t. `pts2d` and `pts2d_std`.
-    The warm-up blending factor of `losses.py:272-276` is a Python float and is frozen at its value for `step`: capture after
-    the ramp (or capture again when it changes).
+        graphed = GraphedLoss(loss_fn, gt_dict, out_dict, epoch, step, steps_per_epoch)
+        loss_dict, w_loss_dict = graphed(gt_dict, out_dict)          # same return value as loss_fn(...)
+        sum(w_loss_dict.values()).backward()                         # backward replays the captured backward graph
+
+    Every tensor entry of `out_dict` is a differentiable input, every tensor entry of `gt_dict` a constant input; non-tensor
+    entries are frozen at capture.  Sparse heads and the continuous-xyz dense heads are supported (the binary-code branch keeps
+    a histogram EMA that is re-bound on every call, `losses.py:207-208`, and is refused).
     """
-    if "pts2d" not in out_dict:
-        raise ValueError("graphed_sparse_loss: the sparse branch needs out_dict['pts2d'] / ['pts2d_std']")
-    rest = {k: v for k, v in gt_dict.items() if k not in ("out_K", "pose_best", "pts3d", "bbox_3d")}
 
-    def run(pts2d, pts2d_std, out_K, pose_best, pts3d, bbox_3d):
-        gt = dict(rest, out_K=out_K, pose_best=pose_best, pts3d=pts3d, bbox_3d=bbox_3d)
-        loss_dict, w_loss_dict = loss_fn(gt, dict(pts2d=pts2d, pts2d_std=pts2d_std), epoch, step, steps_per_epoch)
-        zero = pts2d.new_zeros(())
-        return sum(w_loss_dict.values()), loss_dict.get("loss_kpts", zero), loss_dict.get("loss_pose", zero)
+    def __init__(self, loss_fn, gt_dict: dict, out_dict: dict, epoch: int, step: int, steps_per_epoch: int):
+        if "xyz_noc_bin" in out_dict:
+            raise NotImplementedError("GraphedLoss: the binary-code branch re-binds its histogram buffer every step and is not captured")
+        self.loss_fn = loss_fn
+        self.when = (epoch, step, steps_per_epoch)
+        self.out_keys = [k for k, v in out_dict.items() if isinstance(v, Tensor)]
+        self.gt_keys = [k for k, v in gt_dict.items() if isinstance(v, Tensor)]
+        self._frozen_out = {k: v for k, v in out_dict.items() if not isinstance(v, Tensor)}
+        self._frozen_gt = {k: v for k, v in gt_dict.items() if not isinstance(v, Tensor)}
+        self.dense = "pts2d" not in out_dict
+        self.sample = int(loss_fn.cfg.pose_loss_cfg.get("dense_sample", 2)) if self.dense else 1
+        self._example = ([out_dict[k].detach().clone().requires_grad_(out_dict[k].is_floating_point()) for k in self.out_keys] +
+                         [gt_dict[k].detach().clone() for k in self.gt_keys])
+        self._graphs = {}
+        self._loss_keys = self._w_keys = None
 
-    sample = (out_dict["pts2d"].detach().clone().requires_grad_(True), out_dict["pts2d_std"].detach().clone().requires_grad_(True),
-              gt_dict["out_K"].detach().clone(), gt_dict["pose_best"].detach().clone(), gt_dict["pts3d"].detach().clone(),
-              gt_dict["bbox_3d"].detach().clone())
-    return torch.cuda.make_graphed_callables(run, sample)
+    def _run(self, phase, *flat):
+        n = len(self.out_keys)
+        # Loss_fn hangs its gradient-clipping hooks on the network outputs it is given; the static placeholders of the capture
+        # are reused by every warm-up pass, so hand it fresh aliases (a view: no launch) or the hooks would pile up on them
+        flat = [t.view_as(t) if t.requires_grad else t for t in flat]
+        out = dict(self._frozen_out, **dict(zip(self.out_keys, flat[:n])))
+        gt = dict(self._frozen_gt, **dict(zip(self.gt_keys, flat[n:])))
+        self.loss_fn._forced_phase = phase
+        try:
+            loss_dict, w_loss_dict = self.loss_fn(gt, out, *self.when)
+        finally:
+            self.loss_fn._forced_phase = None
+        if self._loss_keys is None:
+            self._loss_keys, self._w_keys = list(loss_dict), list(w_loss_dict)
+        return tuple(loss_dict[k] for k in self._loss_keys) + tuple(w_loss_dict[k] for k in self._w_keys)
+
+    def _capture(self, phase):
+        # the warm-up iterations of make_graphed_callables run the step for real: keep them out of the clippers' running maxima
+        clippers = [m for m in self.loss_fn.modules() if isinstance(m, NormClipper)]
+        dev = self._example[0].device
+        for c in clippers:
+            if c.max_norm.device != dev:
+                c.max_norm = c.max_norm.to(dev)
+            c._ws(dev)
+        saved = [c.max_norm.detach().clone() for c in clippers]
+        graphed = torch.cuda.make_graphed_callables(lambda *flat: self._run(phase, *flat), tuple(self._example))
+        for c, s in zip(clippers, saved):
+            c.max_norm.copy_(s)
+        return graphed
+
+    def __call__(self, gt_dict: dict, out_dict: dict):
+        phase = tuple(int(v) for v in np.random.randint(0, self.sample, size=2)) if self.dense else None  # losses.py:152
+        if phase not in self._graphs:
+            self._graphs[phase] = self._capture(phase)
+        flat = [out_dict[k] for k in self.out_keys] + [gt_dict[k] for k in self.gt_keys]
+        res = self._graphs[phase](*flat)
+        n = len(self._loss_keys)
+        return dict(zip(self._loss_keys, res[:n])), dict(zip(self._w_keys, res[n:]))

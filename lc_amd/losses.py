@@ -209,11 +209,14 @@ class Loss_fn(nn.Module):
         # phase (losses.py:142-161): one fused HIP launch each way (lc_amd/dense.py)
         sample = cfg.get("dense_sample", 2)
         assert ("xyz_noc" in out_dict) != ("xyz_noc_bin" in out_dict)  # either structure, not both (losses.py:360)
+        # sub-sampling phase: drawn from np.random like the reference (losses.py:152,169) unless a caller that replays this step
+        # as a hipGraph pinned it (lc_amd/graphs.py draws it outside the graph and keeps one graph per phase)
+        phase = getattr(self, "_forced_phase", None)
         if "xyz_noc" in out_dict:
             den_pts2d, den_inv_std2d, den_pts3d = dense_front_end(out_dict["xyz_noc"], xyz_weight_logits, xyz_weights_scale, noc_scale,
-                                                                  sample=sample)
+                                                                  sample=sample, top_left=phase)
         else:
-            top_left = tuple(int(v) for v in np.random.randint(0, sample, size=2))  # losses.py:169
+            top_left = tuple(int(v) for v in np.random.randint(0, sample, size=2)) if phase is None else phase  # losses.py:169
             den_pts2d, den_inv_std2d, _ = dense_front_end(None, xyz_weight_logits, xyz_weights_scale, None, sample=sample, top_left=top_left)
             den_pts3d = _decode_bin_points(out_dict["xyz_noc_bin"], gt_dict["xyz_noc_bin_raw"], gt_dict["msk_noc"], noc_scale, gt_dict,
                                            sample, top_left)

@@ -19,33 +19,45 @@ def test_example_train_step_runs():
     assert all("nan" not in l.lower() for l in lines)
 
 
-def test_graphed_sparse_loss_step_equals_eager_on_new_inputs():
-    """Forward + backward of the sparse Loss_fn step replayed as hipGraphs: same loss values and gradients as the eager call."""
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_graphed_loss_step_equals_eager_on_new_inputs(kind):
+    """Forward + backward of a Loss_fn step replayed as hipGraphs: same loss values, gradients and NormClipper trajectory as
+    the eager calls, step after step (dense: one graph per sub-sampling phase, drawn from np.random like the reference)."""
     import warnings
 
+    import numpy as np
+
     from lc_amd.config import AttrDict
-    from lc_amd.graphs import graphed_sparse_loss
+    from lc_amd.graphs import GraphedLoss
     from lc_amd.losses import Loss_fn
-    from tests.golden.gen_golden_lossfn import SPARSE_CFG, sparse_inputs
+    from tests.golden.gen_golden_lossfn import DENSE_CFG, SPARSE_CFG, dense_inputs, sparse_inputs
 
     dev = torch.device("cuda:0")
-    fn = Loss_fn(AttrDict(SPARSE_CFG), AttrDict(), 0).to(dev)
+    cfg = SPARSE_CFG if kind == "sparse" else DENSE_CFG
 
     def inputs(seed):
-        gt, out = sparse_inputs(B=32, N=16, seed=seed)
-        return {k: v.to(dev) for k, v in gt.items()}, {k: v.to(dev) for k, v in out.items()}
+        gt, out = sparse_inputs(B=32, N=16, seed=seed) if kind == "sparse" else dense_inputs(B=4, H=16, W=16, seed=seed)
+        return ({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}, {k: v.to(dev) for k, v in out.items()})
 
+    eager_fn = Loss_fn(AttrDict(cfg), AttrDict(), 0).to(dev)
+    graph_fn = Loss_fn(AttrDict(cfg), AttrDict(), 0).to(dev)
     gt0, out0 = inputs(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        graphed = graphed_sparse_loss(fn, gt0, out0, 1, 1000, 10)
-        for seed in (0, 1, 2):
+        graphed = GraphedLoss(graph_fn, gt0, out0, 1, 1000, 10)
+        for i, seed in enumerate((0, 1, 2, 3, 4, 5)):
             gt, out = inputs(seed)
-            u, s = out["pts2d"].clone().requires_grad_(True), out["pts2d_std"].clone().requires_grad_(True)
-            total, lk, lp = graphed(u, s, gt["out_K"], gt["pose_best"], gt["pts3d"], gt["bbox_3d"])
-            gu, gs = torch.autograd.grad(total, (u, s))
-            u2, s2 = out["pts2d"].clone().requires_grad_(True), out["pts2d_std"].clone().requires_grad_(True)
-            ld, wd = fn(gt, dict(pts2d=u2, pts2d_std=s2), 1, 1000, 10)
-            ru, rs = torch.autograd.grad(sum(wd.values()), (u2, s2))
-            assert torch.equal(total, sum(wd.values())) and torch.equal(lk, ld["loss_kpts"]) and torch.equal(lp, ld["loss_pose"])
-            assert torch.equal(gu, ru) and torch.equal(gs, rs)
+            la = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+            lb = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+            np.random.seed(100 + i)
+            ld, wd = graphed(gt, la)
+            ga = torch.autograd.grad(sum(wd.values()), list(la.values()), allow_unused=True)
+            np.random.seed(100 + i)
+            rd, rw = eager_fn(gt, lb, 1, 1000, 10)
+            gb = torch.autograd.grad(sum(rw.values()), list(lb.values()), allow_unused=True)
+            assert list(ld) == list(rd) and list(wd) == list(rw)
+            assert all(torch.equal(ld[k], rd[k]) for k in rd) and all(torch.equal(wd[k], rw[k]) for k in rw)
+            for x, y in zip(ga, gb):
+                assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
+            for (ka, va), (kb, vb) in zip(graph_fn.state_dict().items(), eager_fn.state_dict().items()):
+                assert ka == kb and torch.equal(va, vb), (i, ka, va, vb)
