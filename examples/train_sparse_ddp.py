@@ -2,7 +2,8 @@
 """End-to-end training step around the HIP hot path (BASELINE configs[2]/[3] plumbing, synthetic data):
 
     backbone (ResNet-34-style encoder + 3-stage up-sampling decoder, plain PyTorch-ROCm: MIOpen/hipBLASLt own the conv GEMMs)
-      -> keypoint logits (B,S,64,64) -> lc_amd.ptnet.sparse_head   (fused spatial softmax + soft-argmax, HIP)
+      -> keypoint logits (B,S,64,64), bf16 under autocast -> lc_amd.ptnet.sparse_head (fused spatial softmax + soft-argmax, HIP,
+         consumes the 16-bit maps natively)
       -> lc_amd.losses.Loss_fn (Laplace keypoint NLL + LC loss via the fused HIP kernel, warm-up blend)
       -> backward -> gradient all-reduce over RCCL (DistributedDataParallel) -> Adam step
 
@@ -113,7 +114,7 @@ def main():
         t0 = time.perf_counter()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
             logits = net(blob["rgb_in"].contiguous(memory_format=torch.channels_last))
-        out = sparse_head(logits.float())  # fused HIP head, fp32 (ptnet.py:59-66)
+        out = sparse_head(logits)  # fused HIP head (ptnet.py:59-66) on the bf16 logits as they are: fp32 statistics, bf16 gradient
         loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
         loss = sum(w_loss_dict.values())
         opt.zero_grad(set_to_none=True)
