@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Training step of the DENSE-correspondence heads around the HIP hot path (BASELINE configs[4] plumbing, synthetic data):
+
+    backbone (the encoder/decoder of train_sparse_ddp.py, fp16/bf16 autocast)
+      -> (B, C, 64, 64) maps: xyz_noc (3) | xyz_noc_bin (sum of code bits), xyz_weights (2), msk_vis (1) + a per-sample weight scale
+      -> lc_amd.losses.Loss_fn dense branch: joint-softmax front end (HIP), [ZebraPose code decode (HIP)], LC loss at N=1024
+         (HIP), NormClipper hooks (HIP, whole-batch norm all-reduced over RCCL when sharded), L1 / code / segmentation terms
+      -> backward -> DistributedDataParallel gradient all-reduce -> Adam
+
+    python examples/train_dense_ddp.py --steps 10 [--bin]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_dense_ddp.py --steps 10
+
+Targets are geometrically consistent (a synthetic surface seen from a known pose), weights are random-init: the point is the
+plumbing and the step time, not a trained model.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from lc_amd import floatbits, synth  # noqa: E402
+from lc_amd.config import AttrDict  # noqa: E402
+from lc_amd.losses import Loss_fn  # noqa: E402
+from lc_amd.transforms import gen_uv, quaternion_rep_to_RT  # noqa: E402
+from train_sparse_ddp import KeypointNet  # noqa: E402
+
+BITS = (7, 7, 6)  # zlmo bit budget
+
+
+class DenseNet(nn.Module):
+    """ptnet.py:20-38,68-80 structure: one trunk, channel slices per head, weight scale = exp(Linear(mean feature))."""
+
+    def __init__(self, noc_channels, width=64):
+        super().__init__()
+        self.trunk = KeypointNet(sparse_cnt=noc_channels + 3, width=width)
+        self.noc_channels = noc_channels
+        self.weight_scale_layer = nn.Linear(256, 1)
+        nn.init.zeros_(self.weight_scale_layer.weight)
+        nn.init.constant_(self.weight_scale_layer.bias, 3.0)
+
+    def forward(self, rgb):
+        t = self.trunk
+        feature = t.decoder(t.encoder(t.stem(rgb)))
+        raw = t.head(feature)
+        c = self.noc_channels
+        scale = self.weight_scale_layer(feature.flatten(start_dim=-2).mean(dim=-1).float()).exp()[..., None, None]
+        return raw[:, :c], raw[:, c:c + 2], scale, raw[:, c + 2:c + 3]
+
+
+def synthetic_blob(B, dev, seed, binary, S=64):
+    """Blob of the reference's dense shape (dataset.py:451-489): a noisy planar patch at ~500 mm seen through a 64x64 output grid."""
+    g = torch.Generator().manual_seed(seed)
+    b = synth.make_batch(B, 4, seed=seed + 7, rotate_K=False)
+    K = b["K"].clone()
+    K[:, 0, 0] = K[:, 1, 1] = 440.0
+    K[:, 0, 2] = K[:, 1, 2] = S / 2
+    pose = b["pose"].clone()
+    pose[:, 4:6] = 0
+    pose[:, 6] = 500.0
+    R, t = quaternion_rep_to_RT(pose)
+    rays = torch.cat((gen_uv((S, S)), torch.ones(S, S, 1)), -1).reshape(1, -1, 3) @ torch.linalg.inv(K).mT
+    Xm = (rays * (500.0 + 10 * torch.randn(B, S * S, 1, generator=g)) - t[:, None]) @ R
+    noc_scale = torch.tensor(synth.EXTENT_MM).expand(B, 3).contiguous()
+    noc = (Xm / noc_scale[:, None]).mT.reshape(B, 3, S, S).clamp(-0.999, 0.999)
+    msk = (torch.rand(B, S, S, generator=g) > 0.3)
+    blob = dict(rgb_in=torch.rand(B, 3, 256, 256, generator=g), pose_best=pose, out_K=K, bbox_3d=b["bbox_3d"], noc_scale=noc_scale,
+                msk_noc=msk, msk_vis=msk.float())
+    if binary:
+        mod_bits, raw_bits = floatbits.nn_noc2target(noc.permute(0, 2, 3, 1), list(BITS))
+        blob.update(xyz_noc_bin_tgt=mod_bits, xyz_noc_bin_raw=raw_bits, bit_cnt=list(BITS))
+    else:
+        blob["xyz_noc_tgt"] = noc * msk[:, None]
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in blob.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--bin", action="store_true", help="ZebraPose binary-code head (zlmo/zycbv) instead of the continuous xyz head")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        group = dist.group.WORLD
+    torch.manual_seed(0)
+    np.random.seed(rank)
+    model = DenseNet(sum(BITS) if args.bin else 3, args.width).to(dev).to(memory_format=torch.channels_last)
+    cfg = AttrDict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scale_grad=True, clip_pts_grad=not args.bin, dense_sample=2,
+                                      max_err_len=32), pose_loss_start_step=4, pose_loss_start_epoch=0, loss_pose_nz_step=0,
+                   w_loss_seg=1, w_loss_pose=0.05, seg_loss_type="L1", **({"w_loss_noc_bin": 1} if args.bin else {"w_loss_noc": 1}))
+    loss_fn = Loss_fn(cfg, AttrDict(), sum(BITS) if args.bin else 0, group=group).to(dev)  # group: NormClipper norms over the whole batch
+    model.loss_fn = loss_fn
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    amp = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": None}[args.dtype]
+    scaler = torch.amp.GradScaler("cuda", enabled=amp is torch.float16)
+    times = []
+    for step in range(args.steps):
+        blob = synthetic_blob(args.batch, dev, seed=1000 * rank + step, binary=args.bin)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.autocast("cuda", dtype=amp or torch.float16, enabled=amp is not None):
+            noc, wlogits, wscale, vis = net(blob["rgb_in"].contiguous(memory_format=torch.channels_last))
+        # the loss runs at the reference's fp32 precision: half-precision maps are up-cast at the boundary (lc_amd/_lib.py)
+        out = {"xyz_noc_bin" if args.bin else "xyz_noc": noc.float(), "xyz_weight_logits": wlogits.float(), "xyz_weights_scale": wscale.float(),
+               "msk_vis_logits": vis.float()}
+        loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
+        loss = sum(w_loss_dict.values())
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        torch.cuda.synchronize(dev)
+        times.append(time.perf_counter() - t0)
+        if rank == 0:
+            terms = "  ".join(f"{k[5:]} {float(v):8.4f}" for k, v in loss_dict.items())
+            print(f"step {step:3d}  loss {float(loss):9.4f}  {terms}  {times[-1] * 1e3:7.1f} ms")
+        assert torch.isfinite(loss), "non-finite loss"
+    if rank == 0 and len(times) > 3:
+        t = sorted(times[2:])[len(times[2:]) // 2]
+        print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), {args.dtype} backbone, "
+              f"{'binary-code' if args.bin else 'continuous-xyz'} dense head, N=1024 correspondences per sample")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,15 @@ def test_example_train_step_runs():
     assert all("nan" not in l.lower() for l in lines)
 
 
+@pytest.mark.parametrize("extra", [[], ["--bin"]], ids=["xyz", "binary-code"])
+def test_example_dense_train_step_runs(extra):
+    """BASELINE configs[4] plumbing: dense heads (continuous xyz / ZebraPose codes), fp16 autocast backbone, GradScaler, clippers."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_dense_ddp.py"), "--steps", "6", "--batch", "4", "--width", "16"]
+                         + extra, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "median step" in out.stdout
+
+
 @pytest.mark.parametrize("kind", ["sparse", "dense"])
 def test_graphed_loss_step_equals_eager_on_new_inputs(kind):
     """Forward + backward of a Loss_fn step replayed as hipGraphs: same loss values, gradients and NormClipper trajectory as
