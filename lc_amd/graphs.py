@@ -18,7 +18,7 @@ import torch
 from torch import Tensor
 
 from .grad import NormClipper
-from .inference import GraphedSolvePnP  # noqa: F401  (re-exported)
+from .inference import GraphedSolvePnP, quiet_capture  # noqa: F401  (GraphedSolvePnP is re-exported)
 
 
 class GraphedLoss:
@@ -74,7 +74,8 @@ class GraphedLoss:
                 c.max_norm = c.max_norm.to(dev)
             c._ws(dev)
         saved = [c.max_norm.detach().clone() for c in clippers]
-        graphed = torch.cuda.make_graphed_callables(lambda *flat: self._run(phase, *flat), tuple(self._example))
+        with quiet_capture():
+            graphed = torch.cuda.make_graphed_callables(lambda *flat: self._run(phase, *flat), tuple(self._example))
         for c, s in zip(clippers, saved):
             c.max_norm.copy_(s)
         return graphed

@@ -14,6 +14,9 @@ device from the first kernel to the last.  The returned dict has the reference's
 """
 from __future__ import annotations
 
+import contextlib
+import gc
+
 import torch
 from torch import Tensor
 
@@ -92,6 +95,20 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     return out
 
 
+@contextlib.contextmanager
+def quiet_capture():
+    """No Python garbage collection while a stream is capturing: a collected `CUDAGraph` / graph-pool tensor of an earlier
+    capture would run its HIP destructor inside the capture, which the runtime answers with an abort."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 class GraphedSolvePnP:
     """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of ~40 short
     launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 355 us
@@ -118,7 +135,7 @@ class GraphedSolvePnP:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with quiet_capture(), torch.cuda.graph(self.graph):
             self._res = solve_pnp(cfg, self._out, self._gt)
 
     @torch.no_grad()

@@ -80,8 +80,10 @@ def test_clipper_state_recurrence_survives_hipgraph_replay():
         graphed._ws(static_in.device)  # workspace allocated outside the capture
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    from lc_amd.inference import quiet_capture
+
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with quiet_capture(), torch.cuda.graph(graph):
         static_out = graphed.clip(static_in)
     graphed.max_norm.fill_(-1.0)  # the capture itself does not execute: start the recurrence from scratch
     for x, o, st in zip(grads, ref_out, ref_state):
