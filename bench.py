@@ -229,8 +229,10 @@ def main():
             step_eager()
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
+        from lc_amd.inference import quiet_capture  # no Python GC while the stream is capturing
+
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with quiet_capture(), torch.cuda.graph(graph):
             step_eager()
     step = step_eager if graph is None else graph.replay
 
