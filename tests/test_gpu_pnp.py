@@ -163,3 +163,31 @@ def test_pnp_stress_hard_starts_vs_oracle():
     assert ok.mean() >= 0.99, (1 - ok.mean(), np.sort(dq_)[-5:])
     # invalid jobs keep their start pose bit for bit
     assert np.array_equal(st.cpu().numpy()[ret == 1], start.numpy()[ret == 1])
+
+
+@pytest.mark.parametrize("scale", [0.0, 1e-12, 1e-9, 1e-6, 1e-3])
+def test_pnp_identity_and_tiny_rotations_vs_oracle(scale):
+    """Starts and optima at / near the identity rotation: the small-angle branches of QuaternionToAngleAxis,
+    AngleAxisRotatePoint and AngleAxisToQuaternion (ceres.cpp:37,96,131) agree with the oracle to the last bit or two."""
+    from lc_amd.pnp import pnp_ceres
+
+    B, N = 256, 24
+    g = torch.Generator().manual_seed(5)
+    b = synth.make_batch(B, N, seed=3, noise_px=0.5, outlier_frac=0.0, rotate_K=False)
+    q = torch.cat((torch.ones(B, 1), torch.randn(B, 3, generator=g) * scale), -1)
+    q = q / q.norm(dim=-1, keepdim=True)
+    pose = torch.cat((q, b["pose"][:, 4:]), -1)
+    w, x, y, z = q.double().unbind(-1)
+    R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)), -1).reshape(B, 3, 3)
+    xf = (b["pts3d"].double() @ R.mT + pose[:, None, 4:].double()) @ b["K"].double().mT
+    u = (xf[..., :2] / xf[..., 2:3] + 0.3 * torch.randn(B, N, 2, generator=g).double()).float()
+    start = pose.clone()
+    start[:, 4:] *= 1.01
+    dev = torch.device("cuda:0")
+    st, tr, ret = pnp_ceres.solve_device(b["K"].to(dev), b["pts3d"].to(dev), u.to(dev), b["inv_std"].to(dev), start.to(dev))
+    so, tro, reto = pnp_oracle.solve_batched(start.numpy(), b["K"].numpy(), u.numpy(), b["pts3d"].numpy(),
+                                             torch.diag_embed(b["inv_std"]).numpy(), num_threads=8)
+    assert np.array_equal(ret.cpu().numpy(), reto) and reto.sum() == 0
+    d = np.abs(st.cpu().numpy() - so)
+    assert np.isfinite(st.cpu().numpy()).all() and d[:, :4].max() <= 1e-9 and d[:, 4:].max() <= 1e-4
