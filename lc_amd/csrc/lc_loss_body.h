@@ -152,21 +152,6 @@ __device__ __forceinline__ void block_allreduce_small(double (&v)[K], double (*s
     }
 }
 
-// C = A * B for 6x6 row-major matrices in LDS; one output entry per thread (tid < 36)
-__device__ __forceinline__ double mm6_entry(const double* A, const double* B, int i, int j) {
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc += A[6 * i + k] * B[6 * k + j];
-    return acc;
-}
-
-__device__ __forceinline__ double mv6_entry(const double* A, const double* x, int i) {
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc += A[6 * i + k] * x[k];
-    return acc;
-}
-
 __device__ __forceinline__ double quad6(const double* M /*LDS 6x6 symmetric*/, const double* x) {
     double acc = 0;
 #pragma unroll
