@@ -152,18 +152,6 @@ __device__ __forceinline__ void block_allreduce_small(double (&v)[K], double (*s
     }
 }
 
-__device__ __forceinline__ double quad6(const double* M /*LDS 6x6 symmetric*/, const double* x) {
-    double acc = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double row = 0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) row += M[6 * i + j] * x[j];
-        acc += row * x[i];
-    }
-    return acc;
-}
-
 struct Pt {
     double X[3], u[2], s[2], vld;
 };
