@@ -191,3 +191,33 @@ def test_pnp_identity_and_tiny_rotations_vs_oracle(scale):
     assert np.array_equal(ret.cpu().numpy(), reto) and reto.sum() == 0
     d = np.abs(st.cpu().numpy() - so)
     assert np.isfinite(st.cpu().numpy()).all() and d[:, :4].max() <= 1e-9 and d[:, 4:].max() <= 1e-4
+
+
+def test_pnp_degenerate_jobs_vs_oracle():
+    """Zero weights, an object behind the camera, coincident / collinear points, 500 px outliers, a NaN coordinate: the kernel
+    and the oracle agree on which jobs are invalid; invalid jobs keep their start; valid ones agree within the tolerance."""
+    from lc_amd.pnp import pnp_ceres
+
+    B, N = 12, 20
+    b = synth.make_batch(B, N, seed=77, noise_px=0.5, outlier_frac=0.0)
+    K, X, u, s, start = (b[k].clone() for k in ("K", "pts3d", "pts2d", "inv_std", "start"))
+    s[0] = 0.0                                   # zero information: singular normal equations
+    start[1, 6] = -start[1, 6]                   # start behind the camera
+    X[2] = X[2, :1]                              # all points coincide
+    X[3] = X[3, :1] + torch.linspace(0, 1, N)[:, None] * torch.tensor([30.0, 10.0, -20.0])  # collinear points
+    u[4, ::2] += 500.0                           # half of the points are gross outliers
+    u[5, 3, 0] = float("nan")                    # a NaN measurement (cer_solver filters these; the raw solver must not crash)
+    s[6, :, 1] = 0.0                             # information on u only
+    X[7] = 0.0                                   # every point at the origin
+    L = torch.diag_embed(s)
+    dev = torch.device("cuda:0")
+    st, tr, ret = pnp_ceres.solve_device(K.to(dev), X.to(dev), u.to(dev), L.to(dev), start.to(dev))
+    so, tro, reto = pnp_oracle.solve_batched(start.numpy(), K.numpy(), u.numpy(), X.numpy(), L.numpy(), num_threads=4)
+    ret, st = ret.cpu().numpy(), st.cpu().numpy()
+    assert np.array_equal(ret, reto), (ret, reto)
+    assert ret[0] == 0 and ret[5] == 1  # zero information: zero gradient -> CONVERGENCE at the start; NaN residual -> failure
+    assert np.array_equal(st[ret == 1], start.numpy()[ret == 1])
+    ok = ret == 0
+    assert np.isfinite(st[ok]).all()
+    dq, dt = pose_err(st[ok], so[ok])
+    assert dq.max() <= 1e-4 and dt.max() <= 1e-4, (dq, dt)
