@@ -61,6 +61,27 @@ def host_cpu_model():
     return "unknown"
 
 
+def valu_roofline(kernel: str, B: int, N: int, poses_per_s: float):
+    """The bound that actually binds the pose-unit kernels: VALU issue.  From the committed SQ counter pass of the default
+    workload (profiles/<round>/pmc_traffic.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU in quad-cycles, per dispatch of B poses):
+    SIMD-cycles of VALU work per pose -> poses/s if all 1024 SIMDs of the MI355X issued VALU work every cycle at 2.4 GHz."""
+    if (B, N) != (256, 64):
+        return None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
+        try:
+            sq = json.load(open(f)).get(kernel, {}).get("sq")
+            if sq and sq.get("SQ_ACTIVE_INST_VALU"):
+                cyc = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / B
+                bound = 1024 * 2.4e9 / cyc
+                return {"bound": "valu_issue", "valu_insts_per_pose": sq["SQ_INSTS_VALU"] / B, "simd_cycles_per_pose": cyc,
+                        "peak": bound, "unit": "poses/s", "achieved": poses_per_s, "frac": poses_per_s / bound,
+                        "note": "1024 SIMDs x 2.4 GHz / VALU-busy SIMD-cycles per pose (rocprofv3 --pmc SQ_* pass in profiles/)"}
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(B, N, seed, budget_s=15.0):
     """The oracle (CPU restatement of the reference path) timed on this host: torch closed-form LC loss fwd+bwd on all
     cores + the C/OpenMP LM solve on all cores, over a bounded number of B-sized batches."""
@@ -319,6 +340,9 @@ def main():
                          "kernel_us": kernel_us,
                          "algorithmic_bytes_per_pose": {"loss": by_loss, "pnp": by_pnp}},
         }
+        vr = valu_roofline(dom[0], B, N, B / (dom[1] * 1e-3))
+        if vr is not None:
+            out["roofline"]["valu"] = vr
         if world == 1 and not args.no_head:
             # the third kernel family of the path (keypoint head), HBM-bound; its own line: bench_head.py
             from bench_head import measure_head

@@ -64,4 +64,12 @@ for k, d in traffic.items():
     d["bytes_per_launch"] = (d.get("fetch_kb_raw", 0.0) * d["fetch_correction"] + d.get("write_kb_raw", 0.0)) * 1024
     d["note"] = ("FETCH_SIZE x2 (gfx950 correction for 16 B/lane streams)" if wide else
                  "raw counters; 8-12 B/lane accesses are uncalibrated on gfx950 (MI355X_MICROARCH.md, HBM)")
+# issue counters of the latency/VALU-bound kernels (mean per dispatch), for bench.py's roofline.valu
+for f in find("pmc_sq/**/*counter_collection.csv"):
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in acc.items():
+        if k.startswith("lc_"):
+            traffic.setdefault(k, {})["sq"] = {c: sum(v) / len(v) for c, v in d.items()}
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
