@@ -327,7 +327,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         const double inv_radius = fast_rcp(radius);
 #pragma unroll
         for (int i = 0; i < 6; ++i) dg[i] = fmin(fmax(H[tri6(i, i)], 1e-6), 1e32) * inv_radius;
+        LC_PSTAMP(1);
         bool step_ok = ldlt_solve6(H, dg, g, y);
+        LC_PSTAMP(6);
         // model_cost_change = y.g - y^T H y / 2 with (H + D) y = g  =>  (y.g + sum d_i y_i^2) / 2   (step = -y)
         double mcc = 0;
 #pragma unroll
@@ -374,6 +376,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         unsigned long long* o = reinterpret_cast<unsigned long long*>(p.iters) + 8 * (size_t)b;
         for (int i = 0; i < 6; ++i) o[i] = pst_[i];
         o[6] = iter;
+        o[7] = pst_[6];  // LDL^T solve alone (the rest of the LM algebra is in slot 1)
     }
 #endif
     const bool invalid = failed || !converged;

@@ -45,7 +45,8 @@ for rep in range(3):
     torch.cuda.synchronize()
 ps = stamps.cpu().numpy().view(np.uint64).reshape(B, 8).astype(np.int64)
 iters = ps[:, 6]
-tot = ps[:, :6].sum(1)
+tot = ps[:, :6].sum(1) + ps[:, 7]
 print(f"\nPnP: total cycles/wave median {np.median(tot):.0f}; LM iterations mean {iters.mean():.2f} (min {iters.min()}, max {iters.max()})")
-for i, nm in enumerate(["prologue (loads, quat->aa)", "LM algebra (solve, tests)", "make_rot (sincos)", "accumulate J^T J", "reduce-scatter 32", "LDS broadcast"]):
+for i, nm in enumerate(["prologue (loads, quat->aa)", "LM algebra without LDL^T", "make_rot (sincos)", "accumulate J^T J", "reduce-scatter 32", "LDS broadcast"]):
     print(f"  {nm:28s} {np.median(ps[:, i]):8.0f}  {100 * np.median(ps[:, i]) / np.median(tot):5.1f} %   per evaluation {np.median(ps[:, i] / (iters + 1)):7.0f}")
+print(f"  {'LDL^T solve (of the algebra)':28s} {np.median(ps[:, 7]):8.0f}  {100 * np.median(ps[:, 7]) / np.median(tot):5.1f} %   per iteration  {np.median(ps[:, 7] / np.maximum(iters, 1)):7.0f}")
