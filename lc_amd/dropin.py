@@ -9,6 +9,9 @@
     lib.pnp.cer_solver / pnp_ceres -> lc_amd.pnp.cer_solver / pnp_ceres   (registered BEFORE the reference imports them, so the
                                                                           Ceres cffi extension `lib.pnp._ext` is never needed)
     ptnet.softargmax_2d_std        -> lc_amd.ptnet.softargmax_2d_std      (+ ptnet.ptnet.forward's sparse branch fused)
+    lib.utils.grad.NormClipper     -> lc_amd.grad.NormClipper             (same constructor and `max_norm` buffer; also the name in `losses`)
+    losses.Loss_fn.sparse_kpt_loss / .dense_pose_loss -> the fused-launch methods of lc_amd.losses.Loss_fn (they only use the
+                                                          attributes the reference's own Loss_fn instance has)
 """
 from __future__ import annotations
 
@@ -50,6 +53,20 @@ def install(patch_ptnet: bool = True) -> dict:
         done["losses"] = True
     except Exception:  # the reference's losses.py needs scipy/floatbits etc.; absent pieces are the caller's problem
         done["losses"] = False
+    # the launch-bound glue of the reference's own Loss_fn: clipper class and the two methods with fused counterparts
+    try:
+        from . import grad as our_grad
+        from . import losses as our_losses
+
+        ref_grad = importlib.import_module("lib.utils.grad")
+        ref_grad.NormClipper = our_grad.NormClipper
+        if done.get("losses"):
+            ref_losses.NormClipper = our_grad.NormClipper
+            ref_losses.Loss_fn.sparse_kpt_loss = our_losses.Loss_fn.sparse_kpt_loss
+            ref_losses.Loss_fn.dense_pose_loss = our_losses.Loss_fn.dense_pose_loss
+        done["loss_glue"] = bool(done.get("losses"))
+    except Exception:
+        done["loss_glue"] = False
     if patch_ptnet:
         try:
             ref_ptnet = importlib.import_module("ptnet")

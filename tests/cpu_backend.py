@@ -72,22 +72,22 @@ def _decode_with_gt_strided(logits, gt_raw_bits, bit_cnt, gt_msk, sample=1, top_
     return noc.flatten(1, 2)
 
 
-@pytest.fixture
-def oracle_backend(monkeypatch):
+def apply(setter):
+    """Swap every launch function of lc_amd for its oracle twin through `setter(obj, name, value)` (pytest's
+    monkeypatch.setattr in the fixture below; plain setattr in spawned children and one-off subprocesses)."""
     from lc_amd import _lib, cov_mixed, grad, kpt, losses
     from lc_amd.pnp import pnp_ceres
 
-    monkeypatch.setattr(losses, "dense_front_end", _dense_front_end)
-    monkeypatch.setattr(losses.floatbits, "decode_with_gt_strided", _decode_with_gt_strided)
-
-    monkeypatch.setattr(_lib, "require_hip_f32", lambda name, t: t.contiguous())
-    monkeypatch.setattr(cov_mixed, "_launch_loss", _launch_loss)
-    monkeypatch.setattr(cov_mixed, "_launch_scale", _launch_scale)
-    monkeypatch.setattr(kpt, "_launch_kpt", _launch_kpt)
-    monkeypatch.setattr(grad, "_launch_sqnorm", _launch_sqnorm)
-    monkeypatch.setattr(grad, "_launch_apply", _launch_apply)
-    monkeypatch.setattr(grad.NormClipper, "_ws", lambda self, dev: None)
-    monkeypatch.setattr(pnp_ceres, "solve_device", _solve_device)
+    setter(losses, "dense_front_end", _dense_front_end)
+    setter(losses.floatbits, "decode_with_gt_strided", _decode_with_gt_strided)
+    setter(_lib, "require_hip_f32", lambda name, t: t.contiguous())
+    setter(cov_mixed, "_launch_loss", _launch_loss)
+    setter(cov_mixed, "_launch_scale", _launch_scale)
+    setter(kpt, "_launch_kpt", _launch_kpt)
+    setter(grad, "_launch_sqnorm", _launch_sqnorm)
+    setter(grad, "_launch_apply", _launch_apply)
+    setter(grad.NormClipper, "_ws", lambda self, dev: None)
+    setter(pnp_ceres, "solve_device", _solve_device)
     orig_solve = pnp_ceres.solve
 
     def solve(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, num_workers=1, **kw):
@@ -96,5 +96,10 @@ def oracle_backend(monkeypatch):
                                  function_tolerance=kw.get("function_tolerance", 1e-6))
         return orig_solve(cam_mat, pts3d, pts2d, sqrtL, start, n_points, max_iter_count=max_iter_count, num_workers=num_workers, **kw)
 
-    monkeypatch.setattr(pnp_ceres, "solve", solve)
+    setter(pnp_ceres, "solve", solve)
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch):
+    apply(monkeypatch.setattr)
     yield

@@ -18,17 +18,9 @@ def _free_port():
 
 def _patch_backend(monkeypatch=None):
     """What the `oracle_backend` fixture does; without pytest's monkeypatch in the spawned children."""
-    from lc_amd import _lib, cov_mixed, grad, kpt
     from tests import cpu_backend
 
-    setter = monkeypatch.setattr if monkeypatch is not None else setattr
-    setter(_lib, "require_hip_f32", lambda name, t: t.contiguous())
-    setter(cov_mixed, "_launch_loss", cpu_backend._launch_loss)
-    setter(cov_mixed, "_launch_scale", cpu_backend._launch_scale)
-    setter(kpt, "_launch_kpt", cpu_backend._launch_kpt)
-    setter(grad, "_launch_sqnorm", cpu_backend._launch_sqnorm)
-    setter(grad, "_launch_apply", cpu_backend._launch_apply)
-    setter(grad.NormClipper, "_ws", lambda self, dev: None)
+    cpu_backend.apply(monkeypatch.setattr if monkeypatch is not None else setattr)
 
 
 def _model_and_batch(B, N, dtype=torch.float64):

@@ -137,6 +137,23 @@ def test_dropin_install_rebinds_reference_entry_points():
         "assert lib.cov_mixed.Loss_cov_mixed is cm.Loss_cov_mixed and losses.Loss_cov_mixed is cm.Loss_cov_mixed\n"
         "assert cer_solver.__name__ == 'lc_amd.pnp.cer_solver' and pnp_ceres.__name__ == 'lc_amd.pnp.pnp_ceres'\n"
         "assert ptnet.softargmax_2d_std is hp.softargmax_2d_std\n"
-        "assert all(r.values()), r\n" % ROOT)
+        "import lc_amd.grad as g, lc_amd.losses as ol, lib.utils.grad as rg\n"
+        "assert rg.NormClipper is g.NormClipper and losses.NormClipper is g.NormClipper\n"
+        "assert losses.Loss_fn.dense_pose_loss is ol.Loss_fn.dense_pose_loss and losses.Loss_fn.sparse_kpt_loss is ol.Loss_fn.sparse_kpt_loss\n"
+        "from lc_amd.config import AttrDict\n"
+        "fn = losses.Loss_fn(AttrDict(pose_loss_cfg=dict(type='cov', clip_weight_grad=True, clip_scale_grad=True), seg_loss_type='L1'), AttrDict())\n"
+        "assert type(fn.weight_grad_clipper) is g.NormClipper and set(fn.state_dict()) == {'weight_grad_clipper.max_norm', 'scale_grad_clipper.max_norm'}\n"
+        "assert all(r.values()), r\n"
+        # the reference's OWN Loss_fn, running on the swapped entry points (oracle backend on the CPU), reproduces its golden trajectory
+        "import numpy as np, torch\n"
+        "from tests import cpu_backend; cpu_backend.apply(setattr)\n"
+        "from tests.golden.gen_golden_lossfn import run\n"
+        "for kind, steps in (('sparse', [0, 2, 4, 6, 9]), ('dense', [0, 1, 2, 5])):\n"
+        "    rec = run(losses.Loss_fn, kind, steps, torch.float64)\n"
+        "    z = np.load(%r + '/tests/golden/lossfn_' + kind + '_f64.npz')\n"
+        "    for k in z.files:\n"
+        "        if k != 'steps':\n"
+        "            a, b = np.asarray(rec[k], np.float64), np.asarray(z[k], np.float64)\n"
+        "            assert np.abs(a - b).max() <= (1e-6 if '_grad_' in k else 1e-8) * max(1.0, np.abs(b).max()), (kind, k)\n" % (ROOT, ROOT))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
