@@ -9,6 +9,7 @@
     lib.pnp.cer_solver / pnp_ceres -> lc_amd.pnp.cer_solver / pnp_ceres   (registered BEFORE the reference imports them, so the
                                                                           Ceres cffi extension `lib.pnp._ext` is never needed)
     ptnet.softargmax_2d_std        -> lc_amd.ptnet.softargmax_2d_std      (+ ptnet.ptnet.forward's sparse branch fused)
+    lib.pnp.cv2_solver             -> lc_amd.pnp.gpu_solver               (only when OpenCV is absent, or on request)
     lib.utils.grad.NormClipper     -> lc_amd.grad.NormClipper             (same constructor and `max_norm` buffer; also the name in `losses`)
     losses.Loss_fn.sparse_kpt_loss / .dense_pose_loss -> the fused-launch methods of lc_amd.losses.Loss_fn (they only use the
                                                           attributes the reference's own Loss_fn instance has)
@@ -21,18 +22,30 @@ import sys
 import types
 
 
-def install(patch_ptnet: bool = True) -> dict:
+def install(patch_ptnet: bool = True, gpu_initialiser=None) -> dict:
+    """gpu_initialiser: True = also register the RANSAC-P3P kernel as `lib.pnp.cv2_solver` (same `solve` surface,
+    `test.py:59,120`); None (default) = only when OpenCV cannot be imported, so that `test.py` runs without it."""
     from . import cov_mixed as cm
     from . import ptnet as head
-    from .pnp import cer_solver, pnp_ceres
+    from .pnp import cer_solver, gpu_solver, pnp_ceres
 
     done = {}
     # PnP: register our modules under the reference's names first (lib/ and lib/pnp/ are namespace packages)
     sys.modules["lib.pnp.pnp_ceres"] = pnp_ceres
     sys.modules["lib.pnp.cer_solver"] = cer_solver
+    if gpu_initialiser is None:
+        try:
+            importlib.import_module("cv2")
+            gpu_initialiser = False
+        except ImportError:
+            gpu_initialiser = True
+    if gpu_initialiser:
+        sys.modules["lib.pnp.cv2_solver"] = gpu_solver
     try:
         pkg = importlib.import_module("lib.pnp")
         pkg.pnp_ceres, pkg.cer_solver = pnp_ceres, cer_solver
+        if gpu_initialiser:
+            pkg.cv2_solver = gpu_solver
         done["lib.pnp"] = True
     except ImportError:
         done["lib.pnp"] = False

@@ -136,6 +136,7 @@ def test_dropin_install_rebinds_reference_entry_points():
         "from lib.pnp import cer_solver, pnp_ceres\n"
         "assert lib.cov_mixed.Loss_cov_mixed is cm.Loss_cov_mixed and losses.Loss_cov_mixed is cm.Loss_cov_mixed\n"
         "assert cer_solver.__name__ == 'lc_amd.pnp.cer_solver' and pnp_ceres.__name__ == 'lc_amd.pnp.pnp_ceres'\n"
+        "from lib.pnp import cv2_solver; assert cv2_solver.__name__ == 'lc_amd.pnp.gpu_solver'  # no OpenCV in this image\n"
         "assert ptnet.softargmax_2d_std is hp.softargmax_2d_std\n"
         "import lc_amd.grad as g, lc_amd.losses as ol, lib.utils.grad as rg\n"
         "assert rg.NormClipper is g.NormClipper and losses.NormClipper is g.NormClipper\n"
