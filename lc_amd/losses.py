@@ -44,6 +44,22 @@ def nn_out_to_xyz(nn_out: Tensor = None, noc_scale_xfd: Tensor = None, *, raw_bi
     return (xyz_xformed - model_transform[:, None, None, :3, 3]) @ model_transform[:, None, :3, :3]
 
 
+@torch.no_grad()
+def xyz_to_nn_target(xyz: Tensor, noc_scale_xfd: Tensor = None, *, noc_mask=None, model_transform=None, bit_cnt=None):
+    """Inverse of `nn_out_to_xyz` used for label preparation (`losses.py:49-67`): object coordinates (B,H,W,3) in mm -> the
+    network target, either normalised coordinates (B,3,H,W) or (binary code planes, raw bits) of the ZebraPose heads."""
+    xformed = xyz
+    if model_transform is not None:
+        xformed = xyz @ model_transform[:, None, :3, :3].mT + model_transform[:, None, None, :3, 3]
+        if noc_mask is not None:
+            xformed = xformed * noc_mask.unsqueeze(-1)
+    noc = xformed / noc_scale_xfd[:, None, None, :]
+    if bit_cnt is None:
+        assert model_transform is None, "coordinate transform not implemented for continuous xyz output"
+        return noc.permute(0, 3, 1, 2), None
+    return floatbits.nn_noc2target(noc, bit_cnt)
+
+
 def dense_pnp_matching_from_noc_bin(noc_bin_out_logits: Tensor, noc_bin_gt_raw: Tensor, weights_out: Tensor, valid_msk_full: Tensor,
                                     noc_mask: Tensor, noc_scale: Tensor, gt_dict: dict, sample=2, top_left=None):
     """`losses.py:163-184`: strided sub-sampling of a binary-code head; the 3D points are decoded on the sampled pixels only."""

@@ -158,3 +158,14 @@ def test_dropin_install_rebinds_reference_entry_points():
         "            assert np.abs(a - b).max() <= (1e-6 if '_grad_' in k else 1e-8) * max(1.0, np.abs(b).max()), (kind, k)\n" % (ROOT, ROOT))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_xyz_to_nn_target_inverts_nn_out_to_xyz_for_the_continuous_head():
+    from lc_amd.losses import nn_out_to_xyz, xyz_to_nn_target
+
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.randn(2, 5, 6, 3, generator=g) * 30
+    scale = torch.tensor([[37.8, 37.9, 45.8], [10.0, 20.0, 30.0]])
+    tgt, raw = xyz_to_nn_target(xyz, scale)
+    assert raw is None and tgt.shape == (2, 3, 5, 6)
+    assert torch.allclose(nn_out_to_xyz(tgt, scale), xyz, atol=1e-5)
