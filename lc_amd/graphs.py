@@ -29,13 +29,11 @@ class GraphedLoss:
         sum(w_loss_dict.values()).backward()                         # backward replays the captured backward graph
 
     Every tensor entry of `out_dict` is a differentiable input, every tensor entry of `gt_dict` a constant input; non-tensor
-    entries are frozen at capture.  Sparse heads and the continuous-xyz dense heads are supported (the binary-code branch keeps
-    a histogram EMA that is re-bound on every call, `losses.py:207-208`, and is refused).
+    entries (bit counts, ...) are frozen at capture.  Sparse heads, continuous-xyz and binary-code dense heads are supported: the
+    module's state (`NormClipper.max_norm`, the code histogram of `Loss_xyz_bin`) lives at fixed addresses and is updated in place.
     """
 
     def __init__(self, loss_fn, gt_dict: dict, out_dict: dict, epoch: int, step: int, steps_per_epoch: int):
-        if "xyz_noc_bin" in out_dict:
-            raise NotImplementedError("GraphedLoss: the binary-code branch re-binds its histogram buffer every step and is not captured")
         self.loss_fn = loss_fn
         self.when = (epoch, step, steps_per_epoch)
         self.out_keys = [k for k, v in out_dict.items() if isinstance(v, Tensor)]
@@ -66,18 +64,19 @@ class GraphedLoss:
         return tuple(loss_dict[k] for k in self._loss_keys) + tuple(w_loss_dict[k] for k in self._w_keys)
 
     def _capture(self, phase):
-        # the warm-up iterations of make_graphed_callables run the step for real: keep them out of the clippers' running maxima
-        clippers = [m for m in self.loss_fn.modules() if isinstance(m, NormClipper)]
+        # the warm-up iterations of make_graphed_callables run the step for real: keep them out of the module's state
+        # (the clippers' running maxima, the code histogram), which must also sit on the device BEFORE the capture
         dev = self._example[0].device
-        for c in clippers:
-            if c.max_norm.device != dev:
-                c.max_norm = c.max_norm.to(dev)
-            c._ws(dev)
-        saved = [c.max_norm.detach().clone() for c in clippers]
+        self.loss_fn.to(dev)
+        for c in self.loss_fn.modules():
+            if isinstance(c, NormClipper):
+                c._ws(dev)
+        buffers = [b for _, b in self.loss_fn.named_buffers()]
+        saved = [b.detach().clone() for b in buffers]
         with quiet_capture():
             graphed = torch.cuda.make_graphed_callables(lambda *flat: self._run(phase, *flat), tuple(self._example))
-        for c, s in zip(clippers, saved):
-            c.max_norm.copy_(s)
+        for b, s in zip(buffers, saved):
+            b.copy_(s)
         return graphed
 
     def __call__(self, gt_dict: dict, out_dict: dict):

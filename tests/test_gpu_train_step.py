@@ -28,7 +28,7 @@ def test_example_dense_train_step_runs(extra):
     assert "median step" in out.stdout
 
 
-@pytest.mark.parametrize("kind", ["sparse", "dense"])
+@pytest.mark.parametrize("kind", ["sparse", "dense", "bin"])
 def test_graphed_loss_step_equals_eager_on_new_inputs(kind):
     """Forward + backward of a Loss_fn step replayed as hipGraphs: same loss values, gradients and NormClipper trajectory as
     the eager calls, step after step (dense: one graph per sub-sampling phase, drawn from np.random like the reference)."""
@@ -39,17 +39,20 @@ def test_graphed_loss_step_equals_eager_on_new_inputs(kind):
     from lc_amd.config import AttrDict
     from lc_amd.graphs import GraphedLoss
     from lc_amd.losses import Loss_fn
-    from tests.golden.gen_golden_lossfn import DENSE_CFG, SPARSE_CFG, dense_inputs, sparse_inputs
+    from tests.golden.gen_golden_lossfn import BIN_CFG, DENSE_CFG, SPARSE_CFG, bin_inputs, dense_inputs, sparse_inputs
 
     dev = torch.device("cuda:0")
-    cfg = SPARSE_CFG if kind == "sparse" else DENSE_CFG
+    cfg = {"sparse": SPARSE_CFG, "dense": DENSE_CFG, "bin": BIN_CFG}[kind]
+    make = {"sparse": lambda s: sparse_inputs(B=32, N=16, seed=s), "dense": lambda s: dense_inputs(B=4, H=16, W=16, seed=s),
+            "bin": lambda s: bin_inputs(B=4, H=16, W=16, seed=s)}[kind]
+    bits = 17 if kind == "bin" else 0
 
     def inputs(seed):
-        gt, out = sparse_inputs(B=32, N=16, seed=seed) if kind == "sparse" else dense_inputs(B=4, H=16, W=16, seed=seed)
+        gt, out = make(seed)
         return ({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}, {k: v.to(dev) for k, v in out.items()})
 
-    eager_fn = Loss_fn(AttrDict(cfg), AttrDict(), 0).to(dev)
-    graph_fn = Loss_fn(AttrDict(cfg), AttrDict(), 0).to(dev)
+    eager_fn = Loss_fn(AttrDict(cfg), AttrDict(), bits).to(dev)
+    graph_fn = Loss_fn(AttrDict(cfg), AttrDict(), bits).to(dev)
     gt0, out0 = inputs(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
