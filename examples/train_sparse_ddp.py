@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--sparse-cnt", type=int, default=64)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--bf16", action="store_true", default=True)
+    ap.add_argument("--graphs", action="store_true", help="replay the Loss_fn step as hipGraphs once the warm-up ramp is over")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -108,6 +109,7 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     times = []
+    graphed = None
     for step in range(args.steps):
         blob = synthetic_blob(args.batch, args.sparse_cnt, dev, seed=1000 * rank + step)
         torch.cuda.synchronize(dev)
@@ -115,7 +117,13 @@ def main():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
             logits = net(blob["rgb_in"].contiguous(memory_format=torch.channels_last))
         out = sparse_head(logits)  # fused HIP head (ptnet.py:59-66) on the bf16 logits as they are: fp32 statistics, bf16 gradient
-        loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
+        if args.graphs and step > cfg.pose_loss_start_step:  # the blending factor is 1 from here on: the step is static
+            if graphed is None:
+                from lc_amd.graphs import GraphedLoss
+                graphed = GraphedLoss(loss_fn, blob, out, 0, step, 100)
+            loss_dict, w_loss_dict = graphed(blob, out)
+        else:
+            loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
         loss = sum(w_loss_dict.values())
         opt.zero_grad(set_to_none=True)
         loss.backward()
