@@ -329,7 +329,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 (fp32 I/O; Jacobians, 6x6 algebra and LM state in fp64)",
+            "dtype": "f64",
+            "dtype_note": "fp32 I/O (the reference's precision); Jacobians, 6x6 algebra and LM state in fp64 like Ceres",
             "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic B={B} N={N} 2D-3D correspondences per GPU, HIP weighted-PnP + cov-loss",
                        "global_batch": B * world, "n_points": N, "sharding": f"poses over {world} rank(s), no data-path collective",
