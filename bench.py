@@ -127,6 +127,8 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
     dt = time.perf_counter() - t0
     return dict(value=B * n / dt, unit="poses/s", cores=cores, kind="port", host_cores_available=avail, host_cpu=host_cpu_model(),
                 poses_per_s_by_threads=by_threads,
+                reference_anchor="un-restated reference, survey container (8-core Xeon, BASELINE.md section 2): lib.cov_mixed.Loss_cov_mixed "
+                                 "fwd+bwd alone 36.9 ms per 256 poses = 6.9 k poses/s; the Ceres solve cannot be built or timed anywhere here",
                 sample=f"{n} batches of B={B} N={N} (oracle: torch-CPU closed-form loss fwd+bwd + C/OpenMP LM, "
                        f"{cores} threads = fastest of 4..64), {dt:.1f} s")
 
