@@ -3,7 +3,7 @@
 the oracle over many random shapes, noise levels, outlier rates, start perturbations, ragged counts and masks.  Prints
 one line per configuration and a summary; `profiles/<round>/fuzz_parity.txt` keeps the last run.
 
-    python scripts/fuzz_parity.py [--cases 60] [--seed 0]
+    python tests/fuzz_parity.py [--cases 60] [--seed 0]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, ROOT)
 from lc_amd import synth  # noqa: E402
 from lc_amd.cov_mixed import _launch_loss  # noqa: E402
