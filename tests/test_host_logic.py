@@ -169,3 +169,24 @@ def test_xyz_to_nn_target_inverts_nn_out_to_xyz_for_the_continuous_head():
     tgt, raw = xyz_to_nn_target(xyz, scale)
     assert raw is None and tgt.shape == (2, 3, 5, 6)
     assert torch.allclose(nn_out_to_xyz(tgt, scale), xyz, atol=1e-5)
+
+
+def test_rt_to_quaternion_rep_round_trips_all_branches():
+    """Every branch of the component selection (w, x, y or z largest, incl. 180-degree turns) round-trips through quaternion_rep_to_RT."""
+    from lc_amd.transforms import RT_to_quaternion_rep, quaternion_rep_to_RT
+
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(200, 4, generator=g, dtype=torch.float64)
+    q[:4] = torch.eye(4, dtype=torch.float64)          # identity and the three half turns
+    q[4:8] = torch.eye(4, dtype=torch.float64) + 1e-9  # next to them
+    q = q / q.norm(dim=-1, keepdim=True)
+    t = torch.randn(200, 3, generator=g, dtype=torch.float64)
+    R, _ = quaternion_rep_to_RT(torch.cat((q, t), -1))
+    rep = RT_to_quaternion_rep(R, t)
+    assert rep.shape == (200, 7) and torch.allclose(rep[:, :4].norm(dim=-1), torch.ones(200, dtype=torch.float64), atol=1e-12)
+    sgn = torch.sign((rep[:, :4] * q).sum(-1, keepdim=True))
+    assert (rep[:, :4] * sgn - q).abs().max() < 1e-7 and torch.equal(rep[:, 4:], t)
+    k = rep[:, :4].abs().argmax(-1)
+    assert (rep[torch.arange(200), k] > 0).all() and set(k.tolist()) == {0, 1, 2, 3}
+    R2, _ = quaternion_rep_to_RT(rep)
+    assert (R2 - R).abs().max() < 1e-12
