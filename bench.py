@@ -35,20 +35,23 @@ def algorithmic_bytes(N: int, want_pts3d: bool):
     return loss, pnp
 
 
-def pmc_traffic(kernel: str, B: int, N: int):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/<round>/pmc_traffic.json, produced by
-    scripts/profile_r01.sh on the default workload); None for other workloads or when no profile is committed."""
+def static_counters(kernel: str, B: int, N: int):
+    """Per-launch PMC counters of `kernel` on the default workload, from the newest committed rocprofv3 --pmc passes
+    (profiles/<round>/pmc_traffic.json, written by scripts/profile_round.sh; PMC cannot be collected from inside a run).
+    Returns (entry, source) -- source names the file, the round and the git SHA the passes were taken at -- or (None, None)."""
     if (B, N) != (256, 64):
-        return None
+        return None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
         try:
-            d = json.load(open(f)).get(kernel)
-            if d:
-                return d["bytes_per_launch"]
+            d = json.load(open(f))
+            if d.get(kernel):
+                meta = d.get("_meta", {})
+                return d[kernel], {"file": os.path.relpath(f, ROOT), "git_sha": meta.get("git_sha", "unrecorded (round 1)"),
+                                   "command": meta.get("command")}
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def host_cpu_model():
@@ -61,25 +64,14 @@ def host_cpu_model():
     return "unknown"
 
 
-def valu_roofline(kernel: str, B: int, N: int, poses_per_s: float):
-    """The bound that actually binds the pose-unit kernels: VALU issue.  From the committed SQ counter pass of the default
-    workload (profiles/<round>/pmc_traffic.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU in quad-cycles, per dispatch of B poses):
-    SIMD-cycles of VALU work per pose -> poses/s if all 1024 SIMDs of the MI355X issued VALU work every cycle at 2.4 GHz."""
-    if (B, N) != (256, 64):
-        return None
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
-        try:
-            sq = json.load(open(f)).get(kernel, {}).get("sq")
-            if sq and sq.get("SQ_ACTIVE_INST_VALU"):
-                cyc = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / B
-                bound = 1024 * 2.4e9 / cyc
-                return {"bound": "valu_issue", "valu_insts_per_pose": sq["SQ_INSTS_VALU"] / B, "simd_cycles_per_pose": cyc,
-                        "peak": bound, "unit": "poses/s", "achieved": poses_per_s, "frac": poses_per_s / bound,
-                        "note": "1024 SIMDs x 2.4 GHz / VALU-busy SIMD-cycles per pose (rocprofv3 --pmc SQ_* pass in profiles/)"}
-        except Exception:
-            pass
-    return None
+SIMD_CYCLES_PER_S = 1024 * 2.4e9  # 256 CUs x 4 SIMDs x 2.4 GHz (MI355X_MICROARCH.md chip-level parameters)
+
+
+def valu_bound(sq: dict, B: int):
+    """VALU-issue bound from SQ counters of one launch of B poses: SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends issuing
+    VALU work; poses/s if all 1024 SIMDs issued such work every cycle."""
+    cyc = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / B
+    return cyc, SIMD_CYCLES_PER_S / cyc
 
 
 def cpu_baseline(B, N, seed, budget_s=15.0):
@@ -138,6 +130,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=51, help="timed regions of exactly --steps steps each (barrier + synchronize on both "
+                    "sides of every region); the MEDIAN region is reported (one 3 ms region moves +-8 %% with launch jitter)")
+    ap.add_argument("--steady-batch", type=int, default=65536, help="B of the in-run steady-state measurement (0: skip)")
     ap.add_argument("--batch", type=int, default=256, help="poses per GPU per step")
     ap.add_argument("--npts", type=int, default=64)
     ap.add_argument("--slots", type=int, default=4, help="--launch streams: independent batches in flight (own buffers, own stream)")
@@ -268,16 +263,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if share_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from lc_amd import dist as lcd
+
+    region_s = []
+    for _ in range(max(1, args.regions)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        region_s.append(time.perf_counter() - t0)
+    agg = lcd.aggregate_regions(region_s, args.steps, device="cpu" if (share_gpu or dist is None) else dev)
+    elapsed = agg["median_region_s"]
     if args.launch == "streams":
         assert all(int(o["ret"].sum().item()) == 0 and bool(torch.isfinite(o["loss"]).all()) for _, o, _ in slot_state)
     else:
@@ -308,6 +305,24 @@ def main():
         ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
         return [ts[reps // 10], ts[reps // 2], ts[(9 * reps) // 10]]
 
+    def steady_state(Bs):
+        """One large batch: every SIMD holds several pose waves, the per-wave latency chain is hidden."""
+        bb = {k: v.to(dev) for k, v in synth.make_batch(Bs, N, seed=977).items()}
+        o_loss = torch.empty(Bs, device=dev)
+        o = [torch.empty_like(bb["pts2d"]), torch.empty_like(bb["inv_std"]), torch.empty_like(bb["pts3d"]), torch.empty_like(bb["start"]),
+             torch.empty(Bs, device=dev), torch.empty(Bs, device=dev, dtype=torch.int32)]
+        gos = torch.full((Bs,), 1.0 / Bs, device=dev)
+        sd = bb["inv_std"].contiguous()
+
+        def one():
+            rc = lib.lc_pose_unit_f32(P(bb["K"]), P(bb["pose"]), P(bb["pts3d"]), P(bb["pts2d"]), P(bb["inv_std"]), None, P(bb["bbox_3d"]),
+                                      P(gos), Bs, N, 32.0, 3.0, 4.0, P(o_loss), P(o[0]), P(o[1]), P(o[2]), P(sd), P(bb["start"]),
+                                      P(o[3]), P(o[4]), P(o[5]), 50, 1e-6, _lib.stream_ptr(dev))
+            assert rc == 0
+        ms = kernel_ms(one, reps=20)
+        assert int(o[5].sum().item()) == 0
+        return Bs, Bs / (ms * 1e-3), ms
+
     if rank == 0:
         t_loss = kernel_ms(launch_loss)
         t_pnp = kernel_ms(launch_pnp)
@@ -319,7 +334,22 @@ def main():
             dom = ("lc_pose_unit_kernel", t_unit, by_loss + by_pnp)
             kernel_us["lc_pose_unit_kernel"] = t_unit * 1e3
             kernel_us["lc_pose_unit_kernel_p10_p50_p90"] = kernel_percentiles_us(step_fused)
-        achieved = dom[2] * B / (dom[1] * 1e-3) / 1e9
+        hbm_gbs = dom[2] * B / (dom[1] * 1e-3) / 1e9
+        kernel_poses_per_s = B / (dom[1] * 1e-3)
+        ctr, src = static_counters(dom[0], B, N)
+        hbm = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_pose": {"loss": by_loss, "pnp": by_pnp},
+               "note": "secondary: 5 KB working set per pose, one wave per pose -- HBM never binds this kernel"}
+        if ctr is not None and ctr.get("sq", {}).get("SQ_ACTIVE_INST_VALU"):
+            cyc, peak = valu_bound(ctr["sq"], B)
+            roof = {"bound": "valu_issue", "kernel": dom[0], "achieved": kernel_poses_per_s, "peak": peak, "unit": "poses/s",
+                    "frac": kernel_poses_per_s / peak, "traffic": ctr.get("bytes_per_launch"),
+                    "valu_insts_per_pose": ctr["sq"]["SQ_INSTS_VALU"] / B, "simd_cycles_per_pose": cyc,
+                    "note": "the bound that binds: 1024 SIMDs x 2.4 GHz / VALU-issue SIMD-cycles per pose (SQ_ACTIVE_INST_VALU); achieved = "
+                            "B / event-timed launch duration of the kernel, measured in this run",
+                    "counters_from": src, "kernel_us": kernel_us, "hbm": hbm}
+        else:  # no committed counter pass for this workload: only the HBM figure can be formed in-run
+            roof = dict(hbm, kernel=dom[0], traffic=None, kernel_us=kernel_us)
         out = {
             "metric": METRIC,
             "value": B * world * args.steps / elapsed,
@@ -337,15 +367,19 @@ def main():
             "config": {"workload": f"configs[1]: synthetic B={B} N={N} 2D-3D correspondences per GPU, HIP weighted-PnP + cov-loss",
                        "global_batch": B * world, "n_points": N, "sharding": f"poses over {world} rank(s), no data-path collective",
                        "launch": args.launch, **({"slots_in_flight": args.slots} if args.launch == "streams" else {})},
-            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom[0], B, N),
-                         "note": "latency/VALU-bound by construction (5 KB working set per pose, one wave per pose): see DESIGN.md",
-                         "kernel_us": kernel_us,
-                         "algorithmic_bytes_per_pose": {"loss": by_loss, "pnp": by_pnp}},
+            "timing": {"protocol": f"{agg['regions']} regions of exactly {args.steps} steps, barrier + synchronize around each, MAX over ranks "
+                                   f"per region, MEDIAN region reported", "region_ms_per_step": agg["region_ms_per_step"]},
+            "ranks_seen": agg["ranks_seen"], "collective_backend": agg["backend"],
+            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if (world > 1 and not share_gpu) else None,
+            "per_rank_ms_per_step": agg["per_rank_ms_per_step"],
+            "roofline": roof,
         }
-        vr = valu_roofline(dom[0], B, N, B / (dom[1] * 1e-3))
-        if vr is not None:
-            out["roofline"]["valu"] = vr
+        if args.steady_batch > 0 and world == 1 and args.launch == "fused":
+            Bs, pps, ms = steady_state(args.steady_batch)
+            ss = {"B": Bs, "poses_per_s": pps, "ms_per_launch": ms}
+            if roof.get("bound") == "valu_issue":
+                ss["valu_frac"] = pps / roof["peak"]
+            out["steady_state"] = ss
         if world == 1 and not args.no_head:
             # the third kernel family of the path (keypoint head), HBM-bound; its own line: bench_head.py
             from bench_head import measure_head

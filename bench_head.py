@@ -54,28 +54,51 @@ def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3, dtype="f32"):
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
 
-    def ev(fn, reps=10):
+    # in-pattern kernel times: events around each kernel INSIDE the alternating fwd;bwd loop (a forward that follows the
+    # backward's 268 MB of dirty lines is not the forward that re-reads a cache-warm buffer) -- medians over the steps
+    reps = max(steps, 20)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+    for e in evs:
+        e[0].record()
+        fwd()
+        e[1].record()
+        bwd()
+        e[2].record()
+    torch.cuda.synchronize(dev)
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+    t_f = med([e[0].elapsed_time(e[1]) for e in evs])
+    t_b = med([e[1].elapsed_time(e[2]) for e in evs])
+
+    def ev(fn, n=10):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
+        for _ in range(n):
             fn()
         e1.record()
         torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / reps
+        return e0.elapsed_time(e1) / n
 
-    t_f, t_b = ev(fwd), ev(bwd)
+    bb_f, bb_b = ev(fwd), ev(bwd)  # the same kernel launched back to back over the same buffer (Infinity-Cache assisted: NOT the step)
     map_bytes = H * W * esz
     by_f, by_b = M * map_bytes, 2 * M * map_bytes
+    step_gbs = (by_f + by_b) / (el / steps) / 1e9
+    gbs = lambda by, ms: by / (ms * 1e-3) / 1e9  # noqa: E731
     return {
         "metric": "keypoint-head samples/sec (spatial softmax + soft-argmax fwd+bwd)",
         "value": B * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3,
         "dtype": dtype,
         "config": {"workload": f"logits ({B},{S},{H},{W}) {dtype}, synthetic"},
-        "roofline": {"bound": "hbm", "kernel": "lc_head_bwd_kernel", "achieved": by_b / (t_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": by_b / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "fwd": {"kernel": "lc_head_fwd_wave64_kernel" if (H, W) == (64, 64) else "lc_head_fwd_rows_kernel", "achieved": by_f / (t_f * 1e-3) / 1e9,
-                             "frac": by_f / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": t_f},
-                     "bwd_ms": t_b, "algorithmic_bytes_per_sample": 3 * S * map_bytes},
+        "roofline": {"bound": "hbm", "kernel": "lc_head_bwd_kernel", "achieved": gbs(by_b, t_b), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": gbs(by_b, t_b) / HBM_PEAK_GBS, "traffic": None,
+                     "timing": "events around each kernel inside the alternating fwd;bwd loop (median)",
+                     "fwd": {"kernel": "lc_head_fwd_wave64_kernel" if (H, W) == (64, 64) else "lc_head_fwd_rows_kernel",
+                             "achieved": gbs(by_f, t_f), "frac": gbs(by_f, t_f) / HBM_PEAK_GBS, "ms": t_f},
+                     "bwd_ms": t_b,
+                     "step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "note": "wall-clock fwd+bwd step, all algorithmic bytes"},
+                     "back_to_back_same_buffer": {"fwd_ms": bb_f, "fwd_frac": gbs(by_f, bb_f) / HBM_PEAK_GBS, "bwd_ms": bb_b,
+                                                  "bwd_frac": gbs(by_b, bb_b) / HBM_PEAK_GBS,
+                                                  "note": "cache-assisted best case, not what a training step sees"},
+                     "algorithmic_bytes_per_sample": 3 * S * map_bytes},
     }
 
 

@@ -57,6 +57,17 @@ int lc_pnp_lm_f32(const float *K, const float *pts3d, const float *pts2d, const 
                   const int *counts, const float *start, float *states, float *result_tr, int *rets, int *iters, int B,
                   int Nmax, int max_iter, float function_tolerance, void *stream);
 
+/* (2a') Parity diagnostics of (2a): the same solve (same template body, so the same arithmetic) that also records the
+ *      trust-region schedule -- what `Solver::Summary::iterations` holds after ceres::Solve (ceres.cpp:126-130) --
+ *      into trace (B,trace_rows,8) doubles, one row per iteration i < trace_rows:
+ *        [kind (0 invalid step | 1 accepted | 2 rejected | 3 parameter tolerance | 4 function tolerance),
+ *         cost at x, candidate cost, model cost change, relative decrease, ||step||, radius after, max|gradient| after].
+ *      The caller zero-fills trace.  Not a hot path (separate, slower kernel). */
+int lc_pnp_lm_trace_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL,
+                        const float *sqrt_diag, const int *counts, const float *start, float *states, float *result_tr,
+                        int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, double *trace,
+                        int trace_rows, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (2b) Linear-covariance loss, forward + backward in one launch -- replaces the autograd graph of
  *      lib/cov_mixed.py:100-150 Loss_cov_mixed (cov_2d=False).  K (B,3,3) pose (B,7) pts3d (B,N,3) pts2d (B,N,2)

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "lc_amd_last_error": (ctypes.c_char_p, []),
     "pnp_ceres_f32_omp": (None, [_FP, _FP, _FP, _FP, _FP, _I, c_int, c_float, c_int, _F, _I, c_int, c_int]),
     "lc_pnp_lm_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "lc_pnp_lm_trace_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "lc_cov_loss_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 6),
     "lc_cov_loss2_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float, c_int] + [c_void_p] * 6),
     "lc_pose_unit_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 9 +
@@ -60,10 +61,18 @@ def load(build_if_missing: bool = True):
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
+    if path == _build.SO_PATH and _build.is_stale():
+        # missing, or built from other .hip/.h contents than the ones on disk: rebuild (hipcc cross-compiles without a GPU);
+        # never load a library that silently ignores edited sources
         if not build_if_missing:
-            raise RuntimeError(f"lc_amd: {path} is missing; run `python __graft_entry__.py build`")
-        _build.build()
+            raise RuntimeError(f"lc_amd: {path} is missing or stale; run `python __graft_entry__.py build`")
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError(f"lc_amd: {path} is missing or older than lc_amd/csrc and could not be rebuilt ({e}); "
+                               f"run `python __graft_entry__.py build` where hipcc is available") from e
+    elif not os.path.exists(path):
+        raise RuntimeError(f"lc_amd: LC_AMD_LIB={path} does not exist")
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

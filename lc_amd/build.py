@@ -24,25 +24,57 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+HASH_PATH = SO_PATH + ".srchash"
+
+
+def _deps():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(PKG), "include", "lc_amd.h")]
+
+
+def source_hash() -> str:
+    """sha256 over the names and contents of every source the library is built from (mtimes do not survive the copy onto a
+    GPU box; contents do)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in _deps():
+        if os.path.exists(d):
+            h.update(os.path.basename(d).encode())
+            h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(SO_PATH):
+    """True when liblc_amd.so is missing or was built from other source contents than the ones on disk now."""
+    if not os.path.exists(SO_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(SO_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(PKG), "include", "lc_amd.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return open(HASH_PATH).read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return SO_PATH
     os.makedirs(OUT_DIR, exist_ok=True)
-    tmp = SO_PATH + ".tmp"
+    import fcntl
+
+    with open(SO_PATH + ".lock", "w") as lock:  # one builder at a time (pytest-xdist workers, torchrun ranks)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():
+            return SO_PATH
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose: bool) -> str:
+    tmp = SO_PATH + f".tmp{os.getpid()}"
+    digest = source_hash()
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
            *sources(), "-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(tmp, SO_PATH)
+    with open(HASH_PATH, "w") as f:
+        f.write(digest + "\n")
     return SO_PATH
 
 

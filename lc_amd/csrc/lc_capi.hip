@@ -172,6 +172,7 @@ static bool misaligned(size_t bytes, P... ptrs) {
 extern "C" {
 
 int lc_amd_version(void) { return LC_AMD_VERSION; }
+void lc_debug_head_variant(int v) { lc::debug_head_variant(v); }  // TUNING ONLY: removed once the policy is fixed
 const char* lc_amd_last_error(void) { return g_err.c_str(); }
 
 void pnp_ceres_f32_omp(float** init_states, float** cam_Ks, float** pts2ds, float** pts3ds, float** icov_sqrtLs,
@@ -205,6 +206,21 @@ int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const 
     lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
                     B, Nmax, max_iter, function_tolerance};
     if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
+    return 0;
+}
+
+int lc_pnp_lm_trace_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* sqrt_diag,
+                        const int* counts, const float* start, float* states, float* result_tr, int* rets, int* iters, int B, int Nmax,
+                        int max_iter, float function_tolerance, double* trace, int trace_rows, void* stream) {
+    if (B < 0 || Nmax < 0 || trace_rows < 0) return fail(1, "negative size");
+    if (B == 0) return 0;
+    if ((sqrtL == nullptr) == (sqrt_diag == nullptr)) return fail(1, "exactly one of sqrtL / sqrt_diag must be given");
+    if (!K || !pts3d || !pts2d || !states || !result_tr || !rets || !trace) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, sqrt_diag, trace);
+    LC_REQUIRE_ALIGNED(16, sqrtL);
+    lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
+                    B, Nmax, max_iter, function_tolerance, trace, trace_rows};
+    if (lc::launch_pnp_lm_trace(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp trace kernel launch failed");
     return 0;
 }
 

@@ -24,6 +24,37 @@ template <> struct Vec4<float> { using type = float4; };
 template <> struct Vec4<_Float16> { using type = uint2; };
 template <> struct Vec4<__bf16> { using type = uint2; };
 
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+// streaming (non-temporal) forms: a map that is read once / a gradient that is written once and not re-read by this kernel
+template <typename T>
+__device__ __forceinline__ float4 load4_nt(const T* q) {
+    if constexpr (sizeof(T) == 4) {
+        const v4f_t r = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(q));
+        return make_float4(r.x, r.y, r.z, r.w);
+    } else {
+        const v2u_t r = __builtin_nontemporal_load(reinterpret_cast<const v2u_t*>(q));
+        T h[4];
+        __builtin_memcpy(h, &r, 8);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4_nt(T* q, float4 v) {
+    if constexpr (sizeof(T) == 4) {
+        v4f_t r = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(r, reinterpret_cast<v4f_t*>(q));
+    } else {
+        const T h[4] = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+        v2u_t r;
+        __builtin_memcpy(&r, h, 8);
+        __builtin_nontemporal_store(r, reinterpret_cast<v2u_t*>(q));
+    }
+}
+
+int g_head_variant = 0;  // TUNING ONLY (lc_debug_head_variant): bit0 nt stores bwd, bit1 nt loads bwd, bit2 reverse map order bwd, bit3 nt loads fwd
+
 template <typename T>
 __device__ __forceinline__ float4 load4(const T* q) {
     if constexpr (sizeof(T) == 4) {
@@ -305,11 +336,12 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
     const T* in = static_cast<const T*>(p.in) + m * HW + 8 * lane;
     const bool is_prob = p.is_prob != 0;
     const int g = lane >> 3, c = lane & 7;
+    const bool ntl = (p.variant & 8) != 0;
 
     float x[8][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float4 a = load4<T>(in + 512 * k), b = load4<T>(in + 512 * k + 4);
+        const float4 a = ntl ? load4_nt<T>(in + 512 * k) : load4<T>(in + 512 * k), b = ntl ? load4_nt<T>(in + 512 * k + 4) : load4<T>(in + 512 * k + 4);
         x[k][0] = a.x; x[k][1] = a.y; x[k][2] = a.z; x[k][3] = a.w;
         x[k][4] = b.x; x[k][5] = b.y; x[k][6] = b.z; x[k][7] = b.w;
     }
@@ -375,7 +407,8 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
 template <typename T, int VEC>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwdParams p) {
     const int H = p.H, W = p.W, HW = H * W;
-    const size_t m = blockIdx.x;
+    const size_t m = (p.variant & 4) ? (size_t)(p.M - 1) - blockIdx.x : (size_t)blockIdx.x;
+    const bool nts = (p.variant & 1) != 0, ntl = (p.variant & 2) != 0;
     const T* in = static_cast<const T*>(p.in) + m * HW;
     T* out = static_cast<T*>(p.g_in) + m * HW;
     const float mx = p.mean[m * 2], my = p.mean[m * 2 + 1];
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwd
         const float qy = gmy * (float)h + gvy * dy * dy + ey * (float)h;
         float xin[VEC], g[VEC];
         if constexpr (VEC == 4) {
-            const float4 v = load4<T>(in + e);
+            const float4 v = ntl ? load4_nt<T>(in + e) : load4<T>(in + e);
             xin[0] = v.x; xin[1] = v.y; xin[2] = v.z; xin[3] = v.w;
         } else {
             xin[0] = (float)in[e];
@@ -407,7 +440,8 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwd
             g[j] = is_prob ? q : __expf(xin[j] - s0) * (q - cdot);
         }
         if constexpr (VEC == 4) {
-            store4<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
+            if (nts) store4_nt<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
+            else store4<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
         } else {
             out[e] = (T)g[0];
         }
@@ -473,8 +507,12 @@ int launch_head_bwd_t(const HeadBwdParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int launch_head_fwd(const HeadParams& p, hipStream_t stream) {
-    if (p.M <= 0) return 0;
+void debug_head_variant(int v) { g_head_variant = v; }
+
+int launch_head_fwd(const HeadParams& p_in, hipStream_t stream) {
+    if (p_in.M <= 0) return 0;
+    HeadParams p = p_in;
+    p.variant = g_head_variant;
     switch (p.dtype) {
         case kHeadF32: return launch_head_fwd_t<float>(p, stream);
         case kHeadF16: return launch_head_fwd_t<_Float16>(p, stream);
@@ -483,8 +521,10 @@ int launch_head_fwd(const HeadParams& p, hipStream_t stream) {
     }
 }
 
-int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream) {
-    if (p.M <= 0) return 0;
+int launch_head_bwd(const HeadBwdParams& p_in, hipStream_t stream) {
+    if (p_in.M <= 0) return 0;
+    HeadBwdParams p = p_in;
+    p.variant = g_head_variant;
     switch (p.dtype) {
         case kHeadF32: return launch_head_bwd_t<float>(p, stream);
         case kHeadF16: return launch_head_bwd_t<_Float16>(p, stream);

@@ -43,8 +43,11 @@ struct PnpParams {
     int* iters;           // (B,) LM iterations used, or null
     int B, Nmax, max_iter;
     float ftol;
+    double* trace;        // diagnostic launch only (launch_pnp_lm_trace): (B,trace_rows,8) per-iteration rows, else null
+    int trace_rows;
 };
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream);
+int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream);  // same solve + p.trace rows (parity diagnostics, not a hot path)
 // both of the above in one grid (N <= 64 only; returns 3 otherwise)
 int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stream);
 
@@ -58,7 +61,9 @@ struct HeadParams {
     int M, H, W;
     int is_prob;
     int dtype;
+    int variant;          // memory-policy bits, filled by the launcher
 };
+void debug_head_variant(int v);  // TUNING ONLY
 int launch_head_fwd(const HeadParams& p, hipStream_t stream);
 
 struct HeadBwdParams {
@@ -72,6 +77,7 @@ struct HeadBwdParams {
     int M, H, W;
     int is_prob;
     int dtype;
+    int variant;           // memory-policy bits, filled by the launcher
 };
 int launch_head_bwd(const HeadBwdParams& p, hipStream_t stream);
 

@@ -19,7 +19,24 @@ __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) 
     pnp::solve_pose<REG, 4>(p, blockIdx.x, threadIdx.x, bc);
 }
 
+// diagnostic twins that also record the per-iteration trace (tests/test_gpu_pnp_trace.py)
+__global__ __launch_bounds__(64, 1) void lc_pnp_lm_trace_kernel(const PnpParams p) {
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<1>];
+    pnp::solve_pose<true, 1, true>(p, blockIdx.x, threadIdx.x, bc);
+}
+__global__ __launch_bounds__(256) void lc_pnp_lm_wide_trace_kernel(const PnpParams p) {
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
+    pnp::solve_pose<false, 4, true>(p, blockIdx.x, threadIdx.x, bc);
+}
+
 }  // namespace
+
+int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream) {
+    if (p.B <= 0) return 0;
+    if (p.Nmax <= 64) hipLaunchKernelGGL(lc_pnp_lm_trace_kernel, dim3(p.B), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL(lc_pnp_lm_wide_trace_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;

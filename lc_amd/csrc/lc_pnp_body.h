@@ -208,7 +208,9 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 // N = 1024..1849, where four waves cut the per-evaluation point loop by four; the wave-uniform LM algebra is simply
 // replicated in every wave).  bc: kPnpLdsDoubles<NW> doubles of LDS.
 // REG: Nmax <= 64*NW, each thread keeps its correspondence in registers across the whole solve.
-template <bool REG, int NW = 1>
+// TRACE: diagnostic instantiation (lc_pnp_lm_trace_f32) that also writes one row per trust-region iteration to p.trace, in the
+// column layout of oracle/pnp_lm_oracle.c's PNP_TRACE_COLS; the shipped kernels are instantiated with TRACE = false.
+template <bool REG, int NW = 1, bool TRACE = false>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
     LC_PSTAMP_DECL;
@@ -316,6 +318,16 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     double radius = 1e4, dfac = 2.0;
     int iter = 0, n_invalid = 0;
     bool converged = false;
+    // kind: 0 invalid step, 1 accepted, 2 rejected, 3 parameter tolerance, 4 function tolerance
+    auto trace = [&](int kind, double cost_x, double cost_cand, double mcc, double rho, double step_norm) {
+        if constexpr (TRACE) {
+            if (lane == 0 && p.trace && iter <= p.trace_rows) {
+                double* row = p.trace + ((size_t)b * p.trace_rows + (iter - 1)) * 8;
+                row[0] = kind; row[1] = cost_x; row[2] = cost_cand; row[3] = mcc; row[4] = rho; row[5] = step_norm;
+                row[6] = radius; row[7] = gmax;
+            }
+        }
+    };
 
     while (uniform(!failed && !converged)) {
         // FinalizeIterationAndCheckIfMinimizerCanContinue
@@ -337,8 +349,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         mcc *= 0.5;
         step_ok = step_ok && (mcc > 0.0) && (mcc <= DBL_MAX);  // a non-finite y makes mcc non-finite
         if (uniform(!step_ok)) {  // HandleInvalidStep
-            if (++n_invalid >= 5) { failed = true; break; }
+            if (++n_invalid >= 5) { failed = true; trace(0, cost, 0.0, mcc, 0.0, 0.0); break; }
             radius /= dfac; dfac *= 2.0;
+            trace(0, cost, 0.0, mcc, 0.0, 0.0);
             continue;
         }
         n_invalid = 0;
@@ -351,21 +364,28 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         double cost_c;
         const bool cand_ok = evaluate(xc, scale, H, g, cost_c);
         if (!cand_ok) cost_c = DBL_MAX;
-        if (uniform(step_norm <= ptol * (xnorm + ptol))) { converged = true; break; }  // ParameterToleranceReached
+        if (uniform(step_norm <= ptol * (xnorm + ptol))) {  // ParameterToleranceReached
+            converged = true; trace(3, cost, cost_c, mcc, 0.0, step_norm); break;
+        }
         const double cost_change = cost - cost_c;
-        if (uniform(fabs(cost_change) <= ftol * cost)) { converged = true; break; }    // FunctionToleranceReached
+        if (uniform(fabs(cost_change) <= ftol * cost)) {    // FunctionToleranceReached
+            converged = true; trace(4, cost, cost_c, mcc, cost_change * fast_rcp(mcc), step_norm); break;
+        }
         const double rel = cost_change * fast_rcp(mcc);
         if (uniform(rel > 1e-3)) {  // HandleSuccessfulStep
 #pragma unroll
             for (int j = 0; j < 6; ++j) x[j] = xc[j];
+            const double cost_prev = cost;
             cost = cost_c;
             xnorm = norm6(x);
             gmax = grad_max(g);
             const double tq = 2.0 * rel - 1.0;
             radius = fmin(1e16, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - tq * tq * tq)));
             dfac = 2.0;
+            trace(1, cost_prev, cost_c, mcc, rel, step_norm);
         } else {
             radius /= dfac; dfac *= 2.0;
+            trace(2, cost, cost_c, mcc, rel, step_norm);
             double cost_again;
             if (!evaluate(x, scale, H, g, cost_again)) { failed = true; break; }
         }

@@ -53,8 +53,34 @@ def global_mean(local_sum: torch.Tensor, local_count: int, group=None) -> torch.
     return (buf[0] / buf[1]).to(local_sum.dtype)
 
 
+def aggregate_regions(region_seconds, steps: int, device=None, group=None) -> Dict[str, object]:
+    """bench.py's timing aggregation: every rank timed the same R regions of `steps` steps (each bracketed by a barrier);
+    a region lasts as long as its slowest rank (MAX over ranks), the reported step time is the MEDIAN region.  Also returns
+    what proves the collective saw every rank: world size, backend, per-rank median ms/step."""
+    t = torch.tensor(list(region_seconds), dtype=torch.float64, device=device or "cpu")
+    world, backend = 1, "none"
+    per_rank = t[None]
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        world, backend = dist.get_world_size(group), dist.get_backend(group)
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t, group=group)
+        per_rank = torch.stack(bufs)
+    per_rank = per_rank.cpu()
+    region_max = per_rank.max(0).values
+    srt = region_max.sort().values
+    R = len(srt)
+    q = lambda f: float(srt[min(R - 1, int(f * R))])  # noqa: E731
+    med = float(region_max.median())
+    return {"ranks_seen": world, "backend": backend, "regions": R, "median_region_s": med, "ms_per_step": med / steps * 1e3,
+            "region_ms_per_step": {"min": q(0.0) / steps * 1e3, "p10": q(0.1) / steps * 1e3, "p50": med / steps * 1e3,
+                                   "p90": q(0.9) / steps * 1e3, "max": float(srt[-1]) / steps * 1e3},
+            "per_rank_ms_per_step": [float(r.median()) / steps * 1e3 for r in per_rank]}
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, average: bool = True):
-    """Sum (or average) `.grad` across ranks through flat buckets of ~bucket_bytes."""
+    """Sum (or average) `.grad` across ranks through flat buckets of ~bucket_bytes.  TEST HELPER (blocking, after backward):
+    the world-size-2 gloo tests use it to check the sharded step against the full batch; training scripts wrap the model in
+    `torch.nn.parallel.DistributedDataParallel` instead (examples/train_*_ddp.py), whose bucketed all-reduce overlaps backward."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)

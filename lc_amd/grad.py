@@ -84,7 +84,8 @@ class NormClipper(torch.nn.Module):
         tensors = [grads] if single else list(grads)
         if not tensors:
             return tensors
-        tensors = [_lib.require_hip_f32("grad", g) for g in tensors]
+        in_dtypes = [g.dtype for g in tensors]  # fp16 / bf16 gradients of a mixed-precision head are clipped in fp32 and handed
+        tensors = [_lib.require_hip_f32("grad", g) for g in tensors]  # back in their own dtype (autograd rejects a hook that changes it)
         dev = tensors[0].device
         if self.max_norm.device != dev:  # module left on the CPU: the state follows the gradients (once)
             self.max_norm = self.max_norm.to(device=dev)
@@ -94,4 +95,5 @@ class NormClipper(torch.nn.Module):
 
             dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
         clipped, self.last_norm = _launch_apply(tensors, sq, before, self.max_norm, self.initial_max_norm, self.scale, self.momentum)
+        clipped = [o if o.dtype == dt else o.to(dt) for o, dt in zip(clipped, in_dtypes)]  # lib/utils/grad.py:78-82 keeps the dtype
         return clipped[0] if single else clipped

@@ -9,7 +9,9 @@ What makes the step capturable: no host synchronisation anywhere in the path, th
 maximum at a fixed address (updated in place, `lc_amd/grad.py`), and the two host-side sources of variation are handled
 outside the graph -- the dense heads' random sub-sampling phase (`np.random.randint`, `losses.py:152`) is drawn per call and
 selects one of `dense_sample**2` lazily captured graphs; the warm-up blending factor (`losses.py:272-276`, a Python float) is
-frozen at its value for the `step` given at construction, so capture after the ramp (or build a new `GraphedLoss` when it moves).
+baked into a captured graph, so graphs are keyed by it: pass `step` to `__call__` and a call whose factor differs from the
+captured one is never replayed with the stale blend -- inside the ramp (0 < factor < 1, a different value every step) the
+step runs eagerly, at the plateaus (factor 0 or 1) a graph for that value is captured once.
 """
 from __future__ import annotations
 
@@ -18,6 +20,7 @@ import torch
 from torch import Tensor
 
 from .grad import NormClipper
+from .losses import pose_loss_factor
 from .inference import GraphedSolvePnP, quiet_capture  # noqa: F401  (GraphedSolvePnP is re-exported)
 
 
@@ -46,6 +49,12 @@ class GraphedLoss:
                          [gt_dict[k].detach().clone() for k in self.gt_keys])
         self._graphs = {}
         self._loss_keys = self._w_keys = None
+
+    def _factor(self, when):
+        cfg = self.loss_fn.cfg
+        if not self.dense and not cfg.get("w_loss_pose", 0) > 0:
+            return 1.0  # sparse heads without a pose term: nothing is blended
+        return float(pose_loss_factor(cfg, when[1], when[2]))
 
     def _run(self, phase, *flat):
         n = len(self.out_keys)
@@ -79,7 +88,17 @@ class GraphedLoss:
             b.copy_(s)
         return graphed
 
-    def __call__(self, gt_dict: dict, out_dict: dict):
+    def __call__(self, gt_dict: dict, out_dict: dict, epoch: int = None, step: int = None, steps_per_epoch: int = None):
+        """Replays the step.  `step` (and optionally epoch / steps_per_epoch) are the arguments `loss_fn(...)` would get now: when
+        the warm-up factor they imply is not the captured one, the stale graph is not used (see the module docstring)."""
+        if step is not None:
+            when = (self.when[0] if epoch is None else epoch, step, self.when[2] if steps_per_epoch is None else steps_per_epoch)
+            factor = self._factor(when)
+            if 0.0 < factor < 1.0:  # inside the ramp: a new blend every step -> run the step itself
+                return self.loss_fn(gt_dict, out_dict, *when)
+            if factor != self._factor(self.when):
+                self._graphs.clear()  # plateau reached (or left): capture for the new constant blend
+            self.when = when
         phase = tuple(int(v) for v in np.random.randint(0, self.sample, size=2)) if self.dense else None  # losses.py:152
         if phase not in self._graphs:
             self._graphs[phase] = self._capture(phase)

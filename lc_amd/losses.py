@@ -8,6 +8,12 @@ through `lc_amd.dense` (one launch each way); what remains of `losses.py:261-386
 
 The ZebraPose binary-code branch (`xyz_noc_bin`, `losses.py:163-184,196-216`) decodes through `lc_amd.floatbits`
 (HIP kernels).
+
+Label preparation (`annots_on_the_fly`, `selete_best_pose`, `xyz_from_homo_z`: `losses.py:68-139`, called at
+`train.py:58,116`) is OUTSIDE the hot path and is not rebuilt: the three names exist here as
+pass-throughs to the reference's own `losses` module (found through `LC_REFERENCE` or an already imported `losses`), so
+`import lc_amd.losses as losses` runs `train.py` wherever the reference checkout is present and raises a clear
+ImportError where it is not.
 """
 from __future__ import annotations
 
@@ -25,6 +31,39 @@ from .cov_mixed import Loss_cov_mixed
 from .dense import dense_front_end
 from .grad import NormClipper
 from .kpt import kpt_nll_mean
+
+
+def _reference_losses():
+    """The reference's own `losses` module, for the label-preparation names this package does not rebuild."""
+    import importlib
+    import os
+    import sys
+
+    mod = sys.modules.get("losses")
+    if mod is not None and getattr(mod, "__file__", None) != __file__ and hasattr(mod, "annots_on_the_fly"):
+        return mod
+    ref = os.environ.get("LC_REFERENCE")
+    if ref and os.path.exists(os.path.join(ref, "losses.py")):
+        if ref not in sys.path:
+            sys.path.insert(0, ref)
+        return importlib.import_module("losses")
+    raise ImportError("lc_amd.losses: label preparation (annots_on_the_fly / selete_best_pose / xyz_from_homo_z) is outside the "
+                      "MI355X hot path and lives in the reference's losses.py; set LC_REFERENCE=<fulliu/lc checkout> or use lc_amd.dropin")
+
+
+def annots_on_the_fly(gt_dict, out_dict, cfg_global, step):
+    """`losses.py:121-139` (label preparation; pass-through to the reference module)."""
+    return _reference_losses().annots_on_the_fly(gt_dict, out_dict, cfg_global, step)
+
+
+def selete_best_pose(gt_dict, out_dict, sym_aware_started):
+    """`losses.py:68-118` (symmetry-aware pose selection; pass-through to the reference module)."""
+    return _reference_losses().selete_best_pose(gt_dict, out_dict, sym_aware_started)
+
+
+def xyz_from_homo_z(*args, **kwargs):
+    """Pass-through to the reference's `losses.xyz_from_homo_z`."""
+    return _reference_losses().xyz_from_homo_z(*args, **kwargs)
 
 
 def nn_out_to_xyz(nn_out: Tensor = None, noc_scale_xfd: Tensor = None, *, raw_bits_gt=None, noc_mask=None,

@@ -23,9 +23,10 @@ def _to_np(val):
 
 
 def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6,
-                 return_iters=False):
+                 return_iters=False, trace_rows=0):
     """Device route. cam_mat (B,3,3) pts3d (B,N,3) pts2d (B,N,2) start (B,7); sqrtL (B,N,2,2) lower factor or
-    (B,N,2) diagonal; n_points (B,) int or None."""
+    (B,N,2) diagonal; n_points (B,) int or None.  trace_rows > 0 runs the diagnostic twin of the kernel and appends the
+    (B,trace_rows,8) float64 per-iteration schedule (`lc_pnp_lm_trace_f32`, include/lc_amd.h) to the returned tuple."""
     lib = _lib.load()
     K = _lib.require_hip_f32("cam_mat", cam_mat)
     X = _lib.require_hip_f32("pts3d", pts3d)
@@ -42,6 +43,15 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     ret = torch.empty(B, device=dev, dtype=torch.int32)
     iters = torch.empty(B, device=dev, dtype=torch.int32) if return_iters else None
     full = L.dim() == 4
+    if trace_rows > 0:
+        trace = torch.zeros(B, int(trace_rows), 8, device=dev, dtype=torch.float64)
+        with torch.cuda.device(dev):
+            rc = lib.lc_pnp_lm_trace_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
+                                         None if full else _lib.ptr(L), _lib.ptr(counts), _lib.ptr(start), _lib.ptr(state), _lib.ptr(tr),
+                                         _lib.ptr(ret), _lib.ptr(iters), B, N, int(max_iter_count), float(function_tolerance),
+                                         _lib.ptr(trace), int(trace_rows), _lib.stream_ptr(dev))
+        _lib.check(rc, "lc_pnp_lm_trace_f32")
+        return (state, tr, ret, iters, trace) if return_iters else (state, tr, ret, trace)
     with torch.cuda.device(dev):
         rc = lib.lc_pnp_lm_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
                                None if full else _lib.ptr(L), _lib.ptr(counts), _lib.ptr(start), _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret),

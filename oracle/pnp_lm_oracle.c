@@ -177,15 +177,38 @@ static int qr_solve6(double *A, double *b, int m, double y[6]) {
     return 1;
 }
 
-void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d, const float *pts3d,
-                   const float *icov_sqrtL, int ptCnt, int maxIterCnt, float function_tolerance, int printSummary,
-                   float *result_tr, int *ret) {
+/* The linear solver of the LM step.  DENSE_QR (ceres.cpp:119) is the restatement; scripts/pnp_numerics/ re-includes this
+ * file with another PNP_STEP_SOLVER to measure how far other factorisations drift from it (never used by the tests). */
+#ifndef PNP_STEP_SOLVER
+#define PNP_STEP_SOLVER qr_solve6
+#endif
+
+/* Optional per-iteration trace (tests/test_gpu_pnp_trace.py locks the kernel's schedule to it step by step).
+ * One row of PNP_TRACE_COLS doubles per trust-region iteration:
+ *   0 kind (0 invalid step, 1 accepted, 2 rejected, 3 parameter tolerance, 4 function tolerance)
+ *   1 cost at x before the step   2 candidate cost   3 model cost change   4 relative decrease rho
+ *   5 ||delta|| (unscaled step)   6 radius AFTER the iteration's update    7 max|gradient| after the iteration */
+#define PNP_TRACE_COLS 8
+enum { TR_INVALID = 0, TR_ACCEPT = 1, TR_REJECT = 2, TR_PTOL = 3, TR_FTOL = 4 };
+
+static void solve_core(float *io_state_quat, const float *cam_K, const float *pts2d, const float *pts3d,
+                       const float *icov_sqrtL, int ptCnt, int maxIterCnt, float function_tolerance, int printSummary,
+                       float *result_tr, int *ret, double *trace, int trace_rows, int *n_iter) {
+    if (n_iter) *n_iter = 0;
     if (ptCnt < 3) { /* ceres.cpp:84-91 */
         *ret = 1;
         *result_tr = 1;
         if (printSummary) printf("skipped problem with less than 3 points\n");
         return;
     }
+#define TRACE(kind, cc, mcc, rho, sn)                                                          \
+    do {                                                                                       \
+        if (trace && iter <= trace_rows) {                                                     \
+            double *row_ = trace + (size_t)(iter - 1) * PNP_TRACE_COLS;                        \
+            row_[0] = (kind); row_[1] = x_cost; row_[2] = (cc); row_[3] = (mcc); row_[4] = (rho); \
+            row_[5] = (sn); row_[6] = radius; row_[7] = gmax;                                  \
+        }                                                                                      \
+    } while (0)
     problem_t P;
     P.n = ptCnt; P.u = pts2d; P.X = pts3d; P.L = icov_sqrtL;
     for (int i = 0; i < 6; ++i) P.cam[i] = cam_K[i];
@@ -237,7 +260,7 @@ void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d,
         }
         memcpy(Aw, J, sizeof(double) * (size_t)m * 6);
         memcpy(rc, r, sizeof(double) * (size_t)m);
-        int step_ok = qr_solve6(Aw, rc, m + 6, y);
+        int step_ok = PNP_STEP_SOLVER(Aw, rc, m + 6, y);
         double model_cost_change = 0;
         if (step_ok) {
             for (int j = 0; j < 6; ++j) step[j] = -y[j];
@@ -249,8 +272,9 @@ void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d,
             step_ok = model_cost_change > 0.0;
         }
         if (!step_ok) { /* HandleInvalidStep */
-            if (++n_invalid >= 5) { failed = 1; break; }
+            if (++n_invalid >= 5) { failed = 1; TRACE(TR_INVALID, 0.0, model_cost_change, 0.0, 0.0); break; }
             radius /= decrease_factor; decrease_factor *= 2.0;
+            TRACE(TR_INVALID, 0.0, model_cost_change, 0.0, 0.0);
             continue;
         }
         n_invalid = 0;
@@ -259,11 +283,16 @@ void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d,
         step_norm = sqrt(step_norm);
         double cand_cost;
         if (!evaluate(&P, xc, rc, NULL, &cand_cost)) cand_cost = DBL_MAX;
-        if (step_norm <= ptol * (x_norm + ptol)) { converged = 1; break; }          /* ParameterToleranceReached */
+        if (step_norm <= ptol * (x_norm + ptol)) {                                   /* ParameterToleranceReached */
+            converged = 1; TRACE(TR_PTOL, cand_cost, model_cost_change, 0.0, step_norm); break;
+        }
         const double cost_change = x_cost - cand_cost;
-        if (fabs(cost_change) <= ftol * x_cost) { converged = 1; break; }           /* FunctionToleranceReached */
+        if (fabs(cost_change) <= ftol * x_cost) {                                    /* FunctionToleranceReached */
+            converged = 1; TRACE(TR_FTOL, cand_cost, model_cost_change, cost_change / model_cost_change, step_norm); break;
+        }
         const double rel = cost_change / model_cost_change;
         if (rel > min_rel_decrease) { /* HandleSuccessfulStep */
+            const double prev_cost = x_cost;
             memcpy(x, xc, sizeof(xc));
             x_norm = 0;
             for (int j = 0; j < 6; ++j) x_norm += x[j] * x[j];
@@ -281,12 +310,16 @@ void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d,
             radius = radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
             radius = fmin(max_radius, radius);
             decrease_factor = 2.0;
+            { const double now_cost = x_cost; x_cost = prev_cost; TRACE(TR_ACCEPT, cand_cost, model_cost_change, rel, step_norm); x_cost = now_cost; }
         } else {
             radius /= decrease_factor; decrease_factor *= 2.0;
+            TRACE(TR_REJECT, cand_cost, model_cost_change, rel, step_norm);
         }
         if (printSummary) printf("iter %d cost %.9e radius %.3e\n", iter, x_cost, radius);
     }
     free(r); free(J);
+#undef TRACE
+    if (n_iter) *n_iter = iter;
     const int invalid = !(converged && !failed);
     *ret = invalid;
     *result_tr = (float)radius;
@@ -294,6 +327,13 @@ void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d,
     aa_to_quat(x, quat);
     for (int i = 0; i < 4; ++i) io_state_quat[i] = (float)quat[i];
     for (int i = 0; i < 3; ++i) io_state_quat[4 + i] = (float)x[3 + i];
+}
+
+void pnp_ceres_f32(float *io_state_quat, const float *cam_K, const float *pts2d, const float *pts3d,
+                   const float *icov_sqrtL, int ptCnt, int maxIterCnt, float function_tolerance, int printSummary,
+                   float *result_tr, int *ret) {
+    solve_core(io_state_quat, cam_K, pts2d, pts3d, icov_sqrtL, ptCnt, maxIterCnt, function_tolerance, printSummary, result_tr, ret,
+               NULL, 0, NULL);
 }
 
 void pnp_ceres_f32_omp(float **init_states, float **cam_Ks, float **pts2ds, float **pts3ds, float **icov_sqrtLs,
@@ -325,4 +365,19 @@ void pnp_oracle_batched_f32(float *states, const float *Ks, const float *pts2d, 
     for (int i = 0; i < job_count; ++i)
         pnp_ceres_f32(states + 7 * (size_t)i, Ks + 9 * (size_t)i, pts2d + 2 * (size_t)i * nmax, pts3d + 3 * (size_t)i * nmax,
                       sqrtL + 4 * (size_t)i * nmax, ptCnts[i], maxIterCnt, function_tolerance, 0, result_trs + i, rets + i);
+}
+
+/* Same, recording the per-iteration trace: trace is (job_count, trace_rows, PNP_TRACE_COLS) doubles (zero-filled by the
+ * caller), iters (job_count) receives the number of trust-region iterations of every job. */
+void pnp_oracle_batched_trace_f32(float *states, const float *Ks, const float *pts2d, const float *pts3d, const float *sqrtL,
+                                  const int *ptCnts, int nmax, int maxIterCnt, float function_tolerance, float *result_trs,
+                                  int *rets, int job_count, int num_threads, double *trace, int trace_rows, int *iters) {
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#endif
+#pragma omp parallel for if (num_threads > 1)
+    for (int i = 0; i < job_count; ++i)
+        solve_core(states + 7 * (size_t)i, Ks + 9 * (size_t)i, pts2d + 2 * (size_t)i * nmax, pts3d + 3 * (size_t)i * nmax,
+                   sqrtL + 4 * (size_t)i * nmax, ptCnts[i], maxIterCnt, function_tolerance, 0, result_trs + i, rets + i,
+                   trace + (size_t)i * trace_rows * PNP_TRACE_COLS, trace_rows, iters + i);
 }

@@ -37,6 +37,8 @@ def lib():
         _lib.pnp_oracle_batched_f32.argtypes = [fp, fp, fp, fp, fp, ip, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                 fp, ip, ctypes.c_int, ctypes.c_int]
         _lib.pnp_oracle_batched_f32.restype = None
+        _lib.pnp_oracle_batched_trace_f32.argtypes = _lib.pnp_oracle_batched_f32.argtypes + [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ip]
+        _lib.pnp_oracle_batched_trace_f32.restype = None
     return _lib
 
 
@@ -80,3 +82,25 @@ def solve_batched(states, Ks, pts2d, pts3d, sqrtL, counts=None, max_iter=50, fto
     L.pnp_oracle_batched_f32(_fp(states), _fp(Ks), _fp(pts2d), _fp(pts3d), _fp(sqrtL), counts.ctypes.data_as(ip), N,
                              int(max_iter), float(ftol), _fp(tr), ret.ctypes.data_as(ip), B, int(num_threads))
     return states, tr, ret
+
+
+TRACE_COLS = 8  # PNP_TRACE_COLS: kind, cost at x, candidate cost, model cost change, rho, ||step||, radius after, max|g| after
+
+
+def solve_batched_trace(states, Ks, pts2d, pts3d, sqrtL, counts=None, max_iter=50, ftol=1e-6, num_threads=1, trace_rows=50):
+    """`solve_batched` + the per-iteration trust-region schedule: returns (states, trust_radius, invalid, iters, trace)
+    with trace (B, trace_rows, TRACE_COLS) float64 (rows beyond a job's iteration count stay zero)."""
+    L = lib()
+    states = np.ascontiguousarray(states, np.float32).copy()
+    Ks, pts2d, pts3d, sqrtL = (np.ascontiguousarray(a, np.float32) for a in (Ks, pts2d, pts3d, sqrtL))
+    B, N = pts3d.shape[:2]
+    counts = np.full(B, N, np.int32) if counts is None else np.ascontiguousarray(counts, np.int32)
+    tr = np.zeros(B, np.float32)
+    ret = np.zeros(B, np.int32)
+    iters = np.zeros(B, np.int32)
+    trace = np.zeros((B, trace_rows, TRACE_COLS), np.float64)
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.pnp_oracle_batched_trace_f32(_fp(states), _fp(Ks), _fp(pts2d), _fp(pts3d), _fp(sqrtL), counts.ctypes.data_as(ip), N,
+                                   int(max_iter), float(ftol), _fp(tr), ret.ctypes.data_as(ip), B, int(num_threads),
+                                   trace.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(trace_rows), iters.ctypes.data_as(ip))
+    return states, tr, ret, iters, trace

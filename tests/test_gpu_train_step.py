@@ -3,6 +3,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -74,3 +75,73 @@ def test_graphed_loss_step_equals_eager_on_new_inputs(kind):
                 assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
             for (ka, va), (kb, vb) in zip(graph_fn.state_dict().items(), eager_fn.state_dict().items()):
                 assert ka == kb and torch.equal(va, vb), (i, ka, va, vb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["dense", "bin"])
+def test_loss_fn_dense_branch_takes_half_precision_heads(kind, dtype):
+    """A mixed-precision backbone hands fp16 / bf16 head outputs straight to Loss_fn (BASELINE configs 3 and 5): the NormClipper
+    hooks sit on those half tensors, so they must return gradients in the same dtype (autograd rejects a hook that changes
+    it), and the step must agree with the fp32 step on the same (rounded) values to half-precision accuracy."""
+    from lc_amd.config import AttrDict
+    from lc_amd.losses import Loss_fn
+    from tests.golden.gen_golden_lossfn import BIN_CFG, DENSE_CFG, bin_inputs, dense_inputs
+
+    dev = torch.device("cuda:0")
+    cfg = dict({"dense": DENSE_CFG, "bin": BIN_CFG}[kind])
+    cfg["pose_loss_cfg"] = dict(cfg["pose_loss_cfg"], clip_weight_grad=True, clip_scale_grad=True, clip_pts_grad=True)
+    gt, out = (dense_inputs if kind == "dense" else bin_inputs)(B=4, H=16, W=16, seed=3)
+    gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
+    bits = 17 if kind == "bin" else 0
+    res = {}
+    for name, dt in (("half", dtype), ("ref", torch.float32)):
+        fn = Loss_fn(AttrDict(cfg), AttrDict(), bits).to(dev)
+        o = {k: v.to(dev).to(dtype).to(dt).requires_grad_(True) for k, v in out.items()}  # same rounded values in both runs
+        np.random.seed(5)
+        ld, wd = fn(gt, o, 1, 1000, 10)
+        total = sum(wd.values())
+        total.backward()
+        assert all(v.grad is None or v.grad.dtype == dt for v in o.values())
+        res[name] = (float(total), {k: v.grad.float() for k, v in o.items() if v.grad is not None}, float(fn.weight_grad_clipper.max_norm))
+    assert abs(res["half"][0] - res["ref"][0]) <= 2e-2 * max(1.0, abs(res["ref"][0]))
+    assert res["half"][1].keys() == res["ref"][1].keys()
+    for k, g in res["ref"][1].items():
+        assert torch.isfinite(res["half"][1][k]).all()
+        err = (res["half"][1][k] - g).abs().max() / g.abs().max().clamp_min(1e-20)
+        assert err <= (5e-2 if dtype == torch.bfloat16 else 1e-2), (k, float(err))
+    assert abs(res["half"][2] - res["ref"][2]) <= 5e-2 * abs(res["ref"][2])
+
+
+def test_graphed_loss_never_replays_a_stale_warmup_blend():
+    """GraphedLoss bakes the warm-up factor (losses.py:272-276) into its graphs: called with `step` inside the ramp it must run
+    the step itself (new blend every step), and at the plateau it must capture for THAT factor -- always equal to eager."""
+    import warnings
+
+    from lc_amd.config import AttrDict
+    from lc_amd.graphs import GraphedLoss
+    from lc_amd.losses import Loss_fn, pose_loss_factor
+    from tests.golden.gen_golden_lossfn import SPARSE_CFG, sparse_inputs
+
+    dev = torch.device("cuda:0")
+    cfg = dict(SPARSE_CFG, pose_loss_start_step=40, loss_pose_nz_step=10, w_loss_pose=0.7)
+    eager_fn = Loss_fn(AttrDict(cfg), AttrDict()).to(dev)
+    graph_fn = Loss_fn(AttrDict(cfg), AttrDict()).to(dev)
+    gt, out = sparse_inputs(B=16, N=16, seed=0)
+    gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
+    out = {k: v.to(dev) for k, v in out.items()}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        graphed = GraphedLoss(graph_fn, gt, out, 0, 0, 10)  # captured BEFORE the ramp (factor 0)
+        seen = set()
+        for step in (0, 5, 12, 25, 39, 40, 41, 100):
+            f = pose_loss_factor(AttrDict(cfg), step, 10)
+            seen.add(0 if f == 0 else 1 if f == 1 else 2)
+            la = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+            lb = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+            ld, wd = graphed(gt, la, step=step)
+            rd, rw = eager_fn(gt, lb, 0, step, 10)
+            assert all(torch.equal(ld[k], rd[k]) for k in rd), (step, f, {k: (float(ld[k]), float(rd[k])) for k in rd})
+            ga = torch.autograd.grad(sum(wd.values()), list(la.values()))
+            gb = torch.autograd.grad(sum(rw.values()), list(lb.values()))
+            assert all(torch.equal(x, y) for x, y in zip(ga, gb)), step
+    assert seen == {0, 1, 2}  # the sweep did cross both plateaus and the ramp

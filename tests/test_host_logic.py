@@ -190,3 +190,34 @@ def test_rt_to_quaternion_rep_round_trips_all_branches():
     assert (rep[torch.arange(200), k] > 0).all() and set(k.tolist()) == {0, 1, 2, 3}
     R2, _ = quaternion_rep_to_RT(rep)
     assert (R2 - R).abs().max() < 1e-12
+
+
+def test_label_prep_names_pass_through_to_the_reference(monkeypatch):
+    """`lc_amd.losses.annots_on_the_fly / selete_best_pose / xyz_from_homo_z` (label preparation, outside the hot path) delegate to
+    the reference's own module when a checkout is reachable, and raise ImportError otherwise."""
+    import os
+    import sys
+
+    import lc_amd.losses as L
+
+    monkeypatch.delenv("LC_REFERENCE", raising=False)
+    monkeypatch.delitem(sys.modules, "losses", raising=False)
+    with pytest.raises(ImportError):
+        L.xyz_from_homo_z(None, None, None, None)
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "losses.py")):
+        pytest.skip("no reference checkout on this machine (GPU box)")
+    monkeypatch.setenv("LC_REFERENCE", ref)
+    monkeypatch.setattr(sys, "path", list(sys.path))
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 2, 4, 5
+    homo_z = torch.randn(B, H, W, 3, generator=g)
+    R = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+    t, K = torch.randn(B, 3, generator=g), torch.eye(3).expand(B, 3, 3) + 0.1 * torch.randn(B, 3, 3, generator=g)
+    got = L.xyz_from_homo_z(homo_z, R, t, K)
+    want = homo_z @ (torch.linalg.inv(K).unsqueeze(-3).mT @ R.unsqueeze(-3)) - (t[:, None, None, :] @ R.unsqueeze(-3))
+    assert torch.allclose(got, want, atol=1e-5)
+    gt = dict(Rt_candi=[torch.cat((R, t[..., None]), -1).unsqueeze(-3)], homo_z_out=homo_z, R_no_aug=R, t_no_aug=t, K_no_aug=K,
+              msk_noc=torch.ones(B, H, W))
+    Rt_best, pose_best, xyz_gt = L.selete_best_pose(gt, {}, False)
+    assert Rt_best.shape == (B, 3, 4) and pose_best.shape == (B, 7) and torch.allclose(xyz_gt, want, atol=1e-5)
