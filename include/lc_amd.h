@@ -151,6 +151,14 @@ int lc_pnp_ransac_init_f32(const float *K, const float *pts3d, const float *pts2
                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, void *stream);
 
+/* Same, plus best_hyp (B)|NULL: the index of the winning hypothesis of every pose (-1 when invalid).  Hypothesis h of pose b
+ * draws its four point indices from a counter-based hash of (seed, b, h) -- oracle/p3p_ransac_oracle.py restates the stream
+ * bit for bit, which makes best_hyp, n_inliers and inlier_mask integer outputs that are compared EXACTLY. */
+int lc_pnp_ransac_init2_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
+                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
+                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
+                            void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (2f) ZebraPose binary surface codes -- floatbits.py.  logits (B,C,H,W), C = n0+n1+n2 code bits
  *      (x,y,z axes back to back, floatbits.py:35-48); black_background as floatbits.py:7-11.

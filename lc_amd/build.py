@@ -78,5 +78,18 @@ def _build_locked(verbose: bool) -> str:
     return SO_PATH
 
 
+def build_variant(name: str, flags, verbose: bool = False) -> str:
+    """An experiment build of the same sources with extra compiler flags (-D switches) next to the shipped library:
+    lc_amd/_C/liblc_amd_<name>.so; select it with LC_AMD_LIB=<path>.  Used by the A/B scripts under scripts/ only."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    out = os.path.join(OUT_DIR, f"liblc_amd_{name}.so")
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
+           *flags, *sources(), "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

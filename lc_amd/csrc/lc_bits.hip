@@ -82,7 +82,7 @@ __device__ __forceinline__ void load_px(const unsigned char* g, bool (&v)[V]) {
 }
 template <int V>
 __device__ __forceinline__ void store_px(float* o, const float (&v)[V]) {
-    if constexpr (V == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (V == 4) store_stream4(o, v[0], v[1], v[2], v[3]);  // d_logits: written once, read by the next kernel of the backward pass
     else o[0] = v[0];
 }
 

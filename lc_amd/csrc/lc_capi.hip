@@ -172,7 +172,6 @@ static bool misaligned(size_t bytes, P... ptrs) {
 extern "C" {
 
 int lc_amd_version(void) { return LC_AMD_VERSION; }
-void lc_debug_head_variant(int v) { lc::debug_head_variant(v); }  // TUNING ONLY: removed once the policy is fixed
 const char* lc_amd_last_error(void) { return g_err.c_str(); }
 
 void pnp_ceres_f32_omp(float** init_states, float** cam_Ks, float** pts2ds, float** pts3ds, float** icov_sqrtLs,
@@ -356,6 +355,17 @@ int lc_pnp_ransac_init_f32(const float* K, const float* pts3d, const float* pts2
     if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
     lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
                        (iterations + 63) / 64, reproj_err, seed};
+    return lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream)) ? fail(11, "ransac kernel launch failed") : 0;
+}
+
+int lc_pnp_ransac_init2_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
+                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, void* stream) {
+    if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
+    lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
+                       (iterations + 63) / 64, reproj_err, seed, best_hyp};
     return lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream)) ? fail(11, "ransac kernel launch failed") : 0;
 }
 

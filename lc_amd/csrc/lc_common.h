@@ -8,6 +8,22 @@
 
 namespace lc {
 
+// 16-byte store of a write-once stream (a gradient map the kernel never re-reads): non-temporal, so that it does not push the
+// maps the next kernel re-reads out of L2 / Infinity Cache (measured on the keypoint head: profiles/r02/head_policy.txt).
+#ifndef LC_NT_GRAD_STORES
+#define LC_NT_GRAD_STORES 1
+#endif
+typedef float lc_v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream4(float* q, float a, float b, float c, float d) {
+#if LC_NT_GRAD_STORES
+    lc_v4f_t r = {a, b, c, d};
+    __builtin_nontemporal_store(r, reinterpret_cast<lc_v4f_t*>(q));
+#else
+    *reinterpret_cast<float4*>(q) = make_float4(a, b, c, d);
+#endif
+}
+
+
 constexpr int kWave = 64;
 
 // DPP controls (cdna4 ISA 'DPP_CTRL')

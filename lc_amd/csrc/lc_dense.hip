@@ -164,13 +164,13 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_bwd_kernel(const D
         }
         if constexpr (VEC) {
             if (owl) {
-                *reinterpret_cast<float4*>(owl + px0) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-                *reinterpret_cast<float4*>(owl + HW + px0) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                store_stream4(owl + px0, o0[0], o0[1], o0[2], o0[3]);
+                store_stream4(owl + HW + px0, o1[0], o1[1], o1[2], o1[3]);
             }
             if (oxyz) {
-                *reinterpret_cast<float4*>(oxyz + px0) = make_float4(gx[0], gx[1], gx[2], gx[3]);
-                *reinterpret_cast<float4*>(oxyz + HW + px0) = make_float4(gy[0], gy[1], gy[2], gy[3]);
-                *reinterpret_cast<float4*>(oxyz + 2 * HW + px0) = make_float4(gz[0], gz[1], gz[2], gz[3]);
+                store_stream4(oxyz + px0, gx[0], gx[1], gx[2], gx[3]);
+                store_stream4(oxyz + HW + px0, gy[0], gy[1], gy[2], gy[3]);
+                store_stream4(oxyz + 2 * HW + px0, gz[0], gz[1], gz[2], gz[3]);
             }
         } else {
             if (owl) { owl[px0] = o0[0]; owl[HW + px0] = o1[0]; }

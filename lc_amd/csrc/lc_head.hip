@@ -53,7 +53,14 @@ __device__ __forceinline__ void store4_nt(T* q, float4 v) {
     }
 }
 
-int g_head_variant = 0;  // TUNING ONLY (lc_debug_head_variant): bit0 nt stores bwd, bit1 nt loads bwd, bit2 reverse map order bwd, bit3 nt loads fwd
+// Memory policy of the fwd;bwd pair (HeadParams::variant bits), fixed from a sweep of all 16 combinations inside the alternating
+// step on (256,64,64,64) maps (scripts/ubench/head_policy.py, profiles/r02/head_policy.txt):
+//   bit0 non-temporal stores of the gradient: the 268 MB write-once stream no longer evicts the logits from the Infinity Cache /
+//        leaves them dirty in L2 -- the forward that FOLLOWS a backward went from 73 us to 44 us (fp32), the step 163 -> 129 us;
+//   bit2 backward walks the maps last-to-first: it starts on the lines the forward touched last (helps when the maps fit the
+//        256 MiB Infinity Cache: bf16/fp16 86 -> 77 us per step; neutral for fp32);
+//   bit1 / bit3 non-temporal LOADS (backward / forward) lose in every combination (the other kernel of the pair re-reads the map).
+constexpr int kHeadPolicyF32 = 1, kHeadPolicy16 = 5;
 
 template <typename T>
 __device__ __forceinline__ float4 load4(const T* q) {
@@ -507,12 +514,10 @@ int launch_head_bwd_t(const HeadBwdParams& p, hipStream_t stream) {
 
 }  // namespace
 
-void debug_head_variant(int v) { g_head_variant = v; }
-
 int launch_head_fwd(const HeadParams& p_in, hipStream_t stream) {
     if (p_in.M <= 0) return 0;
     HeadParams p = p_in;
-    p.variant = g_head_variant;
+    p.variant = p.dtype == kHeadF32 ? kHeadPolicyF32 : kHeadPolicy16;
     switch (p.dtype) {
         case kHeadF32: return launch_head_fwd_t<float>(p, stream);
         case kHeadF16: return launch_head_fwd_t<_Float16>(p, stream);
@@ -524,7 +529,7 @@ int launch_head_fwd(const HeadParams& p_in, hipStream_t stream) {
 int launch_head_bwd(const HeadBwdParams& p_in, hipStream_t stream) {
     if (p_in.M <= 0) return 0;
     HeadBwdParams p = p_in;
-    p.variant = g_head_variant;
+    p.variant = p.dtype == kHeadF32 ? kHeadPolicyF32 : kHeadPolicy16;
     switch (p.dtype) {
         case kHeadF32: return launch_head_bwd_t<float>(p, stream);
         case kHeadF16: return launch_head_bwd_t<_Float16>(p, stream);

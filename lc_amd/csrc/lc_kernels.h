@@ -63,7 +63,6 @@ struct HeadParams {
     int dtype;
     int variant;          // memory-policy bits, filled by the launcher
 };
-void debug_head_variant(int v);  // TUNING ONLY
 int launch_head_fwd(const HeadParams& p, hipStream_t stream);
 
 struct HeadBwdParams {
@@ -94,6 +93,7 @@ struct RansacParams {
     int B, Nmax, rounds;
     float reproj_err;
     unsigned seed;
+    int* best_hyp;         // (B,) out or null: index of the winning hypothesis (-1 when invalid) -- parity diagnostics
 };
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);
 

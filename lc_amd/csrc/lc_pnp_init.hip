@@ -241,6 +241,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
             st[0] = 1; st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0;
             p.invalid[b] = 1;
             p.n_inliers[b] = 0;
+            if (p.best_hyp) p.best_hyp[b] = -1;
         }
         return;
     }
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
             p.n_inliers[b] = 0;
         }
         p.invalid[b] = ok ? 0 : 1;
+        if (p.best_hyp) p.best_hyp[b] = ok ? win_hyp : -1;
     }
 }
 

@@ -14,8 +14,10 @@ from .. import _lib
 from . import cer_solver, pnp_ceres
 
 
-def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True):
-    """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool."""
+def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True,
+                 return_hypothesis=False):
+    """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool
+    [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly]."""
     lib = _lib.load()
     K = _lib.require_hip_f32("cam_mat", cam_mat)
     X = _lib.require_hip_f32("coord_3d", coord_3d)
@@ -31,17 +33,20 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     mask = torch.empty(B, N, device=dev, dtype=torch.uint8)
     n_in = torch.empty(B, device=dev, dtype=torch.int32)
     invalid = torch.empty(B, device=dev, dtype=torch.int32)
+    hyp = torch.empty(B, device=dev, dtype=torch.int32) if return_hypothesis else None
     with torch.cuda.device(dev):
-        rc = lib.lc_pnp_ransac_init_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError),
-                                        _lib.ptr(per_pose), int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask),
-                                        _lib.ptr(n_in), _lib.ptr(invalid), _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_pnp_ransac_init_f32")
+        rc = lib.lc_pnp_ransac_init2_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError),
+                                         _lib.ptr(per_pose), int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask),
+                                         _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_ransac_init2_f32")
     inl = mask.bool()
     bad = invalid.bool()
     if refine:
         w = inl.to(torch.float32).unsqueeze(-1).expand(B, N, 2).contiguous()  # unit information on inliers, zero elsewhere
         st, _, ret = pnp_ceres.solve_device(K, X, U, w, states, counts, max_iter_count=20)
         states = torch.where((ret != 0)[:, None] | bad[:, None], states, st)
+    if return_hypothesis:
+        return states, inl, bad, hyp, n_in
     return states, inl, bad
 
 

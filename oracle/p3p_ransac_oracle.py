@@ -1,0 +1,179 @@
+"""CPU oracle of the GPU PnP initialiser (TEST INFRASTRUCTURE ONLY -- never imported by the product path).
+
+Stands where `lib/pnp/cv2_solver.py:69-88` (cv2.solvePnPRansac, EPnP flag, 150 iterations) stands in the reference.
+OpenCV's RNG and its EPnP minimal solver cannot be matched bit for bit (and OpenCV 4.6.0.66, pinned in
+`scripts/req_0.txt:13`, is not in this image), so PARITY WITH OpenCV IS UNPINNED; what this oracle pins is the kernel's own
+contract, with integer outputs compared exactly:
+
+  * the hypothesis stream: hypothesis h of pose b draws its 4 point indices from the same counter-based hash of
+    (seed, b, h) as `lc_pnp_init.hip` -- integer arithmetic, restated here bit for bit;
+  * every hypothesis is solved by an INDEPENDENT float64 P3P (Grunert's elimination to a quartic in the depth ratio,
+    roots by numpy's companion-matrix eigenvalues, rotation by orthogonal Procrustes/SVD) -- the kernel uses a different
+    algorithm (pencil of quadrics, cubic, Gauss-Newton polish), so agreement is not shared code;
+  * scoring, the (inlier count, inlier error, hypothesis id) arg-max and the winner's inlier index set follow the kernel's
+    definition in float64; `decide()` reports for which poses the float32 kernel MUST agree exactly: no point of any
+    competing hypothesis within `margin` of the inlier threshold and no error-sum tie within `margin`.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+M32 = 0xFFFFFFFF
+
+
+def hash_u32(a: int) -> int:
+    """lowbias32, as `hash_u32` in lc_pnp_init.hip."""
+    a &= M32
+    a ^= a >> 16
+    a = (a * 0x7FEB352D) & M32
+    a ^= a >> 15
+    a = (a * 0x846CA68B) & M32
+    a ^= a >> 16
+    return a
+
+
+def sample_indices(seed: int, b: int, hyp: int, nl: int):
+    """The 4 point indices of hypothesis `hyp` of pose `b` (3 for P3P + 1 to disambiguate), exactly as the kernel draws them."""
+    h = hash_u32((seed & M32) ^ hash_u32((b * 0x9E3779B9 + hyp) & M32))
+    idx = []
+    for k in range(4):
+        h = hash_u32((h + 0x6D2B79F5) & M32)
+        v = h % nl
+        for _ in range(8):
+            if v not in idx:
+                break
+            v = (v + 1) % nl
+        idx.append(v)
+    return idx
+
+
+def p3p_grunert(y, x):
+    """All poses (R, t) with  s_i y_i = R x_i + t,  s_i > 0, for unit bearings y (3,3) and model points x (3,3) (rows)."""
+    d12, d13, d23 = x[0] - x[1], x[0] - x[2], x[1] - x[2]
+    c2, b2, a2 = d12 @ d12, d13 @ d13, d23 @ d23          # c = |x1-x2|, b = |x1-x3|, a = |x2-x3|
+    n = np.cross(d12, d13)
+    if not (n @ n > 1e-12 * c2 * b2):
+        return []
+    cg, cb, ca = y[0] @ y[1], y[0] @ y[2], y[1] @ y[2]     # gamma: (1,2), beta: (1,3), alpha: (2,3)
+    # s2 = u s1, s3 = v s1.  (E1) b2 (1 + u^2 - 2 u cg) = c2 (1 + v^2 - 2 v cb);  (E2) b2 (u^2 + v^2 - 2 u v ca) = a2 (1 + v^2 - 2 v cb)
+    # (E1) - (E2) is linear in u:  u * 2 b2 (v ca - cg) = (c2 - a2) (1 + v^2 - 2 v cb) - b2 (1 - v^2)  ->  u = N(v) / D(v)
+    P = np.array([1.0, -2.0 * cb, 1.0])                    # 1 - 2 cb v + v^2   (highest power first)
+    N = np.polysub((c2 - a2) * P, b2 * np.array([-1.0, 0.0, 1.0]))
+    D = 2.0 * b2 * np.array([ca, -cg])
+    # substitute into (E1) * D^2:  b2 (D^2 + N^2 - 2 cg N D) - c2 P D^2 = 0   -- a quartic in v
+    D2 = np.polymul(D, D)
+    quartic = np.polysub(b2 * np.polyadd(np.polyadd(D2, np.polymul(N, N)), -2.0 * cg * np.polymul(N, D)), c2 * np.polymul(P, D2))
+    sols = []
+    for v in np.roots(quartic):
+        if abs(v.imag) > 1e-7 * max(1.0, abs(v.real)) or v.real <= 0:
+            continue
+        v = v.real
+        den = np.polyval(D, v)
+        if abs(den) < 1e-14:
+            continue
+        u = np.polyval(N, v) / den
+        if u <= 0:
+            continue
+        s = np.array([1.0, u, v]) * np.sqrt(b2 / np.polyval(P, v))
+        for _ in range(4):  # Newton on the three distance constraints (removes the root finder's 1e-10)
+            r = np.array([s[0] ** 2 + s[1] ** 2 - 2 * cg * s[0] * s[1] - c2, s[0] ** 2 + s[2] ** 2 - 2 * cb * s[0] * s[2] - b2,
+                          s[1] ** 2 + s[2] ** 2 - 2 * ca * s[1] * s[2] - a2])
+            J = 2 * np.array([[s[0] - cg * s[1], s[1] - cg * s[0], 0.0], [s[0] - cb * s[2], 0.0, s[2] - cb * s[0]],
+                              [0.0, s[1] - ca * s[2], s[2] - ca * s[1]]])
+            try:
+                s = s - np.linalg.solve(J, r)
+            except np.linalg.LinAlgError:
+                break
+        if not (s > 0).all():
+            continue
+        z = s[:, None] * y
+        # orthogonal Procrustes on the centred triangles (+ their normals, which fixes the reflection)
+        zc, xc = z - z.mean(0), x - x.mean(0)
+        A = np.vstack((zc, np.cross(zc[0] - zc[1], zc[0] - zc[2]))).T @ np.vstack((xc, np.cross(xc[0] - xc[1], xc[0] - xc[2])))
+        U, _, Vt = np.linalg.svd(A)
+        R = U @ np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))]) @ Vt
+        t = z.mean(0) - R @ x.mean(0)
+        if any(np.allclose(R, R2, atol=1e-7) and np.allclose(t, t2, atol=1e-6 * (1 + np.abs(t).max())) for R2, t2 in sols):
+            continue  # double root
+        sols.append((R, t))
+    return sols
+
+
+def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3, max_lds_pts=2048):
+    """One pose.  Returns dict(invalid, best_hyp, n_inliers, inliers (sorted indices), R, t, decided, per_hyp_count)."""
+    n = int(min(count, len(pts3d)))
+    if n < 4:
+        return dict(invalid=1, best_hyp=-1, n_inliers=0, inliers=np.zeros(0, np.int64), R=np.eye(3), t=np.zeros(3), decided=True)
+    k = K.astype(np.float64).reshape(-1)
+    idet = 1.0 / (k[0] * k[4] - k[1] * k[3])
+    X = pts3d[:n].astype(np.float64)
+    du, dv = pts2d[:n, 0].astype(np.float64) - k[2], pts2d[:n, 1].astype(np.float64) - k[5]
+    # the kernel keeps the normalised image points and the model points as float32 in LDS
+    un = np.stack(((k[4] * du - k[1] * dv) * idet, (-k[3] * du + k[0] * dv) * idet), -1).astype(np.float32).astype(np.float64)
+    Xs = X.astype(np.float32).astype(np.float64)
+    nl = min(n, max_lds_pts)
+    thr = float(np.float32(reproj_err) * np.float32(np.sqrt(abs(idet))))
+    thr2 = float(np.float32(thr) * np.float32(thr))
+    rounds = (iterations + 63) // 64
+    cand = []  # (count, err, hyp, R, t, uncertain)
+    for hyp in range(rounds * 64):
+        idx = sample_indices(seed, b, hyp, nl)
+        yb = np.concatenate((un[idx[:3]], np.ones((3, 1))), 1)
+        yb /= np.linalg.norm(yb, axis=1, keepdims=True)
+        sols = p3p_grunert(yb, Xs[idx[:3]])
+        pick, pick_e, pick_gap = None, np.inf, np.inf
+        for R, t in sols:
+            c = R @ Xs[idx[3]] + t
+            if not c[2] > 0:
+                continue
+            e = float(((c[:2] / c[2] - un[idx[3]]) ** 2).sum())
+            if e < pick_e:
+                pick_gap = pick_e - e
+                pick, pick_e = (R, t), e
+            else:
+                pick_gap = min(pick_gap, e - pick_e)
+        if pick is None:
+            cand.append((-1, np.inf, hyp, None, None, False, False))
+            continue
+        R, t = pick
+        c = Xs[:nl] @ R.T + t
+        e = ((c[:, :2] / c[:, 2:3] - un[:nl]) ** 2).sum(1)
+        inl = (c[:, 2] > 0) & (e < thr2)
+        unsure = bool((np.abs(e - thr2) < margin * thr2).any()) or bool((np.abs(c[:, 2]) < 1e-6).any())
+        ambiguous_pick = pick_gap < margin * max(pick_e, 1e-12)
+        cand.append((int(inl.sum()), float(e[inl].sum()), hyp, R, t, unsure, ambiguous_pick))
+    best = max(cand, key=lambda c: (c[0], -c[1], -c[2]))
+    ok = best[0] >= 4
+    out = dict(invalid=0 if ok else 1, best_hyp=best[2], best_count=best[0], per_hyp_count=np.array([c[0] for c in cand]))
+    # decided: the float32 kernel cannot legitimately pick another hypothesis -- the winner and every hypothesis within reach
+    # of it have no point near the threshold and no ambiguous 4th-point pick, and the winner's (count, err) lead is strict
+    rivals = [c for c in cand if c[2] != best[2] and c[0] >= best[0] - 0 and c[0] >= 0]
+    decided = not best[5] and not best[6]
+    for c in cand:
+        if c[2] == best[2] or c[0] < 0:
+            continue
+        if c[5] or c[6]:  # an uncertain rival could gain / lose points: needs a count lead beyond what could flip -- be strict
+            decided = decided and c[0] + 2 < best[0]
+        elif c[0] == best[0]:
+            decided = decided and (c[1] - best[1]) > margin * max(best[1], 1e-12)
+    del rivals
+    if not ok:
+        out.update(n_inliers=0, inliers=np.zeros(0, np.int64), R=np.eye(3), t=np.zeros(3), decided=decided)
+        return out
+    R, t = best[3], best[4]
+    Rf, tf = R.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
+    c = X.astype(np.float32).astype(np.float64) @ Rf.T + tf
+    un_all = np.stack(((k[4] * du - k[1] * dv) * idet, (-k[3] * du + k[0] * dv) * idet), -1).astype(np.float32).astype(np.float64)
+    e = ((c[:, :2] / c[:, 2:3] - un_all) ** 2).sum(1)
+    inl = (c[:, 2] > 0) & (e < thr2)
+    mask_sure = not bool((np.abs(e - thr2) < margin * thr2).any())
+    out.update(n_inliers=int(inl.sum()), inliers=np.nonzero(inl)[0], R=R, t=t, decided=decided, mask_decided=decided and mask_sure)
+    return out
+
+
+def rot_to_quat(R):
+    """wxyz, w >= 0 (same convention as `mat_to_quat` in the kernel)."""
+    from scipy.spatial.transform import Rotation
+
+    q = np.roll(Rotation.from_matrix(R).as_quat(), 1)
+    return q if q[0] >= 0 else -q

@@ -17,6 +17,9 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
     raw = ctypes.CDLL(_lib.lib_path())
+    if not hasattr(raw, "lc_debug_head_variant"):
+        raise SystemExit("this sweep needs the tuning hook (commit dd139a8: lc_debug_head_variant); the shipped library has the "
+                         "policy fixed (lc_head.hip: kHeadPolicyF32 / kHeadPolicy16) -- results: profiles/r02/head_policy.txt")
     P = _lib.ptr
     for dtype in (torch.float32, torch.bfloat16):
         M, H, W = 256 * 64, 64, 64
