@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--bin", action="store_true", help="ZebraPose binary-code head (zlmo/zycbv) instead of the continuous xyz head")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--graphs", action="store_true", help="replay the Loss_fn step as hipGraphs (one per sub-sampling phase; eager inside the warm-up ramp)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -112,6 +113,7 @@ def main():
     amp = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": None}[args.dtype]
     scaler = torch.amp.GradScaler("cuda", enabled=amp is torch.float16)
     times = []
+    graphed = None
     for step in range(args.steps):
         blob = synthetic_blob(args.batch, dev, seed=1000 * rank + step, binary=args.bin)
         torch.cuda.synchronize(dev)
@@ -121,7 +123,14 @@ def main():
         # the loss runs at the reference's fp32 precision: half-precision maps are up-cast at the boundary (lc_amd/_lib.py)
         out = {"xyz_noc_bin" if args.bin else "xyz_noc": noc.float(), "xyz_weight_logits": wlogits.float(), "xyz_weights_scale": wscale.float(),
                "msk_vis_logits": vis.float()}
-        loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
+        if args.graphs:
+            if graphed is None:
+                from lc_amd.graphs import GraphedLoss
+                labels = {k: v for k, v in blob.items() if k != "rgb_in"}  # the crops are no input of the loss: keep them out of the graph's static inputs
+                graphed = GraphedLoss(loss_fn, labels, out, 0, step, 100)
+            loss_dict, w_loss_dict = graphed({k: v for k, v in blob.items() if k != "rgb_in"}, out, step=step)  # the guard runs the ramp steps eagerly, captures at the plateau
+        else:
+            loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
         loss = sum(w_loss_dict.values())
         opt.zero_grad(set_to_none=True)
         scaler.scale(loss).backward()

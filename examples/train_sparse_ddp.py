@@ -120,8 +120,9 @@ def main():
         if args.graphs and step > cfg.pose_loss_start_step:  # the blending factor is 1 from here on: the step is static
             if graphed is None:
                 from lc_amd.graphs import GraphedLoss
-                graphed = GraphedLoss(loss_fn, blob, out, 0, step, 100)
-            loss_dict, w_loss_dict = graphed(blob, out)
+                labels = {k: v for k, v in blob.items() if k != "rgb_in"}  # the crops are no input of the loss: keep them out of the graph's static inputs
+                graphed = GraphedLoss(loss_fn, labels, out, 0, step, 100)
+            loss_dict, w_loss_dict = graphed({k: v for k, v in blob.items() if k != "rgb_in"}, out)
         else:
             loss_dict, w_loss_dict = loss_fn(blob, out, 0, step, 100)
         loss = sum(w_loss_dict.values())

@@ -1,0 +1,28 @@
+#!/bin/bash
+# g1: a REAL-WIDTH training step around the hot path (ResNet-34-width encoder + decoder, bf16 autocast, PyTorch-ROCm owns the
+# conv GEMMs) under rocprofv3: per-kernel table, share of the step in lc_* kernels vs MIOpen/hipBLASLt/elementwise, MFMA busy
+# cycles of the conv kernels, eager vs GraphedLoss.  Run on the GPU box through gpurun from the repo root:
+#   bash scripts/profile_g1.sh r02
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/g1_${1:-r02}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+DENSE="python3 $ROOT/examples/train_dense_ddp.py --dtype bf16 --batch 32 --width 64 --steps 14"
+SPARSE="python3 $ROOT/examples/train_sparse_ddp.py --batch 256 --sparse-cnt 64 --width 64 --steps 14"
+# wall-clock step, eager vs hipGraph-replayed Loss_fn (no profiler)
+$DENSE > "$OUT/dense_eager.log" 2>&1
+$DENSE --graphs > "$OUT/dense_graphs.log" 2>&1
+$SPARSE > "$OUT/sparse_eager.log" 2>&1
+$SPARSE --graphs > "$OUT/sparse_graphs.log" 2>&1
+# kernel trace + stats
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/dense_trace" -o dense -- $DENSE > "$OUT/dense_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sparse_trace" -o sparse -- $SPARSE > "$OUT/sparse_trace.log" 2>&1
+# MFMA busy cycles per dispatch (own pass: --pmc with --kernel-trace only)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/dense_pmc" -o dense -- $DENSE > "$OUT/dense_pmc.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sparse_pmc" -o sparse -- $SPARSE > "$OUT/sparse_pmc.log" 2>&1
+cd "$ROOT"
+python3 scripts/summarize_g1.py "$OUT" > "$OUT/G1_SUMMARY.md" 2>&1
+find "$OUT" -name "*.csv" -size +1500k -delete
+find "$OUT" -name "*.db" -delete
+du -sh "$OUT"; head -60 "$OUT/G1_SUMMARY.md"

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Summarise scripts/profile_g1.sh: per-kernel table of a real-width training step, share of GPU time per kernel family,
+MFMA utilisation of the conv/GEMM kernels (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles =
+GRBM_GUI_ACTIVE / 8 because rocprofv3 sums that counter over the 8 XCDs -- MI355X_MICROARCH.md), eager vs GraphedLoss wall clock."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def family(name):
+    n = name.lower()
+    if name.startswith("lc_") or "lc::" in name or "lc_" in name.split("(")[0]:
+        return "lc_* (this repo's HIP kernels)"
+    if "nccl" in n or "rccl" in n:
+        return "RCCL"
+    if any(k in n for k in ("igemm", "conv", "cijk", "gemm", "xdlops", "winograd", "miopen", "implicit", "naive_conv", "sp3asm", "gridwise", "wrw", "fwd_", "bwd_")) and "batchnorm" not in n and "elementwise" not in n:
+        return "conv / GEMM (MIOpen, hipBLASLt, Tensile)"
+    if "batchnorm" in n or "batch_norm" in n or "bn" in n.split("_")[:2]:
+        return "batch norm"
+    if "at::native" in name or "elementwise" in n or "vectorized" in n or "reduce" in n or "copy" in n or "fill" in n or "cat" in n:
+        return "PyTorch elementwise / reduce / copy"
+    return "other"
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = re.sub(r"<.*", "", name)
+    return name[-70:]
+
+
+def first(pattern):
+    f = sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+    return f[0] if f else None
+
+
+print("# g1: real-width training step around the hot path (one MI355X, bf16 autocast backbone, synthetic data)\n")
+for tag, title in (("dense", "dense head (glmo shape, configs[2]): ResNet-34-width encoder + decoder, B=32, 64x64 maps, N=1024 correspondences"),
+                   ("sparse", "sparse head: same backbone, B=256, 64 keypoint maps of 64x64 (the metric's B=256, N=64 inside a training step)")):
+    print(f"## {title}\n")
+    for mode in ("eager", "graphs"):
+        f = os.path.join(out, f"{tag}_{mode}.log")
+        if os.path.exists(f):
+            m = [ln.strip() for ln in open(f) if ln.startswith("median step")]
+            print(f"* wall clock, Loss_fn {mode}: {m[-1] if m else 'no result (see log)'}")
+    print()
+    f = first(f"{tag}_trace/**/*kernel_stats.csv")
+    if not f:
+        print("(no kernel stats)\n")
+        continue
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    fam = defaultdict(float)
+    for r in rows:
+        fam[family(r["Name"])] += float(r["TotalDurationNs"])
+    print("| kernel family | GPU time share | ms over the run |")
+    print("|---|---|---|")
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]):
+        print(f"| {k} | {100 * v / tot:.2f} % | {v / 1e6:.2f} |")
+    print(f"\nAll kernels: {tot / 1e6:.1f} ms over 14 steps (incl. 2 warm-up steps).\n")
+    print("| kernel (top 14 by time + every lc_*) | family | calls | avg us | % |")
+    print("|---|---|---|---|---|")
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    for i, r in enumerate(rows):
+        if i < 14 or family(r["Name"]).startswith("lc_"):
+            print(f"| {short(r['Name'])} | {family(r['Name']).split(' ')[0]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    print()
+    f = first(f"{tag}_pmc/**/*counter_collection.csv")
+    if f:
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(int)
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cnt[r["Kernel_Name"]] += 1
+        mf = [(k, d) for k, d in acc.items() if d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and d.get("GRBM_GUI_ACTIVE", 0) > 0]
+        mf.sort(key=lambda kd: -kd[1]["GRBM_GUI_ACTIVE"])
+        tot_busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"] for _, d in mf)
+        tot_cyc = sum(d["GRBM_GUI_ACTIVE"] for _, d in mf)
+        all_cyc = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in acc.values())
+        print("MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), kernels that issue MFMA:\n")
+        print("| kernel | dispatches | MFMA utilisation | share of all GPU cycles |")
+        print("|---|---|---|---|")
+        for k, d in mf[:12]:
+            print(f"| {short(k)} | {cnt[k]} | {100 * d['SQ_VALU_MFMA_BUSY_CYCLES'] / (128 * d['GRBM_GUI_ACTIVE']):.1f} % | {100 * d['GRBM_GUI_ACTIVE'] / all_cyc:.1f} % |")
+        if tot_cyc:
+            print(f"\nAll MFMA kernels together: {100 * tot_busy / (128 * tot_cyc):.1f} % MFMA utilisation over {100 * tot_cyc / all_cyc:.1f} % of the GPU cycles; "
+                  f"whole step: {100 * tot_busy / (128 * all_cyc):.1f} %.\n")
