@@ -11,6 +11,7 @@
 #include "lc_common.h"
 #include <cstdint>
 
+#include "lc_host_stage.h"
 #include "lc_kernels.h"
 
 namespace {
@@ -55,19 +56,7 @@ struct PnpHostWorkspace {
     size_t bytes = 0;
     hipStream_t stream = nullptr;
 
-    static size_t layout(size_t B, size_t P, size_t off[8]) {
-        size_t o = 0;
-        auto take = [&](size_t n) { size_t r = o; o += (n + 255) & ~size_t(255); return r; };
-        off[0] = take(B * 9 * 4);       // K
-        off[1] = take(B * P * 3 * 4);   // pts3d
-        off[2] = take(B * P * 2 * 4);   // pts2d
-        off[3] = take(B * P * 4 * 4);   // sqrtL
-        off[4] = take(B * 4);           // counts
-        off[5] = take(B * 7 * 4);       // states
-        off[6] = take(B * 4);           // result_tr
-        off[7] = take(B * 4);           // rets
-        return o;
-    }
+    static size_t layout(size_t B, size_t P, size_t off[8]) { return lc::host::stage_layout(B, P, off); }
     int ensure(size_t B, size_t P) {
         if (!stream) LC_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (B <= cap_jobs && P <= cap_pts) return 0;
@@ -91,35 +80,14 @@ PnpHostWorkspace g_ws;
 
 int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pts3ds, float** icov_sqrtLs, int* ptCnts,
                  int maxIterCnt, float ftol, float* result_trs, int* rets, int B) {
-    int pmax = 1;
-    for (int i = 0; i < B; ++i) pmax = ptCnts[i] > pmax ? ptCnts[i] : pmax;
+    const int pmax = lc::host::stage_max_points(ptCnts, B);
     std::lock_guard<std::mutex> lock(g_ws.mu);
     if (int rc = g_ws.ensure(B, pmax)) return rc;
     const size_t P = pmax;
     size_t off[8];
     const size_t used = PnpHostWorkspace::layout(B, P, off);
     char* h = g_ws.host;
-    float* hK = reinterpret_cast<float*>(h + off[0]);
-    float* hX = reinterpret_cast<float*>(h + off[1]);
-    float* hU = reinterpret_cast<float*>(h + off[2]);
-    float* hL = reinterpret_cast<float*>(h + off[3]);
-    int* hC = reinterpret_cast<int*>(h + off[4]);
-    float* hS = reinterpret_cast<float*>(h + off[5]);
-    for (int i = 0; i < B; ++i) {
-        const int n = ptCnts[i] > 0 ? ptCnts[i] : 0;
-        std::memcpy(hK + 9 * (size_t)i, cam_Ks[i], 6 * sizeof(float));  // only 6 floats are guaranteed readable
-        hK[9 * (size_t)i + 6] = 0; hK[9 * (size_t)i + 7] = 0; hK[9 * (size_t)i + 8] = 1;
-        std::memcpy(hX + 3 * P * i, pts3ds[i], sizeof(float) * 3 * n);
-        std::memcpy(hU + 2 * P * i, pts2ds[i], sizeof(float) * 2 * n);
-        std::memcpy(hL + 4 * P * i, icov_sqrtLs[i], sizeof(float) * 4 * n);
-        if ((size_t)n < P) {
-            std::memset(hX + 3 * P * i + 3 * n, 0, sizeof(float) * 3 * (P - n));
-            std::memset(hU + 2 * P * i + 2 * n, 0, sizeof(float) * 2 * (P - n));
-            std::memset(hL + 4 * P * i + 4 * n, 0, sizeof(float) * 4 * (P - n));
-        }
-        hC[i] = ptCnts[i];
-        std::memcpy(hS + 7 * (size_t)i, init_states[i], 7 * sizeof(float));
-    }
+    lc::host::stage_gather(h, off, P, init_states, cam_Ks, pts2ds, pts3ds, icov_sqrtLs, ptCnts, B);  // lc_host_stage.h (sanitised on the CPU)
     // Small batches: the kernel reads the pinned staging buffer and writes its results there directly over PCIe (no copy
     // commands: two API calls and their DMA set-up cost more than the ~2 KB/pose they move); large ones: one H2D, one D2H.
     static const int zc_env = [] { const char* e = std::getenv("LC_AMD_HOST_ZEROCOPY"); return e ? std::atoi(e) : -1; }();
@@ -143,14 +111,7 @@ int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pt
     if (lc::launch_pnp_lm(p, st)) return fail(11, "pnp kernel launch failed");
     if (!zero_copy) LC_HIP_OK(hipMemcpyAsync(h + off[5], d + off[5], used - off[5], hipMemcpyDeviceToHost, st));
     LC_HIP_OK(hipStreamSynchronize(st));
-    const float* oS = reinterpret_cast<float*>(h + off[5]);
-    const float* oT = reinterpret_cast<float*>(h + off[6]);
-    const int* oR = reinterpret_cast<int*>(h + off[7]);
-    for (int i = 0; i < B; ++i) {
-        rets[i] = oR[i];
-        result_trs[i] = oT[i];
-        if (oR[i] == 0) std::memcpy(init_states[i], oS + 7 * (size_t)i, 7 * sizeof(float));
-    }
+    lc::host::stage_scatter(h, off, init_states, result_trs, rets, B);
     return 0;
 }
 

@@ -218,6 +218,46 @@ def gen_head():
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def head_compact_inputs(B, S, seed):
+    """Seeded inputs of the compact head fixtures: logits are regenerated (bit-identically: torch CPU generator) instead of
+    stored, the fixture holds their bit checksum."""
+    logits = synth.make_head_logits(B, S, 64, 64, seed=seed)
+    g = torch.Generator().manual_seed(199 + seed)
+    ct_mean = torch.randn(B, S, 2, generator=g)
+    ct_std = torch.randn(B, S, 2, generator=g)
+    probe = torch.randn(2, B, S, 64, 64, generator=g, dtype=torch.float64)  # two random functionals of the input gradient per map
+    return logits, ct_mean, ct_std, probe
+
+
+def gen_head_compact():
+    """The sizes SURVEY.md 8c names -- (4,16,64,64) and (2,64,64,64) = the S = 64 map count of the metric -- without storing
+    12 MB of maps: per-map outputs in full, the input gradient in full for 6 maps and through two seeded random linear
+    functionals for EVERY map (reference-computed float64 scalars)."""
+    _stub_modules()
+    import ptnet
+
+    for name, (B, S, seed) in dict(b4_s16_64x64=(4, 16, 11), b2_s64_64x64=(2, 64, 12)).items():
+        logits, ct_mean, ct_std, probe = head_compact_inputs(B, S, seed)
+        rec = dict(in_shape=np.array([B, S, 64, 64]), in_seed=np.int32(seed),
+                   in_logits_bits_xor=np.bitwise_xor.reduce(logits.numpy().view(np.uint32).ravel()),
+                   in_logits_sum=logits.double().sum().numpy())
+        pick = [(0, 0), (0, S - 1), (B - 1, 0), (B - 1, S - 1), (B // 2, S // 2), (1, 3)]
+        rec["g_maps"] = np.array(pick)
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            lg = logits.to(dt).requires_grad_(True)
+            prob = lg.flatten(start_dim=-2).softmax(dim=-1).reshape_as(lg)  # ptnet.py:61
+            mean, std = ptnet.softargmax_2d_std(prob)
+            (gl,) = torch.autograd.grad([mean, std], [lg], [ct_mean.to(dt), ct_std.to(dt)])
+            rec.update({f"{tag}_mean": mean.detach().numpy(), f"{tag}_std": std.detach().numpy(),
+                        f"{tag}_g_probe": (gl.double()[None] * probe).sum((-1, -2)).numpy(),
+                        f"{tag}_g_absmax": gl.abs().amax((-1, -2)).numpy()})
+            if tag == "f64":
+                rec["f64_g_logits_maps"] = np.stack([gl[b, s].numpy() for b, s in pick]).astype(np.float32)
+        path = os.path.join(HERE, f"headc_{name}.npz")
+        np.savez_compressed(path, **rec)
+        print(f"headc {name}: -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def gen_pose_errors():
     """lib/utils/error6d.py (numpy/scipy only) on random pose pairs and a random vertex cloud."""
     from lib.utils import error6d
@@ -281,6 +321,8 @@ if __name__ == "__main__":
         gen_loss()
     if "head" in what:
         gen_head()
+    if "headc" in what:
+        gen_head_compact()
     if "lossfn" in what:
         from gen_golden_lossfn import gen_lossfn  # noqa
 

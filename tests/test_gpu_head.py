@@ -120,3 +120,21 @@ def test_softargmax_1d_cov_matches_the_reference_formula():
     (g64,) = torch.autograd.grad((m64 * ct[..., 0].double()).sum() + (c64 * ct[..., 1].double()).sum(), p64)
     assert m.shape == (5, 7) and (m.cpu().double() - m64).abs().max() <= 1e-5 and (c.cpu().double() - c64).abs().max() <= 1e-4
     assert (gx.cpu().double() - g64).abs().max() <= 1e-3 * g64.abs().max()
+
+
+@pytest.mark.parametrize("path", golden_files("headc_"), ids=[case_name(p, "headc_") for p in golden_files("headc_")])
+def test_head_vs_golden_survey_sizes(path):
+    """(4,16,64,64) and (2,64,64,64) -- the sizes SURVEY.md 8c names, S = 64 being the metric's map count -- against outputs of
+    the reference's ptnet.softargmax_2d_std: every map's mean/std, every map's input gradient through two random functionals,
+    six maps' gradients in full (tests/golden/gen_golden.py: gen_head_compact)."""
+    from lc_amd.ptnet import spatial_softargmax_2d_std
+    from tests.test_oracle_head import check_compact, compact_case
+
+    z, logits, ct_mean, ct_std, probe = compact_case(path)
+    dev = torch.device("cuda:0")
+    lg = logits.to(dev).requires_grad_(True)
+    mean, std = spatial_softargmax_2d_std(lg)
+    (g,) = torch.autograd.grad([mean, std], [lg], [ct_mean.to(dev), ct_std.to(dev)])
+    check_compact(z, mean.detach(), std.detach(), g, probe, 2e-4, 2e-6)
+    # the fp32 reference run sits as close to the fp64 one as the kernel does
+    assert (torch.from_numpy(z["f32_mean"]).double() - torch.from_numpy(z["f64_mean"])).abs().max().item() <= 2e-4
