@@ -7,6 +7,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+git_sha = sys.argv[2] if len(sys.argv) > 2 else "unrecorded"
+bench_cmd = sys.argv[3] if len(sys.argv) > 3 else None
 
 
 def find(pattern):
@@ -72,4 +74,47 @@ for f in find("pmc_sq/**/*counter_collection.csv"):
     for k, d in acc.items():
         if k.startswith("lc_"):
             traffic.setdefault(k, {})["sq"] = {c: sum(v) / len(v) for c, v in d.items()}
+traffic["_meta"] = {"git_sha": git_sha, "command": bench_cmd, "profiler": "rocprofv3 --kernel-trace --pmc <one counter group per pass>",
+                    "round": os.path.basename(out.rstrip("/")).replace("prof_", "")}
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+
+# ---- batch-size sweep of the pose unit: dispatches grouped by grid size (grid = 2 B workgroups of 64 threads) ----
+sweep = {}
+for f in find("sweep_trace/**/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "lc_pose_unit_kernel" in r["Kernel_Name"]:
+            B = int(r["Grid_Size_X"]) // 128
+            sweep.setdefault(B, {"ns": [], "vgpr": r.get("VGPR_Count")})["ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+sq = {}
+for f in find("sweep_pmc_sq/**/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "lc_pose_unit_kernel" in r["Kernel_Name"]:
+            B = int(r["Grid_Size"]) // 128
+            sq.setdefault(B, defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+ev = {}
+p_ev = os.path.join(out, "sweep_events.jsonl")
+if os.path.exists(p_ev):
+    for ln in open(p_ev):
+        if ln.startswith("{"):
+            d = json.loads(ln)
+            ev[d["B"]] = d
+if sweep or ev:
+    print("## pose-unit launch over batch size (N = 64): rocprofv3 kernel-trace duration per dispatch, SQ counters per dispatch\n")
+    print("| B | VGPRs | avg us (trace) | min us | poses/s (trace avg) | us (events, un-profiled) | VALU insts / pose | VALU-issue SIMD-cycles / pose | VALU-issue bound poses/s | achieved / bound | wave-cycles VALU-active |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    table = {}
+    for B in sorted(set(sweep) | set(ev)):
+        ns = sorted(sweep.get(B, {}).get("ns", []))
+        ns = ns[len(ns) // 5:] if len(ns) > 5 else ns  # drop nothing systematic; the first launches are not special under the trace
+        avg = sum(ns) / len(ns) / 1e3 if ns else float("nan")
+        c = {k: sum(v) / len(v) for k, v in sq.get(B, {}).items()}
+        cyc = 4.0 * c["SQ_ACTIVE_INST_VALU"] / B if c.get("SQ_ACTIVE_INST_VALU") else float("nan")
+        bound = 1024 * 2.4e9 / cyc if cyc == cyc else float("nan")
+        pps = B / (avg * 1e-6) if avg == avg else float("nan")
+        act = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else float("nan")
+        table[B] = {"avg_us": avg, "poses_per_s": pps, "valu_insts_per_pose": c.get("SQ_INSTS_VALU", float("nan")) / B, "simd_cycles_per_pose": cyc,
+                    "valu_bound_poses_per_s": bound, "frac": pps / bound if bound == bound else None, "events_us": ev.get(B, {}).get("us_per_launch")}
+        print(f"| {B} | {sweep.get(B, {}).get('vgpr', '')} | {avg:.1f} | {min(ns) / 1e3 if ns else float('nan'):.1f} | {pps:.3g} | {ev.get(B, {}).get('us_per_launch', float('nan'))} | "
+              f"{c.get('SQ_INSTS_VALU', float('nan')) / B:.0f} | {cyc:.0f} | {bound:.3g} | {pps / bound if bound == bound else float('nan'):.3f} | {act:.2f} |")
+    json.dump({"_meta": traffic["_meta"], "sweep": table}, open(os.path.join(out, "sweep_pose_unit.json"), "w"), indent=1)
+    print()

@@ -116,3 +116,43 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _agg_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lc_amd import dist as lcd
+
+        # five regions of 10 steps: rank 1 is the slow one in regions 0-2, rank 0 in regions 3-4
+        regions = [[1.0, 1.1, 1.2, 3.0, 5.0], [2.0, 2.1, 2.2, 1.0, 1.0]][rank]
+        agg = lcd.aggregate_regions(regions, steps=10)
+        if rank == 0:
+            ret["agg"] = agg
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_timing_aggregation_two_ranks():
+    """bench.py's multi-rank timing (lc_amd.dist.aggregate_regions): a region lasts as long as its slowest rank, the median
+    region is reported, and the line carries the proof that the collective saw every rank (ranks_seen, backend, per-rank times)."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_agg_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    agg = ret["agg"]
+    assert agg["ranks_seen"] == 2 and agg["backend"] == "gloo" and agg["regions"] == 5
+    # per-region MAX over ranks = [2.0, 2.1, 2.2, 3.0, 5.0] -> median 2.2 s per 10 steps
+    assert abs(agg["median_region_s"] - 2.2) < 1e-12 and abs(agg["ms_per_step"] - 220.0) < 1e-9
+    assert abs(agg["region_ms_per_step"]["min"] - 200.0) < 1e-9 and abs(agg["region_ms_per_step"]["max"] - 500.0) < 1e-9
+    assert [round(v, 6) for v in agg["per_rank_ms_per_step"]] == [120.0, 200.0]  # each rank's own median region
+    # single process: no collective
+    from lc_amd import dist as lcd
+
+    one = lcd.aggregate_regions([0.3, 0.1, 0.2], steps=100)
+    assert one["ranks_seen"] == 1 and one["backend"] == "none" and abs(one["ms_per_step"] - 2.0) < 1e-12
