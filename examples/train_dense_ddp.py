@@ -136,10 +136,10 @@ def main():
         blob = synthetic_blob(args.batch, dev, seed=1000 * rank + step, binary=args.bin)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        if args.graph_step and world == 1 and step > cfg.pose_loss_start_step:  # blending factor constant from here on
+        if args.graph_step and world == 1:  # every step is the replayed graph; the blending factor is the post-ramp one (1) throughout
             if whole is None:
                 from lc_amd.graphs import GraphedTrainStep
-                whole = GraphedTrainStep(lambda inp, ph, s=step: loss_of(inp, ph, s), opt, {k: v for k, v in blob.items() if isinstance(v, torch.Tensor)})
+                whole = GraphedTrainStep(lambda inp, ph, s=cfg.pose_loss_start_step + 1: loss_of(inp, ph, s), opt, {k: v for k, v in blob.items() if isinstance(v, torch.Tensor)})
                 frozen = {k: v for k, v in blob.items() if not isinstance(v, torch.Tensor)}
                 whole.static_in.update(frozen)
             phase = tuple(int(v) for v in np.random.randint(0, 2, size=2))  # losses.py:152

@@ -126,10 +126,10 @@ def main():
         blob = synthetic_blob(args.batch, args.sparse_cnt, dev, seed=1000 * rank + step)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        if args.graph_step and world == 1 and step > cfg.pose_loss_start_step:  # blending factor constant from here on
+        if args.graph_step and world == 1:  # every step is the replayed graph; the blending factor is the post-ramp one (1) throughout
             if whole is None:
                 from lc_amd.graphs import GraphedTrainStep
-                whole = GraphedTrainStep(lambda inp, s=step: loss_of(inp, s), opt, blob)
+                whole = GraphedTrainStep(lambda inp, s=cfg.pose_loss_start_step + 1: loss_of(inp, s), opt, blob)
             replay = None in whole._graphs
             loss, loss_dict = whole(blob)
             torch.cuda.synchronize(dev)

@@ -174,21 +174,37 @@ __device__ __forceinline__ bool ldlt_solve6(const double (&A)[21], const double 
     return ok;
 }
 
-__device__ __forceinline__ Point load_point(const PnpParams& p, size_t base, int n, const double cam[6]) {
-    Point o;
+// one correspondence as it sits in HBM (fp32): the loads are issued first thing in the kernel, the conversion to the fp64 working
+// form waits until the pose-independent set-up (quaternion -> angle-axis, ~700 cycles) has run in their shadow
+struct RawPoint {
+    float X[3];
+    float2 u;
+    float a, b, c;
+};
+__device__ __forceinline__ RawPoint load_raw_point(const PnpParams& p, size_t base, int n) {
+    RawPoint o;
     const float* X = p.pts3d + (base + n) * 3;
-    const float2 u = *reinterpret_cast<const float2*>(p.pts2d + (base + n) * 2);
+    o.u = *reinterpret_cast<const float2*>(p.pts2d + (base + n) * 2);
     o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
-    o.u = (double)u.x - cam[2];
-    o.v = (double)u.y - cam[5];
     if (p.sqrtL) {
         const float4 L = *reinterpret_cast<const float4*>(p.sqrtL + (base + n) * 4);
         o.a = L.x; o.b = L.z; o.c = L.w;
     } else {
         const float2 L = *reinterpret_cast<const float2*>(p.sqrt_diag + (base + n) * 2);
-        o.a = L.x; o.b = 0; o.c = L.y;
+        o.a = L.x; o.b = 0.f; o.c = L.y;
     }
     return o;
+}
+__device__ __forceinline__ Point to_point(const RawPoint& r, const double cam[6]) {
+    Point o;
+    o.X[0] = r.X[0]; o.X[1] = r.X[1]; o.X[2] = r.X[2];
+    o.u = (double)r.u.x - cam[2];
+    o.v = (double)r.u.y - cam[5];
+    o.a = r.a; o.b = r.b; o.c = r.c;
+    return o;
+}
+__device__ __forceinline__ Point load_point(const PnpParams& p, size_t base, int n, const double cam[6]) {
+    return to_point(load_raw_point(p, base, n), cam);
 }
 
 __device__ __forceinline__ double max_abs6(const double (&v)[6]) {
@@ -227,6 +243,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         return;
     }
     const size_t base = (size_t)b * p.Nmax;
+    const bool active = lane < n;
+    RawPoint raw;
+    if constexpr (REG) raw = load_raw_point(p, base, active ? lane : 0);  // n >= 3 here: correspondence 0 exists
     double cam[6];
     {
         const float* Kp = p.K + 9 * (size_t)b;
@@ -248,10 +267,14 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         x[3] = st_in[4]; x[4] = st_in[5]; x[5] = st_in[6];
     }
     LC_PSTAMP(0);
-    Point rp = {{0.0, 0.0, 1.0}, 0.0, 0.0, 0.0, 0.0, 0.0};  // harmless dummy for lanes without a correspondence
-    const bool active = lane < n;
+    // Lanes without a correspondence (lane >= n) carry a copy of correspondence 0 with a ZERO information factor: their residuals
+    // and Jacobian rows are exact zeros, so they add nothing to the sums and need no masking in the evaluation (56 selects per
+    // evaluation before); their projection is finite exactly when correspondence 0's is, and a non-finite correspondence fails the
+    // job either way (ceres.cpp:126-138 -> invalid).
+    Point rp;
     if constexpr (REG) {
-        if (active) rp = load_point(p, base, lane, cam);
+        rp = to_point(raw, cam);
+        if (!active) { rp.a = 0.0; rp.b = 0.0; rp.c = 0.0; }
     }
 
     // full evaluation at xe with column scaling sc: H = Js^T Js (21), g = Js^T r (6), cost; false when anything is non-finite
@@ -263,11 +286,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         const double t[3] = {xe[3], xe[4], xe[5]};
         double acc[28];
         if constexpr (REG) {
-            accumulate_point<true>(rp, rt, t, cam, sc, acc);  // inactive lanes hold a dummy point; zeroed below
-            if (!active) {
-#pragma unroll
-                for (int i = 0; i < 28; ++i) acc[i] = 0;
-            }
+            accumulate_point<true>(rp, rt, t, cam, sc, acc);  // lanes beyond n hold zero-weight copies: exact zeros
         } else {
 #pragma unroll
             for (int i = 0; i < 28; ++i) acc[i] = 0;
@@ -414,7 +433,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             if (t2 > 0.0) {
                 const double th = sqrt(t2), h = 0.5 * th;
                 double sh, ch;
-                sincos(h, &sh, &ch);
+                sincos_small(h, sh, ch);  // < 1 ulp on the reduced interval, like the libm call it replaces
                 q0 = ch;
                 kk = sh / th;
             }

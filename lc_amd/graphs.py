@@ -129,6 +129,7 @@ class GraphedTrainStep:
         self.fn, self.opt, self.warmup = fn, optimizer, warmup
         self.static_in = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in example_inputs.items()}
         self._graphs = {}
+        self._side = None
 
     def _one(self, key):
         self.opt.zero_grad(set_to_none=True)
@@ -139,7 +140,9 @@ class GraphedTrainStep:
 
     def _capture(self, key):
         dev = next(v for v in self.static_in.values() if isinstance(v, Tensor)).device
-        side = torch.cuda.Stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        side = self._side
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up on a side stream: MIOpen solver selection, workspaces, optimizer state
             for _ in range(self.warmup):
@@ -148,7 +151,10 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
-        with quiet_capture(), torch.cuda.graph(graph):
+        # Capture on the SAME stream the warm-up ran on: the parameters' AccumulateGrad nodes remember the stream they were created
+        # on, and a node that outlives the warm-up (kept alive by any tensor of an earlier graph) would otherwise make the autograd
+        # engine hop streams inside the capture -- observed as a first replay that wrote non-finite parameters in ~1 run out of 5.
+        with quiet_capture(), torch.cuda.graph(graph, stream=side):
             loss, aux = self._one(key)
         return graph, loss, aux
 
@@ -157,8 +163,7 @@ class GraphedTrainStep:
             if isinstance(v, Tensor):
                 self.static_in[k].copy_(v, non_blocking=True)
         if key not in self._graphs:
-            self._graphs[key] = self._capture(key)  # NOTE: the warm-up and the capture pass are real optimizer steps on these inputs
-            return self._graphs[key][1], self._graphs[key][2]
+            self._graphs[key] = self._capture(key)  # NOTE: the warm-up passes are real optimizer steps on these inputs
         graph, loss, aux = self._graphs[key]
         graph.replay()
         return loss, aux

@@ -28,6 +28,9 @@ def family(name):
 
 
 def short(name):
+    m = re.search(r"lc_\w+?_kernel", name)
+    if m:
+        return m.group(0)
     name = re.sub(r"\(.*", "", name)
     name = re.sub(r"<.*", "", name)
     return name[-70:]

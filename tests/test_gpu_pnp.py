@@ -132,9 +132,12 @@ def test_pnp_full_size_properties():
 
 def test_pnp_stress_hard_starts_vs_oracle():
     """2048 hard problems (12 points, 2 px noise, 20 % outliers, starts 0.3 rad / 10 % off): many LM iterations, rejected
-    steps, NO_CONVERGENCE exits.  The kernel (normal equations) and the oracle (dense QR) follow the same schedule; a
-    termination test may flip on round-off in a handful of jobs, so the bound is statistical: >= 99.5 % identical validity
-    flags and, among jobs both accept, >= 99 % within the 1e-4 pose tolerance."""
+    steps, NO_CONVERGENCE exits.  Trajectories of up to 50 iterations through ill-conditioned steps amplify last-bit
+    differences: ANY two correct implementations differ in `rets` on ~0.04 % of such jobs -- the DENSE_QR oracle against
+    itself with the column sums accumulated in reverse order flips 0.038 %, normal equations 0.042 %, double-double normal
+    equations 0.040 % (profiles/r02/pnp_flip_rates.txt) -- so exact equality is not a property of the algorithm here.
+    Bound: at most 4 of 2048 flags differ (0.2 %), >= 99.8 % of the jointly accepted poses within the 1e-4 tolerance;
+    tests/test_gpu_pnp_trace.py pins the schedule itself row by row."""
     from lc_amd.pnp import pnp_ceres
 
     B, N = 2048, 12
@@ -156,11 +159,12 @@ def test_pnp_stress_hard_starts_vs_oracle():
     so, tro, reto = pnp_oracle.solve_batched(start.numpy(), b["K"].numpy(), b["pts2d"].numpy(), b["pts3d"].numpy(), L.numpy(), num_threads=8)
     ret = ret.cpu().numpy()
     assert iters.max().item() > 10  # the batch does contain long solves
-    assert (ret == reto).mean() >= 0.995, (ret != reto).sum()
+    print(f"stress: {int((ret != reto).sum())} of {B} flags differ")
+    assert (ret != reto).sum() <= 4, (ret != reto).sum()
     both = (ret == 0) & (reto == 0)
     dq_, dt_ = pose_err(st.cpu().numpy()[both], so[both])
     ok = (dq_ <= 1e-4) & (dt_ <= 1e-4)
-    assert ok.mean() >= 0.99, (1 - ok.mean(), np.sort(dq_)[-5:])
+    assert ok.mean() >= 0.998, (1 - ok.mean(), np.sort(dq_)[-5:])
     # invalid jobs keep their start pose bit for bit
     assert np.array_equal(st.cpu().numpy()[ret == 1], start.numpy()[ret == 1])
 
