@@ -88,8 +88,6 @@ def main():
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--bin", action="store_true", help="ZebraPose binary-code head (zlmo/zycbv) instead of the continuous xyz head")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
-    ap.add_argument("--graph-step", action="store_true", help="replay the WHOLE step (forward, loss, backward, Adam) as hipGraphs, one per "
-                    "sub-sampling phase, once the warm-up ramp is over (single process, bf16/fp32; lc_amd.graphs.GraphedTrainStep)")
     ap.add_argument("--graphs", action="store_true", help="replay the Loss_fn step as hipGraphs (one per sub-sampling phase; eager inside the warm-up ramp)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -111,48 +109,15 @@ def main():
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph_step)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     amp = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": None}[args.dtype]
     scaler = torch.amp.GradScaler("cuda", enabled=amp is torch.float16)
     times = []
     graphed = None
-    whole = None
-    replayed = []
-    assert not (args.graph_step and args.dtype == "fp16"), "--graph-step: bf16 or fp32 (the GradScaler's inf check synchronises with the host)"
-
-    def loss_of(inp, phase, step_for_factor):
-        with torch.autocast("cuda", dtype=amp or torch.float16, enabled=amp is not None):
-            noc_, wl_, ws_, vis_ = net(inp["rgb_in"].contiguous(memory_format=torch.channels_last))
-        o = {"xyz_noc_bin" if args.bin else "xyz_noc": noc_.float(), "xyz_weight_logits": wl_.float(), "xyz_weights_scale": ws_.float(),
-             "msk_vis_logits": vis_.float()}
-        loss_fn._forced_phase = phase  # the sub-sampling phase is host-side randomness: one graph per phase
-        try:
-            ld, wd = loss_fn(inp, o, 0, step_for_factor, 100)
-        finally:
-            loss_fn._forced_phase = None
-        return sum(wd.values()), dict(ld)
-
     for step in range(args.steps):
         blob = synthetic_blob(args.batch, dev, seed=1000 * rank + step, binary=args.bin)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        if args.graph_step and world == 1:  # every step is the replayed graph; the blending factor is the post-ramp one (1) throughout
-            if whole is None:
-                from lc_amd.graphs import GraphedTrainStep
-                whole = GraphedTrainStep(lambda inp, ph, s=cfg.pose_loss_start_step + 1: loss_of(inp, ph, s), opt, {k: v for k, v in blob.items() if isinstance(v, torch.Tensor)})
-                frozen = {k: v for k, v in blob.items() if not isinstance(v, torch.Tensor)}
-                whole.static_in.update(frozen)
-            phase = tuple(int(v) for v in np.random.randint(0, 2, size=2))  # losses.py:152
-            replay = phase in whole._graphs
-            loss, loss_dict = whole({k: v for k, v in blob.items() if isinstance(v, torch.Tensor)}, key=phase)
-            torch.cuda.synchronize(dev)
-            times.append(time.perf_counter() - t0)
-            if replay:
-                replayed.append(times[-1])
-            if rank == 0:
-                terms = "  ".join(f"{k[5:]} {float(v):8.4f}" for k, v in loss_dict.items())
-                print(f"step {step:3d}  loss {float(loss):9.4f}  {terms}  {times[-1] * 1e3:7.1f} ms  ({'replay' if replay else 'capture'}, phase {phase})")
-            continue
         with torch.autocast("cuda", dtype=amp or torch.float16, enabled=amp is not None):
             noc, wlogits, wscale, vis = net(blob["rgb_in"].contiguous(memory_format=torch.channels_last))
         # the loss runs at the reference's fp32 precision: half-precision maps are up-cast at the boundary (lc_amd/_lib.py)
@@ -178,8 +143,12 @@ def main():
             print(f"step {step:3d}  loss {float(loss):9.4f}  {terms}  {times[-1] * 1e3:7.1f} ms")
         assert torch.isfinite(loss), "non-finite loss"
     if rank == 0 and len(times) > 3:
-        tail = sorted(replayed) if replayed else sorted(times[2:])  # whole-step graphs: the replayed steps (captures are one-off)
+        tail = sorted(times[2:])
         t = tail[len(tail) // 2]
+        q = lambda f: tail[min(len(tail) - 1, int(f * len(tail)))] * 1e3  # noqa: E731
+        # (on the shared pool a fraction of the steps carries a ~55-70 ms stall that is also there when the step is a single graph
+        # replay with no host work in it; the quartiles show both modes)
+        print(f"step time ms: min {q(0):.1f}  p25 {q(0.25):.1f}  median {q(0.5):.1f}  p75 {q(0.75):.1f}  max {q(1):.1f}")
         print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), {args.dtype} backbone, "
               f"{'binary-code' if args.bin else 'continuous-xyz'} dense head, N=1024 correspondences per sample")
     if world > 1:

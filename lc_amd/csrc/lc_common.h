@@ -147,14 +147,33 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 template <int NW>
 constexpr int sum_bcast_lds_doubles(int K) { return K * 68 * NW + K; }
 
+// The two halves of the sum can be called separately: block_sum_open() (barrier: the previous totals have been read), then the
+// caller stores its K values itself with block_sum_put() AS IT PRODUCES THEM -- the LDS stores of a lone wave drain at about
+// 40 B/clk (MI355X_MICROARCH.md, LDS: one wave gets half the store rate), 360 cycles for 28 doubles x 64 lanes, and issued early they
+// drain behind the arithmetic that produces the later values -- then block_sum_close() for the reduction and the broadcast.
+template <int NW>
+__device__ __forceinline__ int block_sum_open(int tid) {
+    __syncthreads();  // the previous totals have been read
+    return tid + 2 * (tid >> 5);
+}
+template <int NW>
+__device__ __forceinline__ void block_sum_put(double* lds, int pos, int k, double v) { lds[k * (68 * NW) + pos] = v; }
+
+template <int K, int NW>
+__device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int tid);
+
 template <int K, int NW>
 __device__ __forceinline__ void block_sum_bcast_lds(double (&v)[K], double* lds, int tid) {
+    const int pos = block_sum_open<NW>(tid);
+#pragma unroll
+    for (int k = 0; k < K; ++k) block_sum_put<NW>(lds, pos, k, v[k]);
+    block_sum_close<K, NW>(v, lds, tid);
+}
+
+template <int K, int NW>
+__device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int tid) {
     static_assert(K <= 32 && (NW == 1 || NW == 4), "unsupported shape");
     constexpr int LD = 68 * NW, S = 2 * NW;
-    __syncthreads();  // the previous totals have been read
-    const int pos = tid + 2 * (tid >> 5);
-#pragma unroll
-    for (int k = 0; k < K; ++k) lds[k * LD + pos] = v[k];
     __syncthreads();
     double s = 0;
     if (tid < K * S) {

@@ -45,6 +45,10 @@
 #define LC_PSTAMP(i) do {} while (0)
 #endif
 
+#ifndef LC_PNP_STREAM_SUM
+#define LC_PNP_STREAM_SUM 1  // A/B switch of the streamed block sum (scripts/ubench/pnp_ab.py); 1 in the shipped library
+#endif
+
 namespace lc {
 namespace pnp {
 
@@ -91,9 +95,10 @@ __device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
 // adds one correspondence's contribution to acc = [J^T J upper (21) | J^T r (6) | r^T r | pad]
 // (columns of J pre-multiplied by the Jacobi scaling sc: acc holds Js^T Js and Js^T r directly)
 // FIRST: acc is written (not added to) -- saves zero-filling 32 accumulators and one add per entry when a lane owns one point.
-template <bool FIRST>
+// STREAM: (FIRST only) every finished entry goes straight to its LDS slot of the block sum instead of into acc[]
+template <bool FIRST, bool STREAM = false, int NW = 1>
 __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt, const double t[3], const double k[6],
-                                                 const double (&sc)[6], double (&acc)[28]) {
+                                                 const double (&sc)[6], double (&acc)[28], double* lds = nullptr, int pos = 0) {
     double q[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) q[d] = rt.R[3 * d] * pt.X[0] + rt.R[3 * d + 1] * pt.X[1] + rt.R[3 * d + 2] * pt.X[2] + t[d];
@@ -127,13 +132,16 @@ __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt,
 #pragma unroll
         for (int j = i; j < 6; ++j) {
             const double v = __builtin_fma(J[0][i], J[0][j], J[1][i] * J[1][j]);
-            acc[tri6(i, j)] = FIRST ? v : acc[tri6(i, j)] + v;
+            if constexpr (STREAM) block_sum_put<NW>(lds, pos, tri6(i, j), v);
+            else acc[tri6(i, j)] = FIRST ? v : acc[tri6(i, j)] + v;
         }
         const double gi = __builtin_fma(J[0][i], r[0], J[1][i] * r[1]);
-        acc[21 + i] = FIRST ? gi : acc[21 + i] + gi;
+        if constexpr (STREAM) block_sum_put<NW>(lds, pos, 21 + i, gi);
+        else acc[21 + i] = FIRST ? gi : acc[21 + i] + gi;
     }
     const double ss = __builtin_fma(r[0], r[0], r[1] * r[1]);
-    acc[27] = FIRST ? ss : acc[27] + ss;
+    if constexpr (STREAM) block_sum_put<NW>(lds, pos, 27, ss);
+    else acc[27] = FIRST ? ss : acc[27] + ss;
 }
 
 // solve (A + diag(dg)) y = rhs for symmetric A (packed upper 21) by LDL^T; false if a pivot is not positive/finite
@@ -285,15 +293,23 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         LC_PSTAMP(2);
         const double t[3] = {xe[3], xe[4], xe[5]};
         double acc[28];
-        if constexpr (REG) {
-            accumulate_point<true>(rp, rt, t, cam, sc, acc);  // lanes beyond n hold zero-weight copies: exact zeros
+        if constexpr (REG && LC_PNP_STREAM_SUM) {
+            // lanes beyond n hold zero-weight copies (exact zeros); the 28 partial sums go to LDS as they are produced
+            const int pos = block_sum_open<NW>(lane);
+            accumulate_point<true, true, NW>(rp, rt, t, cam, sc, acc, bc, pos);
+            LC_PSTAMP(3);
+            block_sum_close<28, NW>(acc, bc, lane);
+        } else if constexpr (REG) {
+            accumulate_point<true>(rp, rt, t, cam, sc, acc);
+            LC_PSTAMP(3);
+            block_sum_bcast_lds<28, NW>(acc, bc, lane);
         } else {
 #pragma unroll
             for (int i = 0; i < 28; ++i) acc[i] = 0;
             for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point(p, base, i, cam), rt, t, cam, sc, acc);
+            LC_PSTAMP(3);
+            block_sum_bcast_lds<28, NW>(acc, bc, lane);
         }
-        LC_PSTAMP(3);
-        block_sum_bcast_lds<28, NW>(acc, bc, lane);
         LC_PSTAMP(4);
 #pragma unroll
         for (int i = 0; i < 21; ++i) H[i] = acc[i];

@@ -107,63 +107,3 @@ class GraphedLoss:
         n = len(self._loss_keys)
         return dict(zip(self._loss_keys, res[:n])), dict(zip(self._w_keys, res[n:]))
 
-
-class GraphedTrainStep:
-    """A WHOLE training step -- forward, loss, backward, optimizer update -- captured once per `key` as a hipGraph and replayed.
-
-    Why: a real-width step around the hot path is ~1500 short launches (ResNet-34-width convolutions, batch norms, elementwise
-    glue); at the reference's batch of 32 the GPU needs ~14 ms for them while the host needs ~70 ms to issue them
-    (profiles/r02/g1: `dense_eager` 72.5 ms wall for 13.9 ms of kernels), so the step is bound by the host's launch rate.  Every
-    piece of this package's loss path is synchronisation-free by construction (device-side counts, in-place clipper state), so
-    the step can be replayed as ONE graph launch.
-
-        step = GraphedTrainStep(lambda inp: loss_of(net, inp), optimizer, example_inputs)   # capture (after warm-up) on first use
-        loss, aux = step(inputs)              # copies `inputs` into the static buffers, replays; returns the static outputs
-
-    `fn(inputs: dict) -> (loss, aux: dict of tensors)` must not synchronise with the host and must draw any host-side randomness
-    through `key` (one graph per key: the dense heads' sub-sampling phase).  The optimizer must be capturable (`Adam(...,
-    capturable=True)`); bf16 / fp32 only (a GradScaler's inf check is a host sync).  Single-process: under DDP keep the eager step.
-    """
-
-    def __init__(self, fn, optimizer, example_inputs: dict, warmup: int = 3):
-        self.fn, self.opt, self.warmup = fn, optimizer, warmup
-        self.static_in = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in example_inputs.items()}
-        self._graphs = {}
-        self._side = None
-
-    def _one(self, key):
-        self.opt.zero_grad(set_to_none=True)
-        loss, aux = self.fn(self.static_in) if key is None else self.fn(self.static_in, key)
-        loss.backward()
-        self.opt.step()
-        return loss, aux
-
-    def _capture(self, key):
-        dev = next(v for v in self.static_in.values() if isinstance(v, Tensor)).device
-        if self._side is None:
-            self._side = torch.cuda.Stream(dev)
-        side = self._side
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):  # warm-up on a side stream: MIOpen solver selection, workspaces, optimizer state
-            for _ in range(self.warmup):
-                self._one(key)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        self.opt.zero_grad(set_to_none=True)
-        # Capture on the SAME stream the warm-up ran on: the parameters' AccumulateGrad nodes remember the stream they were created
-        # on, and a node that outlives the warm-up (kept alive by any tensor of an earlier graph) would otherwise make the autograd
-        # engine hop streams inside the capture -- observed as a first replay that wrote non-finite parameters in ~1 run out of 5.
-        with quiet_capture(), torch.cuda.graph(graph, stream=side):
-            loss, aux = self._one(key)
-        return graph, loss, aux
-
-    def __call__(self, inputs: dict, key=None):
-        for k, v in inputs.items():
-            if isinstance(v, Tensor):
-                self.static_in[k].copy_(v, non_blocking=True)
-        if key not in self._graphs:
-            self._graphs[key] = self._capture(key)  # NOTE: the warm-up passes are real optimizer steps on these inputs
-        graph, loss, aux = self._graphs[key]
-        graph.replay()
-        return loss, aux

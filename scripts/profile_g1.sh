@@ -10,11 +10,11 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 DENSE="python3 $ROOT/examples/train_dense_ddp.py --dtype bf16 --batch 32 --width 64 --steps 14"
 SPARSE="python3 $ROOT/examples/train_sparse_ddp.py --batch 256 --sparse-cnt 64 --width 64 --steps 14"
-# wall-clock step, eager vs hipGraph-replayed Loss_fn (no profiler)
-$DENSE > "$OUT/dense_eager.log" 2>&1
-$DENSE --graphs > "$OUT/dense_graphs.log" 2>&1
-$SPARSE > "$OUT/sparse_eager.log" 2>&1
-$SPARSE --graphs > "$OUT/sparse_graphs.log" 2>&1
+# wall-clock step, eager vs hipGraph-replayed Loss_fn (no profiler; 40 steps: the pool shows a bimodal step time)
+${DENSE/--steps 14/--steps 40} > "$OUT/dense_eager.log" 2>&1
+${DENSE/--steps 14/--steps 40} --graphs > "$OUT/dense_graphs.log" 2>&1
+${SPARSE/--steps 14/--steps 40} > "$OUT/sparse_eager.log" 2>&1
+${SPARSE/--steps 14/--steps 40} --graphs > "$OUT/sparse_graphs.log" 2>&1
 # kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/dense_trace" -o dense -- $DENSE > "$OUT/dense_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sparse_trace" -o sparse -- $SPARSE > "$OUT/sparse_trace.log" 2>&1
