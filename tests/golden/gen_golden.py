@@ -240,7 +240,7 @@ def gen_head_compact():
         logits, ct_mean, ct_std, probe = head_compact_inputs(B, S, seed)
         rec = dict(in_shape=np.array([B, S, 64, 64]), in_seed=np.int32(seed),
                    in_logits_bits_xor=np.bitwise_xor.reduce(logits.numpy().view(np.uint32).ravel()),
-                   in_logits_sum=logits.double().sum().numpy())
+                   in_logits_bits_sum=np.sum(logits.numpy().view(np.uint32).ravel().astype(np.uint64)))  # integer: order-independent
         pick = [(0, 0), (0, S - 1), (B - 1, 0), (B - 1, S - 1), (B // 2, S // 2), (1, 3)]
         rec["g_maps"] = np.array(pick)
         for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):

@@ -32,7 +32,7 @@ def compact_case(path):
     B, S = int(z["in_shape"][0]), int(z["in_shape"][1])
     logits, ct_mean, ct_std, probe = head_compact_inputs(B, S, int(z["in_seed"]))
     assert np.bitwise_xor.reduce(logits.numpy().view(np.uint32).ravel()) == z["in_logits_bits_xor"]
-    assert logits.double().sum().item() == float(z["in_logits_sum"])
+    assert int(np.sum(logits.numpy().view(np.uint32).ravel().astype(np.uint64))) == int(z["in_logits_bits_sum"])
     return z, logits, ct_mean, ct_std, probe
 
 
