@@ -140,7 +140,7 @@ def main():
         q = lambda f: tail[min(len(tail) - 1, int(f * len(tail)))] * 1e3  # noqa: E731
         # (on the shared pool a fraction of the steps carries a ~55-70 ms stall that is also there when the step is a single graph
         # replay with no host work in it; the quartiles show both modes)
-        print(f"step time ms: min {q(0):.1f}  p25 {q(0.25):.1f}  median {q(0.5):.1f}  p75 {q(0.75):.1f}  max {q(1):.1f}")
+        print(f"quartiles of the step time [ms]: min {q(0):.1f}  p25 {q(0.25):.1f}  median {q(0.5):.1f}  p75 {q(0.75):.1f}  max {q(1):.1f}")
         print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), bf16 backbone, fp32/fp64 LC loss")
     if world > 1:
         dist.destroy_process_group()

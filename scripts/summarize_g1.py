@@ -49,7 +49,7 @@ for tag, title in (("dense", "dense head (glmo shape, configs[2]): ResNet-34-wid
         f = os.path.join(out, f"{tag}_{mode}.log")
         if os.path.exists(f):
             m = [ln.strip() for ln in open(f) if ln.startswith("median step")]
-            d = [ln.strip() for ln in open(f) if ln.startswith("step time ms")]
+            d = [ln.strip() for ln in open(f) if ln.startswith("quartiles of the step time")]
             print(f"* wall clock, Loss_fn {mode}: {m[-1] if m else 'no result (see log)'}{' [' + d[-1] + ']' if d else ''}")
     print()
     f = first(f"{tag}_trace/**/*kernel_stats.csv")

@@ -218,15 +218,20 @@ def gen_head():
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def head_compact_inputs(B, S, seed):
-    """Seeded inputs of the compact head fixtures: logits are regenerated (bit-identically: torch CPU generator) instead of
-    stored, the fixture holds their bit checksum."""
-    logits = synth.make_head_logits(B, S, 64, 64, seed=seed)
+def head_compact_inputs(B, S, seed, logits_q=None):
+    """Inputs of the compact head fixtures.  The logits are stored as int16 multiples of 1/1024 (half the bytes of fp32, and exact:
+    `q / 1024` is the same float on every machine -- the synthetic generator itself is not, its exp() differs in the last bit
+    between CPUs); the cotangents are stored in the fixture, the two probe tensors come from the integer generator."""
+    if logits_q is None:
+        logits_q = (synth.make_head_logits(B, S, 64, 64, seed=seed) * 1024).round().clamp(-32768, 32767).to(torch.int16)
+    logits = logits_q.float() / 1024
     g = torch.Generator().manual_seed(199 + seed)
     ct_mean = torch.randn(B, S, 2, generator=g)
     ct_std = torch.randn(B, S, 2, generator=g)
-    probe = torch.randn(2, B, S, 64, 64, generator=g, dtype=torch.float64)  # two random functionals of the input gradient per map
-    return logits, ct_mean, ct_std, probe
+    # two random functionals of the input gradient per map, from the INTEGER generator (exact and identical on every machine;
+    # randn goes through log/sin/cos, whose last bit is not)
+    probe = torch.randint(-(1 << 20), 1 << 20, (2, B, S, 64, 64), generator=torch.Generator().manual_seed(299 + seed)).double() / (1 << 20)
+    return logits_q, logits, ct_mean, ct_std, probe
 
 
 def gen_head_compact():
@@ -237,10 +242,9 @@ def gen_head_compact():
     import ptnet
 
     for name, (B, S, seed) in dict(b4_s16_64x64=(4, 16, 11), b2_s64_64x64=(2, 64, 12)).items():
-        logits, ct_mean, ct_std, probe = head_compact_inputs(B, S, seed)
-        rec = dict(in_shape=np.array([B, S, 64, 64]), in_seed=np.int32(seed),
-                   in_logits_bits_xor=np.bitwise_xor.reduce(logits.numpy().view(np.uint32).ravel()),
-                   in_logits_bits_sum=np.sum(logits.numpy().view(np.uint32).ravel().astype(np.uint64)))  # integer: order-independent
+        logits_q, logits, ct_mean, ct_std, probe = head_compact_inputs(B, S, seed)
+        rec = dict(in_shape=np.array([B, S, 64, 64]), in_seed=np.int32(seed), in_logits_q=logits_q.numpy(),
+                   in_ct_mean=ct_mean.numpy(), in_ct_std=ct_std.numpy(), in_probe_xor=np.bitwise_xor.reduce(probe.numpy().view(np.uint64).ravel()))
         pick = [(0, 0), (0, S - 1), (B - 1, 0), (B - 1, S - 1), (B // 2, S // 2), (1, 3)]
         rec["g_maps"] = np.array(pick)
         for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):

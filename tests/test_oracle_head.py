@@ -25,15 +25,15 @@ COMPACT = golden_files("headc_")
 
 
 def compact_case(path):
-    """Inputs of a compact head fixture, regenerated from its seed and checked bit for bit against the stored checksum."""
+    """Inputs of a compact head fixture: logits from the stored int16 grid (exact on every machine), cotangents as stored, the
+    probe tensors regenerated from the seed and checked bit for bit against the stored checksum."""
     from tests.golden.gen_golden import head_compact_inputs
 
     z = np.load(path)
     B, S = int(z["in_shape"][0]), int(z["in_shape"][1])
-    logits, ct_mean, ct_std, probe = head_compact_inputs(B, S, int(z["in_seed"]))
-    assert np.bitwise_xor.reduce(logits.numpy().view(np.uint32).ravel()) == z["in_logits_bits_xor"]
-    assert int(np.sum(logits.numpy().view(np.uint32).ravel().astype(np.uint64))) == int(z["in_logits_bits_sum"])
-    return z, logits, ct_mean, ct_std, probe
+    _, logits, _, _, probe = head_compact_inputs(B, S, int(z["in_seed"]), logits_q=torch.from_numpy(z["in_logits_q"]))
+    assert np.bitwise_xor.reduce(probe.numpy().view(np.uint64).ravel()) == z["in_probe_xor"]  # integer stream: same bits everywhere
+    return z, logits, torch.from_numpy(z["in_ct_mean"]), torch.from_numpy(z["in_ct_std"]), probe
 
 
 def check_compact(z, mean, std, g, probe, tol_px, tol_g):

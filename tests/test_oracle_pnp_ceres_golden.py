@@ -21,9 +21,12 @@ RETS_SLACK = {"hard_B512_N12": 0.01, "minimal_B256_N4": 0.01}
 def check_against_ceres(path, solve):
     z = np.load(path)
     name = os.path.basename(path)[len("pnp_ceres_"):-4]
-    c = pnp_case(name)
-    for k, v in c.items():  # the fixture was generated from the same seeded inputs
-        np.testing.assert_array_equal(z["in_" + k], v, err_msg=f"{name}: input {k} differs from tests/pnp_cases.py")
+    # the STORED inputs are the truth (the machine that ran Ceres may round the synthetic generator's transcendental functions
+    # differently in the last bit); they must still be the seeded case, to fp32 rounding
+    c = {k[3:]: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k.startswith("in_")}
+    for k, v in pnp_case(name).items():
+        np.testing.assert_allclose(np.asarray(c[k], np.float64), np.asarray(v, np.float64), rtol=1e-5, atol=1e-4,
+                                   err_msg=f"{name}: input {k} is not the case of tests/pnp_cases.py")
     st, tr, ret = solve(c)
     ref_st, ref_tr, ref_ret = z["states"], z["result_tr"], z["rets"]
     flips = int((ret != ref_ret).sum())
