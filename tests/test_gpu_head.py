@@ -135,6 +135,6 @@ def test_head_vs_golden_survey_sizes(path):
     lg = logits.to(dev).requires_grad_(True)
     mean, std = spatial_softargmax_2d_std(lg)
     (g,) = torch.autograd.grad([mean, std], [lg], [ct_mean.to(dev), ct_std.to(dev)])
-    check_compact(z, mean.detach(), std.detach(), g, probe, 2e-4, 2e-6)
+    check_compact(z, mean.detach(), std.detach(), g, probe, 2e-4, 2e-6, tol_map=2e-4)  # same bounds as test_head_vs_golden (fp32 kernel, __expf)
     # the fp32 reference run sits as close to the fp64 one as the kernel does
     assert (torch.from_numpy(z["f32_mean"]).double() - torch.from_numpy(z["f64_mean"])).abs().max().item() <= 2e-4

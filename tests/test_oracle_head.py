@@ -36,7 +36,7 @@ def compact_case(path):
     return z, logits, torch.from_numpy(z["in_ct_mean"]), torch.from_numpy(z["in_ct_std"]), probe
 
 
-def check_compact(z, mean, std, g, probe, tol_px, tol_g):
+def check_compact(z, mean, std, g, probe, tol_px, tol_g, tol_map=2e-7):
     """mean/std of every map; the input gradient of every map through the two stored random functionals; six maps in full."""
     assert (mean.double().cpu() - torch.from_numpy(z["f64_mean"])).abs().max().item() <= tol_px
     assert (std.double().cpu() - torch.from_numpy(z["f64_std"])).abs().max().item() <= tol_px
@@ -45,7 +45,7 @@ def check_compact(z, mean, std, g, probe, tol_px, tol_g):
     scale = torch.from_numpy(z["f64_g_absmax"]).double() * 64  # |sum of 4096 terms g*N(0,1)| ~ 64 x typical |g|
     assert ((got - torch.from_numpy(z["f64_g_probe"])).abs() / scale).max().item() <= tol_g
     for (b, s), ref in zip(z["g_maps"], z["f64_g_logits_maps"]):
-        assert rel_err(g[b, s], ref) <= max(tol_g, 2e-7)  # the stored maps are float32 roundings of the float64 gradient
+        assert rel_err(g[b, s], ref) <= tol_map  # (the stored maps are float32 roundings of the float64 gradient: 6e-8)
 
 
 @pytest.mark.parametrize("path", COMPACT, ids=[case_name(p, "headc_") for p in COMPACT])
