@@ -151,9 +151,22 @@ constexpr int sum_bcast_lds_doubles(int K) { return K * 68 * NW + K; }
 // caller stores its K values itself with block_sum_put() AS IT PRODUCES THEM -- the LDS stores of a lone wave drain at about
 // 40 B/clk (MI355X_MICROARCH.md, LDS: one wave gets half the store rate), 360 cycles for 28 doubles x 64 lanes, and issued early they
 // drain behind the arithmetic that produces the later values -- then block_sum_close() for the reduction and the broadcast.
+// Ordering point of the LDS hand-offs inside the block sum.  A workgroup of ONE wavefront needs no barrier and no drain: the
+// DS operations of a wave execute in program order (a ds_read issued after a ds_write of another lane's slot returns the new
+// value), so the reads simply queue behind the stores and the wave stalls only where it consumes a loaded value; a
+// __syncthreads() here costs an `s_waitcnt lgkmcnt(0)` -- a full drain of the LDS queue -- three times per sum.
+#ifndef LC_WAVE_SYNC
+#define LC_WAVE_SYNC 0  // A/B switch (scripts/ubench/pnp_ab.py): 1 restores the drains for one-wave workgroups
+#endif
+template <int NW>
+__device__ __forceinline__ void block_sum_sync() {
+    if constexpr (NW == 1 && !LC_WAVE_SYNC) __builtin_amdgcn_wave_barrier();  // compiler-only: keeps the DS operations in program order
+    else __syncthreads();
+}
+
 template <int NW>
 __device__ __forceinline__ int block_sum_open(int tid) {
-    __syncthreads();  // the previous totals have been read
+    block_sum_sync<NW>();  // the previous totals have been read
     return tid + 2 * (tid >> 5);
 }
 template <int NW>
@@ -174,7 +187,7 @@ template <int K, int NW>
 __device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int tid) {
     static_assert(K <= 32 && (NW == 1 || NW == 4), "unsupported shape");
     constexpr int LD = 68 * NW, S = 2 * NW;
-    __syncthreads();
+    block_sum_sync<NW>();
     double s = 0;
     if (tid < K * S) {
         const double2* row = reinterpret_cast<const double2*>(lds + (tid / S) * LD + 34 * (tid % S));
@@ -201,7 +214,7 @@ __device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int
     }
     double* tot = lds + K * LD;
     if (tid < K * S && (tid % S) == 0) tot[tid / S] = s;
-    __syncthreads();
+    block_sum_sync<NW>();
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = tot[k];
 }

@@ -133,6 +133,13 @@ __device__ __forceinline__ PointJac point_jac(const PoseConst& pc, const double 
     return o;
 }
 
+// Workgroup-wide ordering point of the LDS hand-offs.  One-wave workgroups (N <= 64: the metric's shape) need neither a barrier nor
+// a drain of the LDS queue -- a wave's DS operations execute in program order (lc_common.h: block_sum_sync).
+__device__ __forceinline__ void wg_sync(int nw) {
+    if (nw == 1 && !LC_WAVE_SYNC) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
+
 template <int K>
 __device__ __forceinline__ void block_allreduce_small(double (&v)[K], double (*scratch)[4], int lane, int wave, int nw) {
     wave_allreduce<K>(v);
@@ -338,14 +345,14 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 #pragma unroll
         for (int i = 0; i < 3; ++i) sh.red[wave][bs + i] = acc[i];
     }
-    __syncthreads();
+    wg_sync(nw);
     if (nw > 1) {  // combine the waves' partials into sh.red[0]
         if (tid < 48) {
             double s = 0;
             for (int w = 0; w < nw; ++w) s += sh.red[w][tid];
             sh.red[0][tid] = s;
         }
-        __syncthreads();
+        wg_sync(nw);
     }
     // packed totals (upper triangles, so H and Mc are symmetric by construction: make_sure_symmetric, pnp_utils.py:134-137)
     const double* Hp = &sh.red[0][0];    // H  (21)
@@ -377,7 +384,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         if (tid < 36) sh.A0[tid] = cur;
         if (tid == 0) sh.bad[2] = ok ? 0 : 1;
     }
-    __syncthreads();
+    wg_sync(nw);
     const bool spd = sh.bad[2] == 0;
     LC_STAMP(6);
     const double* S = sh.A0;
@@ -445,7 +452,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         if (!(pd > 0)) sh.bad[0] = 1;  // loss_cov_3d / loss_cov_2d 'good' (cov_mixed.py:83-97)
         if (!(cd > 0)) sh.bad[1] = 1;
     }
-    __syncthreads();
+    wg_sync(nw);
     LC_STAMP(7);
     // step B: sqrt of the 8 corner traces (P, C) and the 8 corner norms (L) and their reciprocals; S v on six idle lanes
     if (tid < 24) {
@@ -463,7 +470,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         for (int k = 0; k < 6; ++k) acc2 += S[6 * a + k] * vp[k];
         sh.sv[a] = acc2;
     }
-    __syncthreads();
+    wg_sync(nw);
     LC_STAMP(8);
     double sP[8], sC[8], sL[8], Pm = 0, Cm = 0, Lm = 0;
 #pragma unroll
@@ -526,7 +533,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         sh.Hbar[tid] = spd ? hb : 0.0;
         if (mj == 0) sh.mu[mi] = mua;
     }
-    __syncthreads();
+    wg_sync(nw);
 
     LC_STAMP(10);
     // ---------------- pass 4: per-point gradients ----------------

@@ -237,6 +237,9 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 template <bool REG, int NW = 1, bool TRACE = false>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
+#ifdef LC_TRACE_CLOCK
+    const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
+#endif
     LC_PSTAMP_DECL;
     LC_PSTAMP_BEGIN();
     const int n = p.counts ? p.counts[b] : p.Nmax;
@@ -267,7 +270,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         const double s2 = q1 * q1 + q2 * q2 + q3 * q3;
         double kk = 2.0;
         if (s2 > 0.0) {
-            const double s = sqrt(s2);
+            const double s = fast_sqrt(s2);
             const double two_theta = 2.0 * ((q0 < 0.0) ? atan2(-s, -q0) : atan2(s, q0));
             kk = two_theta / s;
         }
@@ -333,7 +336,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         failed = !evaluate(x, one, H, g, cost);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {  // Jacobi scaling 1/(1+||J_j||), fixed at iteration 0
-            iscale[j] = 1.0 + sqrt(H[tri6(j, j)]);
+            iscale[j] = 1.0 + fast_sqrt(H[tri6(j, j)]);  // 4e-15 relative (lc_common.h); the libm sqrt costs ~100 cycles x 6 on the start-up path
             scale[j] = fast_rcp(iscale[j]);
         }
 #pragma unroll
@@ -360,6 +363,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
                 double* row = p.trace + ((size_t)b * p.trace_rows + (iter - 1)) * 8;
                 row[0] = kind; row[1] = cost_x; row[2] = cost_cand; row[3] = mcc; row[4] = rho; row[5] = step_norm;
                 row[6] = radius; row[7] = gmax;
+#ifdef LC_TRACE_CLOCK  // timing diagnostics only (scripts/ubench/pnp_iter_clock.py): shader cycles since the wave started
+                row[7] = (double)(__builtin_amdgcn_s_memtime() - t_start_);
+#endif
             }
         }
     };
@@ -447,7 +453,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             const double t2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
             double q0 = 1.0, kk = 0.5;
             if (t2 > 0.0) {
-                const double th = sqrt(t2), h = 0.5 * th;
+                const double th = fast_sqrt(t2), h = 0.5 * th;
                 double sh, ch;
                 sincos_small(h, sh, ch);  // < 1 ulp on the reduced interval, like the libm call it replaces
                 q0 = ch;
