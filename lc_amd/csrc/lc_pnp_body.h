@@ -271,7 +271,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         double kk = 2.0;
         if (s2 > 0.0) {
             const double s = fast_sqrt(s2);
-            const double two_theta = 2.0 * ((q0 < 0.0) ? atan2(-s, -q0) : atan2(s, q0));
+            // ceres/rotation.h: 2 atan2(s, c) with c >= 0, or 2 atan2(-s, -c) with c < 0: both are +-2 atan(s / |c|), s > 0
+            const double half = atan_ratio_pos(s, fabs(q0));
+            const double two_theta = 2.0 * ((q0 < 0.0) ? -half : half);
             kk = two_theta / s;
         }
         x[0] = q1 * kk; x[1] = q2 * kk; x[2] = q3 * kk;
@@ -352,7 +354,14 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         for (int j = 0; j < 6; ++j) m = fmax(m, fabs(gs[j]) * iscale[j]);
         return m;
     };
-    double gmax = grad_max(g), xnorm = norm6(x);
+    double gmax = grad_max(g);
+    auto sqnorm6 = [](const double (&v)[6]) {
+        double m = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m += v[j] * v[j];
+        return m;
+    };
+    double xn2 = sqnorm6(x);  // ||x||^2; the norm itself is only formed when the parameter-tolerance test is in reach
     double radius = 1e4, dfac = 2.0;
     int iter = 0, n_invalid = 0;
     bool converged = false;
@@ -399,13 +408,23 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         double xc[6], delta[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) { delta[j] = -y[j] * scale[j]; xc[j] = x[j] + delta[j]; }
-        const double step_norm = norm6(delta);
+        // ParameterToleranceReached is  ||delta|| <= ptol (||x|| + ptol).  Since (a + b)^2 <= 2 (a^2 + b^2), a step with
+        // ||delta||^2 > 2 ptol^2 (||x||^2 + ptol^2) cannot pass: two square roots per iteration are only taken next to convergence
+        // (and by the diagnostic twin, which records the step norm).
+        const double sn2 = sqnorm6(delta);
+        const bool ptol_in_reach = TRACE || uniform(!(sn2 > 2.0 * ptol * ptol * (xn2 + ptol * ptol)));
+        double step_norm = 0.0;
+        bool ptol_hit = false;
+        if (ptol_in_reach) {  // scalar branch
+            step_norm = fast_sqrt(sn2);
+            ptol_hit = uniform(step_norm <= ptol * (fast_sqrt(xn2) + ptol));
+        }
         // the candidate's H, g overwrite the current ones (an accepted step then needs no copy and no second Jacobian);
         // a rejected step -- rare -- restores them by re-evaluating at x
         double cost_c;
         const bool cand_ok = evaluate(xc, scale, H, g, cost_c);
         if (!cand_ok) cost_c = DBL_MAX;
-        if (uniform(step_norm <= ptol * (xnorm + ptol))) {  // ParameterToleranceReached
+        if (ptol_hit) {  // ParameterToleranceReached
             converged = true; trace(3, cost, cost_c, mcc, 0.0, step_norm); break;
         }
         const double cost_change = cost - cost_c;
@@ -418,7 +437,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             for (int j = 0; j < 6; ++j) x[j] = xc[j];
             const double cost_prev = cost;
             cost = cost_c;
-            xnorm = norm6(x);
+            xn2 = sqnorm6(x);
             gmax = grad_max(g);
             const double tq = 2.0 * rel - 1.0;
             radius = fmin(1e16, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - tq * tq * tq)));
