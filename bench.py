@@ -267,12 +267,15 @@ def main():
 
     region_s = []
     for _ in range(max(1, args.regions)):
-        fence()
+        fence()  # synchronize + barrier + synchronize: every rank starts the region together
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        fence()
+        torch.cuda.synchronize(dev)  # this rank's K steps are done ...
         region_s.append(time.perf_counter() - t0)
+        if dist is not None:
+            dist.barrier()  # ... and the region ends when the slowest rank is (MAX over ranks below); the collective's own
+            # latency (tens of us over RCCL) is not part of the K steps
     agg = lcd.aggregate_regions(region_s, args.steps, device="cpu" if (share_gpu or dist is None) else dev)
     elapsed = agg["median_region_s"]
     if args.launch == "streams":

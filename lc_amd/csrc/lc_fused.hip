@@ -30,7 +30,7 @@ int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stre
     const int blocks = (lp.B > 0 ? lp.B : 0) + (pp.B > 0 ? pp.B : 0);
     if (blocks == 0) return 0;
     if (blocks > kLatencyGridMax)
-        hipLaunchKernelGGL(lc_pose_unit_kernel<2>, dim3(blocks), dim3(64), 0, stream, lp, pp);
+        hipLaunchKernelGGL(lc_pose_unit_kernel<LC_BIG_WPS>, dim3(blocks), dim3(64), 0, stream, lp, pp);
     else
         hipLaunchKernelGGL(lc_pose_unit_kernel<1>, dim3(blocks), dim3(64), 0, stream, lp, pp);
     return hipGetLastError() == hipSuccess ? 0 : 2;

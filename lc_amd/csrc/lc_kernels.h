@@ -7,6 +7,9 @@ namespace lc {
 constexpr int kLossAuxStride = 40;
 // up to this many one-wave workgroups use the register-rich 'latency' build (1 wave/SIMD, no spills); beyond it the
 // 2-waves/SIMD build wins (measured: B = 768 -> 19 us, B = 1024 -> 57 us with the latency build vs 19.5 us with the other)
+#ifndef LC_BIG_WPS
+#define LC_BIG_WPS 2  // waves per SIMD the large-grid builds of the pose kernels are register-limited to (A/B: scripts/ubench/pnp_ab.py)
+#endif
 constexpr int kLatencyGridMax = 768;  // P, C, L, not_spd, Hinv[36]
 
 struct LossParams {

@@ -42,7 +42,7 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     const bool big = p.B > kLatencyGridMax;
     if (p.Nmax <= 64) {
-        if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 2>), dim3(p.B), dim3(64), 0, stream, p);
+        if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS>), dim3(p.B), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);
     } else if (p.Nmax <= 256) {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);
