@@ -85,6 +85,41 @@ __device__ __forceinline__ void store4(T* q, float4 v) {
     }
 }
 
+// Eight consecutive elements per access: two 16-byte accesses for fp32 maps, ONE 16-byte access for the 16-bit types (an 8-byte
+// access per lane moved 4.6-5.6 TB/s on bf16 maps where the 16-byte fp32 form moves 6.7 TB/s).
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ void load8(const T* q, float (&x)[8], bool nt) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 a = nt ? load4_nt<T>(q) : load4<T>(q), b = nt ? load4_nt<T>(q + 4) : load4<T>(q + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+        const v4u_t r = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(q)) : *reinterpret_cast<const v4u_t*>(q);
+        T h[8];
+        __builtin_memcpy(h, &r, 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (float)h[j];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* q, const float (&g)[8], bool nt) {
+    if constexpr (sizeof(T) == 4) {
+        if (nt) { store4_nt<T>(q, make_float4(g[0], g[1], g[2], g[3])); store4_nt<T>(q + 4, make_float4(g[4], g[5], g[6], g[7])); }
+        else { store4<T>(q, make_float4(g[0], g[1], g[2], g[3])); store4<T>(q + 4, make_float4(g[4], g[5], g[6], g[7])); }
+    } else {
+        T h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (T)g[j];
+        v4u_t r;
+        __builtin_memcpy(&r, h, 16);
+        if (nt) __builtin_nontemporal_store(r, reinterpret_cast<v4u_t*>(q));
+        else *reinterpret_cast<v4u_t*>(q) = r;
+    }
+}
+
+constexpr float kLog2e = 1.44269504088896340736f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (1 ulp; no denormal range fix-up needed: x <= 0 here or the product with it underflows to 0 anyway)
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
@@ -347,11 +382,7 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
 
     float x[8][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float4 a = ntl ? load4_nt<T>(in + 512 * k) : load4<T>(in + 512 * k), b = ntl ? load4_nt<T>(in + 512 * k + 4) : load4<T>(in + 512 * k + 4);
-        x[k][0] = a.x; x[k][1] = a.y; x[k][2] = a.z; x[k][3] = a.w;
-        x[k][4] = b.x; x[k][5] = b.y; x[k][6] = b.z; x[k][7] = b.w;
-    }
+    for (int k = 0; k < 8; ++k) load8<T>(in + 512 * k, x[k], ntl);
     float bmax = 0.f;
     if (!is_prob) {
         float lmax = -INFINITY;
@@ -361,6 +392,7 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
             for (int j = 0; j < 8; ++j) lmax = fmaxf(lmax, x[k][j]);
         bmax = wave_max(lmax);
     }
+    const float nbmax = -bmax * kLog2e;
     float col[8], row[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[j] = 0.f;
@@ -369,7 +401,7 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
         float r = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float e = is_prob ? x[k][j] : __expf(x[k][j] - bmax);
+            const float e = is_prob ? x[k][j] : exp2_fast(__builtin_fmaf(x[k][j], kLog2e, nbmax));  // exp(x - max): one fma + v_exp_f32
             col[j] += e;
             r += e;
         }
@@ -411,8 +443,11 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
     }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool COLFIX = false>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwdParams p) {
+    // every fused multiply-add of this kernel is written out and contraction is off: the VEC = 1 / 4 (fp32) and VEC = 8 (16-bit)
+    // instantiations must produce the same bits -- the 16-bit gradient is DEFINED as the fp32 one rounded to nearest even
+#pragma clang fp contract(off)
     const int H = p.H, W = p.W, HW = H * W;
     const size_t m = (p.variant & 4) ? (size_t)(p.M - 1) - blockIdx.x : (size_t)blockIdx.x;
     const bool nts = (p.variant & 1) != 0, ntl = (p.variant & 2) != 0;
@@ -428,12 +463,49 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwd
     const float cdot = gmx * mx + gmy * my + gvx * vx + gvy * vy;
     const float ex = is_prob ? -2.f * gvx * mx * (1.f - s0) : 0.f;
     const float ey = is_prob ? -2.f * gvy * my * (1.f - s0) : 0.f;
+    [[maybe_unused]] const float cdot_l = is_prob ? 0.f : cdot;
+    if constexpr (COLFIX) {
+        // (kHeadThreads * VEC) % W == 0: a thread meets the same VEC columns in every iteration, so the column part of
+        //   q[h,w] = gmx w + gvx (w - mx)^2 + ex w  +  qy[h]
+        // is formed once per thread and an element costs: fma + v_exp (exp(x - lse)), one add, one mul (+ the conversion for 16-bit maps)
+        // -- the generic loop below spends ~12 VALU instructions per element, which made the 16-bit backward VALU-bound (53 us for
+        // 268 MB = 5.0 TB/s) instead of HBM-bound.
+        const int e0 = threadIdx.x * VEC, w0 = e0 % W;
+        float qx[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float wf = (float)(w0 + j), dx = wf - mx;
+            qx[j] = __builtin_fmaf(gvx * dx, dx, __builtin_fmaf(gmx, wf, -cdot_l));
+        }
+        const float ns0 = -s0 * kLog2e;
+        const int rows_per_iter = kHeadThreads * VEC / W;
+        int h = e0 / W;
+        for (int e = e0; e < HW; e += kHeadThreads * VEC, h += rows_per_iter) {
+            const float dy = (float)h - my;
+            const float qy = __builtin_fmaf(gvy * dy, dy, gmy * (float)h);
+            float xin[VEC], g[VEC];
+            if constexpr (VEC == 8) load8<T>(in + e, xin, ntl);
+            else {
+                const float4 v = ntl ? load4_nt<T>(in + e) : load4<T>(in + e);
+                xin[0] = v.x; xin[1] = v.y; xin[2] = v.z; xin[3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g[j] = exp2_fast(__builtin_fmaf(xin[j], kLog2e, ns0)) * (qx[j] + qy);  // (logits form: ex = ey = 0)
+            if constexpr (VEC == 8) store8<T>(out + e, g, nts);
+            else if (nts) store4_nt<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
+            else store4<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
+        }
+        return;
+    }
+    // generic form (any shape, probability input): explicit fused multiply-adds like the fast path
     for (int e = threadIdx.x * VEC; e < HW; e += kHeadThreads * VEC) {
         const int h = e / W, w0 = e - h * W;
-        const float dy = (float)h - my;
-        const float qy = gmy * (float)h + gvy * dy * dy + ey * (float)h;
+        const float dy = (float)h - my, hf = (float)h;
+        const float qy = __builtin_fmaf(gvy * dy, dy, __builtin_fmaf(gmy, hf, ey * hf));
         float xin[VEC], g[VEC];
-        if constexpr (VEC == 4) {
+        if constexpr (VEC == 8) {
+            load8<T>(in + e, xin, ntl);
+        } else if constexpr (VEC == 4) {
             const float4 v = ntl ? load4_nt<T>(in + e) : load4<T>(in + e);
             xin[0] = v.x; xin[1] = v.y; xin[2] = v.z; xin[3] = v.w;
         } else {
@@ -443,10 +515,12 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_bwd_kernel(const HeadBwd
         for (int j = 0; j < VEC; ++j) {
             const float wf = (float)(w0 + j);
             const float dx = wf - mx;
-            const float q = gmx * wf + gvx * dx * dx + ex * wf + qy;
+            const float q = __builtin_fmaf(gvx * dx, dx, __builtin_fmaf(gmx, wf, __builtin_fmaf(ex, wf, qy)));
             g[j] = is_prob ? q : __expf(xin[j] - s0) * (q - cdot);
         }
-        if constexpr (VEC == 4) {
+        if constexpr (VEC == 8) {
+            store8<T>(out + e, g, nts);
+        } else if constexpr (VEC == 4) {
             if (nts) store4_nt<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
             else store4<T>(out + e, make_float4(g[0], g[1], g[2], g[3]));
         } else {
@@ -483,7 +557,7 @@ int launch_head_fwd_t(const HeadParams& p, hipStream_t stream) {
     while (nvp < nv) nvp <<= 1;
     const bool out8 = ((reinterpret_cast<uintptr_t>(p.mean) | reinterpret_cast<uintptr_t>(p.std)) & 7) == 0 &&
                       (reinterpret_cast<uintptr_t>(p.stats) & 15) == 0;
-    if (vec4 && out8 && p.W == 64 && p.H == 64) {
+    if (vec4 && out8 && p.W == 64 && p.H == 64 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0) {  // 16-byte accesses (load8)
         const int waves = kHeadThreads / kWave;
         hipLaunchKernelGGL(lc_head_fwd_wave64_kernel<T>, dim3((p.M + waves - 1) / waves), dim3(kHeadThreads), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : 2;
@@ -505,7 +579,15 @@ template <typename T>
 int launch_head_bwd_t(const HeadBwdParams& p, hipStream_t stream) {
     const uintptr_t vec_mask = 4 * sizeof(T) - 1;
     const bool vec4 = (p.W % 4 == 0) && (((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.g_in)) & vec_mask) == 0);
-    if (vec4)
+    const bool vec8 = sizeof(T) == 2 && (p.W % 8 == 0) && (((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.g_in)) & 15) == 0);
+    const bool logits = p.is_prob == 0;  // the column-fixed fast path covers the logits form (every training call site)
+    if (vec8 && logits && (kHeadThreads * 8) % p.W == 0)
+        hipLaunchKernelGGL((lc_head_bwd_kernel<T, 8, true>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+    else if (vec8)  // 16-bit maps: one 16-byte access per eight elements
+        hipLaunchKernelGGL((lc_head_bwd_kernel<T, 8>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+    else if (vec4 && logits && (kHeadThreads * 4) % p.W == 0)
+        hipLaunchKernelGGL((lc_head_bwd_kernel<T, 4, true>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
+    else if (vec4)
         hipLaunchKernelGGL((lc_head_bwd_kernel<T, 4>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
     else
         hipLaunchKernelGGL((lc_head_bwd_kernel<T, 1>), dim3(p.M), dim3(kHeadThreads), 0, stream, p);
