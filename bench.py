@@ -284,16 +284,21 @@ def main():
         assert int(ret.sum().item()) == 0 and bool(torch.isfinite(loss).all())
 
     # per-kernel launch duration with events on the launch stream (torch's current stream == the kernels' stream)
-    def kernel_ms(fn, reps=200):
+    def kernel_ms(fn, reps=200, windows=5):
+        """Average launch duration: HIP events around `reps` back-to-back launches on the launch stream, MEDIAN of `windows` such
+        windows (the shared pool shows occasional ~60 ms stalls; one of them inside a 3 ms window would wreck a single reading)."""
         fn()
         torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / reps
+        out = []
+        for _ in range(windows):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            out.append(e0.elapsed_time(e1) / reps)
+        return sorted(out)[len(out) // 2]
 
     def kernel_percentiles_us(fn, reps=200):
         """p10 / median / p90 of individually event-timed launches (SURVEY.md 8d timing protocol)."""
@@ -322,7 +327,7 @@ def main():
                                       P(gos), Bs, N, 32.0, 3.0, 4.0, P(o_loss), P(o[0]), P(o[1]), P(o[2]), P(sd), P(bb["start"]),
                                       P(o[3]), P(o[4]), P(o[5]), 50, 1e-6, _lib.stream_ptr(dev))
             assert rc == 0
-        ms = kernel_ms(one, reps=20)
+        ms = kernel_ms(one, reps=6, windows=5)
         assert int(o[5].sum().item()) == 0
         return Bs, Bs / (ms * 1e-3), ms
 

@@ -225,3 +225,36 @@ def test_pnp_degenerate_jobs_vs_oracle():
     assert np.isfinite(st[ok]).all()
     dq, dt = pose_err(st[ok], so[ok])
     assert dq.max() <= 1e-4 and dt.max() <= 1e-4, (dq, dt)
+
+
+def test_pnp_full_size_permutation_and_batch_independence():
+    """B = 4096 x N = 64: (a) the solve does not depend on the order of the correspondences beyond round-off (sums over points);
+    (b) jobs are independent: a slice of the batch alone returns the same rows bit for bit; (c) the in-place form (`start` aliasing
+    `states`, the reference's contract) equals the out-of-place form."""
+    from lc_amd import _lib
+    from lc_amd.pnp import pnp_ceres
+
+    dev = torch.device("cuda:0")
+    B, N = 4096, 64
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=77).items()}
+    st, tr, ret = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"])
+    assert int(ret.sum()) == 0
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).to(dev)
+    stp, trp, retp = pnp_ceres.solve_device(b["K"], b["pts3d"][:, perm].contiguous(), b["pts2d"][:, perm].contiguous(),
+                                            b["inv_std"][:, perm].contiguous(), b["start"])
+    assert torch.equal(retp, ret)
+    dq, dt = pose_err(stp.cpu().numpy(), st.cpu().numpy())
+    assert dq.max() <= 1e-5 and dt.max() <= 1e-5, (dq.max(), dt.max())
+    sl = slice(2000, 2049)
+    sts, trs, rets = pnp_ceres.solve_device(*(b[k][sl].contiguous() for k in ("K", "pts3d", "pts2d", "inv_std", "start")))
+    assert torch.equal(sts, st[sl]) and torch.equal(trs, tr[sl]) and torch.equal(rets, ret[sl])
+    # in place: states holds the start poses on entry (lc_pnp_lm_f32 with start == NULL)
+    lib = _lib.load()
+    inplace = b["start"].clone()
+    tr2 = torch.empty(B, device=dev)
+    ret2 = torch.empty(B, device=dev, dtype=torch.int32)
+    rc = lib.lc_pnp_lm_f32(_lib.ptr(b["K"]), _lib.ptr(b["pts3d"]), _lib.ptr(b["pts2d"]), None, _lib.ptr(b["inv_std"]), None, None, _lib.ptr(inplace),
+                           _lib.ptr(tr2), _lib.ptr(ret2), None, B, N, 50, 1e-6, _lib.stream_ptr(dev))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(inplace, st) and torch.equal(tr2, tr) and torch.equal(ret2, ret)
