@@ -191,16 +191,16 @@ static int qr_solve6(double *A, double *b, int m, double y[6]) {
 #define PNP_TRACE_COLS 8
 enum { TR_INVALID = 0, TR_ACCEPT = 1, TR_REJECT = 2, TR_PTOL = 3, TR_FTOL = 4 };
 
-static void solve_core(float *io_state_quat, const float *cam_K, const float *pts2d, const float *pts3d,
-                       const float *icov_sqrtL, int ptCnt, int maxIterCnt, float function_tolerance, int printSummary,
-                       float *result_tr, int *ret, double *trace, int trace_rows, int *n_iter) {
-    if (n_iter) *n_iter = 0;
-    if (ptCnt < 3) { /* ceres.cpp:84-91 */
-        *ret = 1;
-        *result_tr = 1;
-        if (printSummary) printf("skipped problem with less than 3 points\n");
-        return;
-    }
+/* The minimiser itself -- Ceres 2.1.0's TrustRegionMinimizer with the LevenbergMarquardtStrategy and DENSE_QR, as restated in
+ * the header -- over ANY residual function of six parameters (fewer: pad with parameters that no residual depends on; their
+ * Jacobian columns are zero, the damping rows keep [J; D] full rank and their step is exactly zero).  The PnP solve below and the
+ * published-trace check (oracle_powell_trace: Powell's function from the Ceres tutorial) both run through it.
+ *   eval(ctx, x, r, J or NULL, &cost) -> 0 if anything is non-finite;  m residuals;  x in/out.
+ *   returns 1 when the termination type is CONVERGENCE (gradient / parameter / function tolerance or minimum radius), else 0. */
+typedef int (*eval_fn)(const void *ctx, const double x[6], double *r, double *J, double *cost);
+
+static int lm_minimize(eval_fn evaluate_fn, const void *ctx, int m, double x[6], int maxIterCnt, double ftol, int printSummary,
+                       double *radius_out, double *trace, int trace_rows, int *n_iter) {
 #define TRACE(kind, cc, mcc, rho, sn)                                                          \
     do {                                                                                       \
         if (trace && iter <= trace_rows) {                                                     \
@@ -209,26 +209,18 @@ static void solve_core(float *io_state_quat, const float *cam_K, const float *pt
             row_[5] = (sn); row_[6] = radius; row_[7] = gmax;                                  \
         }                                                                                      \
     } while (0)
-    problem_t P;
-    P.n = ptCnt; P.u = pts2d; P.X = pts3d; P.L = icov_sqrtL;
-    for (int i = 0; i < 6; ++i) P.cam[i] = cam_K[i];
-    double x[6], quat[4] = {io_state_quat[0], io_state_quat[1], io_state_quat[2], io_state_quat[3]};
-    quat_to_aa(quat, x);
-    for (int i = 0; i < 3; ++i) x[3 + i] = io_state_quat[4 + i];
-
-    const int m = 2 * ptCnt;
     double *r = (double *)malloc(sizeof(double) * (size_t)(m + 6) * 2);
     double *rc = r + (m + 6);
     double *J = (double *)malloc(sizeof(double) * (size_t)(m + 6) * 6 * 2);
     double *Aw = J + (size_t)(m + 6) * 6;
 
-    const double ftol = function_tolerance, ptol = 1e-8, gtol = 1e-10;
+    const double ptol = 1e-8, gtol = 1e-10;
     const double min_rel_decrease = 1e-3, max_radius = 1e16, min_radius = 1e-32;
     double radius = 1e4, decrease_factor = 2.0;
     double x_cost = 0, scale[6], g[6], gmax = 0, x_norm = 0;
     int converged = 0, failed = 0, iter = 0, n_invalid = 0;
 
-    if (!evaluate(&P, x, r, J, &x_cost)) failed = 1; /* "Initial residual and Jacobian evaluation failed." */
+    if (!evaluate_fn(ctx, x, r, J, &x_cost)) failed = 1; /* "Initial residual and Jacobian evaluation failed." */
     if (!failed) {
         for (int j = 0; j < 6; ++j) {
             double cn = 0;
@@ -282,7 +274,7 @@ static void solve_core(float *io_state_quat, const float *cam_K, const float *pt
         for (int j = 0; j < 6; ++j) { delta[j] = step[j] * scale[j]; xc[j] = x[j] + delta[j]; step_norm += delta[j] * delta[j]; }
         step_norm = sqrt(step_norm);
         double cand_cost;
-        if (!evaluate(&P, xc, rc, NULL, &cand_cost)) cand_cost = DBL_MAX;
+        if (!evaluate_fn(ctx, xc, rc, NULL, &cand_cost)) cand_cost = DBL_MAX;
         if (step_norm <= ptol * (x_norm + ptol)) {                                   /* ParameterToleranceReached */
             converged = 1; TRACE(TR_PTOL, cand_cost, model_cost_change, 0.0, step_norm); break;
         }
@@ -297,7 +289,7 @@ static void solve_core(float *io_state_quat, const float *cam_K, const float *pt
             x_norm = 0;
             for (int j = 0; j < 6; ++j) x_norm += x[j] * x[j];
             x_norm = sqrt(x_norm);
-            if (!evaluate(&P, x, r, J, &x_cost)) { failed = 1; break; }
+            if (!evaluate_fn(ctx, x, r, J, &x_cost)) { failed = 1; break; }
             gmax = 0;
             for (int j = 0; j < 6; ++j) {
                 g[j] = 0;
@@ -320,7 +312,34 @@ static void solve_core(float *io_state_quat, const float *cam_K, const float *pt
     free(r); free(J);
 #undef TRACE
     if (n_iter) *n_iter = iter;
-    const int invalid = !(converged && !failed);
+    *radius_out = radius;
+    return converged && !failed;
+}
+
+static int evaluate_pnp(const void *ctx, const double x[6], double *r, double *J, double *cost) {
+    return evaluate((const problem_t *)ctx, x, r, J, cost);
+}
+
+static void solve_core(float *io_state_quat, const float *cam_K, const float *pts2d, const float *pts3d,
+                       const float *icov_sqrtL, int ptCnt, int maxIterCnt, float function_tolerance, int printSummary,
+                       float *result_tr, int *ret, double *trace, int trace_rows, int *n_iter) {
+    if (n_iter) *n_iter = 0;
+    if (ptCnt < 3) { /* ceres.cpp:84-91 */
+        *ret = 1;
+        *result_tr = 1;
+        if (printSummary) printf("skipped problem with less than 3 points\n");
+        return;
+    }
+    problem_t P;
+    P.n = ptCnt; P.u = pts2d; P.X = pts3d; P.L = icov_sqrtL;
+    for (int i = 0; i < 6; ++i) P.cam[i] = cam_K[i];
+    double x[6], quat[4] = {io_state_quat[0], io_state_quat[1], io_state_quat[2], io_state_quat[3]};
+    quat_to_aa(quat, x); /* ceres.cpp:96 */
+    for (int i = 0; i < 3; ++i) x[3 + i] = io_state_quat[4 + i];
+    double radius;
+    const int ok = lm_minimize(evaluate_pnp, &P, 2 * ptCnt, x, maxIterCnt, (double)function_tolerance, printSummary, &radius, trace, trace_rows,
+                               n_iter);
+    const int invalid = !ok;
     *ret = invalid;
     *result_tr = (float)radius;
     if (invalid) return; /* ceres.cpp:134-138: state untouched unless CONVERGENCE */
@@ -380,4 +399,62 @@ void pnp_oracle_batched_trace_f32(float *states, const float *Ks, const float *p
         solve_core(states + 7 * (size_t)i, Ks + 9 * (size_t)i, pts2d + 2 * (size_t)i * nmax, pts3d + 3 * (size_t)i * nmax,
                    sqrtL + 4 * (size_t)i * nmax, ptCnts[i], maxIterCnt, function_tolerance, 0, result_trs + i, rets + i,
                    trace + (size_t)i * trace_rows * PNP_TRACE_COLS, trace_rows, iters + i);
+}
+
+
+/* ---- Published-trace check of the minimiser: Powell's function, the second example of the Ceres tutorial ("Non-linear Least
+ * Squares", examples/powell.cc): f1 = x1 + 10 x2, f2 = sqrt(5) (x3 - x4), f3 = (x2 - 2 x3)^2, f4 = sqrt(10) (x1 - x4)^2 from
+ * x = (3, -1, 0, 1) with DENSE_QR and default options -- the documentation prints the per-iteration log of that run (cost,
+ * cost_change, |gradient|, |step|, tr_ratio, tr_radius), which tests/test_oracle_ceres_published.py compares row by row.
+ * Parameters 5 and 6 are padding (see lm_minimize). */
+static int evaluate_powell(const void *ctx, const double x[6], double *r, double *J, double *cost) {
+    (void)ctx;
+    const double s5 = sqrt(5.0), s10 = sqrt(10.0);
+    r[0] = x[0] + 10.0 * x[1];
+    r[1] = s5 * (x[2] - x[3]);
+    r[2] = (x[1] - 2.0 * x[2]) * (x[1] - 2.0 * x[2]);
+    r[3] = s10 * (x[0] - x[3]) * (x[0] - x[3]);
+    *cost = 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    if (J) {
+        memset(J, 0, sizeof(double) * 4 * 6);
+        J[0 * 6 + 0] = 1.0; J[0 * 6 + 1] = 10.0;
+        J[1 * 6 + 2] = s5; J[1 * 6 + 3] = -s5;
+        J[2 * 6 + 1] = 2.0 * (x[1] - 2.0 * x[2]); J[2 * 6 + 2] = -4.0 * (x[1] - 2.0 * x[2]);
+        J[3 * 6 + 0] = 2.0 * s10 * (x[0] - x[3]); J[3 * 6 + 3] = -2.0 * s10 * (x[0] - x[3]);
+    }
+    return isfinite(*cost);
+}
+
+/* x: 4 doubles in/out; trace: (trace_rows, PNP_TRACE_COLS); returns 1 on CONVERGENCE; *initial = {cost, max|gradient|} at the start */
+int oracle_powell_trace(double *x4, int max_iter, double ftol, double *trace, int trace_rows, int *n_iter, double *radius, double *initial) {
+    double x[6] = {x4[0], x4[1], x4[2], x4[3], 0.0, 0.0};
+    double r[4], J[24], c;
+    evaluate_powell(NULL, x, r, J, &c);
+    initial[0] = c;
+    initial[1] = 0;
+    for (int j = 0; j < 4; ++j) {
+        double gj = 0;
+        for (int i = 0; i < 4; ++i) gj += J[i * 6 + j] * r[i];
+        initial[1] = fmax(initial[1], fabs(gj));
+    }
+    const int ok = lm_minimize(evaluate_powell, NULL, 4, x, max_iter, ftol, 0, radius, trace, trace_rows, n_iter);
+    for (int j = 0; j < 4; ++j) x4[j] = x[j];
+    return ok;
+}
+
+/* The first example of the same tutorial ("Hello World!", examples/helloworld.cc): one residual f = 10 - x from x = 0.5.  Its
+ * published log pins the Levenberg-Marquardt damping at radius 1e4 (cost 4.511598e-07 after one step) and the exit by the
+ * parameter tolerance in the third iteration. */
+static int evaluate_hello(const void *ctx, const double x[6], double *r, double *J, double *cost) {
+    (void)ctx;
+    r[0] = 10.0 - x[0];
+    *cost = 0.5 * r[0] * r[0];
+    if (J) { memset(J, 0, sizeof(double) * 6); J[0] = -1.0; }
+    return isfinite(*cost);
+}
+int oracle_hello_trace(double *x1, int max_iter, double ftol, double *trace, int trace_rows, int *n_iter, double *radius) {
+    double x[6] = {x1[0], 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int ok = lm_minimize(evaluate_hello, NULL, 1, x, max_iter, ftol, 0, radius, trace, trace_rows, n_iter);
+    x1[0] = x[0];
+    return ok;
 }

@@ -39,6 +39,11 @@ def lib():
         _lib.pnp_oracle_batched_f32.restype = None
         _lib.pnp_oracle_batched_trace_f32.argtypes = _lib.pnp_oracle_batched_f32.argtypes + [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ip]
         _lib.pnp_oracle_batched_trace_f32.restype = None
+        dp = ctypes.POINTER(ctypes.c_double)
+        _lib.oracle_powell_trace.argtypes = [dp, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, ip, dp, dp]
+        _lib.oracle_powell_trace.restype = ctypes.c_int
+        _lib.oracle_hello_trace.argtypes = [dp, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, ip, dp]
+        _lib.oracle_hello_trace.restype = ctypes.c_int
     return _lib
 
 
@@ -104,3 +109,30 @@ def solve_batched_trace(states, Ks, pts2d, pts3d, sqrtL, counts=None, max_iter=5
                                    int(max_iter), float(ftol), _fp(tr), ret.ctypes.data_as(ip), B, int(num_threads),
                                    trace.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(trace_rows), iters.ctypes.data_as(ip))
     return states, tr, ret, iters, trace
+
+
+def powell_trace(x0=(3.0, -1.0, 0.0, 1.0), max_iter=100, ftol=1e-6, trace_rows=100):
+    """The oracle's minimiser (the same `lm_minimize` the PnP solve runs through) on Powell's function, the example whose
+    per-iteration log the Ceres documentation prints.  -> (converged, x (4,), iterations, final radius, (cost0, max|g0|), trace)."""
+    L = lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    x = np.array(x0, np.float64)
+    trace = np.zeros((trace_rows, TRACE_COLS), np.float64)
+    n = ctypes.c_int(0)
+    radius, initial = np.zeros(1), np.zeros(2)
+    ok = L.oracle_powell_trace(x.ctypes.data_as(dp), int(max_iter), float(ftol), trace.ctypes.data_as(dp), int(trace_rows), ctypes.byref(n),
+                               radius.ctypes.data_as(dp), initial.ctypes.data_as(dp))
+    return bool(ok), x, n.value, float(radius[0]), (float(initial[0]), float(initial[1])), trace[:n.value]
+
+
+def hello_trace(x0=0.5, max_iter=100, ftol=1e-6, trace_rows=10):
+    """`lm_minimize` on f = 10 - x (the tutorial's first example).  -> (converged, x, iterations, final radius, trace)."""
+    L = lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    x = np.array([x0], np.float64)
+    trace = np.zeros((trace_rows, TRACE_COLS), np.float64)
+    n = ctypes.c_int(0)
+    radius = np.zeros(1)
+    ok = L.oracle_hello_trace(x.ctypes.data_as(dp), int(max_iter), float(ftol), trace.ctypes.data_as(dp), int(trace_rows), ctypes.byref(n),
+                              radius.ctypes.data_as(dp))
+    return bool(ok), float(x[0]), n.value, float(radius[0]), trace[:n.value]
