@@ -16,9 +16,18 @@
  *   max|g| <= 1e-10 (CONVERGENCE), iteration >= max_num_iterations (NO_CONVERGENCE -> invalid),
  *   5 consecutive invalid steps (FAILURE -> invalid).
  *
- * PARITY UNPINNED against Ceres itself: the reference holds no test or golden vector for this
- * boundary.  tests/test_oracle_pnp.py anchors it with known-answer tests instead
- * (noise-free recovery, stationarity, SciPy least_squares cross-check, <3 points, full 2x2 icov).
+ * PARITY STATUS.  No vector produced by the reference's own pnp_ceres_f32 exists (Ceres is not buildable here, the
+ * reference holds no test at this boundary: SURVEY.md 8c), so the COMPOSITE is unpinned in the strict sense; its two halves
+ * are pinned separately:
+ *   - the optimiser (lm_minimize below: the loop every PnP solve runs through) reproduces, to every printed digit, the
+ *     per-iteration logs that the Ceres documentation publishes for its tutorial problems -- Powell's function (14 iterations:
+ *     cost, cost change, |gradient|, |step|, trust-region ratio and radius, termination by the gradient tolerance, final x)
+ *     and hello-world (the LM damping at radius 1e4, exit by the parameter tolerance): tests/golden/ceres_*_published.txt,
+ *     tests/test_oracle_ceres_published.py;
+ *   - the residual model (ceres.cpp:15-65) by optimisers that share nothing with this file (SciPy/MINPACK minimisers,
+ *     tests/test_oracle_pnp.py, tests/golden/pnp_minimiser_*.npz) and known-answer tests (noise-free recovery, stationarity,
+ *     <3 points, full 2x2 icov);
+ *   - tests/golden/gen_golden_pnp_ceres.py produces reference vectors of the composite wherever the reference's extension exists.
  *
  * Residual model (ceres.cpp:15-65): p = R(aa) X + t; up = (p0 k0 + p1 k1)/p2, vp = (p0 k3 + p1 k4)/p2,
  * du = up-(u-k2), dv = vp-(v-k5); r = [du*L00 + dv*L10, dv*L11]; no z clamp; doubles inside.
