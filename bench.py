@@ -54,6 +54,13 @@ def static_counters(kernel: str, B: int, N: int):
     return None, None
 
 
+def rccl_version():
+    try:
+        return ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception as e:  # noqa: BLE001  (never let a version query take the measurement down)
+        return f"unavailable ({type(e).__name__})"
+
+
 def host_cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -378,7 +385,7 @@ def main():
             "timing": {"protocol": f"{agg['regions']} regions of exactly {args.steps} steps, barrier + synchronize around each, MAX over ranks "
                                    f"per region, MEDIAN region reported", "region_ms_per_step": agg["region_ms_per_step"]},
             "ranks_seen": agg["ranks_seen"], "collective_backend": agg["backend"],
-            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if (world > 1 and not share_gpu) else None,
+            "rccl_version": rccl_version() if (world > 1 and not share_gpu) else None,
             "per_rank_ms_per_step": agg["per_rank_ms_per_step"],
             "roofline": roof,
         }
