@@ -208,6 +208,27 @@ enum { TR_INVALID = 0, TR_ACCEPT = 1, TR_REJECT = 2, TR_PTOL = 3, TR_FTOL = 4 };
  *   returns 1 when the termination type is CONVERGENCE (gradient / parameter / function tolerance or minimum radius), else 0. */
 typedef int (*eval_fn)(const void *ctx, const double x[6], double *r, double *J, double *cost);
 
+/* LevenbergMarquardtStrategy::StepAccepted / StepRejected (StepIsInvalid == StepRejected(0)): the radius schedule */
+static void radius_step_accepted(double *radius, double *decrease_factor, double step_quality) {
+    const double tq = 2.0 * step_quality - 1.0;
+    *radius = *radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
+    *radius = fmin(1e16, *radius); /* max_trust_region_radius */
+    *decrease_factor = 2.0;
+}
+static void radius_step_rejected(double *radius, double *decrease_factor) {
+    *radius = *radius / *decrease_factor;
+    *decrease_factor *= 2.0;
+}
+/* test hook: the schedule driven by a given accept (quality > 0) / reject (quality <= 0) sequence */
+void oracle_radius_schedule(const double *quality, int n, double *radii) {
+    double radius = 1e4, factor = 2.0;
+    for (int i = 0; i < n; ++i) {
+        if (quality[i] > 1e-3) radius_step_accepted(&radius, &factor, quality[i]);
+        else radius_step_rejected(&radius, &factor);
+        radii[i] = radius;
+    }
+}
+
 static int lm_minimize(eval_fn evaluate_fn, const void *ctx, int m, double x[6], int maxIterCnt, double ftol, int printSummary,
                        double *radius_out, double *trace, int trace_rows, int *n_iter) {
 #define TRACE(kind, cc, mcc, rho, sn)                                                          \
@@ -224,7 +245,7 @@ static int lm_minimize(eval_fn evaluate_fn, const void *ctx, int m, double x[6],
     double *Aw = J + (size_t)(m + 6) * 6;
 
     const double ptol = 1e-8, gtol = 1e-10;
-    const double min_rel_decrease = 1e-3, max_radius = 1e16, min_radius = 1e-32;
+    const double min_rel_decrease = 1e-3, min_radius = 1e-32;
     double radius = 1e4, decrease_factor = 2.0;
     double x_cost = 0, scale[6], g[6], gmax = 0, x_norm = 0;
     int converged = 0, failed = 0, iter = 0, n_invalid = 0;
@@ -274,7 +295,7 @@ static int lm_minimize(eval_fn evaluate_fn, const void *ctx, int m, double x[6],
         }
         if (!step_ok) { /* HandleInvalidStep */
             if (++n_invalid >= 5) { failed = 1; TRACE(TR_INVALID, 0.0, model_cost_change, 0.0, 0.0); break; }
-            radius /= decrease_factor; decrease_factor *= 2.0;
+            radius_step_rejected(&radius, &decrease_factor);
             TRACE(TR_INVALID, 0.0, model_cost_change, 0.0, 0.0);
             continue;
         }
@@ -307,13 +328,10 @@ static int lm_minimize(eval_fn evaluate_fn, const void *ctx, int m, double x[6],
             }
             for (int i = 0; i < m; ++i)
                 for (int j = 0; j < 6; ++j) J[i * 6 + j] *= scale[j];
-            const double tq = 2.0 * rel - 1.0;
-            radius = radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
-            radius = fmin(max_radius, radius);
-            decrease_factor = 2.0;
+            radius_step_accepted(&radius, &decrease_factor, rel);
             { const double now_cost = x_cost; x_cost = prev_cost; TRACE(TR_ACCEPT, cand_cost, model_cost_change, rel, step_norm); x_cost = now_cost; }
         } else {
-            radius /= decrease_factor; decrease_factor *= 2.0;
+            radius_step_rejected(&radius, &decrease_factor);
             TRACE(TR_REJECT, cand_cost, model_cost_change, rel, step_norm);
         }
         if (printSummary) printf("iter %d cost %.9e radius %.3e\n", iter, x_cost, radius);

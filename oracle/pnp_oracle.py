@@ -44,6 +44,8 @@ def lib():
         _lib.oracle_powell_trace.restype = ctypes.c_int
         _lib.oracle_hello_trace.argtypes = [dp, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, ip, dp]
         _lib.oracle_hello_trace.restype = ctypes.c_int
+        _lib.oracle_radius_schedule.argtypes = [dp, ctypes.c_int, dp]
+        _lib.oracle_radius_schedule.restype = None
     return _lib
 
 
@@ -136,3 +138,14 @@ def hello_trace(x0=0.5, max_iter=100, ftol=1e-6, trace_rows=10):
     ok = L.oracle_hello_trace(x.ctypes.data_as(dp), int(max_iter), float(ftol), trace.ctypes.data_as(dp), int(trace_rows), ctypes.byref(n),
                               radius.ctypes.data_as(dp))
     return bool(ok), float(x[0]), n.value, float(radius[0]), trace[:n.value]
+
+
+def radius_schedule(quality):
+    """The minimiser's own radius updates (`radius_step_accepted` / `radius_step_rejected`) driven by a sequence of step qualities
+    (<= 1e-3: rejected), starting from the initial radius 1e4.  -> radii after every step."""
+    L = lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    q = np.asarray(quality, np.float64)
+    out = np.zeros(len(q), np.float64)
+    L.oracle_radius_schedule(q.ctypes.data_as(dp), len(q), out.ctypes.data_as(dp))
+    return out

@@ -69,3 +69,17 @@ def test_minimiser_reproduces_the_published_ceres_log_of_hello_world():
         mine = [f"{i + 1:d}", f"{t[CAND]:.6e}", f"{t[COST] - t[CAND]:.2e}", f"{t[GMAX]:.2e}", f"{t[STEP]:.2e}", f"{t[RHO]:.2e}", f"{t[RADIUS]:.2e}"]
         assert mine == row, (mine, row)
     assert f"{x:.6g}" == "10" and f"Final cost: {trace[1][CAND]:.6e}" in " ".join(notes)
+
+
+def test_radius_schedule_reproduces_the_published_curve_fitting_log():
+    """The third tutorial example (curve fitting, examples/curve_fitting.cc) starts with FIVE rejected steps; its published log
+    prints, per iteration, the step quality `tr_ratio` and the radius that follows.  The residual data of that example are not
+    restated here, but the radius column is a pure function of the tr_ratio column and of the schedule -- initial radius 1e4,
+    rejected: radius /= 2, 4, 8, 16, 32 (the divisor doubles, reset by a success), accepted: radius /= max(1/3, 1 - (2 rho - 1)^3) --
+    and the oracle's own update functions reproduce every printed radius from the printed ratios."""
+    tr_ratio = [-1.87e+01, -1.86e+01, -1.85e+01, -1.70e+01, -6.32e+00, 1.37e+00, 1.10e+00, 1.03e+00, 9.94e-01, 9.89e-01, 9.97e-01,
+                1.00e+00, 1.00e+00]
+    tr_radius = ["5.00e+03", "1.25e+03", "1.56e+02", "9.77e+00", "3.05e-01", "9.16e-01", "2.75e+00", "8.24e+00", "2.47e+01", "7.42e+01",
+                 "2.22e+02", "6.67e+02", "2.00e+03"]
+    got = [f"{r:.2e}" for r in pnp_oracle.radius_schedule(tr_ratio)]
+    assert got == tr_radius, got
