@@ -7,8 +7,8 @@
 //
 // MI355X mapping: lane = correspondence (wave-stride when N > 64); the pose x = (angle-axis, t), the 6x6 normal
 // equations and the LM state are wave-uniform values every lane carries.  One evaluation per LM iteration:
-//   residuals in fp64 from R(x) X + t;  Jacobian rows from the closed form  J_rot = Jr(w)^T (X x R^T J_t)
-//   (d(R(w)X)/dw = -R [X]x Jr(w), Jr = right Jacobian of SO(3)) -- no per-point 3x3 derivative, no autodiff;
+//   residuals in fp64 from R(x) X + t;  Jacobian rows from the closed form  J_rot = Jr(w) (R X x J_t)
+//   (d(R(w)X)/dw = -R [X]x Jr(w) = -[R X]x Jr(w)^T, Jr = right Jacobian of SO(3)) -- no per-point 3x3 derivative, no autodiff;
 //   J^T J (21) | J^T r (6) | r^T r (1) reduced with permlane-swap/DPP reduce-scatter + ONE LDS broadcast;
 //   damped, Jacobi-scaled 6x6 system solved in registers (LDL^T, fp64).
 // Only the final 7-float state, the trust radius and the flag go back to HBM.
@@ -99,9 +99,12 @@ __device__ __forceinline__ void make_rot(const double aa[3], Rot& o) {
 template <bool FIRST, bool STREAM = false, int NW = 1>
 __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt, const double t[3], const double k[6],
                                                  const double (&sc)[6], double (&acc)[28], double* lds = nullptr, int pos = 0) {
-    double q[3];
+    double rx[3], q[3];  // R X and R X + t
 #pragma unroll
-    for (int d = 0; d < 3; ++d) q[d] = rt.R[3 * d] * pt.X[0] + rt.R[3 * d + 1] * pt.X[1] + rt.R[3 * d + 2] * pt.X[2] + t[d];
+    for (int d = 0; d < 3; ++d) {
+        rx[d] = rt.R[3 * d] * pt.X[0] + rt.R[3 * d + 1] * pt.X[1] + rt.R[3 * d + 2] * pt.X[2];
+        q[d] = rx[d] + t[d];
+    }
     const double iz = fast_rcp(q[2]);
     const double up = (q[0] * k[0] + q[1] * k[1]) * iz, vp = (q[0] * k[3] + q[1] * k[4]) * iz;
     const double du = up - pt.u, dv = vp - pt.v;
@@ -116,14 +119,14 @@ __device__ __forceinline__ void accumulate_point(const Point& pt, const Rot& rt,
     }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        double av[3], cr[3];
+        // d(R(w) X)/dw = -R [X]x Jr(w) = -[R X]x Jl(w) with the left Jacobian Jl = R Jr = Jr^T: the row a = J_t of the residual gives
+        // J_rot = Jl^T (R X x a) = Jr (R X x a) -- R X is at hand from the projection, so no R^T a is formed (9 fma fewer per row)
+        double cr[3];
+        cr[0] = rx[1] * J[rr][5] - rx[2] * J[rr][4];
+        cr[1] = rx[2] * J[rr][3] - rx[0] * J[rr][5];
+        cr[2] = rx[0] * J[rr][4] - rx[1] * J[rr][3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) av[m] = rt.R[m] * J[rr][3] + rt.R[3 + m] * J[rr][4] + rt.R[6 + m] * J[rr][5];  // R^T J_t
-        cr[0] = pt.X[1] * av[2] - pt.X[2] * av[1];
-        cr[1] = pt.X[2] * av[0] - pt.X[0] * av[2];
-        cr[2] = pt.X[0] * av[1] - pt.X[1] * av[0];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) J[rr][m] = (rt.Jr[m] * cr[0] + rt.Jr[3 + m] * cr[1] + rt.Jr[6 + m] * cr[2]) * sc[m];  // Jr^T (X x a)
+        for (int m = 0; m < 3; ++m) J[rr][m] = (rt.Jr[3 * m] * cr[0] + rt.Jr[3 * m + 1] * cr[1] + rt.Jr[3 * m + 2] * cr[2]) * sc[m];  // Jr (R X x a)
 #pragma unroll
         for (int m = 0; m < 3; ++m) J[rr][3 + m] *= sc[3 + m];
     }
