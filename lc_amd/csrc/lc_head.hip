@@ -369,14 +369,20 @@ __device__ __forceinline__ float across_groups_sum(float x) {  // over lanes dif
     return x;
 }
 
-template <typename T>
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+// PROB (the probabilities-in form, ptnet.softargmax_2d_std on its own) is a template flag: as a run-time one it cost a select per
+// element.  The element loop works on PAIRS (v_pk_fma_f32 / v_pk_add_f32: two fp32 lanes per issue slot): with 16-bit maps the
+// forward is VALU-bound, not HBM-bound (27.5 us for 134 MB before this form), and an element now costs the conversion, half a
+// max3, half an fma, the v_exp_f32 and two half adds.
+template <typename T, bool PROB>
 __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const HeadParams p) {
     constexpr int S = 64, HW = S * S;
     const int lane = threadIdx.x & 63;
     const size_t m = (size_t)blockIdx.x * (kHeadThreads / kWave) + (threadIdx.x >> 6);
     if (m >= (size_t)p.M) return;
     const T* in = static_cast<const T*>(p.in) + m * HW + 8 * lane;
-    const bool is_prob = p.is_prob != 0;
+    constexpr bool is_prob = PROB;
     const int g = lane >> 3, c = lane & 7;
     const bool ntl = (p.variant & 8) != 0;
 
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
 #pragma unroll
     for (int k = 0; k < 8; ++k) load8<T>(in + 512 * k, x[k], ntl);
     float bmax = 0.f;
-    if (!is_prob) {
+    if constexpr (!PROB) {
         float lmax = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -393,49 +399,56 @@ __global__ __launch_bounds__(kHeadThreads) void lc_head_fwd_wave64_kernel(const 
         bmax = wave_max(lmax);
     }
     const float nbmax = -bmax * kLog2e;
-    float col[8], row[8];
+    v2f_t col2[4];
+    float row[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) col[j] = 0.f;
+    for (int j = 0; j < 4; ++j) col2[j] = v2f_t{0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float r = 0.f;
+        v2f_t r2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float e = is_prob ? x[k][j] : exp2_fast(__builtin_fmaf(x[k][j], kLog2e, nbmax));  // exp(x - max): one fma + v_exp_f32
-            col[j] += e;
-            r += e;
+        for (int j = 0; j < 4; ++j) {
+            v2f_t e = {x[k][2 * j], x[k][2 * j + 1]};
+            if constexpr (!PROB) {  // exp(x - max): one (packed) fma + v_exp_f32
+                const v2f_t t = __builtin_elementwise_fma(e, v2f_t{kLog2e, kLog2e}, v2f_t{nbmax, nbmax});
+                e = v2f_t{exp2_fast(t.x), exp2_fast(t.y)};
+            }
+            col2[j] += e;
+            r2 += e;
         }
-        row[k] = group8_sum(r);  // un-normalised mass of row 8k+g, in all 8 lanes of the group
+        row[k] = group8_sum(r2.x + r2.y);  // un-normalised mass of row 8k+g, in all 8 lanes of the group
     }
     float tot = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        col[j] = across_groups_sum(col[j]);  // un-normalised mass of column 8c+j, in every row group
-        tot += col[j];
+    for (int j = 0; j < 4; ++j) {
+        col2[j] = v2f_t{across_groups_sum(col2[j].x), across_groups_sum(col2[j].y)};  // un-normalised mass of columns 8c+2j, +1, in every row group
+        tot += col2[j].x + col2[j].y;
     }
     const float bsum = group8_sum(tot);
     const float inv = is_prob ? 1.f : 1.f / bsum;
-    // softargmax_1d_cov (ptnet.py:85-97) on the two marginals
-    float mx = 0.f, my = 0.f;
+    // softargmax_1d_cov (ptnet.py:85-97) on the two marginals, two coordinates per instruction
+    const float cx = (float)(8 * c), gy = (float)g;
+    v2f_t wx[4], wy[4], row2[4], mx2 = {0.f, 0.f}, my2 = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) mx += (float)(8 * c + j) * (col[j] * inv);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) my += (float)(8 * k + g) * (row[k] * inv);
-    mx = group8_sum(mx);
-    my = across_groups_sum(my);
-    float vx = 0.f, vy = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float d = (float)(8 * c + j) - mx;
-        vx += d * d * (col[j] * inv);
+    for (int j = 0; j < 4; ++j) {
+        wx[j] = v2f_t{cx, cx} + v2f_t{(float)(2 * j), (float)(2 * j + 1)};
+        wy[j] = v2f_t{gy, gy} + v2f_t{(float)(16 * j), (float)(16 * j + 8)};
+        col2[j] *= v2f_t{inv, inv};
+        row2[j] = v2f_t{row[2 * j], row[2 * j + 1]} * v2f_t{inv, inv};
+        mx2 = __builtin_elementwise_fma(wx[j], col2[j], mx2);
+        my2 = __builtin_elementwise_fma(wy[j], row2[j], my2);
     }
+    const float mx = group8_sum(mx2.x + mx2.y);
+    const float my = across_groups_sum(my2.x + my2.y);
+    v2f_t vx2 = {0.f, 0.f}, vy2 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float d = (float)(8 * k + g) - my;
-        vy += d * d * (row[k] * inv);
+    for (int j = 0; j < 4; ++j) {
+        const v2f_t dx = wx[j] - v2f_t{mx, mx}, dy = wy[j] - v2f_t{my, my};
+        vx2 = __builtin_elementwise_fma(dx * dx, col2[j], vx2);
+        vy2 = __builtin_elementwise_fma(dy * dy, row2[j], vy2);
     }
-    vx = group8_sum(vx);
-    vy = across_groups_sum(vy);
+    const float vx = group8_sum(vx2.x + vx2.y);
+    const float vy = across_groups_sum(vy2.x + vy2.y);
     if (lane == 0) {
         *reinterpret_cast<float2*>(p.mean + m * 2) = make_float2(mx, my);
         *reinterpret_cast<float2*>(p.std + m * 2) = make_float2(sqrtf(vx + 1e-6f), sqrtf(vy + 1e-6f));
@@ -559,7 +572,8 @@ int launch_head_fwd_t(const HeadParams& p, hipStream_t stream) {
                       (reinterpret_cast<uintptr_t>(p.stats) & 15) == 0;
     if (vec4 && out8 && p.W == 64 && p.H == 64 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0) {  // 16-byte accesses (load8)
         const int waves = kHeadThreads / kWave;
-        hipLaunchKernelGGL(lc_head_fwd_wave64_kernel<T>, dim3((p.M + waves - 1) / waves), dim3(kHeadThreads), 0, stream, p);
+        if (p.is_prob) hipLaunchKernelGGL((lc_head_fwd_wave64_kernel<T, true>), dim3((p.M + waves - 1) / waves), dim3(kHeadThreads), 0, stream, p);
+        else hipLaunchKernelGGL((lc_head_fwd_wave64_kernel<T, false>), dim3((p.M + waves - 1) / waves), dim3(kHeadThreads), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     if (vec4 && p.W == 64 && p.H == 64) {
