@@ -86,8 +86,8 @@ def main():
     for mode in ("mask", "quantile", "quantile_in_mask"):
         us = ev(lambda: dense.dense_select(pts2d_d, inv_std_d, pts3d_d, mode, mask=seg, quantile=0.7), dev, a.reps)
         line("lc_dense_select_kernel (%s)" % mode, us, B * N * (28 + 1) + B * int(N * 0.5) * 32, B, "samples",
-             note="one workgroup per sample; quantile modes sort N weights in LDS (bitonic, %d compare-exchange stages)"
-                  % (12 * 13 // 2), B=B, N=N, mode=mode)
+             note="one workgroup per sample; quantile modes radix-select the two order statistics from keys staged in LDS; the time here is "
+                  "the Python call (output allocation included), the kernel alone is in next_kernel_stats.csv", B=B, N=N, mode=mode)
 
     # ---- f3: ZebraPose codes: 3x7-bit logits over 128x128 ----
     C, bits = 21, 7
