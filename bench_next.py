@@ -119,13 +119,14 @@ def main():
     line("lc_pose_errors_kernel (add only)", us, Bp * (24 * 4 + 16) + M * 12, Bp, "poses", B=Bp, M=M)
 
     # ---- f2: RANSAC initialiser ----
-    for (Br, Nr) in ((256, 64), (256, 1024)):
+    for (Br, Nr) in ((256, 64), (64, 1024), (256, 1024)):
         bt = synth.make_batch(Br, Nr, seed=2, outlier_frac=0.2)
         K, X, U = bt["K"].to(dev), bt["pts3d"].to(dev), bt["pts2d"].to(dev)
-        us = ev(lambda: gpu_solver.solve_device(K, X, U, reprojectionError=3.0, refine=False), dev, a.reps)
-        line("lc_pnp_ransac_kernel", us, Br * (Nr * 21 + 36 + 40), Br, "poses",
-             note="compute-shaped: 150 P3P hypotheses x N reprojections per pose (%.1f G reprojections/s)" % (Br * 150 * Nr / (us * 1e-6) / 1e9),
-             B=Br, N=Nr, hypotheses=150)
+        for split, label in ((False, "lc_pnp_ransac_kernel (single launch)"), (True, "lc_ransac_{hypotheses,score,select}_kernel (split form)")):
+            us = ev(lambda: gpu_solver.solve_device(K, X, U, reprojectionError=3.0, refine=False, split=split), dev, a.reps)
+            line(label, us, Br * (Nr * 21 + 36 + 40), Br, "poses",
+                 note="compute-shaped: 192 P3P hypotheses x N reprojections per pose (%.1f G reprojections/s); gpu_solver picks the form from "
+                      "the shape (split when N ceil(B/256) > 256)" % (Br * 192 * Nr / (us * 1e-6) / 1e9), B=Br, N=Nr, hypotheses=192)
 
     # ---- LC loss on the dense heads' shapes (training step of the dense configs): N = 1024 / 4096 points per sample ----
     from lc_amd import cov_mixed

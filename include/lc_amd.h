@@ -16,6 +16,8 @@
 #ifndef LC_AMD_H
 #define LC_AMD_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -56,6 +58,20 @@ void pnp_ceres_f32_omp(float **init_states, float **cam_Ks, float **pts2ds, floa
 int lc_pnp_lm_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *sqrt_diag,
                   const int *counts, const float *start, float *states, float *result_tr, int *rets, int *iters, int B,
                   int Nmax, int max_iter, float function_tolerance, void *stream);
+
+/* lc_pnp_lm_f32 with the element-wise work of its callers folded into the load (each was a separate launch in front of the solve):
+ *   weights_diag + LC_PNP_WEIGHTS_ARE_ICOV: the (B,Nmax,2) tensor holds inverse VARIANCES; their square root is the information
+ *       factor (lib/pnp/cer_solver.py:33-36 `icovs.sqrt()`);
+ *   LC_PNP_NAN_TO_NUM: torch.nan_to_num (NaN -> 0, +-inf -> +-FLT_MAX) on K, pts3d, pts2d, the weights and start
+ *       (cer_solver.py:29-31 `filter_input_nan`); an invalid job returns the FILTERED start;
+ *   weight_mask (B,Nmax) uint8: unit information on the flagged correspondences, none on the others (the RANSAC inlier
+ *       refinement of lc_amd/pnp/gpu_solver.py); exactly one of sqrtL / weights_diag / weight_mask is given.
+ * options = 0 with sqrtL or weights_diag is lc_pnp_lm_f32. */
+#define LC_PNP_WEIGHTS_ARE_ICOV 1
+#define LC_PNP_NAN_TO_NUM 2
+int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
+                   const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,
+                   int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, void *stream);
 
 /* (2a') Parity diagnostics of (2a): the same solve (same template body, so the same arithmetic) that also records the
  *      trust-region schedule -- what `Solver::Summary::iterations` holds after ceres::Solve (ceres.cpp:126-130) --
@@ -158,6 +174,17 @@ int lc_pnp_ransac_init2_f32(const float *K, const float *pts3d, const float *pts
                             float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
                             float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
                             void *stream);
+
+/* Split form of the same RANSAC for batches that do not fill the chip with one workgroup per pose (64 objects x 150 hypotheses
+ * x 1000+ dense correspondences): three launches -- hypotheses (one lane each), scoring (point chunks x hypotheses, spread over
+ * all compute units), selection -- over a caller-provided device workspace of lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)
+ * bytes (8-byte aligned; contents undefined before and after).  Same hypothesis stream, same per-point arithmetic and the same
+ * (count, error, hypothesis index) ordering as the single launch; results do not depend on scheduling (no atomics). */
+size_t lc_pnp_ransac_workspace_bytes(int B, int Nmax, int iterations);
+int lc_pnp_ransac_init3_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
+                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
+                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2f) ZebraPose binary surface codes -- floatbits.py.  logits (B,C,H,W), C = n0+n1+n2 code bits

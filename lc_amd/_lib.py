@@ -24,6 +24,7 @@ _SIGNATURES = {
     "lc_amd_last_error": (ctypes.c_char_p, []),
     "pnp_ceres_f32_omp": (None, [_FP, _FP, _FP, _FP, _FP, _I, c_int, c_float, c_int, _F, _I, c_int, c_int]),
     "lc_pnp_lm_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "lc_pnp_lm2_f32": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "lc_pnp_lm_trace_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "lc_cov_loss_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 6),
     "lc_cov_loss2_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float, c_int] + [c_void_p] * 6),
@@ -35,6 +36,9 @@ _SIGNATURES = {
     "lc_dense_frontend_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p] * 4),
     "lc_pnp_ransac_init_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 5),
     "lc_pnp_ransac_init2_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6),
+    "lc_pnp_ransac_init3_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6 +
+                                [ctypes.c_size_t, c_void_p]),
+    "lc_pnp_ransac_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "lc_bits_decode_gt_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_gt_bwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_f32": (c_int, [c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),

@@ -169,6 +169,24 @@ int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const 
     return 0;
 }
 
+int lc_pnp_lm2_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
+                   const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
+                   int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, void* stream) {
+    if (B < 0 || Nmax < 0) return fail(1, "negative size");
+    if (B == 0) return 0;
+    if ((sqrtL != nullptr) + (weights_diag != nullptr) + (weight_mask != nullptr) != 1)
+        return fail(1, "exactly one of sqrtL / weights_diag / weight_mask must be given");
+    if (options & ~(LC_PNP_WEIGHTS_ARE_ICOV | LC_PNP_NAN_TO_NUM)) return fail(1, "unknown option bit");
+    if ((options & LC_PNP_WEIGHTS_ARE_ICOV) && !weights_diag) return fail(1, "LC_PNP_WEIGHTS_ARE_ICOV needs weights_diag");
+    if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, weights_diag);
+    LC_REQUIRE_ALIGNED(16, sqrtL);
+    lc::PnpParams p{K, pts2d, pts3d, sqrtL, weights_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
+                    B, Nmax, max_iter, function_tolerance, nullptr, 0, options, weight_mask};
+    if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
+    return 0;
+}
+
 int lc_pnp_lm_trace_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* sqrt_diag,
                         const int* counts, const float* start, float* states, float* result_tr, int* rets, int* iters, int B, int Nmax,
                         int max_iter, float function_tolerance, double* trace, int trace_rows, void* stream) {
@@ -328,6 +346,26 @@ int lc_pnp_ransac_init2_f32(const float* K, const float* pts3d, const float* pts
     lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
                        (iterations + 63) / 64, reproj_err, seed, best_hyp};
     return lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream)) ? fail(11, "ransac kernel launch failed") : 0;
+}
+
+size_t lc_pnp_ransac_workspace_bytes(int B, int Nmax, int iterations) {
+    if (B <= 0 || Nmax < 0 || iterations <= 0) return 0;
+    return lc::pnp_ransac_workspace_bytes(B, Nmax, (iterations + 63) / 64);
+}
+
+int lc_pnp_ransac_init3_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
+                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid || !workspace) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, workspace);
+    lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
+                       (iterations + 63) / 64, reproj_err, seed, best_hyp, workspace, workspace_bytes};
+    const int rc = lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream));
+    if (rc == 3) return fail(1, "workspace smaller than lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)");
+    return rc ? fail(11, "ransac kernel launch failed") : 0;
 }
 
 static int bits_check(int B, int C, int H, int W, int n0, int n1, int n2, int top, int left, int sample) {

@@ -48,7 +48,11 @@ struct PnpParams {
     float ftol;
     double* trace;        // diagnostic launch only (launch_pnp_lm_trace): (B,trace_rows,8) per-iteration rows, else null
     int trace_rows;
+    int options;          // kPnp* bits (launch_pnp_lm only): what the callers otherwise do with element-wise launches in front
+    const unsigned char* weight_mask;  // (B,Nmax) or null: unit information where non-zero, none elsewhere (instead of sqrtL / sqrt_diag)
 };
+enum PnpOptions { kPnpWeightsAreIcov = 1,  // sqrt_diag holds inverse VARIANCES: take the square root at the load (cer_solver.py:33-36)
+                  kPnpNanToNum = 2 };      // torch.nan_to_num on K, points, weights and start at the load (cer_solver.py:29-31)
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream);
 int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream);  // same solve + p.trace rows (parity diagnostics, not a hot path)
 // both of the above in one grid (N <= 64 only; returns 3 otherwise)
@@ -97,8 +101,11 @@ struct RansacParams {
     float reproj_err;
     unsigned seed;
     int* best_hyp;         // (B,) out or null: index of the winning hypothesis (-1 when invalid) -- parity diagnostics
+    void* workspace;       // null: single launch (one workgroup per pose); else the split form (hypotheses / scoring / selection)
+    size_t workspace_bytes;
 };
-int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);
+int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);  // 3: workspace too small
+size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds);
 
 struct BitsParams {
     const float* logits;          // (B,C,H,W) code logits, C = bits[0]+bits[1]+bits[2]

@@ -6,17 +6,18 @@ namespace {
 
 // WPS = waves per SIMD the register allocator must allow: 1 for small grids (latency: B <= ~1000 poses leave most SIMDs
 // idle anyway, spilling would only lengthen the lone wave), 2 for large grids (+43 % throughput at B = 16384).
-template <bool REG, int WPS>
+// OPTS: honours PnpParams::options / weight_mask (lc_pnp_lm2_f32); the plain instantiations are the ones the metric runs
+template <bool REG, int WPS, bool OPTS = false>
 __global__ __launch_bounds__(64, WPS) void lc_pnp_lm_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<1>];
-    pnp::solve_pose<REG, 1>(p, blockIdx.x, threadIdx.x, bc);
+    pnp::solve_pose<REG, 1, false, OPTS>(p, blockIdx.x, threadIdx.x, bc);
 }
 
 // four wavefronts per pose for N > 64 (dense heads, ragged inference batches)
-template <bool REG>
+template <bool REG, bool OPTS = false>
 __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
-    pnp::solve_pose<REG, 4>(p, blockIdx.x, threadIdx.x, bc);
+    pnp::solve_pose<REG, 4, false, OPTS>(p, blockIdx.x, threadIdx.x, bc);
 }
 
 // diagnostic twins that also record the per-iteration trace (tests/test_gpu_pnp_trace.py)
@@ -41,6 +42,17 @@ int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream) {
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     const bool big = p.B > kLatencyGridMax;
+    if (p.options || p.weight_mask) {  // input filtering / weight forms folded into the load
+        if (p.Nmax <= 64) {
+            if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS, true>), dim3(p.B), dim3(64), 0, stream, p);
+            else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1, true>), dim3(p.B), dim3(64), 0, stream, p);
+        } else if (p.Nmax <= 256) {
+            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<true, true>), dim3(p.B), dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true>), dim3(p.B), dim3(256), 0, stream, p);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     if (p.Nmax <= 64) {
         if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS>), dim3(p.B), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);

@@ -192,17 +192,34 @@ struct RawPoint {
     float2 u;
     float a, b, c;
 };
+// torch.nan_to_num with its defaults: NaN -> 0, +-inf -> +-FLT_MAX (cer_solver.py:29-31 applies it to every input when asked to)
+__device__ __forceinline__ float nan_to_num(float f) { return f != f ? 0.f : fminf(fmaxf(f, -FLT_MAX), FLT_MAX); }
+
+// OPTS: the instantiation that honours PnpParams::options / weight_mask (input filtering and weight forms of the callers, done at
+// the load instead of by separate element-wise launches); the plain instantiation does not even test the fields
+template <bool OPTS = false>
 __device__ __forceinline__ RawPoint load_raw_point(const PnpParams& p, size_t base, int n) {
     RawPoint o;
     const float* X = p.pts3d + (base + n) * 3;
     o.u = *reinterpret_cast<const float2*>(p.pts2d + (base + n) * 2);
     o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
-    if (p.sqrtL) {
+    if (OPTS && p.weight_mask) {  // unit information on the flagged correspondences, none on the others
+        const float m = p.weight_mask[base + n] ? 1.f : 0.f;
+        o.a = m; o.b = 0.f; o.c = m;
+    } else if (p.sqrtL) {
         const float4 L = *reinterpret_cast<const float4*>(p.sqrtL + (base + n) * 4);
         o.a = L.x; o.b = L.z; o.c = L.w;
     } else {
         const float2 L = *reinterpret_cast<const float2*>(p.sqrt_diag + (base + n) * 2);
         o.a = L.x; o.b = 0.f; o.c = L.y;
+    }
+    if constexpr (OPTS) {
+        if (p.options & kPnpNanToNum) {
+            o.u.x = nan_to_num(o.u.x); o.u.y = nan_to_num(o.u.y);
+            o.X[0] = nan_to_num(o.X[0]); o.X[1] = nan_to_num(o.X[1]); o.X[2] = nan_to_num(o.X[2]);
+            o.a = nan_to_num(o.a); o.b = nan_to_num(o.b); o.c = nan_to_num(o.c);
+        }
+        if (p.options & kPnpWeightsAreIcov) { o.a = sqrtf(o.a); o.c = sqrtf(o.c); }  // diagonal inverse covariance -> its factor (cer_solver.py:33-36)
     }
     return o;
 }
@@ -214,8 +231,9 @@ __device__ __forceinline__ Point to_point(const RawPoint& r, const double cam[6]
     o.a = r.a; o.b = r.b; o.c = r.c;
     return o;
 }
+template <bool OPTS = false>
 __device__ __forceinline__ Point load_point(const PnpParams& p, size_t base, int n, const double cam[6]) {
-    return to_point(load_raw_point(p, base, n), cam);
+    return to_point(load_raw_point<OPTS>(p, base, n), cam);
 }
 
 __device__ __forceinline__ double max_abs6(const double (&v)[6]) {
@@ -237,7 +255,7 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 // REG: Nmax <= 64*NW, each thread keeps its correspondence in registers across the whole solve.
 // TRACE: diagnostic instantiation (lc_pnp_lm_trace_f32) that also writes one row per trust-region iteration to p.trace, in the
 // column layout of oracle/pnp_lm_oracle.c's PNP_TRACE_COLS; the shipped kernels are instantiated with TRACE = false.
-template <bool REG, int NW = 1, bool TRACE = false>
+template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
 #ifdef LC_TRACE_CLOCK
@@ -247,29 +265,31 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     LC_PSTAMP_BEGIN();
     const int n = p.counts ? p.counts[b] : p.Nmax;
     const float* st_in = (p.start ? p.start : p.states) + 7 * (size_t)b;
+    const bool filter = OPTS && (p.options & kPnpNanToNum);
+    auto fin = [&](float f) { return filter ? nan_to_num(f) : f; };
     if (n < 3) {  // ceres.cpp:84-91
         if (lane == 0) {
             p.rets[b] = 1;
             p.result_tr[b] = 1.f;
             if (p.iters) p.iters[b] = 0;
         }
-        if (p.start && lane < 7) p.states[7 * (size_t)b + lane] = st_in[lane];
+        if ((p.start || filter) && lane < 7) p.states[7 * (size_t)b + lane] = fin(st_in[lane]);
         return;
     }
     const size_t base = (size_t)b * p.Nmax;
     const bool active = lane < n;
     RawPoint raw;
-    if constexpr (REG) raw = load_raw_point(p, base, active ? lane : 0);  // n >= 3 here: correspondence 0 exists
+    if constexpr (REG) raw = load_raw_point<OPTS>(p, base, active ? lane : 0);  // n >= 3 here: correspondence 0 exists
     double cam[6];
     {
         const float* Kp = p.K + 9 * (size_t)b;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) cam[i] = Kp[i];  // only the first 6 floats are read (ceres.cpp:99-101)
+        for (int i = 0; i < 6; ++i) cam[i] = fin(Kp[i]);  // only the first 6 floats are read (ceres.cpp:99-101)
     }
     double x[6];
     {
         // QuaternionToAngleAxis (ceres.cpp:96)
-        const double q0 = st_in[0], q1 = st_in[1], q2 = st_in[2], q3 = st_in[3];
+        const double q0 = fin(st_in[0]), q1 = fin(st_in[1]), q2 = fin(st_in[2]), q3 = fin(st_in[3]);
         const double s2 = q1 * q1 + q2 * q2 + q3 * q3;
         double kk = 2.0;
         if (s2 > 0.0) {
@@ -280,7 +300,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             kk = two_theta / s;
         }
         x[0] = q1 * kk; x[1] = q2 * kk; x[2] = q3 * kk;
-        x[3] = st_in[4]; x[4] = st_in[5]; x[5] = st_in[6];
+        x[3] = fin(st_in[4]); x[4] = fin(st_in[5]); x[5] = fin(st_in[6]);
     }
     LC_PSTAMP(0);
     // Lanes without a correspondence (lane >= n) carry a copy of correspondence 0 with a ZERO information factor: their residuals
@@ -314,7 +334,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         } else {
 #pragma unroll
             for (int i = 0; i < 28; ++i) acc[i] = 0;
-            for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point(p, base, i, cam), rt, t, cam, sc, acc);
+            for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
             LC_PSTAMP(3);
             block_sum_bcast_lds<28, NW>(acc, bc, lane);
         }
@@ -463,7 +483,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     }
 #endif
     const bool invalid = failed || !converged;
-    if (invalid && p.start && lane < 7) p.states[7 * (size_t)b + lane] = st_in[lane];
+    if (invalid && (p.start || filter) && lane < 7) p.states[7 * (size_t)b + lane] = fin(st_in[lane]);
     if (lane == 0) {
         p.rets[b] = invalid ? 1 : 0;
         p.result_tr[b] = (float)radius;

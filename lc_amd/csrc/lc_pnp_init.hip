@@ -8,6 +8,8 @@
 // here: parity at this boundary is unpinned and outside the metric); the contract kept is the role: a pose
 // inside the LM basin of convergence plus an inlier set for `weighted_filtered` (test.py:129-134).
 //
+// (Divisions and square roots of the P3P are the Newton-refined v_rcp_f64 / v_rsq_f64 forms of lc_common.h, 2-4e-15 relative: the
+// solutions are Gauss-Newton polished and compared at 1e-4.)
 // P3P: depths l_i of three bearings y_i with |l_i y_i - l_j y_j|^2 = |x_i - x_j|^2.  The pencil D1 + g D2 of the two
 // constant-free quadrics is made singular by a root g of a cubic (coefficients from 3x3 determinants), the singular quadric
 // splits into two planes through its eigen-decomposition, each plane cuts D1 in <= 2 rays (a quadratic), the scale comes
@@ -17,8 +19,18 @@
 #include "lc_common.h"
 #include "lc_kernels.h"
 
+#ifdef LC_P3P_STAMPS
+namespace lc { namespace p3p_diag { __device__ unsigned long long g_p3p_stamp[7]; } }
+#endif
+
 namespace lc {
 namespace {
+
+#ifdef LC_P3P_STAMPS  // diagnostic build (scripts/ubench/p3p_stamps.py): shader-clock stamps of the hypothesis kernel's phases
+#define LC_P3P_STAMP(i) ::lc::p3p_diag::g_p3p_stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define LC_P3P_STAMP(i)
+#endif
 
 struct V3 { double x, y, z; };
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -42,157 +54,194 @@ __device__ __forceinline__ V3 null_vec(const Sym3& m) {
     double n = n01;
     if (n02 > n) { v = c02; n = n02; }
     if (n12 > n) { v = c12; n = n12; }
-    return (1.0 / sqrt(fmax(n, DBL_MIN))) * v;
+    double sn, rn;
+    fast_sqrt_rsqrt(fmax(n, DBL_MIN), sn, rn);
+    return rn * v;
 }
 
 struct Pose { double R[9], t[3]; };
 
-// up to 4 poses; returns their count
-__device__ int p3p(const V3 (&y)[3], const V3 (&x)[3], Pose (&out)[4]) {
-    const double c12 = dot(y[0], y[1]), c13 = dot(y[0], y[2]), c23 = dot(y[1], y[2]);
-    const V3 d12 = x[0] - x[1], d13 = x[0] - x[2], d23 = x[1] - x[2];
-    const double a12 = dot(d12, d12), a13 = dot(d13, d13), a23 = dot(d23, d23);
-    const V3 dn = cross(d12, d13);
-    if (!(dot(dn, dn) > 1e-12 * a12 * a13)) return 0;  // collinear sample
-    // D1 = a23 M12 - a12 M23,  D2 = a23 M13 - a13 M23
-    const Sym3 D1{a23, -a23 * c12, 0.0, a23 - a12, a12 * c23, -a12};
-    const Sym3 D2{a23, 0.0, -a23 * c13, -a13, a13 * c23, a23 - a13};
-    // det(D1 + g D2) = k0 + k1 g + k2 g^2 + k3 g^3 by multilinearity in the columns
-    auto col = [](const Sym3& m, int c) { return row(m, c); };
-    auto det_cols = [](V3 p, V3 q, V3 r) { return det3(p.x, q.x, r.x, p.y, q.y, r.y, p.z, q.z, r.z); };
-    const V3 p0 = col(D1, 0), p1 = col(D1, 1), p2 = col(D1, 2), q0 = col(D2, 0), q1 = col(D2, 1), q2 = col(D2, 2);
-    const double k0 = det_cols(p0, p1, p2);
-    const double k1 = det_cols(q0, p1, p2) + det_cols(p0, q1, p2) + det_cols(p0, p1, q2);
-    const double k2 = det_cols(p0, q1, q2) + det_cols(q0, p1, q2) + det_cols(q0, q1, p2);
-    const double k3 = det_cols(q0, q1, q2);
-    // real roots of the cubic (trigonometric / Cardano on the depressed form), Newton-polished
-    double roots[3];
-    int nroots = 0;
-    if (fabs(k3) > 1e-14 * (fabs(k0) + fabs(k1) + fabs(k2) + fabs(k3))) {
-        const double b = k2 / k3, c = k1 / k3, d = k0 / k3;
-        const double p = c - b * b / 3.0, q = 2.0 * b * b * b / 27.0 - b * c / 3.0 + d;
-        const double disc = q * q / 4.0 + p * p * p / 27.0;
-        if (disc > 0) {
-            const double s = sqrt(disc);
-            roots[nroots++] = cbrt(-q / 2.0 + s) + cbrt(-q / 2.0 - s) - b / 3.0;
-        } else {
-            const double m = 2.0 * sqrt(fmax(-p / 3.0, 0.0));
-            const double arg = m > 0 ? fmin(1.0, fmax(-1.0, 3.0 * q / (p * m))) : 0.0;
-            const double th = acos(arg) / 3.0;
-            for (int k = 0; k < 3; ++k) roots[nroots++] = m * cos(th - 2.0943951023931953 * k) - b / 3.0;
-        }
-        for (int r = 0; r < nroots; ++r) {
-            double g = roots[r];
-            for (int it = 0; it < 3; ++it) {
-                const double f = ((g + b) * g + c) * g + d, fp = (3.0 * g + 2.0 * b) * g + c;
-                if (fabs(fp) > 0) g -= f / fp;
-            }
-            roots[r] = g;
-        }
-    } else if (fabs(k2) > 0) {  // degenerate cubic: quadratic
-        const double disc = k1 * k1 - 4.0 * k2 * k0;
-        if (disc >= 0) {
-            const double s = sqrt(disc);
-            roots[nroots++] = (-k1 + s) / (2.0 * k2);
-            roots[nroots++] = (-k1 - s) / (2.0 * k2);
-        }
-    }
-    // X^-1 for the rotation recovery: X = [d12, d13, d12 x d13] (columns)
-    double Xi[9];
-    {
+// Grunert-type P3P through the singular member of the pencil of the two constant-free quadrics.  solve() hands every candidate's
+// three depths to emit(l) (no array of solutions: a dynamically indexed Pose[4] lives in scratch memory); the caller chooses
+// one, polish() refines its depths by Gauss-Newton on the three distance constraints, pose() turns depths into R, t.
+struct P3P {
+    V3 y[3], x[3];
+    double c12, c13, c23, a12, a13, a23;
+    double Xi[9];  // X^-1, X = [x1 - x2, x1 - x3, their cross product] (columns)
+
+    __device__ __forceinline__ bool init(const V3 (&y_)[3], const V3 (&x_)[3]) {
+        for (int k = 0; k < 3; ++k) { y[k] = y_[k]; x[k] = x_[k]; }
+        c12 = dot(y[0], y[1]); c13 = dot(y[0], y[2]); c23 = dot(y[1], y[2]);
+        const V3 d12 = x[0] - x[1], d13 = x[0] - x[2], d23 = x[1] - x[2];
+        a12 = dot(d12, d12); a13 = dot(d13, d13); a23 = dot(d23, d23);
+        const V3 dn = cross(d12, d13);
+        if (!(dot(dn, dn) > 1e-12 * a12 * a13)) return false;  // collinear sample
         const double X[9] = {d12.x, d13.x, dn.x, d12.y, d13.y, dn.y, d12.z, d13.z, dn.z};
         const double dt = det3(X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8]);
-        const double id = 1.0 / dt;
+        const double id = fast_rcp(dt);
         Xi[0] = (X[4] * X[8] - X[5] * X[7]) * id; Xi[1] = (X[2] * X[7] - X[1] * X[8]) * id; Xi[2] = (X[1] * X[5] - X[2] * X[4]) * id;
         Xi[3] = (X[5] * X[6] - X[3] * X[8]) * id; Xi[4] = (X[0] * X[8] - X[2] * X[6]) * id; Xi[5] = (X[2] * X[3] - X[0] * X[5]) * id;
         Xi[6] = (X[3] * X[7] - X[4] * X[6]) * id; Xi[7] = (X[1] * X[6] - X[0] * X[7]) * id; Xi[8] = (X[0] * X[4] - X[1] * X[3]) * id;
+        return true;
     }
-    int nsol = 0;
-    for (int r = 0; r < nroots && nsol == 0; ++r) {
-        const double g = roots[r];
-        const Sym3 D0{D1.a00 + g * D2.a00, D1.a01 + g * D2.a01, D1.a02 + g * D2.a02, D1.a11 + g * D2.a11, D1.a12 + g * D2.a12,
-                      D1.a22 + g * D2.a22};
-        // eigenvalues s1, s2 of the rank-2 matrix: s1 + s2 = trace, s1 s2 = sum of principal 2x2 minors
-        const double tr = D0.a00 + D0.a11 + D0.a22;
-        const double m2 = D0.a00 * D0.a11 - D0.a01 * D0.a01 + D0.a00 * D0.a22 - D0.a02 * D0.a02 + D0.a11 * D0.a22 - D0.a12 * D0.a12;
-        if (!(m2 < 0)) continue;  // needs eigenvalues of opposite sign to split into two real planes
-        const double sq = sqrt(tr * tr - 4.0 * m2);
-        const double s1 = 0.5 * (tr + sq), s2 = 0.5 * (tr - sq);  // s1 > 0 > s2
-        const Sym3 S1{D0.a00 - s1, D0.a01, D0.a02, D0.a11 - s1, D0.a12, D0.a22 - s1};
-        const V3 e1 = null_vec(S1), e0 = null_vec(D0);
-        const V3 e2 = cross(e0, e1);
-        const double sgm = sqrt(-s2 / s1);
-        for (int sign = 0; sign < 2; ++sign) {
-            const V3 pl = e1 + ((sign ? -sgm : sgm) * e2);  // plane pl . lambda = 0
-            // eliminate the component with the largest |pl|: lambda_k = u lambda_i + v lambda_j
-            const double ax = fabs(pl.x), ay = fabs(pl.y), az = fabs(pl.z);
-            const int k = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-            const int i = k == 0 ? 1 : 0, j = k == 2 ? 1 : 2;
-            const double pk = k == 0 ? pl.x : (k == 1 ? pl.y : pl.z), pi = i == 0 ? pl.x : pl.y, pj = j == 1 ? pl.y : pl.z;
-            const double u = -pi / pk, v = -pj / pk;
-            auto ent = [&](int r_, int c_) {
-                const int lo = r_ < c_ ? r_ : c_, hi = r_ < c_ ? c_ : r_;
-                return lo == 0 ? (hi == 0 ? D1.a00 : (hi == 1 ? D1.a01 : D1.a02)) : (lo == 1 ? (hi == 1 ? D1.a11 : D1.a12) : D1.a22);
-            };
-            const double Dii = ent(i, i), Djj = ent(j, j), Dkk = ent(k, k), Dij = ent(i, j), Dik = ent(i, k), Djk = ent(j, k);
-            const double A = Dii + Dkk * u * u + 2.0 * Dik * u;
-            const double C = Djj + Dkk * v * v + 2.0 * Djk * v;
-            const double Bq = 2.0 * (Dkk * u * v + Dij + Dik * v + Djk * u);
-            // A + Bq tau + C tau^2 = 0, tau = lambda_j / lambda_i
-            double taus[2];
-            int nt = 0;
-            if (fabs(C) > 1e-14 * (fabs(A) + fabs(Bq) + fabs(C))) {
-                const double disc = Bq * Bq - 4.0 * A * C;
-                if (disc >= 0) {
-                    const double s = sqrt(disc), qq = -0.5 * (Bq + (Bq >= 0 ? s : -s));
-                    taus[nt++] = qq / C;
-                    if (qq != 0) taus[nt++] = A / qq;
-                }
-            } else if (fabs(Bq) > 0) {
-                taus[nt++] = -A / Bq;
+
+    // R = [z1 - z2, z1 - z3, cross] X^-1 with z_i = l_i y_i, t = z1 - R x1
+    __device__ __forceinline__ void pose(const double (&l)[3], Pose& o) const {
+        const V3 z1 = l[0] * y[0], z2 = l[1] * y[1], z3 = l[2] * y[2];
+        const V3 yd1 = z1 - z2, yd2 = z1 - z3, yn = cross(yd1, yd2);
+        const double Y[9] = {yd1.x, yd2.x, yn.x, yd1.y, yd2.y, yn.y, yd1.z, yd2.z, yn.z};
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) o.R[3 * a + c] = Y[3 * a] * Xi[c] + Y[3 * a + 1] * Xi[3 + c] + Y[3 * a + 2] * Xi[6 + c];
+        const V3 Rx = {o.R[0] * x[0].x + o.R[1] * x[0].y + o.R[2] * x[0].z, o.R[3] * x[0].x + o.R[4] * x[0].y + o.R[5] * x[0].z,
+                       o.R[6] * x[0].x + o.R[7] * x[0].y + o.R[8] * x[0].z};
+        o.t[0] = z1.x - Rx.x; o.t[1] = z1.y - Rx.y; o.t[2] = z1.z - Rx.z;
+    }
+
+    // three Gauss-Newton steps on |l_i y_i - l_j y_j|^2 = a_ij (Cramer's rule on the Jacobian [[J00,J01,0],[J10,0,J12],[0,J21,J22]],
+    // zeros folded by hand: the compiler may not drop 0 * x); false when a depth ends non-positive
+    __device__ __forceinline__ bool polish(double (&l)[3]) const {
+        for (int it = 0; it < 3; ++it) {
+            const double r0 = l[0] * l[0] + l[1] * l[1] - 2.0 * c12 * l[0] * l[1] - a12;
+            const double r1 = l[0] * l[0] + l[2] * l[2] - 2.0 * c13 * l[0] * l[2] - a13;
+            const double r2 = l[1] * l[1] + l[2] * l[2] - 2.0 * c23 * l[1] * l[2] - a23;
+            const double J00 = 2.0 * (l[0] - c12 * l[1]), J01 = 2.0 * (l[1] - c12 * l[0]);
+            const double J10 = 2.0 * (l[0] - c13 * l[2]), J12 = 2.0 * (l[2] - c13 * l[0]);
+            const double J21 = 2.0 * (l[1] - c23 * l[2]), J22 = 2.0 * (l[2] - c23 * l[1]);
+            const double dt = -J00 * J12 * J21 - J01 * J10 * J22;
+            if (!(fabs(dt) > 1e-300)) break;
+            const double id = fast_rcp(dt);
+            const double m = r1 * J22 - J12 * r2;
+            l[0] -= (-r0 * J12 * J21 - J01 * m) * id;
+            l[1] -= (J00 * m - r0 * J10 * J22) * id;
+            l[2] -= (r0 * J10 * J21 - J00 * r1 * J21 - J01 * J10 * r2) * id;
+        }
+        return l[0] > 0 && l[1] > 0 && l[2] > 0;
+    }
+
+    // up to 4 candidates; returns their count
+    template <class Emit>
+    __device__ __forceinline__ int solve(Emit&& emit) const {
+        // D1 = a23 M12 - a12 M23,  D2 = a23 M13 - a13 M23
+        const Sym3 D1{a23, -a23 * c12, 0.0, a23 - a12, a12 * c23, -a12};
+        const Sym3 D2{a23, 0.0, -a23 * c13, -a13, a13 * c23, a23 - a13};
+        // det(D1 + g D2) = k0 + k1 g + k2 g^2 + k3 g^3 by multilinearity in the columns
+        auto col = [](const Sym3& m, int c) { return row(m, c); };
+        auto det_cols = [](V3 p, V3 q, V3 r) { return det3(p.x, q.x, r.x, p.y, q.y, r.y, p.z, q.z, r.z); };
+        const V3 p0 = col(D1, 0), p1 = col(D1, 1), p2 = col(D1, 2), q0 = col(D2, 0), q1 = col(D2, 1), q2 = col(D2, 2);
+        const double k0 = det_cols(p0, p1, p2);
+        const double k1 = det_cols(q0, p1, p2) + det_cols(p0, q1, p2) + det_cols(p0, p1, q2);
+        const double k2 = det_cols(p0, q1, q2) + det_cols(q0, p1, q2) + det_cols(q0, q1, p2);
+        const double k3 = det_cols(q0, q1, q2);
+        LC_P3P_STAMP(2);
+        // real roots of the cubic (trigonometric / Cardano on the depressed form), Newton-polished
+        double roots[3] = {0.0, 0.0, 0.0};
+        int nroots = 0;
+        if (fabs(k3) > 1e-14 * (fabs(k0) + fabs(k1) + fabs(k2) + fabs(k3))) {
+            const double ik3 = fast_rcp(k3);
+            const double b = k2 * ik3, c = k1 * ik3, d = k0 * ik3;
+            const double p = c - b * b / 3.0, q = 2.0 * b * b * b / 27.0 - b * c / 3.0 + d;
+            const double disc = q * q / 4.0 + p * p * p / 27.0;
+            if (disc > 0) {
+                const double s = fast_sqrt(disc);
+                roots[nroots++] = cbrt(-q / 2.0 + s) + cbrt(-q / 2.0 - s) - b / 3.0;
+            } else {
+                const double m = 2.0 * fast_sqrt(fmax(-p / 3.0, 0.0));
+                const double arg = m > 0 ? fmin(1.0, fmax(-1.0, 3.0 * q * fast_rcp(p * m))) : 0.0;
+                const double th = acos(arg) / 3.0;
+                for (int k = 0; k < 3; ++k) roots[nroots++] = m * cos(th - 2.0943951023931953 * k) - b / 3.0;
             }
-            const double cij = (i == 0 && j == 1) ? c12 : ((i == 0 && j == 2) ? c13 : c23);
-            const double aij = (i == 0 && j == 1) ? a12 : ((i == 0 && j == 2) ? a13 : a23);
-            for (int tt = 0; tt < nt && nsol < 4; ++tt) {
-                const double tau = taus[tt];
-                if (!(tau > 0)) continue;
-                const double den = 1.0 + tau * tau - 2.0 * cij * tau;
-                if (!(den > 0)) continue;
-                const double li = sqrt(aij / den), lj = tau * li, lk = u * li + v * lj;
-                if (!(lk > 0)) continue;
-                double l[3];
-                l[i] = li; l[j] = lj; l[k] = lk;
-                // Gauss-Newton polish of the three distance constraints
+            for (int r = 0; r < nroots; ++r) {
+                double g = roots[r];
                 for (int it = 0; it < 3; ++it) {
-                    const double r0 = l[0] * l[0] + l[1] * l[1] - 2.0 * c12 * l[0] * l[1] - a12;
-                    const double r1 = l[0] * l[0] + l[2] * l[2] - 2.0 * c13 * l[0] * l[2] - a13;
-                    const double r2 = l[1] * l[1] + l[2] * l[2] - 2.0 * c23 * l[1] * l[2] - a23;
-                    const double J00 = 2.0 * (l[0] - c12 * l[1]), J01 = 2.0 * (l[1] - c12 * l[0]);
-                    const double J10 = 2.0 * (l[0] - c13 * l[2]), J12 = 2.0 * (l[2] - c13 * l[0]);
-                    const double J21 = 2.0 * (l[1] - c23 * l[2]), J22 = 2.0 * (l[2] - c23 * l[1]);
-                    const double dt = det3(J00, J01, 0, J10, 0, J12, 0, J21, J22);
-                    if (!(fabs(dt) > 1e-300)) break;
-                    const double id = 1.0 / dt;
-                    l[0] -= det3(r0, J01, 0, r1, 0, J12, r2, J21, J22) * id;
-                    l[1] -= det3(J00, r0, 0, J10, r1, J12, 0, r2, J22) * id;
-                    l[2] -= det3(J00, J01, r0, J10, 0, r1, 0, J21, r2) * id;
+                    const double f = ((g + b) * g + c) * g + d, fp = (3.0 * g + 2.0 * b) * g + c;
+                    if (fabs(fp) > 0) g -= f * fast_rcp(fp);
                 }
-                if (!(l[0] > 0 && l[1] > 0 && l[2] > 0)) continue;
-                const V3 z1 = l[0] * y[0], z2 = l[1] * y[1], z3 = l[2] * y[2];
-                const V3 yd1 = z1 - z2, yd2 = z1 - z3, yn = cross(yd1, yd2);
-                const double Y[9] = {yd1.x, yd2.x, yn.x, yd1.y, yd2.y, yn.y, yd1.z, yd2.z, yn.z};
-                Pose& o = out[nsol];
-                for (int a = 0; a < 3; ++a)
-                    for (int c = 0; c < 3; ++c) o.R[3 * a + c] = Y[3 * a] * Xi[c] + Y[3 * a + 1] * Xi[3 + c] + Y[3 * a + 2] * Xi[6 + c];
-                const V3 Rx = {o.R[0] * x[0].x + o.R[1] * x[0].y + o.R[2] * x[0].z, o.R[3] * x[0].x + o.R[4] * x[0].y + o.R[5] * x[0].z,
-                               o.R[6] * x[0].x + o.R[7] * x[0].y + o.R[8] * x[0].z};
-                o.t[0] = z1.x - Rx.x; o.t[1] = z1.y - Rx.y; o.t[2] = z1.z - Rx.z;
-                ++nsol;
+                roots[r] = g;
+            }
+        } else if (fabs(k2) > 0) {  // degenerate cubic: quadratic
+            const double disc = k1 * k1 - 4.0 * k2 * k0;
+            if (disc >= 0) {
+                const double s = sqrt(disc);
+                roots[nroots++] = (-k1 + s) / (2.0 * k2);
+                roots[nroots++] = (-k1 - s) / (2.0 * k2);
             }
         }
-    }
-    return nsol;
-}
+        LC_P3P_STAMP(3);
+        // Roots are tried in order until one yields solutions.  A root whose singular quadric has no real plane pair is skipped by a
+        // CHEAP scan (18 flops), so that the lanes of a wavefront enter the expensive decomposition below together: with the skip
+        // inside one loop body the wavefront ran that body once per root position that ANY lane needed (up to three times).
+        int nsol = 0, r = 0;
+        while (nsol == 0) {
+            Sym3 D0;
+            double tr = 0, m2 = 0;
+            bool found = false;
+            for (; r < nroots && !found; ++r) {
+                const double g = r == 0 ? roots[0] : (r == 1 ? roots[1] : roots[2]);
+                D0 = Sym3{D1.a00 + g * D2.a00, D1.a01 + g * D2.a01, D1.a02 + g * D2.a02, D1.a11 + g * D2.a11, D1.a12 + g * D2.a12,
+                          D1.a22 + g * D2.a22};
+                // eigenvalues s1, s2 of the rank-2 matrix: s1 + s2 = trace, s1 s2 = sum of principal 2x2 minors
+                tr = D0.a00 + D0.a11 + D0.a22;
+                m2 = D0.a00 * D0.a11 - D0.a01 * D0.a01 + D0.a00 * D0.a22 - D0.a02 * D0.a02 + D0.a11 * D0.a22 - D0.a12 * D0.a12;
+                found = m2 < 0;  // needs eigenvalues of opposite sign to split into two real planes
+            }
+            if (!found) break;
+            const double sq = fast_sqrt(tr * tr - 4.0 * m2);
+            const double s1 = 0.5 * (tr + sq), s2 = 0.5 * (tr - sq);  // s1 > 0 > s2
+            const Sym3 S1{D0.a00 - s1, D0.a01, D0.a02, D0.a11 - s1, D0.a12, D0.a22 - s1};
+            const V3 e1 = null_vec(S1), e0 = null_vec(D0);
+            const V3 e2 = cross(e0, e1);
+            const double sgm = fast_sqrt(-s2 * fast_rcp(s1));
+            for (int sign = 0; sign < 2; ++sign) {
+                const V3 pl = e1 + ((sign ? -sgm : sgm) * e2);  // plane pl . lambda = 0
+                // eliminate the component with the largest |pl|: lambda_k = u lambda_i + v lambda_j
+                const double ax = fabs(pl.x), ay = fabs(pl.y), az = fabs(pl.z);
+                const int k = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+                const int i = k == 0 ? 1 : 0, j = k == 2 ? 1 : 2;
+                const double pk = k == 0 ? pl.x : (k == 1 ? pl.y : pl.z), pi = i == 0 ? pl.x : pl.y, pj = j == 1 ? pl.y : pl.z;
+                const double ipk = fast_rcp(pk);
+                const double u = -pi * ipk, v = -pj * ipk;
+                auto ent = [&](int r_, int c_) {
+                    const int lo = r_ < c_ ? r_ : c_, hi = r_ < c_ ? c_ : r_;
+                    return lo == 0 ? (hi == 0 ? D1.a00 : (hi == 1 ? D1.a01 : D1.a02)) : (lo == 1 ? (hi == 1 ? D1.a11 : D1.a12) : D1.a22);
+                };
+                const double Dii = ent(i, i), Djj = ent(j, j), Dkk = ent(k, k), Dij = ent(i, j), Dik = ent(i, k), Djk = ent(j, k);
+                const double A = Dii + Dkk * u * u + 2.0 * Dik * u;
+                const double C = Djj + Dkk * v * v + 2.0 * Djk * v;
+                const double Bq = 2.0 * (Dkk * u * v + Dij + Dik * v + Djk * u);
+                // A + Bq tau + C tau^2 = 0, tau = lambda_j / lambda_i
+                double taus[2];
+                int nt = 0;
+                if (fabs(C) > 1e-14 * (fabs(A) + fabs(Bq) + fabs(C))) {
+                    const double disc = Bq * Bq - 4.0 * A * C;
+                    if (disc >= 0) {
+                        const double s = fast_sqrt(disc), qq = -0.5 * (Bq + (Bq >= 0 ? s : -s));
+                        taus[nt++] = qq * fast_rcp(C);
+                        if (qq != 0) taus[nt++] = A * fast_rcp(qq);
+                    }
+                } else if (fabs(Bq) > 0) {
+                    taus[nt++] = -A * fast_rcp(Bq);
+                }
+                const double cij = (i == 0 && j == 1) ? c12 : ((i == 0 && j == 2) ? c13 : c23);
+                const double aij = (i == 0 && j == 1) ? a12 : ((i == 0 && j == 2) ? a13 : a23);
+                for (int tt = 0; tt < nt && nsol < 4; ++tt) {
+                    const double tau = taus[tt];
+                    if (!(tau > 0)) continue;
+                    const double den = 1.0 + tau * tau - 2.0 * cij * tau;
+                    if (!(den > 0)) continue;
+                    const double li = fast_sqrt(aij * fast_rcp(den)), lj = tau * li, lk = u * li + v * lj;
+                    if (!(lk > 0)) continue;
+                    double l[3];
+                    l[i] = li; l[j] = lj; l[k] = lk;
+                    emit(l);
+                    ++nsol;
+                }
+            }
+        }
+            LC_P3P_STAMP(4);
+            return nsol;
+        }
+    };
+
 
 __device__ __forceinline__ unsigned hash_u32(unsigned a) {  // lowbias32
     a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16;
@@ -222,143 +271,130 @@ __device__ void mat_to_quat(const double R[9], float q[4]) {
 
 constexpr int kMaxLdsPts = 2048;
 
-constexpr int kRansacMaxWaves = 4;  // hypothesis rounds of 64 run on separate wavefronts of the pose's workgroup
+// Hypothesis `hyp` of pose b: four distinct sample indices below nl from a counter-based hash stream
+// (oracle/p3p_ransac_oracle.py:sample_indices restates it bit for bit).
+__device__ __forceinline__ void sample_indices(unsigned seed, int b, int hyp, int nl, int (&idx)[4]) {
+    unsigned h = hash_u32(seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)hyp));
+    for (int k = 0; k < 4; ++k) {
+        h = hash_u32(h + 0x6D2B79F5u);
+        int v = (int)(h % (unsigned)nl);
+        for (int guard = 0; guard < 8; ++guard) {
+            bool dup = false;
+            for (int m = 0; m < k; ++m) dup = dup || (idx[m] == v);
+            if (!dup) break;
+            v = (v + 1) % nl;
+        }
+        idx[k] = v;
+    }
+}
 
-__global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(const RansacParams p) {
-    __shared__ float sx[kMaxLdsPts * 3];   // 3D points
-    __shared__ float su[kMaxLdsPts * 2];   // normalised image coordinates K^-1 (u,v,1)
-    __shared__ double best_pose[kRansacMaxWaves][12];
-    __shared__ int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
-    __shared__ float wv_err[kRansacMaxWaves];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
-    const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+// Minimal-sample pose: P3P on the first three correspondences, the fourth disambiguates the up-to-4 solutions (best reprojection).
+// point(i, X, u): 3D point and normalised image coordinates K^-1 (u,v,1) of correspondence i as floats.  False: no usable solution.
+template <class PointFn>
+__device__ __forceinline__ bool hypothesis_pose(const int (&idx)[4], PointFn&& point, Pose& out) {
+    V3 y[3], x[3];
+    for (int k = 0; k < 3; ++k) {
+        float X[3], u[2];
+        point(idx[k], X, u);
+        const double ux = u[0], uy = u[1];
+        double nrm, inv;
+        fast_sqrt_rsqrt(ux * ux + uy * uy + 1.0, nrm, inv);
+        y[k] = {ux * inv, uy * inv, inv};
+        x[k] = {X[0], X[1], X[2]};
+    }
+    P3P geo;
+    if (!geo.init(y, x)) return false;
+    float X4[3], u4[2];
+    point(idx[3], X4, u4);
+    bool have = false;
+    float pick_e = INFINITY;
+    double lbest[3] = {0.0, 0.0, 0.0};
+    // The candidate that reprojects the 4th point best (first one on ties) is chosen on its closed-form depths; only the chosen one is
+    // Gauss-Newton polished (the closed form is good to ~1e-10, far below the gap between two P3P solutions; polishing all four
+    // candidates before the choice was half of this kernel's instructions).
+    geo.solve([&](const double (&l)[3]) {
+        Pose sol;
+        geo.pose(l, sol);
+        const float X = X4[0], Y = X4[1], Z = X4[2];
+        const float cx = (float)sol.R[0] * X + (float)sol.R[1] * Y + (float)sol.R[2] * Z + (float)sol.t[0];
+        const float cy = (float)sol.R[3] * X + (float)sol.R[4] * Y + (float)sol.R[5] * Z + (float)sol.t[1];
+        const float cz = (float)sol.R[6] * X + (float)sol.R[7] * Y + (float)sol.R[8] * Z + (float)sol.t[2];
+        if (!(cz > 0)) return;
+        const float ex = cx / cz - u4[0], ey = cy / cz - u4[1];
+        const float e = ex * ex + ey * ey;
+        if (e < pick_e) { pick_e = e; lbest[0] = l[0]; lbest[1] = l[1]; lbest[2] = l[2]; have = true; }
+    });
+    if (!have || !geo.polish(lbest)) return false;
+    geo.pose(lbest, out);
+    return true;
+}
+
+// one correspondence against one hypothesis (fp32): inlier flag and squared reprojection error in normalised coordinates.
+// Every fused multiply-add is written out: the pair form below performs the same operations in the same order, so the single
+// launch and the split form see the same inlier bits.
+__device__ __forceinline__ void score_point(const float (&R)[9], const float (&t)[3], float X, float Y, float Z, float u, float v,
+                                            float thr2, int& cnt, float& err) {
+    const float cz = __builtin_fmaf(R[8], Z, __builtin_fmaf(R[7], Y, __builtin_fmaf(R[6], X, t[2])));
+    const float cx = __builtin_fmaf(R[2], Z, __builtin_fmaf(R[1], Y, __builtin_fmaf(R[0], X, t[0])));
+    const float cy = __builtin_fmaf(R[5], Z, __builtin_fmaf(R[4], Y, __builtin_fmaf(R[3], X, t[1])));
+    const float icz = __builtin_amdgcn_rcpf(cz);  // 1 ulp: scoring only
+    const float ex = __builtin_fmaf(cx, icz, -u), ey = __builtin_fmaf(cy, icz, -v);
+    const float e = __builtin_fmaf(ey, ey, ex * ex);
+    const bool in = cz > 0 && e < thr2;
+    cnt += in ? 1 : 0;
+    err += in ? e : 0.f;
+}
+
+// two correspondences per instruction (v_pk_fma_f32): X, Y, Z, nu = -u, nv = -v hold the same coordinate of points i and i+1
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t bc2(float a) { return v2f_t{a, a}; }
+__device__ __forceinline__ void score_pair(const float (&R)[9], const float (&t)[3], v2f_t X, v2f_t Y, v2f_t Z, v2f_t nu, v2f_t nv,
+                                           float thr2, int& cnt, v2f_t& err) {
+    const v2f_t cz = __builtin_elementwise_fma(bc2(R[8]), Z, __builtin_elementwise_fma(bc2(R[7]), Y, __builtin_elementwise_fma(bc2(R[6]), X, bc2(t[2]))));
+    const v2f_t cx = __builtin_elementwise_fma(bc2(R[2]), Z, __builtin_elementwise_fma(bc2(R[1]), Y, __builtin_elementwise_fma(bc2(R[0]), X, bc2(t[0]))));
+    const v2f_t cy = __builtin_elementwise_fma(bc2(R[5]), Z, __builtin_elementwise_fma(bc2(R[4]), Y, __builtin_elementwise_fma(bc2(R[3]), X, bc2(t[1]))));
+    const v2f_t icz = {__builtin_amdgcn_rcpf(cz.x), __builtin_amdgcn_rcpf(cz.y)};
+    const v2f_t ex = __builtin_elementwise_fma(cx, icz, nu), ey = __builtin_elementwise_fma(cy, icz, nv);
+    const v2f_t e = __builtin_elementwise_fma(ey, ey, ex * ex);
+    const bool in0 = cz.x > 0 && e.x < thr2, in1 = cz.y > 0 && e.y < thr2;
+    cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+    err += v2f_t{in0 ? e.x : 0.f, in1 ? e.y : 0.f};
+}
+
+// (count, -error, -hypothesis id) ordering of the hypotheses of a pose
+__device__ __forceinline__ bool better_hyp(int oc, float oe, int oh, int c, float e, int h) {
+    return oc > c || (oc == c && (oe < e || (oe == e && oh < h)));
+}
+
+
+// K^-1 of the upper-triangular-free 2x3 camera block: u = k0 X/Z + k1 Y/Z + k2, v = k3 X/Z + k4 Y/Z + k5 (row 2 of K is (0,0,1) as in
+// ceres.cpp:46-47); normalised coordinates of a pixel, rounded to float once
+struct CamInv {
+    double k0, k1, k2, k3, k4, k5, idet;
+    __device__ explicit CamInv(const float* Kp) : k0(Kp[0]), k1(Kp[1]), k2(Kp[2]), k3(Kp[3]), k4(Kp[4]), k5(Kp[5]) { idet = 1.0 / (k0 * k4 - k1 * k3); }
+    __device__ __forceinline__ void normalise(float px, float py, float& ux, float& uy) const {
+        const double du = (double)px - k2, dv = (double)py - k5;
+        ux = (float)((k4 * du - k1 * dv) * idet);
+        uy = (float)((-k3 * du + k0 * dv) * idet);
+    }
+};
+
+// Winner of pose b -> outputs: inlier mask over ALL n points, their count, the pose as quaternion + translation, flags.
+// Called by every thread of the workgroup; wv_cnt: LDS scratch, one int per wavefront.
+__device__ __forceinline__ void write_result(const RansacParams& p, int b, int n, bool ok, const double* bp, int win_hyp, float thr2,
+                                             const CamInv& kin, int* wv_cnt) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const size_t base = (size_t)b * p.Nmax;
     unsigned char* mask = p.inlier_mask + base;
-    for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
-    if (n < 4) {  // cv2.solvePnPRansac needs >= 4 (EPnP: 5 model points); flagged invalid like a failed call (cv2_solver.py:74-80)
-        if (tid == 0) {
-            float* st = p.states + 7 * (size_t)b;
-            st[0] = 1; st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0;
-            p.invalid[b] = 1;
-            p.n_inliers[b] = 0;
-            if (p.best_hyp) p.best_hyp[b] = -1;
-        }
-        return;
-    }
-    const float* Kp = p.K + 9 * (size_t)b;
-    // u = k0 X/Z + k1 Y/Z + k2, v = k3 X/Z + k4 Y/Z + k5  (row 2 of K is (0,0,1) as in ceres.cpp:46-47)
-    const double k0 = Kp[0], k1 = Kp[1], k2 = Kp[2], k3 = Kp[3], k4 = Kp[4], k5 = Kp[5];
-    const double idet = 1.0 / (k0 * k4 - k1 * k3);
-    const int nl = min(n, kMaxLdsPts);  // hypotheses are scored on the first kMaxLdsPts points (dense heads: N <= 1849)
-    for (int i = tid; i < nl; i += nthr) {
-        sx[3 * i] = p.pts3d[(base + i) * 3]; sx[3 * i + 1] = p.pts3d[(base + i) * 3 + 1]; sx[3 * i + 2] = p.pts3d[(base + i) * 3 + 2];
-        const double du = (double)p.pts2d[(base + i) * 2] - k2, dv = (double)p.pts2d[(base + i) * 2 + 1] - k5;
-        su[2 * i] = (float)((k4 * du - k1 * dv) * idet);
-        su[2 * i + 1] = (float)((-k3 * du + k0 * dv) * idet);
-    }
-    __syncthreads();
-    // inlier threshold in normalised coordinates: reprojectionError px / focal scale (sqrt|det K2|)
-    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
-    const float thr = thr_px * (float)sqrt(fabs(idet));
-    const float thr2 = thr * thr;
-
-    int best_cnt = -1, best_hyp = 0;
-    float best_err = INFINITY;
-    Pose best;
-    for (int round = wave; round < p.rounds; round += nwaves) {  // hypothesis id = round*64 + lane, whatever the wave count
-        // minimal sample: 3 distinct indices + a 4th to disambiguate the up-to-4 P3P solutions
-        unsigned h = hash_u32(p.seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)(round * kWave + lane)));
-        int idx[4];
-        for (int k = 0; k < 4; ++k) {
-            h = hash_u32(h + 0x6D2B79F5u);
-            int v = (int)(h % (unsigned)nl);
-            for (int guard = 0; guard < 8; ++guard) {
-                bool dup = false;
-                for (int m = 0; m < k; ++m) dup = dup || (idx[m] == v);
-                if (!dup) break;
-                v = (v + 1) % nl;
-            }
-            idx[k] = v;
-        }
-        V3 y[3], x[3];
-        for (int k = 0; k < 3; ++k) {
-            const double ux = su[2 * idx[k]], uy = su[2 * idx[k] + 1];
-            const double inv = 1.0 / sqrt(ux * ux + uy * uy + 1.0);
-            y[k] = {ux * inv, uy * inv, inv};
-            x[k] = {sx[3 * idx[k]], sx[3 * idx[k] + 1], sx[3 * idx[k] + 2]};
-        }
-        Pose sols[4];
-        const int ns = p3p(y, x, sols);
-        // pick the solution that reprojects the 4th point best
-        int pick = -1;
-        float pick_e = INFINITY;
-        for (int s = 0; s < ns; ++s) {
-            const float X = sx[3 * idx[3]], Y = sx[3 * idx[3] + 1], Z = sx[3 * idx[3] + 2];
-            const float cx = (float)sols[s].R[0] * X + (float)sols[s].R[1] * Y + (float)sols[s].R[2] * Z + (float)sols[s].t[0];
-            const float cy = (float)sols[s].R[3] * X + (float)sols[s].R[4] * Y + (float)sols[s].R[5] * Z + (float)sols[s].t[1];
-            const float cz = (float)sols[s].R[6] * X + (float)sols[s].R[7] * Y + (float)sols[s].R[8] * Z + (float)sols[s].t[2];
-            if (!(cz > 0)) continue;
-            const float ex = cx / cz - su[2 * idx[3]], ey = cy / cz - su[2 * idx[3] + 1];
-            const float e = ex * ex + ey * ey;
-            if (e < pick_e) { pick_e = e; pick = s; }
-        }
-        // score on all points (every lane walks the LDS arrays: broadcast reads)
-        int cnt = -1;
-        float err = INFINITY;
-        if (pick >= 0) {
-            float R[9], t[3];
-            for (int k = 0; k < 9; ++k) R[k] = (float)sols[pick].R[k];
-            for (int k = 0; k < 3; ++k) t[k] = (float)sols[pick].t[k];
-            cnt = 0;
-            err = 0.f;
-            for (int i = 0; i < nl; ++i) {
-                const float X = sx[3 * i], Y = sx[3 * i + 1], Z = sx[3 * i + 2];
-                const float cz = R[6] * X + R[7] * Y + R[8] * Z + t[2];
-                const float icz = __builtin_amdgcn_rcpf(cz);  // 1 ulp: scoring only
-                const float ex = (R[0] * X + R[1] * Y + R[2] * Z + t[0]) * icz - su[2 * i];
-                const float ey = (R[3] * X + R[4] * Y + R[5] * Z + t[1]) * icz - su[2 * i + 1];
-                const float e = ex * ex + ey * ey;
-                const bool in = cz > 0 && e < thr2;
-                cnt += in ? 1 : 0;
-                err += in ? e : 0.f;
-            }
-        }
-        if (cnt > best_cnt || (cnt == best_cnt && err < best_err)) {
-            best_cnt = cnt; best_err = err; best_hyp = round * kWave + lane;
-            if (pick >= 0) best = sols[pick];
-        }
-    }
-    // arg-max over lanes, then over the waves: (count, -err, -hypothesis id)
-    int win_cnt = best_cnt, win_hyp = best_hyp;
-    float win_err = best_err;
-    auto better = [](int oc, float oe, int oh, int c, float e, int h) { return oc > c || (oc == c && (oe < e || (oe == e && oh < h))); };
-    for (int m = 32; m >= 1; m >>= 1) {
-        const int oc = __shfl_xor(win_cnt, m, kWave), oh = __shfl_xor(win_hyp, m, kWave);
-        const float oe = __shfl_xor(win_err, m, kWave);
-        if (better(oc, oe, oh, win_cnt, win_err, win_hyp)) { win_cnt = oc; win_err = oe; win_hyp = oh; }
-    }
-    if (best_hyp == win_hyp && best_cnt == win_cnt && win_cnt >= 0) {
-        for (int k = 0; k < 9; ++k) best_pose[wave][k] = best.R[k];
-        for (int k = 0; k < 3; ++k) best_pose[wave][9 + k] = best.t[k];
-    }
-    if (lane == 0) { wv_cnt[wave] = win_cnt; wv_err[wave] = win_err; wv_hyp[wave] = win_hyp; }
-    __syncthreads();
-    int ww = 0;
-    win_cnt = wv_cnt[0]; win_err = wv_err[0]; win_hyp = wv_hyp[0];
-    for (int w = 1; w < nwaves; ++w) {
-        if (better(wv_cnt[w], wv_err[w], wv_hyp[w], win_cnt, win_err, win_hyp)) { win_cnt = wv_cnt[w]; win_err = wv_err[w]; win_hyp = wv_hyp[w]; ww = w; }
-    }
-    const double* bp = best_pose[ww];
-    const bool ok = win_cnt >= 4;
-    if (ok) {  // inlier mask of the winner over ALL n points
+    if (ok) {
         float R[9], t[3];
         for (int k = 0; k < 9; ++k) R[k] = (float)bp[k];
         for (int k = 0; k < 3; ++k) t[k] = (float)bp[9 + k];
         int total = 0;
         for (int i = tid; i < n; i += nthr) {
             const float X = p.pts3d[(base + i) * 3], Y = p.pts3d[(base + i) * 3 + 1], Z = p.pts3d[(base + i) * 3 + 2];
-            const double du = (double)p.pts2d[(base + i) * 2] - k2, dv = (double)p.pts2d[(base + i) * 2 + 1] - k5;
-            const float ux = (float)((k4 * du - k1 * dv) * idet), uy = (float)((-k3 * du + k0 * dv) * idet);
+            float ux, uy;
+            kin.normalise(p.pts2d[(base + i) * 2], p.pts2d[(base + i) * 2 + 1], ux, uy);
             const float cz = R[6] * X + R[7] * Y + R[8] * Z + t[2];
             const float ex = (R[0] * X + R[1] * Y + R[2] * Z + t[0]) / cz - ux, ey = (R[3] * X + R[4] * Y + R[5] * Z + t[1]) / cz - uy;
             const bool in = cz > 0 && (ex * ex + ey * ey) < thr2;
@@ -366,7 +402,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
             total += in ? 1 : 0;
         }
         for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m, kWave);
-        __syncthreads();  // wv_cnt was read by every thread above
+        __syncthreads();  // wv_cnt may still be read by the caller's arg-max
         if (lane == 0) wv_cnt[wave] = total;
         __syncthreads();
         if (tid == 0) {
@@ -389,13 +425,322 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
     }
 }
 
+// fewer than 4 correspondences: cv2.solvePnPRansac needs >= 4 (EPnP: 5 model points); flagged invalid like a failed call
+// (cv2_solver.py:74-80)
+__device__ __forceinline__ void write_too_few(const RansacParams& p, int b) {
+    float* st = p.states + 7 * (size_t)b;
+    st[0] = 1; st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0;
+    p.invalid[b] = 1;
+    p.n_inliers[b] = 0;
+    if (p.best_hyp) p.best_hyp[b] = -1;
+}
+
+constexpr int kRansacMaxWaves = 4;  // hypothesis rounds of 64 run on separate wavefronts of the pose's workgroup
+
+__global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(const RansacParams p) {
+    __shared__ float sx[kMaxLdsPts * 3];   // 3D points
+    __shared__ float su[kMaxLdsPts * 2];   // normalised image coordinates K^-1 (u,v,1)
+    __shared__ double best_pose[kRansacMaxWaves][12];
+    __shared__ int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
+    __shared__ float wv_err[kRansacMaxWaves];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
+    const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+    const size_t base = (size_t)b * p.Nmax;
+    unsigned char* mask = p.inlier_mask + base;
+    for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
+    if (n < 4) {
+        if (tid == 0) write_too_few(p, b);
+        return;
+    }
+    const CamInv kin(p.K + 9 * (size_t)b);
+    const int nl = min(n, kMaxLdsPts);  // hypotheses are scored on the first kMaxLdsPts points (dense heads: N <= 1849)
+    for (int i = tid; i < nl; i += nthr) {
+        sx[3 * i] = p.pts3d[(base + i) * 3]; sx[3 * i + 1] = p.pts3d[(base + i) * 3 + 1]; sx[3 * i + 2] = p.pts3d[(base + i) * 3 + 2];
+        kin.normalise(p.pts2d[(base + i) * 2], p.pts2d[(base + i) * 2 + 1], su[2 * i], su[2 * i + 1]);
+    }
+    __syncthreads();
+    // inlier threshold in normalised coordinates: reprojectionError px / focal scale (sqrt|det K2|)
+    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr = thr_px * (float)sqrt(fabs(kin.idet));
+    const float thr2 = thr * thr;
+
+    int best_cnt = -1, best_hyp = 0;
+    float best_err = INFINITY;
+    Pose best;
+    for (int round = wave; round < p.rounds; round += nwaves) {  // hypothesis id = round*64 + lane, whatever the wave count
+        int idx[4];
+        sample_indices(p.seed, b, round * kWave + lane, nl, idx);
+        Pose cand;
+        const bool have = hypothesis_pose(idx, [&](int i, float (&X)[3], float (&u)[2]) {
+            X[0] = sx[3 * i]; X[1] = sx[3 * i + 1]; X[2] = sx[3 * i + 2];
+            u[0] = su[2 * i]; u[1] = su[2 * i + 1];
+        }, cand);
+        // score on all points (every lane walks the LDS arrays: broadcast reads)
+        int cnt = -1;
+        float err = INFINITY;
+        if (have) {
+            float R[9], t[3];
+            for (int k = 0; k < 9; ++k) R[k] = (float)cand.R[k];
+            for (int k = 0; k < 3; ++k) t[k] = (float)cand.t[k];
+            cnt = 0;
+            err = 0.f;
+            for (int i = 0; i < nl; ++i) score_point(R, t, sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], su[2 * i], su[2 * i + 1], thr2, cnt, err);
+        }
+        if (cnt > best_cnt || (cnt == best_cnt && err < best_err)) {
+            best_cnt = cnt; best_err = err; best_hyp = round * kWave + lane;
+            if (have) best = cand;
+        }
+    }
+    // arg-max over lanes, then over the waves: (count, -err, -hypothesis id)
+    int win_cnt = best_cnt, win_hyp = best_hyp;
+    float win_err = best_err;
+    auto better = better_hyp;
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int oc = __shfl_xor(win_cnt, m, kWave), oh = __shfl_xor(win_hyp, m, kWave);
+        const float oe = __shfl_xor(win_err, m, kWave);
+        if (better(oc, oe, oh, win_cnt, win_err, win_hyp)) { win_cnt = oc; win_err = oe; win_hyp = oh; }
+    }
+    if (best_hyp == win_hyp && best_cnt == win_cnt && win_cnt >= 0) {
+        for (int k = 0; k < 9; ++k) best_pose[wave][k] = best.R[k];
+        for (int k = 0; k < 3; ++k) best_pose[wave][9 + k] = best.t[k];
+    }
+    if (lane == 0) { wv_cnt[wave] = win_cnt; wv_err[wave] = win_err; wv_hyp[wave] = win_hyp; }
+    __syncthreads();
+    int ww = 0;
+    win_cnt = wv_cnt[0]; win_err = wv_err[0]; win_hyp = wv_hyp[0];
+    for (int w = 1; w < nwaves; ++w) {
+        if (better(wv_cnt[w], wv_err[w], wv_hyp[w], win_cnt, win_err, win_hyp)) { win_cnt = wv_cnt[w]; win_err = wv_err[w]; win_hyp = wv_hyp[w]; ww = w; }
+    }
+    write_result(p, b, n, win_cnt >= 4, best_pose[ww], win_hyp, thr2, kin, wv_cnt);
+}
+
+
+// ---- split form (lc_pnp_ransac_init3_f32): the same RANSAC as three launches over a caller-provided workspace ---------------------
+// The one-workgroup-per-pose kernel above keeps one pose on ONE compute unit: 64 objects x 150 hypotheses x 1000+ points use a
+// quarter of the chip, and every wavefront walks all points of its pose (1024 x ~22 VALU slots x 4 cycles = 38 us at best).  Here
+//   1. hypotheses: grid rounds x B, one lane per hypothesis: sample, P3P, fourth-point pick -> workspace (fp32 for scoring, fp64
+//      for the answer);
+//   2. scoring: one wavefront per (pose, chunk of 64 points, round of 64 hypotheses): the chunk is staged in LDS, every lane scores
+//      its hypothesis on it and writes (count, error) of the chunk -- no atomics: the chunk partials are summed in chunk order by
+//      step 3, so results do not depend on scheduling;
+//   3. selection: grid B: arg-max of (count, -error, -hypothesis id), inlier mask of the winner over all points, outputs.
+// Same hypothesis stream, same per-point arithmetic, same ordering as the single launch (the error sums are associated by chunk).
+constexpr int kChunkPts = 64;
+
+struct RansacWorkspace {
+    double* hyp64;   // (B, H, 12)
+    float* hyp32;    // (B, H, 12)
+    int* part_cnt;   // (B, C, H)
+    float* part_err; // (B, C, H)
+    int H, C;
+};
+__host__ __device__ inline RansacWorkspace carve_workspace(void* ws, int B, int Nmax, int rounds) {
+    RansacWorkspace w;
+    w.H = rounds * kWave;
+    const int nl = Nmax < kMaxLdsPts ? Nmax : kMaxLdsPts;
+    w.C = (nl + kChunkPts - 1) / kChunkPts;
+    if (w.C < 1) w.C = 1;
+    char* q = static_cast<char*>(ws);
+    w.hyp64 = reinterpret_cast<double*>(q); q += sizeof(double) * 12 * (size_t)B * w.H;
+    w.hyp32 = reinterpret_cast<float*>(q); q += sizeof(float) * 12 * (size_t)B * w.H;
+    w.part_cnt = reinterpret_cast<int*>(q); q += sizeof(int) * (size_t)B * w.C * w.H;
+    w.part_err = reinterpret_cast<float*>(q);
+    return w;
+}
+
+__global__ __launch_bounds__(kWave) void lc_ransac_hypotheses_kernel(const RansacParams p) {
+    LC_P3P_STAMP(0);
+    const int b = blockIdx.x / p.rounds, hyp = (blockIdx.x % p.rounds) * kWave + threadIdx.x;
+    const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+    if (n < 4) return;  // the selection step flags the pose
+    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    const CamInv kin(p.K + 9 * (size_t)b);
+    const size_t base = (size_t)b * p.Nmax;
+    int idx[4];
+    sample_indices(p.seed, b, hyp, min(n, kMaxLdsPts), idx);
+    LC_P3P_STAMP(1);
+    Pose cand;
+    const bool have = hypothesis_pose(idx, [&](int i, float (&X)[3], float (&u)[2]) {
+        X[0] = p.pts3d[(base + i) * 3]; X[1] = p.pts3d[(base + i) * 3 + 1]; X[2] = p.pts3d[(base + i) * 3 + 2];
+        kin.normalise(p.pts2d[(base + i) * 2], p.pts2d[(base + i) * 2 + 1], u[0], u[1]);
+    }, cand);
+    LC_P3P_STAMP(5);
+    double* o64 = w.hyp64 + 12 * ((size_t)b * w.H + hyp);
+    float* o32 = w.hyp32 + 12 * ((size_t)b * w.H + hyp);
+    if (!have) {  // behind the camera for every point: no inliers (the single launch scores such a lane -1, below every usable count)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cand.R[k] = 0.0;
+        cand.t[0] = cand.t[1] = 0.0; cand.t[2] = -1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { o64[k] = cand.R[k]; o32[k] = (float)cand.R[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o64[9 + k] = cand.t[k]; o32[9 + k] = (float)cand.t[k]; }
+    LC_P3P_STAMP(6);
+}
+
+__global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kernel(const RansacParams p) {
+    // One wavefront per (pose, chunk, round of 64 hypotheses); the four wavefronts of a workgroup are independent (own LDS slice, no
+    // barrier).  Structure of arrays: four consecutive points load as one 16-byte LDS read per coordinate, already paired for the
+    // packed math.
+    __shared__ __attribute__((aligned(16))) float lds[kRansacMaxWaves][5][kChunkPts];
+    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long unit = (long long)blockIdx.x * kRansacMaxWaves + wave;
+    const int per_pose = w.C * p.rounds;
+    if (unit >= (long long)p.B * per_pose) return;
+    const int b = (int)(unit / per_pose), rem = (int)(unit % per_pose), c = rem / p.rounds, round = rem % p.rounds;  // neighbours share a chunk
+    float *sX = lds[wave][0], *sY = lds[wave][1], *sZ = lds[wave][2], *sU = lds[wave][3], *sV = lds[wave][4];
+    // Everything that does not depend on the pose's point count is requested first (the count itself, K, this lane's hypothesis,
+    // the chunk's points up to the padded row length): one memory round trip instead of three dependent ones.
+    const int i0 = c * kChunkPts, cap = max(0, min(kChunkPts, min(p.Nmax, kMaxLdsPts) - i0));
+    const size_t base = (size_t)b * p.Nmax + i0;
+    static_assert(kChunkPts == kWave, "one point per lane");
+    const bool in_row = lane < cap;
+    const float gx = in_row ? p.pts3d[(base + lane) * 3] : 0.f, gy = in_row ? p.pts3d[(base + lane) * 3 + 1] : 0.f,
+                gz = in_row ? p.pts3d[(base + lane) * 3 + 2] : 0.f;
+    const float gu = in_row ? p.pts2d[(base + lane) * 2] : 0.f, gv = in_row ? p.pts2d[(base + lane) * 2 + 1] : 0.f;
+    const int hyp = round * kWave + lane;
+    float R[9], t[3];
+    {
+        const float* h32 = w.hyp32 + 12 * ((size_t)b * w.H + hyp);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = h32[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = h32[9 + k];
+    }
+    const CamInv kin(p.K + 9 * (size_t)b);
+    const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+    if (n < 4) return;
+    const int nl = min(n, kMaxLdsPts);
+    const int cnt_pts = max(0, min(kChunkPts, nl - i0)), cnt4 = (cnt_pts + 3) & ~3;
+    if (cnt_pts == 0) return;  // the selection step sums the chunks the pose has
+    if (lane < cnt_pts) {
+        float ux, uy;
+        kin.normalise(gu, gv, ux, uy);
+        sU[lane] = -ux; sV[lane] = -uy;  // stored negated: the residual is one fma
+        sX[lane] = gx; sY[lane] = gy; sZ[lane] = gz;
+    } else if (lane < cnt4) {  // padding of the last group of four: an infinite image coordinate is never an inlier
+        sX[lane] = sY[lane] = sZ[lane] = 0.f;
+        sU[lane] = sV[lane] = -INFINITY;
+    }
+    __builtin_amdgcn_wave_barrier();  // LDS operations of one wavefront execute in order: no wait beyond the compiler's own
+    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr = thr_px * (float)sqrt(fabs(kin.idet));
+    const float thr2 = thr * thr;
+    int cnt = 0;
+    v2f_t err2 = {0.f, 0.f};
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    auto rd = [](const float* a, int i) { return *reinterpret_cast<const v4f_t*>(a + i); };
+    v4f_t X = rd(sX, 0), Y = rd(sY, 0), Z = rd(sZ, 0), U = rd(sU, 0), V = rd(sV, 0);
+    for (int i = 0; i < cnt4; i += 4) {
+        const int nx = i + 4 < cnt4 ? i + 4 : i;  // the next group is in flight while this one is scored
+        const v4f_t Xn = rd(sX, nx), Yn = rd(sY, nx), Zn = rd(sZ, nx), Un = rd(sU, nx), Vn = rd(sV, nx);
+        score_pair(R, t, X.xy, Y.xy, Z.xy, U.xy, V.xy, thr2, cnt, err2);
+        score_pair(R, t, X.zw, Y.zw, Z.zw, U.zw, V.zw, thr2, cnt, err2);
+        X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
+    }
+    const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
+    w.part_cnt[o] = cnt;
+    w.part_err[o] = err2.x + err2.y;
+}
+
+__global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kernel(const RansacParams p) {
+    __shared__ double best_pose[12];
+    __shared__ int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
+    __shared__ float wv_err[kRansacMaxWaves];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
+    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    int win_cnt = -1, win_hyp = 0x7fffffff;
+    float win_err = INFINITY;
+    // the first hypothesis of this thread: its chunk partials are requested together with the point count (rows of chunks the
+    // pose does not have hold stale values and are not summed)
+    int pc0[kMaxLdsPts / kChunkPts];
+    float pe0[kMaxLdsPts / kChunkPts];
+#pragma unroll
+    for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {
+        const bool have = c < w.C && tid < w.H;
+        const size_t o = ((size_t)b * w.C + c) * w.H + tid;
+        pc0[c] = have ? w.part_cnt[o] : 0;
+        pe0[c] = have ? w.part_err[o] : 0.f;
+    }
+    const CamInv kin(p.K + 9 * (size_t)b);
+    const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+    unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
+    for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
+    if (n < 4) {
+        if (tid == 0) write_too_few(p, b);
+        return;
+    }
+    const int chunks = (min(n, kMaxLdsPts) + kChunkPts - 1) / kChunkPts;
+    if (tid < w.H) {
+        int cnt = 0;
+        float err = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {  // chunk order: the sums do not depend on which workgroup finished first
+            cnt += c < chunks ? pc0[c] : 0;
+            err += c < chunks ? pe0[c] : 0.f;
+        }
+        win_cnt = cnt; win_err = err; win_hyp = tid;
+    }
+    for (int hyp = tid + nthr; hyp < w.H; hyp += nthr) {  // more than 256 hypotheses
+        int cnt = 0;
+        float err = 0.f;
+        for (int c = 0; c < chunks; ++c) {
+            const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
+            cnt += w.part_cnt[o];
+            err += w.part_err[o];
+        }
+        if (better_hyp(cnt, err, hyp, win_cnt, win_err, win_hyp)) { win_cnt = cnt; win_err = err; win_hyp = hyp; }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int oc = __shfl_xor(win_cnt, m, kWave), oh = __shfl_xor(win_hyp, m, kWave);
+        const float oe = __shfl_xor(win_err, m, kWave);
+        if (better_hyp(oc, oe, oh, win_cnt, win_err, win_hyp)) { win_cnt = oc; win_err = oe; win_hyp = oh; }
+    }
+    if (lane == 0) { wv_cnt[wave] = win_cnt; wv_err[wave] = win_err; wv_hyp[wave] = win_hyp; }
+    __syncthreads();
+    win_cnt = wv_cnt[0]; win_err = wv_err[0]; win_hyp = wv_hyp[0];
+    for (int v = 1; v < nwaves; ++v)
+        if (better_hyp(wv_cnt[v], wv_err[v], wv_hyp[v], win_cnt, win_err, win_hyp)) { win_cnt = wv_cnt[v]; win_err = wv_err[v]; win_hyp = wv_hyp[v]; }
+    const bool ok = win_cnt >= 4;
+    if (ok && tid < 12) best_pose[tid] = w.hyp64[12 * ((size_t)b * w.H + win_hyp) + tid];
+    __syncthreads();
+    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr = thr_px * (float)sqrt(fabs(kin.idet));
+    write_result(p, b, n, ok, best_pose, win_hyp, thr * thr, kin, wv_cnt);
+}
+
 }  // namespace
+
+size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds) {
+    if (B <= 0 || rounds <= 0) return 0;
+    const int H = rounds * kWave;
+    const int nl = Nmax < kMaxLdsPts ? Nmax : kMaxLdsPts;
+    const int C = nl > 0 ? (nl + kChunkPts - 1) / kChunkPts : 1;
+    return (size_t)B * H * 12 * (sizeof(double) + sizeof(float)) + (size_t)B * C * H * (sizeof(int) + sizeof(float));
+}
 
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     const int waves = p.rounds < kRansacMaxWaves ? (p.rounds < 1 ? 1 : p.rounds) : kRansacMaxWaves;
-    hipLaunchKernelGGL(lc_pnp_ransac_kernel, dim3(p.B), dim3(64 * waves), 0, stream, p);
+    if (!p.workspace) {  // single launch, one workgroup per pose
+        hipLaunchKernelGGL(lc_pnp_ransac_kernel, dim3(p.B), dim3(64 * waves), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    if (p.workspace_bytes < pnp_ransac_workspace_bytes(p.B, p.Nmax, p.rounds)) return 3;
+    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    hipLaunchKernelGGL(lc_ransac_hypotheses_kernel, dim3((unsigned)p.rounds * p.B), dim3(kWave), 0, stream, p);
+    const long long units = (long long)p.B * w.C * p.rounds;
+    hipLaunchKernelGGL(lc_ransac_score_kernel, dim3((unsigned)((units + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
+    hipLaunchKernelGGL(lc_ransac_select_kernel, dim3(p.B), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 }  // namespace lc
+
+#ifdef LC_P3P_STAMPS
+extern "C" __attribute__((visibility("default"))) int lc_debug_p3p_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::p3p_diag::g_p3p_stamp), sizeof(unsigned long long) * 7) == hipSuccess ? 0 : 1;
+}
+#endif

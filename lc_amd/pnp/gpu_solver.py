@@ -15,15 +15,22 @@ from . import cer_solver, pnp_ceres
 
 
 def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True,
-                 return_hypothesis=False):
+                 return_hypothesis=False, split=None):
     """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool
-    [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly]."""
+    [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly].
+
+    split: None picks the launch form from the shape -- the single launch keeps a pose on one compute unit (its scoring loop costs
+    ~0.07 us per point, times ceil(B/256) when the poses outnumber the compute units), the split form pays ~17 us of extra launches
+    and fixed work but spreads the points of a pose over the chip (scripts/ubench/ransac_forms.py: (64, 1024) 83 -> 37 us,
+    (256, 64) 27 vs 33 us); True / False force one."""
     lib = _lib.load()
     K = _lib.require_hip_f32("cam_mat", cam_mat)
     X = _lib.require_hip_f32("coord_3d", coord_3d)
     U = _lib.require_hip_f32("coord_2d", coord_2d)
     B, N = X.shape[:2]
     dev = X.device
+    if split is None:
+        split = N * ((B + 255) // 256) > 256
     counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
     per_pose = None
     if isinstance(reprojectionError, torch.Tensor):
@@ -34,17 +41,23 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     n_in = torch.empty(B, device=dev, dtype=torch.int32)
     invalid = torch.empty(B, device=dev, dtype=torch.int32)
     hyp = torch.empty(B, device=dev, dtype=torch.int32) if return_hypothesis else None
+    args = (_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError), _lib.ptr(per_pose), int(iterations),
+            int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask), _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp))
     with torch.cuda.device(dev):
-        rc = lib.lc_pnp_ransac_init2_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError),
-                                         _lib.ptr(per_pose), int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask),
-                                         _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp), _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_pnp_ransac_init2_f32")
+        if split:  # hypotheses / scoring / selection as three launches over a workspace: spreads one pose over many compute units
+            nbytes = int(lib.lc_pnp_ransac_workspace_bytes(B, N, int(iterations)))
+            ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
+            rc = lib.lc_pnp_ransac_init3_f32(*args, _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+        else:      # one launch, one workgroup per pose
+            rc = lib.lc_pnp_ransac_init2_f32(*args, _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_ransac_init3_f32" if split else "lc_pnp_ransac_init2_f32")
     inl = mask.bool()
     bad = invalid.bool()
     if refine:
-        w = inl.to(torch.float32).unsqueeze(-1).expand(B, N, 2).contiguous()  # unit information on inliers, zero elsewhere
-        st, _, ret = pnp_ceres.solve_device(K, X, U, w, states, counts, max_iter_count=20)
-        states = torch.where((ret != 0)[:, None] | bad[:, None], states, st)
+        # unit information on the inliers (weight_mask), poses RANSAC gave up on are skipped through a zero point count: the solver
+        # returns its start for them and for the solves it flags invalid -- no element-wise launches around the solve
+        rows = torch.full((B,), N, device=dev, dtype=torch.int32) if counts is None else counts
+        states, _, _ = pnp_ceres.solve_device(K, X, U, None, states, torch.where(bad, 0, rows), max_iter_count=20, weight_mask=mask)
     if return_hypothesis:
         return states, inl, bad, hyp, n_in
     return states, inl, bad

@@ -258,3 +258,43 @@ def test_pnp_full_size_permutation_and_batch_independence():
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(inplace, st) and torch.equal(tr2, tr) and torch.equal(ret2, ret)
+
+
+@pytest.mark.parametrize("B,N", [(37, 48), (9, 300), (5, 1500)])
+def test_fused_input_handling_equals_the_elementwise_route(B, N):
+    """lc_pnp_lm2_f32: nan_to_num, the square root of a diagonal inverse covariance and inlier-mask weights are applied at the
+    kernel's loads; results must be the bits of the route that does the same with torch element-wise ops in front of lc_pnp_lm_f32
+    (cer_solver.py:29-36), including the (filtered) start returned for invalid jobs."""
+    from lc_amd import synth
+    from lc_amd.pnp import cer_solver, pnp_ceres
+
+    dev = torch.device("cuda:0")
+    d = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B + N, outlier_frac=0.1).items()}
+    g = torch.Generator().manual_seed(5)
+    icov = d["inv_std"] ** 2
+    pts2d, pts3d, start, K = d["pts2d"].clone(), d["pts3d"].clone(), d["start"].clone(), d["K"].clone()
+    # poison: NaN / inf in every input kind
+    pts2d[0, 1, 0] = float("nan"); pts3d[1, 2, 1] = float("inf"); icov[2, 0, 1] = float("nan"); icov[3, 1, 0] = float("inf")
+    start[4, 5] = float("nan")
+    counts = torch.randint(3, N + 1, (B,), generator=g).to(torch.int32).to(dev)
+    counts[-1] = 2  # too few points: invalid, returns the start
+    # (a) the reference-surface call, now on the fused route
+    inv_a, st_a = cer_solver.solve(K, pts3d, pts2d, icov, start, counts, filter_input_nan=True)
+    # (b) the element-wise route spelled out
+    Kf, Xf, Uf, Wf, Sf = (torch.nan_to_num(t) for t in (K, pts3d, pts2d, icov, start))
+    st_b, _tr, ret_b = pnp_ceres.solve_device(Kf, Xf, Uf, Wf.sqrt(), Sf, counts)
+    st_b = torch.where((ret_b != 0)[:, None], Sf, st_b)
+    assert torch.equal(inv_a["invalids"], ret_b != 0) and bool(inv_a["invalids"][-1])
+    assert torch.equal(st_a, st_b)
+    # without the filter the poisoned jobs fail and hand back their unfiltered start
+    inv_c, st_c = cer_solver.solve(K, pts3d, pts2d, icov, start, counts)
+    st_d, _tr, ret_d = pnp_ceres.solve_device(K, pts3d, pts2d, icov.sqrt(), start, counts)
+    assert torch.equal(inv_c["invalids"], ret_d != 0)
+    same = ~torch.isnan(st_d).any(-1)
+    assert torch.equal(st_c[same], st_d[same]) and bool(inv_c["invalids"][0])
+    # inlier-mask weights == float weights of ones and zeros
+    m = (torch.rand(B, N, generator=g) > 0.3).to(dev)
+    st_m, tr_m, ret_m = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], None, d["start"], counts, max_iter_count=20, weight_mask=m)
+    w = m.float().unsqueeze(-1).expand(B, N, 2).contiguous()
+    st_w, tr_w, ret_w = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], w, d["start"], counts, max_iter_count=20)
+    assert torch.equal(st_m, st_w) and torch.equal(tr_m, tr_w) and torch.equal(ret_m, ret_w)
