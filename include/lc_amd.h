@@ -179,12 +179,14 @@ int lc_pnp_ransac_init2_f32(const float *K, const float *pts3d, const float *pts
  * x 1000+ dense correspondences): three launches -- hypotheses (one lane each), scoring (point chunks x hypotheses, spread over
  * all compute units), selection -- over a caller-provided device workspace of lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)
  * bytes (8-byte aligned; contents undefined before and after).  Same hypothesis stream, same per-point arithmetic and the same
- * (count, error, hypothesis index) ordering as the single launch; results do not depend on scheduling (no atomics). */
+ * (count, error, hypothesis index) ordering as the single launch; results do not depend on scheduling (no atomics).
+ * workspace == NULL runs the single launch through this entry.  valid_counts (B)|NULL: the pose's point count, 0 when the pose is
+ * invalid -- handed as `counts` to a following lc_pnp_lm2_f32 refinement it makes that solve skip the failed poses. */
 size_t lc_pnp_ransac_workspace_bytes(int B, int Nmax, int iterations);
 int lc_pnp_ransac_init3_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
                             float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
                             float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
-                            void *workspace, size_t workspace_bytes, void *stream);
+                            int *valid_counts, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2f) ZebraPose binary surface codes -- floatbits.py.  logits (B,C,H,W), C = n0+n1+n2 code bits

@@ -355,14 +355,14 @@ size_t lc_pnp_ransac_workspace_bytes(int B, int Nmax, int iterations) {
 
 int lc_pnp_ransac_init3_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
                             float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
-                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, void* workspace,
+                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
                             size_t workspace_bytes, void* stream) {
     if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
     if (B == 0) return 0;
-    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid || !workspace) return fail(1, "null pointer");
+    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, workspace);
     lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
-                       (iterations + 63) / 64, reproj_err, seed, best_hyp, workspace, workspace_bytes};
+                       (iterations + 63) / 64, reproj_err, seed, best_hyp, valid_counts, workspace, workspace_bytes};
     const int rc = lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream));
     if (rc == 3) return fail(1, "workspace smaller than lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)");
     return rc ? fail(11, "ransac kernel launch failed") : 0;

@@ -101,6 +101,7 @@ struct RansacParams {
     float reproj_err;
     unsigned seed;
     int* best_hyp;         // (B,) out or null: index of the winning hypothesis (-1 when invalid) -- parity diagnostics
+    int* valid_counts;     // (B,) out or null: the pose's point count, 0 when invalid -- the `counts` of a refinement that must skip failed poses
     void* workspace;       // null: single launch (one workgroup per pose); else the split form (hypotheses / scoring / selection)
     size_t workspace_bytes;
 };

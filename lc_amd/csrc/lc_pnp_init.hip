@@ -422,6 +422,7 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
         }
         p.invalid[b] = ok ? 0 : 1;
         if (p.best_hyp) p.best_hyp[b] = ok ? win_hyp : -1;
+        if (p.valid_counts) p.valid_counts[b] = ok ? n : 0;
     }
 }
 
@@ -433,6 +434,7 @@ __device__ __forceinline__ void write_too_few(const RansacParams& p, int b) {
     p.invalid[b] = 1;
     p.n_inliers[b] = 0;
     if (p.best_hyp) p.best_hyp[b] = -1;
+    if (p.valid_counts) p.valid_counts[b] = 0;
 }
 
 constexpr int kRansacMaxWaves = 4;  // hypothesis rounds of 64 run on separate wavefronts of the pose's workgroup

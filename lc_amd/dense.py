@@ -109,8 +109,11 @@ def dense_select(pts2d: Tensor, inv_std2d: Tensor, pts3d: Tensor, mode: str, *, 
     dev = U.device
     m = None
     if mask is not None:
-        m = mask.to(device=dev).reshape(B, N)
-        m = (m if m.dtype == torch.uint8 else (m != 0).to(torch.uint8)).contiguous()
+        m = mask.to(device=dev).reshape(B, N).contiguous()
+        if m.dtype == torch.bool:
+            m = m.view(torch.uint8)  # same bytes (0 / 1): no launch
+        elif m.dtype != torch.uint8:
+            m = (m != 0).view(torch.uint8)
     cnt_in = None if counts is None else counts.to(device=dev, dtype=torch.int32).contiguous()
     idx_in = None if index is None else index.to(device=dev, dtype=torch.int32).contiguous()
     o_u, o_w, o_x = torch.empty_like(U), torch.empty_like(S), torch.empty_like(X)

@@ -41,23 +41,23 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     n_in = torch.empty(B, device=dev, dtype=torch.int32)
     invalid = torch.empty(B, device=dev, dtype=torch.int32)
     hyp = torch.empty(B, device=dev, dtype=torch.int32) if return_hypothesis else None
-    args = (_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError), _lib.ptr(per_pose), int(iterations),
-            int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask), _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp))
+    rows = torch.empty(B, device=dev, dtype=torch.int32) if refine else None  # point count, 0 for the poses RANSAC gave up on
+    ws, nbytes = None, 0
     with torch.cuda.device(dev):
         if split:  # hypotheses / scoring / selection as three launches over a workspace: spreads one pose over many compute units
             nbytes = int(lib.lc_pnp_ransac_workspace_bytes(B, N, int(iterations)))
             ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
-            rc = lib.lc_pnp_ransac_init3_f32(*args, _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
-        else:      # one launch, one workgroup per pose
-            rc = lib.lc_pnp_ransac_init2_f32(*args, _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_pnp_ransac_init3_f32" if split else "lc_pnp_ransac_init2_f32")
-    inl = mask.bool()
-    bad = invalid.bool()
+        rc = lib.lc_pnp_ransac_init3_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError),
+                                         _lib.ptr(per_pose), int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask),
+                                         _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp), _lib.ptr(rows), _lib.ptr(ws), nbytes,
+                                         _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_ransac_init3_f32")
+    inl = mask.view(torch.bool)  # the kernel writes 0 / 1: same bytes, no launch
+    bad = invalid != 0
     if refine:
-        # unit information on the inliers (weight_mask), poses RANSAC gave up on are skipped through a zero point count: the solver
-        # returns its start for them and for the solves it flags invalid -- no element-wise launches around the solve
-        rows = torch.full((B,), N, device=dev, dtype=torch.int32) if counts is None else counts
-        states, _, _ = pnp_ceres.solve_device(K, X, U, None, states, torch.where(bad, 0, rows), max_iter_count=20, weight_mask=mask)
+        # unit information on the inliers (weight_mask); the poses RANSAC gave up on are skipped through their zero point count: the
+        # solver returns its start for them and for the solves it flags invalid -- no element-wise launches around the solve
+        states, _, _ = pnp_ceres.solve_device(K, X, U, None, states, rows, max_iter_count=20, weight_mask=mask)
     if return_hypothesis:
         return states, inl, bad, hyp, n_in
     return states, inl, bad

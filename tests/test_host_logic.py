@@ -42,7 +42,7 @@ def test_ransac_workspace_contract():
     assert lib.lc_pnp_ransac_workspace_bytes(B, 5000, 150) == B * H * 12 * 12 + B * 32 * H * 8  # scoring stops at 2048 points
     buf = ctypes.create_string_buffer(64)
     p = ctypes.addressof(buf)
-    rc = lib.lc_pnp_ransac_init3_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, p, 64, None)
+    rc = lib.lc_pnp_ransac_init3_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, p, 64, None)
     assert rc != 0 and b"workspace" in lib.lc_amd_last_error()
 
 
