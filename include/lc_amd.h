@@ -66,12 +66,15 @@ int lc_pnp_lm_f32(const float *K, const float *pts3d, const float *pts2d, const 
  *       (cer_solver.py:29-31 `filter_input_nan`); an invalid job returns the FILTERED start;
  *   weight_mask (B,Nmax) uint8: unit information on the flagged correspondences, none on the others (the RANSAC inlier
  *       refinement of lc_amd/pnp/gpu_solver.py); exactly one of sqrtL / weights_diag / weight_mask is given.
- * options = 0 with sqrtL or weights_diag is lc_pnp_lm_f32. */
+ *   pose_mod > 0: K and start have pose_mod rows and pose b reads row b % pose_mod -- several solves of the same objects on
+ *       different correspondence selections (test.py:120,133 'weighted' and 'weighted-filtered') as ONE launch of B = k pose_mod poses.
+ * options = 0, pose_mod = 0 with sqrtL or weights_diag is lc_pnp_lm_f32. */
 #define LC_PNP_WEIGHTS_ARE_ICOV 1
 #define LC_PNP_NAN_TO_NUM 2
 int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
                    const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,
-                   int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, void *stream);
+                   int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod,
+                   void *stream);
 
 /* (2a') Parity diagnostics of (2a): the same solve (same template body, so the same arithmetic) that also records the
  *      trust-region schedule -- what `Solver::Summary::iterations` holds after ceres::Solve (ceres.cpp:126-130) --

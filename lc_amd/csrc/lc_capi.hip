@@ -171,18 +171,19 @@ int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const 
 
 int lc_pnp_lm2_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
                    const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
-                   int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, void* stream) {
-    if (B < 0 || Nmax < 0) return fail(1, "negative size");
+                   int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod, void* stream) {
+    if (B < 0 || Nmax < 0 || pose_mod < 0) return fail(1, "negative size");
     if (B == 0) return 0;
     if ((sqrtL != nullptr) + (weights_diag != nullptr) + (weight_mask != nullptr) != 1)
         return fail(1, "exactly one of sqrtL / weights_diag / weight_mask must be given");
     if (options & ~(LC_PNP_WEIGHTS_ARE_ICOV | LC_PNP_NAN_TO_NUM)) return fail(1, "unknown option bit");
     if ((options & LC_PNP_WEIGHTS_ARE_ICOV) && !weights_diag) return fail(1, "LC_PNP_WEIGHTS_ARE_ICOV needs weights_diag");
+    if (pose_mod > 0 && (!start || start == states)) return fail(1, "pose_mod needs a separate start array");
     if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, pts2d, weights_diag);
     LC_REQUIRE_ALIGNED(16, sqrtL);
     lc::PnpParams p{K, pts2d, pts3d, sqrtL, weights_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
-                    B, Nmax, max_iter, function_tolerance, nullptr, 0, options, weight_mask};
+                    B, Nmax, max_iter, function_tolerance, nullptr, 0, options, weight_mask, pose_mod};
     if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
     return 0;
 }

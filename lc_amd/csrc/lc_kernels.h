@@ -50,6 +50,7 @@ struct PnpParams {
     int trace_rows;
     int options;          // kPnp* bits (launch_pnp_lm only): what the callers otherwise do with element-wise launches in front
     const unsigned char* weight_mask;  // (B,Nmax) or null: unit information where non-zero, none elsewhere (instead of sqrtL / sqrt_diag)
+    int pose_mod;         // > 0: K and start have pose_mod rows, pose b reads row b % pose_mod (start must be given)
 };
 enum PnpOptions { kPnpWeightsAreIcov = 1,  // sqrt_diag holds inverse VARIANCES: take the square root at the load (cer_solver.py:33-36)
                   kPnpNanToNum = 2 };      // torch.nan_to_num on K, points, weights and start at the load (cer_solver.py:29-31)

@@ -42,7 +42,7 @@ int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream) {
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     const bool big = p.B > kLatencyGridMax;
-    if (p.options || p.weight_mask) {  // input filtering / weight forms folded into the load
+    if (p.options || p.weight_mask || p.pose_mod > 0) {  // input filtering / weight forms folded into the load
         if (p.Nmax <= 64) {
             if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS, true>), dim3(p.B), dim3(64), 0, stream, p);
             else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1, true>), dim3(p.B), dim3(64), 0, stream, p);

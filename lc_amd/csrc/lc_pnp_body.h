@@ -264,7 +264,10 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     LC_PSTAMP_DECL;
     LC_PSTAMP_BEGIN();
     const int n = p.counts ? p.counts[b] : p.Nmax;
-    const float* st_in = (p.start ? p.start : p.states) + 7 * (size_t)b;
+    // pose_mod (OPTS launches): K and start hold pose_mod rows shared by the poses b, b + pose_mod, ... (several solves of the same
+    // objects -- different correspondence selections -- batched into one launch)
+    const int bk = (OPTS && p.pose_mod > 0) ? b % p.pose_mod : b;
+    const float* st_in = (p.start ? p.start + 7 * (size_t)bk : p.states + 7 * (size_t)b);
     const bool filter = OPTS && (p.options & kPnpNanToNum);
     auto fin = [&](float f) { return filter ? nan_to_num(f) : f; };
     if (n < 3) {  // ceres.cpp:84-91
@@ -282,7 +285,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     if constexpr (REG) raw = load_raw_point<OPTS>(p, base, active ? lane : 0);  // n >= 3 here: correspondence 0 exists
     double cam[6];
     {
-        const float* Kp = p.K + 9 * (size_t)b;
+        const float* Kp = p.K + 9 * (size_t)bk;
 #pragma unroll
         for (int i = 0; i < 6; ++i) cam[i] = fin(Kp[i]);  // only the first 6 floats are read (ceres.cpp:99-101)
     }

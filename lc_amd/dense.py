@@ -92,7 +92,7 @@ SELECT_MODES = {"mask": 0, "quantile": 1, "quantile_in_mask": 2}
 
 @torch.no_grad()
 def dense_select(pts2d: Tensor, inv_std2d: Tensor, pts3d: Tensor, mode: str, *, mask: Tensor = None, quantile: float = 0.0,
-                 counts: Tensor = None, index: Tensor = None, square_weights: bool = True, min_count: int = 4, seed: int = 0):
+                 counts: Tensor = None, index: Tensor = None, square_weights: bool = True, min_count: int = 4, seed: int = 0, out=None):
     """Test-time point selection (`test.py:39-45,94-113`) as ONE launch: (B,N,.) rows -> survivors compacted to the front of
     padded (B,N,.) rows + `counts` (B,) int32 + their source indices (B,N) int32.  No host synchronisation, no ragged lists:
     the results go straight into `gpu_solver.solve_device(..., n_points=counts)` / `cer_solver.solve(..., n_points=counts)`.
@@ -100,7 +100,8 @@ def dense_select(pts2d: Tensor, inv_std2d: Tensor, pts3d: Tensor, mode: str, *, 
     mode: 'mask' (keep mask), 'quantile' (keep summed weight >= per-sample quantile), 'quantile_in_mask' (the quantile is
     rescaled by the visible fraction and applied inside the mask).  `counts`/`index` describe an already compacted input
     (second-stage selection, e.g. by the RANSAC inlier mask).  Returns (pts2d, weights, pts3d, counts, index);
-    weights = inv_std2d**2 when `square_weights` (the solver's inverse covariance, `test.py:92`)."""
+    weights = inv_std2d**2 when `square_weights` (the solver's inverse covariance, `test.py:92`).
+    out: optional (pts2d, weights, pts3d, counts, index) buffers of those shapes to write into (e.g. halves of a larger batch)."""
     lib = _lib.load()
     U = _lib.require_hip_f32("pts2d", pts2d)
     S = _lib.require_hip_f32("inv_std2d", inv_std2d)
@@ -116,9 +117,16 @@ def dense_select(pts2d: Tensor, inv_std2d: Tensor, pts3d: Tensor, mode: str, *, 
             m = (m != 0).view(torch.uint8)
     cnt_in = None if counts is None else counts.to(device=dev, dtype=torch.int32).contiguous()
     idx_in = None if index is None else index.to(device=dev, dtype=torch.int32).contiguous()
-    o_u, o_w, o_x = torch.empty_like(U), torch.empty_like(S), torch.empty_like(X)
-    o_i = torch.empty(B, N, device=dev, dtype=torch.int32)
-    o_c = torch.empty(B, device=dev, dtype=torch.int32)
+    if out is not None:
+        o_u, o_w, o_x, o_c, o_i = out
+        if not (o_u.shape == U.shape and o_w.shape == S.shape and o_x.shape == X.shape and o_c.shape == (B,) and o_i.shape == (B, N)
+                and o_u.dtype == o_w.dtype == o_x.dtype == torch.float32 and o_c.dtype == o_i.dtype == torch.int32
+                and all(t.is_contiguous() and t.device == dev for t in out)):
+            raise ValueError("dense_select: `out` buffers must be contiguous tensors of the result shapes on the input's device")
+    else:
+        o_u, o_w, o_x = torch.empty_like(U), torch.empty_like(S), torch.empty_like(X)
+        o_i = torch.empty(B, N, device=dev, dtype=torch.int32)
+        o_c = torch.empty(B, device=dev, dtype=torch.int32)
     with torch.cuda.device(dev):
         rc = lib.lc_dense_select_f32(_lib.ptr(U), _lib.ptr(S), _lib.ptr(X), _lib.ptr(m), _lib.ptr(cnt_in), _lib.ptr(idx_in), B, N,
                                      SELECT_MODES[mode], float(quantile), int(square_weights), int(min_count), int(seed) & 0xFFFFFFFF,

@@ -85,20 +85,37 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     mode = cfg.dense_point_select
     if mode not in ("mask", "quantile", "quantile_in_mask"):
         raise ValueError(f"unknown dense_point_select {mode!r}")
-    # survivors compacted to the front of each row; icov = inv_std^2 (test.py:92); counts stay on the device
+    # survivors compacted to the front of each row; icov = inv_std^2 (test.py:92); counts stay on the device.
+    # 'weighted' and 'weighted-filtered' solve the same objects from the same start on two selections: when both are wanted the two
+    # selections are written into the halves of ONE (2B, N, .) batch and solved by ONE launch (K and start shared through
+    # `shared_poses`) -- 64 objects fill a quarter of the chip, the two solves side by side cost what one does.
+    wanted = cfg.solvers
+    both = "weighted_filtered" in wanted and "weighted" in wanted
+    B, N = pts2d.shape[:2]
+    rows = 2 * B if both else B
+    f32 = dict(device=pts2d.device, dtype=torch.float32)
+    i32 = dict(device=pts2d.device, dtype=torch.int32)
+    U2, W2, X2 = torch.empty(rows, N, 2, **f32), torch.empty(rows, N, 2, **f32), torch.empty(rows, N, 3, **f32)
+    C2, I2 = torch.empty(rows, **i32), torch.empty(rows, N, **i32)
+    halves = list(zip(*(t.chunk(2) if both else (t,) for t in (U2, W2, X2, C2, I2))))  # [(u, w, x, counts, index) of each half]
+    half = halves.__getitem__
     u, icov, x, counts, index = dense_select(pts2d, inv_std, pts3d, mode, mask=visible, quantile=float(cfg.get("quantile", 0.0)),
-                                             square_weights=True, min_count=4)
+                                             square_weights=True, min_count=4, out=half(0))
     start, inliers, _bad = gpu_solver.solve_device(K, x, u, counts, reprojectionError=_reprojection_threshold(cfg, gt_dict, 3))
 
-    wanted = cfg.solvers
     out = {}
     if "ransac" in wanted:
         out["ransac"] = start
-    if "weighted_filtered" in wanted:  # test.py:129-133: the selection intersected with the RANSAC inliers
+    if both:  # test.py:129-133: the selection intersected with the RANSAC inliers, next to the unfiltered one
+        dense_select(u, icov, x, "mask", mask=inliers, counts=counts, index=index, square_weights=False, min_count=4, out=half(1))
+        states = pnp_ceres.solve_device(K, X2, U2, W2, start, C2, weights_are_icov=True, nan_to_num=True, shared_poses=B)[0]
+        out["weighted"], out["weighted-filtered"] = states.chunk(2)
+        out = {k: out[k] for k in ("ransac", "weighted-filtered", "weighted") if k in out}  # key order of test.py:129-135
+    elif "weighted_filtered" in wanted:
         fu, ficov, fx, fcounts, _ = dense_select(u, icov, x, "mask", mask=inliers, counts=counts, index=index, square_weights=False,
                                                  min_count=4)
         out["weighted-filtered"] = _weighted(K, fx, fu, ficov, start, fcounts)
-    if "weighted" in wanted:
+    elif "weighted" in wanted:
         out["weighted"] = _weighted(K, x, u, icov, start, counts)
     return out
 
@@ -119,8 +136,8 @@ def quiet_capture():
 
 class GraphedSolvePnP:
     """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of ~13 short
-    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 176 us
-    eager -> 109 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
+    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 173 us
+    eager -> 93 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
 
         solver = GraphedSolvePnP(cfg, out_dict, gt_dict)      # example inputs fix the shapes; captured on a side stream
         poses = solver(out_dict, gt_dict)                     # copies the tensors into the static buffers, replays

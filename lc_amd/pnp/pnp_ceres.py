@@ -26,20 +26,21 @@ LC_PNP_WEIGHTS_ARE_ICOV, LC_PNP_NAN_TO_NUM = 1, 2  # include/lc_amd.h
 
 
 def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6,
-                 return_iters=False, trace_rows=0, weights_are_icov=False, nan_to_num=False, weight_mask=None):
+                 return_iters=False, trace_rows=0, weights_are_icov=False, nan_to_num=False, weight_mask=None, shared_poses=0):
     """Device route. cam_mat (B,3,3) pts3d (B,N,3) pts2d (B,N,2) start (B,7); sqrtL (B,N,2,2) lower factor or
     (B,N,2) diagonal; n_points (B,) int or None.  trace_rows > 0 runs the diagnostic twin of the kernel and appends the
     (B,trace_rows,8) float64 per-iteration schedule (`lc_pnp_lm_trace_f32`, include/lc_amd.h) to the returned tuple.
 
     Folded into the kernel's loads instead of separate element-wise launches (`lc_pnp_lm2_f32`): weights_are_icov (the diagonal
     tensor holds inverse variances), nan_to_num (torch.nan_to_num on every input; an invalid job returns the filtered start),
-    weight_mask (B,N) uint8/bool in place of sqrtL: unit information where set."""
+    weight_mask (B,N) uint8/bool in place of sqrtL: unit information where set; shared_poses = P > 0: cam_mat and start have P rows
+    and pose b of the B = k P correspondence sets reads row b % P (several selections of the same objects in one launch)."""
     lib = _lib.load()
     K = _lib.require_hip_f32("cam_mat", cam_mat)
     X = _lib.require_hip_f32("pts3d", pts3d)
     U = _lib.require_hip_f32("pts2d", pts2d)
     B, N = X.shape[:2]
-    if weights_are_icov or nan_to_num or weight_mask is not None:
+    if weights_are_icov or nan_to_num or weight_mask is not None or shared_poses:
         if trace_rows > 0:
             raise ValueError("the diagnostic trace takes plain inputs")
         M = None
@@ -52,7 +53,9 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
         else:
             L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)
         start = _lib.require_hip_f32("start", start)
-        state = torch.empty_like(start)
+        if shared_poses and (start.shape[0] != shared_poses or K.shape[0] != shared_poses or B % shared_poses):
+            raise ValueError("shared_poses: cam_mat and start need that many rows and B must be a multiple of it")
+        state = torch.empty(B, 7, device=X.device, dtype=torch.float32)
         dev = X.device
         counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
         tr = torch.empty(B, device=dev, dtype=torch.float32)
@@ -64,7 +67,7 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
             rc = lib.lc_pnp_lm2_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
                                     _lib.ptr(L) if (L is not None and not full) else None, _lib.ptr(M), _lib.ptr(counts), _lib.ptr(start),
                                     _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret), _lib.ptr(iters), B, N, int(max_iter_count),
-                                    float(function_tolerance), opts, _lib.stream_ptr(dev))
+                                    float(function_tolerance), opts, int(shared_poses), _lib.stream_ptr(dev))
         _lib.check(rc, "lc_pnp_lm2_f32")
         return (state, tr, ret, iters) if return_iters else (state, tr, ret)
     L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)

@@ -298,3 +298,27 @@ def test_fused_input_handling_equals_the_elementwise_route(B, N):
     w = m.float().unsqueeze(-1).expand(B, N, 2).contiguous()
     st_w, tr_w, ret_w = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], w, d["start"], counts, max_iter_count=20)
     assert torch.equal(st_m, st_w) and torch.equal(tr_m, tr_w) and torch.equal(ret_m, ret_w)
+
+
+def test_shared_poses_batch_equals_separate_solves():
+    """shared_poses: two correspondence selections of the same P objects solved as one launch of 2P poses (K and start given once)
+    return the bits of the two separate solves."""
+    from lc_amd import synth
+    from lc_amd.pnp import pnp_ceres
+
+    dev = torch.device("cuda:0")
+    P, N = 23, 400
+    d = {k: v.to(dev) for k, v in synth.make_batch(P, N, seed=3, outlier_frac=0.1).items()}
+    g = torch.Generator().manual_seed(1)
+    icov_a = d["inv_std"] ** 2
+    icov_b = icov_a * (torch.rand(P, N, 1, generator=g).to(dev) > 0.4)
+    cnt_a = torch.randint(50, N + 1, (P,), generator=g).to(torch.int32).to(dev)
+    cnt_b = torch.randint(3, N + 1, (P,), generator=g).to(torch.int32).to(dev)
+    kw = dict(weights_are_icov=True, nan_to_num=True)
+    st_a, tr_a, ret_a = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], icov_a, d["start"], cnt_a, **kw)
+    st_b, tr_b, ret_b = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], icov_b, d["start"], cnt_b, **kw)
+    X2, U2 = torch.cat([d["pts3d"], d["pts3d"]]), torch.cat([d["pts2d"], d["pts2d"]])
+    st, tr, ret = pnp_ceres.solve_device(d["K"], X2, U2, torch.cat([icov_a, icov_b]), d["start"], torch.cat([cnt_a, cnt_b]), shared_poses=P, **kw)
+    assert torch.equal(st, torch.cat([st_a, st_b])) and torch.equal(tr, torch.cat([tr_a, tr_b])) and torch.equal(ret, torch.cat([ret_a, ret_b]))
+    with pytest.raises(ValueError):
+        pnp_ceres.solve_device(d["K"], X2[:P + 1], U2[:P + 1], torch.cat([icov_a, icov_b])[:P + 1], d["start"], None, shared_poses=P, **kw)
