@@ -1,7 +1,7 @@
 """`lib.pnp.pnp_ceres` call surface (`lib/pnp/pnp_ceres.py:6-140`) on the HIP batched LM solver.
 
 Two routes, same results:
-  * tensors already on the GPU  -> `lc_pnp_lm_f32` on device-resident zero-padded batches (no host round trip);
+  * tensors already on the GPU  -> `lc_pnp_lm2_f32` (= `lc_pnp_lm_f32` + load-time options) on device-resident zero-padded batches (no host round trip);
   * CPU tensors / numpy arrays  -> the reference's own ABI `pnp_ceres_f32_omp` (arrays of host pointers), whose body
     in liblc_amd.so stages the jobs to the GPU.  This is exactly what the reference's cffi marshaller calls.
 Returns `(state, result_tr, invalid_flags)` like the reference (`:61`): float32 (B,7), float32 (B,), int32 (B,).
@@ -40,48 +40,28 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     X = _lib.require_hip_f32("pts3d", pts3d)
     U = _lib.require_hip_f32("pts2d", pts2d)
     B, N = X.shape[:2]
-    if weights_are_icov or nan_to_num or weight_mask is not None or shared_poses:
-        if trace_rows > 0:
-            raise ValueError("the diagnostic trace takes plain inputs")
-        M = None
-        L = None
-        if weight_mask is not None:
-            M = weight_mask.view(torch.uint8) if weight_mask.dtype == torch.bool else weight_mask
-            if M.dtype != torch.uint8 or not M.is_cuda or tuple(M.shape) != (B, N):
-                raise TypeError("weight_mask must be a (B,N) uint8/bool tensor on the GPU")
-            M = M.contiguous()
-        else:
-            L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)
-        start = _lib.require_hip_f32("start", start)
-        if shared_poses and (start.shape[0] != shared_poses or K.shape[0] != shared_poses or B % shared_poses):
-            raise ValueError("shared_poses: cam_mat and start need that many rows and B must be a multiple of it")
-        state = torch.empty(B, 7, device=X.device, dtype=torch.float32)
-        dev = X.device
-        counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
-        tr = torch.empty(B, device=dev, dtype=torch.float32)
-        ret = torch.empty(B, device=dev, dtype=torch.int32)
-        iters = torch.empty(B, device=dev, dtype=torch.int32) if return_iters else None
-        full = L is not None and L.dim() == 4
-        opts = (LC_PNP_WEIGHTS_ARE_ICOV if weights_are_icov else 0) | (LC_PNP_NAN_TO_NUM if nan_to_num else 0)
-        with torch.cuda.device(dev):
-            rc = lib.lc_pnp_lm2_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
-                                    _lib.ptr(L) if (L is not None and not full) else None, _lib.ptr(M), _lib.ptr(counts), _lib.ptr(start),
-                                    _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret), _lib.ptr(iters), B, N, int(max_iter_count),
-                                    float(function_tolerance), opts, int(shared_poses), _lib.stream_ptr(dev))
-        _lib.check(rc, "lc_pnp_lm2_f32")
-        return (state, tr, ret, iters) if return_iters else (state, tr, ret)
-    L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)
-    start = _lib.require_hip_f32("start", start)
-    state = torch.empty_like(start)
     dev = X.device
-    counts = None
-    if n_points is not None:
-        counts = torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
+    L = M = None
+    if weight_mask is not None:
+        M = weight_mask.view(torch.uint8) if weight_mask.dtype == torch.bool else weight_mask
+        if M.dtype != torch.uint8 or not M.is_cuda or tuple(M.shape) != (B, N):
+            raise TypeError("weight_mask must be a (B,N) uint8/bool tensor on the GPU")
+        M = M.contiguous()
+    else:
+        L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)
+    full = L is not None and L.dim() == 4
+    start = _lib.require_hip_f32("start", start)
+    if shared_poses and (start.shape[0] != shared_poses or K.shape[0] != shared_poses or B % shared_poses):
+        raise ValueError("shared_poses: cam_mat and start need that many rows and B must be a multiple of it")
+    state = torch.empty(B, 7, device=dev, dtype=torch.float32)
+    counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
     tr = torch.empty(B, device=dev, dtype=torch.float32)
     ret = torch.empty(B, device=dev, dtype=torch.int32)
     iters = torch.empty(B, device=dev, dtype=torch.int32) if return_iters else None
-    full = L.dim() == 4
+    opts = (LC_PNP_WEIGHTS_ARE_ICOV if weights_are_icov else 0) | (LC_PNP_NAN_TO_NUM if nan_to_num else 0)
     if trace_rows > 0:
+        if opts or M is not None or shared_poses:
+            raise ValueError("the diagnostic trace takes plain inputs")
         trace = torch.zeros(B, int(trace_rows), 8, device=dev, dtype=torch.float64)
         with torch.cuda.device(dev):
             rc = lib.lc_pnp_lm_trace_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
@@ -90,11 +70,12 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
                                          _lib.ptr(trace), int(trace_rows), _lib.stream_ptr(dev))
         _lib.check(rc, "lc_pnp_lm_trace_f32")
         return (state, tr, ret, iters, trace) if return_iters else (state, tr, ret, trace)
-    with torch.cuda.device(dev):
-        rc = lib.lc_pnp_lm_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
-                               None if full else _lib.ptr(L), _lib.ptr(counts), _lib.ptr(start), _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret),
-                               _lib.ptr(iters), B, N, int(max_iter_count), float(function_tolerance), _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_pnp_lm_f32")
+    with torch.cuda.device(dev):  # options = 0 without a mask is lc_pnp_lm_f32 (same kernel instantiation)
+        rc = lib.lc_pnp_lm2_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
+                                _lib.ptr(L) if (L is not None and not full) else None, _lib.ptr(M), _lib.ptr(counts), _lib.ptr(start),
+                                _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret), _lib.ptr(iters), B, N, int(max_iter_count),
+                                float(function_tolerance), opts, int(shared_poses), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_lm2_f32")
     return (state, tr, ret, iters) if return_iters else (state, tr, ret)
 
 
