@@ -54,7 +54,7 @@ def test_ransac_kernel_vs_oracle_fixture(path, split):
         assert decided.sum() >= 0.6 * valid.sum()
 
 
-@pytest.mark.parametrize("B,N,iters", [(64, 1024, 150), (5, 300, 64), (3, 2500, 200), (40, 64, 150), (7, 129, 150)])
+@pytest.mark.parametrize("B,N,iters", [(64, 1024, 150), (5, 300, 64), (3, 2500, 200), (40, 64, 150), (7, 129, 150), (6, 700, 300)])
 def test_split_form_equals_single_launch(B, N, iters):
     """lc_pnp_ransac_init3_f32 (three launches, point chunks spread over the chip) against the one-workgroup-per-pose launch on
     noisy correspondences with outliers: the per-hypothesis inlier counts are the same integers, so the winner has the same count;
