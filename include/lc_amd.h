@@ -154,6 +154,11 @@ int lc_softargmax2d_bwd(const void *in, int dtype, const float *mean, const floa
 int lc_dense_frontend_fwd_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale, int B,
                               int H, int W, int top, int left, int sample, float *pts2d, float *inv_std, float *pts3d,
                               float *lse, void *stream);
+/* Forward + the test-time visibility mask of the sampled pixels (test.py:88-90: sigmoid(msk_vis_logits) > seg_thresh, then the
+ * stride slice): vis_logits (B,H,W), vis_thresh -> vis_mask (B,N) uint8; both NULL = lc_dense_frontend_fwd_f32. */
+int lc_dense_frontend_fwd2_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale,
+                               const float *vis_logits, float vis_thresh, int B, int H, int W, int top, int left, int sample,
+                               float *pts2d, float *inv_std, float *pts3d, float *lse, unsigned char *vis_mask, void *stream);
 int lc_dense_frontend_bwd_f32(const float *wlogits, const float *wscale, const float *noc_scale, const float *lse,
                               const float *g_inv_std, const float *g_pts3d, int B, int H, int W, int top, int left,
                               int sample, float *d_xyz, float *d_wlogits, float *d_wscale, void *stream);

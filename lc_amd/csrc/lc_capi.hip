@@ -315,6 +315,19 @@ int lc_dense_frontend_fwd_f32(const float* xyz, const float* wlogits, const floa
     return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
 }
 
+int lc_dense_frontend_fwd2_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
+                               float vis_thresh, int B, int H, int W, int top, int left, int sample, float* pts2d, float* inv_std,
+                               float* pts3d, float* lse, unsigned char* vis_mask, void* stream) {
+    if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!wlogits || !wscale || !pts2d || !inv_std || !lse || (xyz != nullptr) != (pts3d != nullptr)) return fail(1, "null pointer");
+    if ((vis_logits != nullptr) != (vis_mask != nullptr)) return fail(1, "vis_logits and vis_mask go together");
+    LC_REQUIRE_ALIGNED(8, pts2d, inv_std);
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    lc::DenseParams p{xyz, wlogits, wscale, noc_scale, pts2d, inv_std, pts3d, lse, B, H, W, N, top, left, sample, vis_logits, vis_thresh, vis_mask};
+    return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
+}
+
 int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const float* noc_scale, const float* lse,
                               const float* g_inv_std, const float* g_pts3d, int B, int H, int W, int top, int left, int sample,
                               float* d_xyz, float* d_wlogits, float* d_wscale, void* stream) {

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_fwd_kernel(const D
         *reinterpret_cast<float2*>(p.pts2d + (ob + n) * 2) = make_float2((float)x, (float)y);
         *reinterpret_cast<float2*>(p.inv_std + (ob + n) * 2) =
             make_float2(__expf(lg[px] - lse) * scale, __expf(lg[HW + px] - lse) * scale);
+        // test time: the segmentation mask of the sampled pixel, torch.sigmoid's own formula (full-precision exp, IEEE divide)
+        if (p.vis_mask) p.vis_mask[ob + n] = (1.f / (1.f + expf(-p.vis_logits[(size_t)b * HW + px]))) > p.vis_thresh ? 1 : 0;
     }
     if (p.xyz) {  // binary-code heads decode their 3D points with lc_bits_decode_gt_* instead
         const float* __restrict__ xyz = p.xyz + (size_t)b * 3 * HW;

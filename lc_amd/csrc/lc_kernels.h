@@ -147,6 +147,9 @@ struct DenseParams {
     float* pts3d;            // (B,N,3)
     float* lse;              // (B,) saved for backward
     int B, H, W, N, top, left, sample;
+    const float* vis_logits; // (B,H,W) visibility logits or null: test-time selection mask of the sampled pixels (test.py:88-90)
+    float vis_thresh;        //   sigmoid(logit) > vis_thresh
+    unsigned char* vis_mask; // (B,N) out (with vis_logits)
 };
 int launch_dense_fwd(const DenseParams& p, hipStream_t stream);
 

@@ -18,19 +18,20 @@ def _n_points(H, W, top, left, sample):
     return ((H - top + sample - 1) // sample) * ((W - left + sample - 1) // sample)
 
 
-def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample):
+def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample, vis_logits=None, vis_thresh=0.5):
     lib = _lib.load()
     B, _, H, W = wlogits.shape
     N = _n_points(H, W, top, left, sample)
     f = dict(device=wlogits.device, dtype=torch.float32)
     pts2d, inv_std, lse = torch.empty(B, N, 2, **f), torch.empty(B, N, 2, **f), torch.empty(B, **f)
     pts3d = torch.empty(B, N, 3, **f) if xyz is not None else None
+    vis = torch.empty(B, N, device=wlogits.device, dtype=torch.uint8) if vis_logits is not None else None
     with torch.cuda.device(wlogits.device):
-        rc = lib.lc_dense_frontend_fwd_f32(_lib.ptr(xyz), _lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), B, H, W, top, left,
-                                           sample, _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(pts3d), _lib.ptr(lse),
-                                           _lib.stream_ptr(wlogits.device))
-    _lib.check(rc, "lc_dense_frontend_fwd_f32")
-    return pts2d, inv_std, pts3d, lse
+        rc = lib.lc_dense_frontend_fwd2_f32(_lib.ptr(xyz), _lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(vis_logits),
+                                            float(vis_thresh), B, H, W, top, left, sample, _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(pts3d),
+                                            _lib.ptr(lse), _lib.ptr(vis), _lib.stream_ptr(wlogits.device))
+    _lib.check(rc, "lc_dense_frontend_fwd2_f32")
+    return (pts2d, inv_std, pts3d, lse) if vis_logits is None else (pts2d, inv_std, pts3d, lse, vis)
 
 
 def _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, shape, top, left, sample, need):
@@ -85,6 +86,23 @@ def dense_front_end(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scal
     ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
     pts2d, inv_std, pts3d = _DenseFrontEndFn.apply(xyz, wl, ws, ns, int(top), int(left), int(sample))
     return pts2d, inv_std, (pts3d if xyz is not None else None)
+
+
+@torch.no_grad()
+def dense_front_end_with_visibility(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scale: Tensor, noc_scale: Tensor,
+                                    msk_vis_logits: Tensor, seg_thresh: float = 0.5, sample: int = 2, top_left=(0, 0)):
+    """Test-time form of `dense_front_end` (no autograd) that also returns the visibility mask of the sampled pixels,
+    `sigmoid(msk_vis_logits) > seg_thresh` on the stride slice (`test.py:88-90`), from the same launch: (pts2d, inv_std2d, pts3d,
+    visible (B,N) bool)."""
+    top, left = top_left
+    B, _, H, W = xyz_weight_logits.shape
+    xyz = None if xyz_noc is None else _lib.require_hip_f32("xyz_noc", xyz_noc)
+    wl = _lib.require_hip_f32("xyz_weight_logits", xyz_weight_logits)
+    ws = _lib.require_hip_f32("xyz_weights_scale", xyz_weights_scale.reshape(B))
+    ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
+    vl = _lib.require_hip_f32("msk_vis_logits", msk_vis_logits.reshape(B, H, W))
+    pts2d, inv_std, pts3d, _lse, vis = _launch_fwd(xyz, wl, ws, ns, int(top), int(left), int(sample), vl, seg_thresh)
+    return pts2d, inv_std, pts3d, vis.view(torch.bool)
 
 
 SELECT_MODES = {"mask": 0, "quantile": 1, "quantile_in_mask": 2}

@@ -20,7 +20,7 @@ import gc
 import torch
 from torch import Tensor
 
-from .dense import dense_front_end, dense_select
+from .dense import dense_front_end_with_visibility, dense_select
 from .losses import nn_out_to_xyz
 from .pnp import gpu_solver, pnp_ceres
 
@@ -67,20 +67,21 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     """Dense heads (`test.py:67-136`)."""
     K = gt_dict["out_K"]
     stride = cfg.get("dense_sample", 2)
-    # joint softmax x scale and the (0,0)-phase stride sub-sampling (test.py:85-92) in one launch
+    # joint softmax x scale, the (0,0)-phase stride sub-sampling (test.py:85-92) and the visibility mask of the sampled pixels
+    # (test.py:88-90) in one launch
+    thr = cfg.get("seg_thresh", 0.5)
     if "xyz_noc" in out_dict and gt_dict.get("model_transform", None) is None and gt_dict.get("bit_cnt", None) is None:
         # continuous head: the kernel scales the normalised coordinates itself (losses.py:17-22 is that one multiply)
-        pts2d, inv_std, pts3d = dense_front_end(out_dict["xyz_noc"], out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"],
-                                                gt_dict["noc_scale"], sample=stride, top_left=(0, 0))
+        pts2d, inv_std, pts3d, visible = dense_front_end_with_visibility(
+            out_dict["xyz_noc"], out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"], gt_dict["noc_scale"],
+            out_dict["msk_vis_logits"], thr, sample=stride)
     else:
         head = out_dict["xyz_noc"] if "xyz_noc" in out_dict else out_dict["xyz_noc_bin"]
         xyz = nn_out_to_xyz(head, gt_dict["noc_scale"], model_transform=gt_dict.get("model_transform", None),
                             bit_cnt=gt_dict.get("bit_cnt", None), inference=True)  # (B,H,W,3), object frame
-        pts2d, inv_std, pts3d = dense_front_end(xyz.permute(0, 3, 1, 2), out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"],
-                                                None, sample=stride, top_left=(0, 0))
-    # visibility on the sampled pixels only (test.py:88-90 thresholds the full map and then slices it)
-    vis_logits = out_dict["msk_vis_logits"].squeeze(-3)[..., 0::stride, 0::stride]
-    visible = (torch.sigmoid(vis_logits) > cfg.get("seg_thresh", 0.5)).flatten(start_dim=-2)
+        pts2d, inv_std, pts3d, visible = dense_front_end_with_visibility(
+            xyz.permute(0, 3, 1, 2), out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"], None, out_dict["msk_vis_logits"], thr,
+            sample=stride)
 
     mode = cfg.dense_point_select
     if mode not in ("mask", "quantile", "quantile_in_mask"):
@@ -135,9 +136,9 @@ def quiet_capture():
 
 
 class GraphedSolvePnP:
-    """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of ~13 short
-    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 173 us
-    eager -> 93 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
+    """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of 8 short
+    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 145 us
+    eager -> 86 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
 
         solver = GraphedSolvePnP(cfg, out_dict, gt_dict)      # example inputs fix the shapes; captured on a side stream
         poses = solver(out_dict, gt_dict)                     # copies the tensors into the static buffers, replays

@@ -53,7 +53,7 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
                                          _lib.stream_ptr(dev))
     _lib.check(rc, "lc_pnp_ransac_init3_f32")
     inl = mask.view(torch.bool)  # the kernel writes 0 / 1: same bytes, no launch
-    bad = invalid != 0
+    bad = invalid.view(torch.bool).view(B, 4)[:, 0]  # the flag is 0 / 1: its low byte as bool, no launch
     if refine:
         # unit information on the inliers (weight_mask); the poses RANSAC gave up on are skipped through their zero point count: the
         # solver returns its start for them and for the solves it flags invalid -- no element-wise launches around the solve

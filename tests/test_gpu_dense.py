@@ -90,3 +90,25 @@ def test_bin_loss_fn_end_to_end_on_gpu():
             assert rel_err(rec[k], z[k]) <= 2e-3, k
         else:
             assert rel_err(rec[k], z[k]) <= 1e-3, k
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.3, 0.9])
+def test_front_end_visibility_mask_equals_torch(thr):
+    """dense_front_end_with_visibility: the mask of the sampled pixels from the front-end launch is torch's
+    `sigmoid(logits) > thr` on the stride slice (test.py:88-90) bit for bit, and the other outputs are those of dense_front_end."""
+    from lc_amd.dense import dense_front_end, dense_front_end_with_visibility
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(int(thr * 100))
+    B, H, W, s = 5, 48, 40, 2
+    xyz, wl, ws = torch.randn(B, 3, H, W, generator=g).to(dev), torch.randn(B, 2, H, W, generator=g).to(dev), torch.rand(B, 1, 1, 1, generator=g).to(dev) + 0.5
+    ns = torch.rand(B, 3, generator=g).to(dev) + 0.5
+    # logits around the decision boundary logit(thr), incl. exact ties of the fp32 sigmoid
+    base = float(np.log(thr / (1 - thr)))
+    vl = (base + torch.randn(B, 1, H, W, generator=g) * 1e-3).to(dev)
+    vl[0, 0, :4] = base
+    p2, w2, x3, vis = dense_front_end_with_visibility(xyz, wl, ws, ns, vl, thr, sample=s)
+    q2, v2, y3 = dense_front_end(xyz, wl, ws, ns, sample=s, top_left=(0, 0))
+    assert torch.equal(p2, q2) and torch.equal(w2, v2) and torch.equal(x3, y3)
+    want = (torch.sigmoid(vl) > thr).squeeze(1)[..., 0::s, 0::s].flatten(-2)
+    assert vis.dtype == torch.bool and torch.equal(vis, want) and 0 < int(want.sum()) < want.numel()
