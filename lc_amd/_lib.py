@@ -125,6 +125,26 @@ def require_hip_map(name: str, t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """`torch.cuda.device(device)` for the launch, at no cost in the usual case that `device` already is the current one
+    (the context manager itself is ~3 us of the ~15 us a wrapper call costs on the host)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
 def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 

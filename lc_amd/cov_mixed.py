@@ -22,7 +22,7 @@ def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_
     d_s = torch.empty_like(inv_std) if want_grads else None
     d_x = torch.empty_like(pts3d) if (want_grads and want_pts3d) else None
     aux = torch.empty(B, 40, device=pts3d.device, dtype=torch.float32) if want_aux else None
-    with torch.cuda.device(pts3d.device):
+    with _lib.on_device(pts3d.device):
         rc = lib.lc_cov_loss2_fwd_bwd_f32(
             _lib.ptr(K), _lib.ptr(pose), _lib.ptr(pts3d), _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(valid), _lib.ptr(bbox),
             _lib.ptr(grad_out), B, N, float(max_err_len), float(rel_thresh), float(w_e_thresh), int(cov_2d), _lib.ptr(loss), _lib.ptr(d_u),
@@ -38,7 +38,7 @@ def _launch_scale(scale, srcs):
     args = []
     for s, o in zip(srcs, outs):
         args += [_lib.ptr(s), _lib.ptr(o), 0 if s is None else s.numel() // B]
-    with torch.cuda.device(scale.device):
+    with _lib.on_device(scale.device):
         rc = lib.lc_scale_rows_f32(_lib.ptr(scale), B, *args, _lib.stream_ptr(scale.device))
     _lib.check(rc, "lc_scale_rows_f32")
     return outs

@@ -26,7 +26,7 @@ def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample, vis_logits=N
     pts2d, inv_std, lse = torch.empty(B, N, 2, **f), torch.empty(B, N, 2, **f), torch.empty(B, **f)
     pts3d = torch.empty(B, N, 3, **f) if xyz is not None else None
     vis = torch.empty(B, N, device=wlogits.device, dtype=torch.uint8) if vis_logits is not None else None
-    with torch.cuda.device(wlogits.device):
+    with _lib.on_device(wlogits.device):
         rc = lib.lc_dense_frontend_fwd2_f32(_lib.ptr(xyz), _lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(vis_logits),
                                             float(vis_thresh), B, H, W, top, left, sample, _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(pts3d),
                                             _lib.ptr(lse), _lib.ptr(vis), _lib.stream_ptr(wlogits.device))
@@ -41,7 +41,7 @@ def _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, shape, top,
     d_xyz = torch.empty(B, 3, H, W, **f) if need[0] else None
     d_wl = torch.empty(B, 2, H, W, **f) if need[1] else None
     d_ws = torch.empty(B, **f) if need[2] else None
-    with torch.cuda.device(wlogits.device):
+    with _lib.on_device(wlogits.device):
         rc = lib.lc_dense_frontend_bwd_f32(_lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(lse), _lib.ptr(g_inv_std),
                                            _lib.ptr(g_pts3d), B, H, W, top, left, sample, _lib.ptr(d_xyz), _lib.ptr(d_wl), _lib.ptr(d_ws),
                                            _lib.stream_ptr(wlogits.device))
@@ -145,7 +145,7 @@ def dense_select(pts2d: Tensor, inv_std2d: Tensor, pts3d: Tensor, mode: str, *, 
         o_u, o_w, o_x = torch.empty_like(U), torch.empty_like(S), torch.empty_like(X)
         o_i = torch.empty(B, N, device=dev, dtype=torch.int32)
         o_c = torch.empty(B, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.lc_dense_select_f32(_lib.ptr(U), _lib.ptr(S), _lib.ptr(X), _lib.ptr(m), _lib.ptr(cnt_in), _lib.ptr(idx_in), B, N,
                                      SELECT_MODES[mode], float(quantile), int(square_weights), int(min_count), int(seed) & 0xFFFFFFFF,
                                      _lib.ptr(o_u), _lib.ptr(o_w), _lib.ptr(o_x), _lib.ptr(o_i), _lib.ptr(o_c), _lib.stream_ptr(dev))

@@ -46,7 +46,7 @@ def _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample):
     B, C, H, W = logits.shape
     N = ((H - top + sample - 1) // sample) * ((W - left + sample - 1) // sample)
     noc = torch.empty(B, N, 3, device=logits.device, dtype=torch.float32)
-    with torch.cuda.device(logits.device):
+    with _lib.on_device(logits.device):
         rc = lib.lc_bits_decode_gt_fwd_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), B, C, H, W, *bits, int(_black_background),
                                            top, left, sample, _lib.ptr(noc), _lib.stream_ptr(logits.device))
     _lib.check(rc, "lc_bits_decode_gt_fwd_f32")
@@ -57,7 +57,7 @@ def _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g_noc, bits, top, left, sampl
     lib = _lib.load()
     B, C, H, W = logits.shape
     d = torch.empty_like(logits)
-    with torch.cuda.device(logits.device):
+    with _lib.on_device(logits.device):
         rc = lib.lc_bits_decode_gt_bwd_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(g_noc), B, C, H, W, *bits, int(black),
                                            top, left, sample, _lib.ptr(d), _lib.stream_ptr(logits.device))
     _lib.check(rc, "lc_bits_decode_gt_bwd_f32")
@@ -106,7 +106,7 @@ def nn_logits2noc(logits: Tensor, bit_cnt: Union[int, List[int]], nearest_lut: T
     B, C, H, W = lg.shape
     bits = _bits3(bit_cnt, C)
     noc = torch.empty(B, H, W, 3, device=lg.device, dtype=torch.float32)
-    with torch.cuda.device(lg.device):
+    with _lib.on_device(lg.device):
         rc = lib.lc_bits_decode_f32(_lib.ptr(lg), B, C, H, W, *bits, int(_black_background), _lib.ptr(noc), _lib.stream_ptr(lg.device))
     _lib.check(rc, "lc_bits_decode_f32")
     return noc

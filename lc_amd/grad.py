@@ -28,7 +28,7 @@ def _launch_sqnorm(grads, workspace, state):
     dev = grads[0].device
     partials, ticket, snap = workspace
     sq = torch.empty((), device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         for i, g in enumerate(grads):
             last = i == len(grads) - 1
             rc = lib.lc_sqnorm_f32(_lib.ptr(g), g.numel(), _lib.ptr(partials), _lib.ptr(ticket), _lib.ptr(sq), int(i > 0),
@@ -44,7 +44,7 @@ def _launch_apply(grads, sq, state_before, state, initial_max_norm, scale, momen
     dev = grads[0].device
     norm = torch.empty((), device=dev, dtype=torch.float32)
     outs = []
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         for i, g in enumerate(grads):
             o = torch.empty_like(g)
             last = i == len(grads) - 1

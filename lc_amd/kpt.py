@@ -19,7 +19,7 @@ def _launch_kpt(K, pose, pts3d, pts2d, std, want_grads: bool):
     nll = torch.empty(B, device=pts2d.device, dtype=torch.float32)
     d_u = torch.empty_like(pts2d) if want_grads else None
     d_s = torch.empty_like(std) if want_grads else None
-    with torch.cuda.device(pts2d.device):
+    with _lib.on_device(pts2d.device):
         rc = lib.lc_kpt_nll_fwd_bwd_f32(_lib.ptr(K), _lib.ptr(pose), _lib.ptr(pts3d), _lib.ptr(pts2d), _lib.ptr(std), B, N, _lib.ptr(nll),
                                         _lib.ptr(d_u), _lib.ptr(d_s), _lib.stream_ptr(pts2d.device))
     _lib.check(rc, "lc_kpt_nll_fwd_bwd_f32")

@@ -25,7 +25,7 @@ def compute_pose_errors(R_est: Tensor, t_est: Tensor, R_gt: Tensor, t_gt: Tensor
         pts_off = pts_off.to(device=dev, dtype=torch.int32).contiguous()
         pts_cnt = pts_cnt.to(device=dev, dtype=torch.int32).contiguous()
     out = torch.empty(B, 4, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.lc_pose_errors_f32(_lib.ptr(Re), _lib.ptr(te), _lib.ptr(Rg), _lib.ptr(tg), _lib.ptr(P), _lib.ptr(pts_off), _lib.ptr(pts_cnt),
                                     B, P.shape[0], int(want_adi), _lib.ptr(out), _lib.stream_ptr(dev))
     _lib.check(rc, "lc_pose_errors_f32")

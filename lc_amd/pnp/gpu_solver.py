@@ -43,7 +43,7 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     hyp = torch.empty(B, device=dev, dtype=torch.int32) if return_hypothesis else None
     rows = torch.empty(B, device=dev, dtype=torch.int32) if refine else None  # point count, 0 for the poses RANSAC gave up on
     ws, nbytes = None, 0
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if split:  # hypotheses / scoring / selection as three launches over a workspace: spreads one pose over many compute units
             nbytes = int(lib.lc_pnp_ransac_workspace_bytes(B, N, int(iterations)))
             ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)

@@ -63,14 +63,14 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
         if opts or M is not None or shared_poses:
             raise ValueError("the diagnostic trace takes plain inputs")
         trace = torch.zeros(B, int(trace_rows), 8, device=dev, dtype=torch.float64)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.lc_pnp_lm_trace_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
                                          None if full else _lib.ptr(L), _lib.ptr(counts), _lib.ptr(start), _lib.ptr(state), _lib.ptr(tr),
                                          _lib.ptr(ret), _lib.ptr(iters), B, N, int(max_iter_count), float(function_tolerance),
                                          _lib.ptr(trace), int(trace_rows), _lib.stream_ptr(dev))
         _lib.check(rc, "lc_pnp_lm_trace_f32")
         return (state, tr, ret, iters, trace) if return_iters else (state, tr, ret, trace)
-    with torch.cuda.device(dev):  # options = 0 without a mask is lc_pnp_lm_f32 (same kernel instantiation)
+    with _lib.on_device(dev):  # options = 0 without a mask is lc_pnp_lm_f32 (same kernel instantiation)
         rc = lib.lc_pnp_lm2_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
                                 _lib.ptr(L) if (L is not None and not full) else None, _lib.ptr(M), _lib.ptr(counts), _lib.ptr(start),
                                 _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret), _lib.ptr(iters), B, N, int(max_iter_count),

@@ -20,7 +20,7 @@ def _fwd(x: Tensor, is_prob: bool):
     mean = torch.empty(x.shape[:-2] + (2,), device=x.device, dtype=torch.float32)
     std = torch.empty_like(mean)
     stats = torch.empty(x.shape[:-2] + (4,), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.lc_softargmax2d_fwd(_lib.ptr(x), _lib.MAP_DTYPES[x.dtype], M, H, W, int(is_prob), _lib.ptr(mean), _lib.ptr(std),
                                      _lib.ptr(stats), _lib.stream_ptr(x.device))
     _lib.check(rc, "lc_softargmax2d_fwd")
@@ -45,7 +45,7 @@ class _SoftArgmax2dFn(torch.autograd.Function):
         g_mean = torch.zeros_like(mean) if g_mean is None else g_mean.contiguous().to(torch.float32)
         g_std = torch.zeros_like(std) if g_std is None else g_std.contiguous().to(torch.float32)
         g_in = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = lib.lc_softargmax2d_bwd(_lib.ptr(x), _lib.MAP_DTYPES[x.dtype], _lib.ptr(mean), _lib.ptr(std), _lib.ptr(stats),
                                          _lib.ptr(g_mean), _lib.ptr(g_std), M, H, W, int(ctx.is_prob), _lib.ptr(g_in),
                                          _lib.stream_ptr(x.device))
