@@ -46,6 +46,28 @@ def test_ransac_workspace_contract():
     assert rc != 0 and b"workspace" in lib.lc_amd_last_error()
 
 
+def test_extended_entry_points_reject_bad_arguments_before_launching():
+    """lc_pnp_lm2_f32 / lc_dense_frontend_fwd2_f32: argument errors are reported by return code + lc_amd_last_error, nothing is
+    launched (runs without a GPU)."""
+    from lc_amd import _lib
+
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.addressof(buf)
+    err = lambda: lib.lc_amd_last_error().decode()
+    # two weight forms at once / none at all
+    assert lib.lc_pnp_lm2_f32(p, p, p, p, p, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 0, None) != 0 and "exactly one" in err()
+    assert lib.lc_pnp_lm2_f32(p, p, p, None, None, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 0, None) != 0 and "exactly one" in err()
+    # unknown option bit, icov flag without the diagonal weights, shared poses without a separate start
+    assert lib.lc_pnp_lm2_f32(p, p, p, None, p, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 8, 0, None) != 0 and "option" in err()
+    assert lib.lc_pnp_lm2_f32(p, p, p, None, None, p, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 1, 0, None) != 0 and "weights_diag" in err()
+    assert lib.lc_pnp_lm2_f32(p, p, p, None, p, None, None, None, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 1, None) != 0 and "start" in err()
+    # visibility logits without a mask buffer
+    assert lib.lc_dense_frontend_fwd2_f32(p, p, p, None, p, 0.5, 1, 4, 4, 0, 0, 2, p, p, p, p, None, None) != 0 and "vis_" in err()
+    # empty batches are fine
+    assert lib.lc_pnp_lm2_f32(p, p, p, None, p, None, None, p, p + 64, p, p, None, 0, 4, 5, 1e-6, 0, 0, None) == 0
+
+
 def test_product_path_has_no_cpu_fallback():
     from lc_amd import synth
     from lc_amd.cov_mixed import Loss_cov_mixed
