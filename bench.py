@@ -169,7 +169,21 @@ def main():
         if share_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            try:  # RCCL over xGMI; one tiny all-reduce proves the communicator works before anything is timed
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+                assert int(probe.item()) == world
+            except Exception as e:  # noqa: BLE001 -- the data path has no collective: the backend only carries the timing barrier,
+                # so a node whose RCCL cannot initialise still yields a valid per-N number (reported in collective_backend)
+                print(f"bench.py rank {rank}: RCCL unavailable ({type(e).__name__}: {e}); timing barrier falls back to gloo", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                dist.init_process_group("gloo")
+                share_gpu = True  # from here on: CPU tensors for the timing collectives (each rank keeps its own GPU)
 
     from lc_amd import _lib, synth
 
