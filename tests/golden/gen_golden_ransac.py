@@ -4,7 +4,7 @@ kernel's own hypothesis stream).  OpenCV (cv2.solvePnPRansac, lib/pnp/cv2_solver
 RNG is not reproducible, so these are ORACLE vectors, not reference vectors; they freeze the integer outputs -- best hypothesis
 index, inlier count, inlier index set -- for the poses the oracle marks as decided (no point within 1e-3 of the threshold).
 
-    python tests/golden/gen_golden_ransac.py      (build container, CPU, ~1 min)
+    python tests/golden/gen_golden_ransac.py [case ...]     (build container, CPU, ~1 min)
 """
 import os
 import sys
@@ -23,6 +23,7 @@ CASES = {  # name: (B, N, seed, noise_px, gross outlier fraction, reprojectionEr
     "outliers_B24_N64": (24, 64, 6, 0.5, 0.25, 2.0, 150, 0),
     "dense_B6_N400": (6, 400, 8, 1.0, 0.4, 3.0, 192, 7),
     "ragged_B8_N40": (8, 40, 7, 0.2, 0.1, 2.0, 150, 3),
+    "capped_B6_N2300": (6, 2300, 9, 0.3, 0.3, 2.5, 192, 4),  # more points than the 2048 the hypotheses are scored on (36 chunks of 64)
 }
 
 
@@ -40,7 +41,7 @@ def make_inputs(name):
 
 
 def main():
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):  # optionally only the named cases
         c = make_inputs(name)
         B, N = c["pts3d"].shape[:2]
         res = [O.ransac(c["K"][i], c["pts3d"][i], c["pts2d"][i], int(c["counts"][i]), float(c["reproj_err"]), int(c["iterations"]),
