@@ -219,6 +219,19 @@ __device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int
     for (int k = 0; k < K; ++k) v[k] = tot[k];
 }
 
+#ifndef LC_HORNER_ASM
+#define LC_HORNER_ASM 1  // A/B switch (scripts/ubench/pnp_ab.py)
+#endif
+__device__ __forceinline__ double horner_step(double p, double z, double c) {
+#if LC_HORNER_ASM
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "v"(c));
+    return r;
+#else
+    return __builtin_fma(p, z, c);
+#endif
+}
+
 // sin and cos of a rotation angle 0 <= x <~ 8 (angle-axis norms; the LM keeps them within a few pi): Cody-Waite reduction
 // by pi/2 into [-pi/4, pi/4] and the fdlibm minimax polynomials (|error| < 1 ulp on that interval).  About a third of the
 // instructions of the general sincos(), whose Payne-Hanek path for huge arguments is never needed here.
@@ -234,19 +247,20 @@ __device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
     r = __builtin_fma(-kf, 2.02226624879595063154e-21, r);
     const double z = r * r;
     // sin(r) ~ r + r^3 (S1 + z (S2 + ... )),  cos(r) ~ 1 - z/2 + z^2 (C1 + z (C2 + ...))   (fdlibm k_sin.c / k_cos.c)
-    double ps = 1.58969099521155010221e-10;
-    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    // Horner steps p z + C with the coefficient as the ADDEND: written as three-address v_fma_f64 with C in a register pair that stays
+    // live across the LM loop -- the compiler's own form is `v_mov_b64 tmp, C; v_fmac_f64 tmp, z, p` (the accumulating two-address
+    // encoding needs the addend in the destination), one extra VALU issue slot per coefficient and evaluation
+    double ps = horner_step(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+    ps = horner_step(ps, z, 2.75573137070700676789e-06);
+    ps = horner_step(ps, z, -1.98412698298579493134e-04);
+    ps = horner_step(ps, z, 8.33333333332248946124e-03);
+    ps = horner_step(ps, z, -1.66666666666666324348e-01);
     const double sr = __builtin_fma(ps * z, r, r);
-    double pc = -1.13596475577881948265e-11;
-    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    double pc = horner_step(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+    pc = horner_step(pc, z, -2.75573143513906633035e-07);
+    pc = horner_step(pc, z, 2.48015872894767294178e-05);
+    pc = horner_step(pc, z, -1.38888888888741095749e-03);
+    pc = horner_step(pc, z, 4.16666666666666019037e-02);
     const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
     const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
     s = (q & 2) ? -ss : ss;
@@ -267,16 +281,15 @@ __device__ __forceinline__ double atan_ratio_pos(double s, double c) {
         t = t * fast_rcp(1.0 + h);
     }
     const double w = t * t;
-    double p = -1.0 / 21.0;
-    p = __builtin_fma(p, w, 1.0 / 19.0);
-    p = __builtin_fma(p, w, -1.0 / 17.0);
-    p = __builtin_fma(p, w, 1.0 / 15.0);
-    p = __builtin_fma(p, w, -1.0 / 13.0);
-    p = __builtin_fma(p, w, 1.0 / 11.0);
-    p = __builtin_fma(p, w, -1.0 / 9.0);
-    p = __builtin_fma(p, w, 1.0 / 7.0);
-    p = __builtin_fma(p, w, -1.0 / 5.0);
-    p = __builtin_fma(p, w, 1.0 / 3.0);
+    double p = horner_step(-1.0 / 21.0, w, 1.0 / 19.0);
+    p = horner_step(p, w, -1.0 / 17.0);
+    p = horner_step(p, w, 1.0 / 15.0);
+    p = horner_step(p, w, -1.0 / 13.0);
+    p = horner_step(p, w, 1.0 / 11.0);
+    p = horner_step(p, w, -1.0 / 9.0);
+    p = horner_step(p, w, 1.0 / 7.0);
+    p = horner_step(p, w, -1.0 / 5.0);
+    p = horner_step(p, w, 1.0 / 3.0);
     const double at = 4.0 * __builtin_fma(-(p * w), t, t);  // 4 * (t - t^3 (1/3 - t^2/5 + ...))
     return swap ? 1.57079632679489661923 - at : at;
 }
