@@ -143,9 +143,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="poses per GPU per step")
     ap.add_argument("--npts", type=int, default=64)
     ap.add_argument("--slots", type=int, default=4, help="--launch streams: independent batches in flight (own buffers, own stream)")
-    ap.add_argument("--launch", default="fused", choices=["fused", "eager", "eager2", "graph", "graph2", "graph_fused", "streams"],
-                    help="fused (default): loss and PnP workgroups share ONE grid (lc_pose_unit_f32); eager: two launches on "
-                         "one stream; eager2: LM solve forked onto a second stream; graph*: the same step replayed as a hipGraph")
+    ap.add_argument("--launch", default="graph_region", choices=["fused", "eager", "eager2", "graph", "graph2", "graph_fused", "graph_region", "streams"],
+                    help="graph_region (default): a step is ONE fused launch (lc_pose_unit_f32: loss and PnP workgroups share a grid) and "
+                         "the K steps of a timed region are K kernel nodes of one hipGraph launch; fused: the same K launches issued one by "
+                         "one from Python; eager: two launches per step on one stream; eager2: LM solve forked onto a second stream; "
+                         "graph / graph2 / graph_fused: one step replayed as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-head", action="store_true", help="skip the keypoint-head measurement attached as out['head']")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -256,9 +258,9 @@ def main():
                                   P(bb["start"]), P(o["states"]), P(o["tr"]), P(o["ret"]), 50, 1e-6, ctypes.c_void_p(stream.cuda_stream))
         assert rc == 0
 
-    if args.launch == "fused" and N > 64:
+    if args.launch in ("fused", "graph_region") and N > 64:
         args.launch = "eager"
-    step_eager = {"eager": step_serial, "graph": step_serial, "fused": step_fused, "graph_fused": step_fused,
+    step_eager = {"eager": step_serial, "graph": step_serial, "fused": step_fused, "graph_fused": step_fused, "graph_region": step_fused,
                   "streams": step_streams}.get(args.launch, step_forked)
     graph = None
     if args.launch.startswith("graph"):
@@ -272,10 +274,12 @@ def main():
 
         graph = torch.cuda.CUDAGraph()
         with quiet_capture(), torch.cuda.graph(graph):
-            step_eager()
+            for _ in range(args.steps if args.launch == "graph_region" else 1):  # graph_region: the K steps of a region as ONE graph
+                step_eager()
     step = step_eager if graph is None else graph.replay
+    steps_per_call = args.steps if args.launch == "graph_region" else 1
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup // steps_per_call)):
         step()
 
     def fence():
@@ -290,7 +294,7 @@ def main():
     for _ in range(max(1, args.regions)):
         fence()  # synchronize + barrier + synchronize: every rank starts the region together
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // steps_per_call):
             step()
         torch.cuda.synchronize(dev)  # this rank's K steps are done ...
         region_s.append(time.perf_counter() - t0)
@@ -358,10 +362,14 @@ def main():
         by_loss, by_pnp = algorithmic_bytes(N, True)
         dom = ("lc_cov_loss_kernel", t_loss, by_loss) if t_loss >= t_pnp else ("lc_pnp_lm_kernel", t_pnp, by_pnp)
         kernel_us = {"lc_cov_loss_kernel": t_loss * 1e3, "lc_pnp_lm_kernel": t_pnp * 1e3}
-        if args.launch in ("fused", "graph_fused"):
-            t_unit = kernel_ms(step_fused)
-            dom = ("lc_pose_unit_kernel", t_unit, by_loss + by_pnp)
+        if args.launch in ("fused", "graph_fused", "graph_region"):
+            t_unit = kernel_ms(step_fused)  # launches issued one by one (stream order)
             kernel_us["lc_pose_unit_kernel"] = t_unit * 1e3
+            if args.launch == "graph_region":  # the pattern of the timed region: the kernel as a node of the K-step graph (events around replays)
+                kernel_us["lc_pose_unit_kernel_stream_order"] = t_unit * 1e3
+                t_unit = kernel_ms(graph.replay, reps=max(1, 200 // args.steps)) / args.steps
+                kernel_us["lc_pose_unit_kernel"] = t_unit * 1e3
+            dom = ("lc_pose_unit_kernel", t_unit, by_loss + by_pnp)
             kernel_us["lc_pose_unit_kernel_p10_p50_p90"] = kernel_percentiles_us(step_fused)
         hbm_gbs = dom[2] * B / (dom[1] * 1e-3) / 1e9
         kernel_poses_per_s = B / (dom[1] * 1e-3)
@@ -397,13 +405,15 @@ def main():
                        "global_batch": B * world, "n_points": N, "sharding": f"poses over {world} rank(s), no data-path collective",
                        "launch": args.launch, **({"slots_in_flight": args.slots} if args.launch == "streams" else {})},
             "timing": {"protocol": f"{agg['regions']} regions of exactly {args.steps} steps, barrier + synchronize around each, MAX over ranks "
-                                   f"per region, MEDIAN region reported", "region_ms_per_step": agg["region_ms_per_step"]},
+                                   f"per region, MEDIAN region reported"
+                                   + ("; the K steps of a region are K kernel nodes of one hipGraph launch" if args.launch == "graph_region" else ""),
+                       "region_ms_per_step": agg["region_ms_per_step"]},
             "ranks_seen": agg["ranks_seen"], "collective_backend": agg["backend"],
             "rccl_version": rccl_version() if (world > 1 and not share_gpu) else None,
             "per_rank_ms_per_step": agg["per_rank_ms_per_step"],
             "roofline": roof,
         }
-        if args.steady_batch > 0 and world == 1 and args.launch == "fused":
+        if args.steady_batch > 0 and world == 1 and args.launch in ("fused", "graph_region"):
             Bs, pps, ms = steady_state(args.steady_batch)
             ss = {"B": Bs, "poses_per_s": pps, "ms_per_launch": ms}
             if roof.get("bound") == "valu_issue":
