@@ -1,19 +1,24 @@
 // GPU initialiser for the weighted PnP solve: RANSAC over minimal P3P hypotheses.
 //
 // Takes the place of lib/pnp/cv2_solver.py:69-88 (cv2.solvePnPRansac, EPnP kernel, 150 iterations, multiprocessing.Pool)
-// in front of cer_solver.solve (test.py:59,120): one wavefront per pose, one hypothesis per lane and round (64 x rounds
-// hypotheses >= the reference's 150), every lane scores its own hypothesis against all correspondences staged in LDS,
-// the wave keeps the hypothesis with most inliers (ties: smaller inlier error), and writes the pose + the inlier mask.
-// No device->host->device trip, no process pool.  OpenCV's RNG/EPnP cannot be reproduced bit for bit (and OpenCV is absent
-// here: parity at this boundary is unpinned and outside the metric); the contract kept is the role: a pose
-// inside the LM basin of convergence plus an inlier set for `weighted_filtered` (test.py:129-134).
+// in front of cer_solver.solve (test.py:59,120): one hypothesis per lane (64 x rounds hypotheses >= the reference's 150), every
+// hypothesis is scored against the correspondences, the one with most inliers wins (ties: smaller inlier error, then the smaller
+// index) and the pose + the inlier mask are written.  No device->host->device trip, no process pool.  Two launch forms with the same
+// hypothesis stream, per-point arithmetic and ordering:
+//   * lc_pnp_ransac_kernel: one workgroup per pose, its rounds on separate wavefronts, points staged in LDS -- for batches that fill
+//     the chip with one workgroup per pose (or few points);
+//   * lc_ransac_{hypotheses,score,select}_kernel: three launches over a workspace that spread the points of one pose over the chip
+//     (further down).
+// OpenCV's RNG/EPnP cannot be reproduced bit for bit (and OpenCV is absent here: parity at this boundary is unpinned and outside the
+// metric); the contract kept is the role: a pose inside the LM basin of convergence plus an inlier set for
+// `weighted_filtered` (test.py:129-134); the kernels' own contract is pinned by oracle/p3p_ransac_oracle.py.
 //
-// (Divisions and square roots of the P3P are the Newton-refined v_rcp_f64 / v_rsq_f64 forms of lc_common.h, 2-4e-15 relative: the
-// solutions are Gauss-Newton polished and compared at 1e-4.)
 // P3P: depths l_i of three bearings y_i with |l_i y_i - l_j y_j|^2 = |x_i - x_j|^2.  The pencil D1 + g D2 of the two
 // constant-free quadrics is made singular by a root g of a cubic (coefficients from 3x3 determinants), the singular quadric
 // splits into two planes through its eigen-decomposition, each plane cuts D1 in <= 2 rays (a quadratic), the scale comes
-// from one distance constraint; depths are polished by Gauss-Newton and R,t follow from the three point pairs.
+// from one distance constraint; the candidate that reprojects a fourth correspondence best is Gauss-Newton polished and R,t follow
+// from the three point pairs.  (Divisions and square roots are the Newton-refined v_rcp_f64 / v_rsq_f64 forms of lc_common.h,
+// 2-4e-15 relative: the result is polished and compared at 1e-4.)
 #include <cfloat>
 
 #include "lc_common.h"
