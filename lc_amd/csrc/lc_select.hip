@@ -54,8 +54,8 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
     __syncthreads();
     if (p.mode != 0 && n > 0) {
         // torch.quantile needs only the two order statistics around q (n - 1): a most-significant-digit RADIX SELECT over the
-        // order-preserving integer image of the weights (4 passes of 8 bits: LDS histogram, one-wave scan) finds each of them in
-        // O(n) -- the bitonic sort it replaces took 78 barrier-separated stages for n = 4096 (44.8 -> ~10 us per launch).  The
+        // order-preserving integer image of the weights (4 passes of 8 bits: LDS histogram, one-wave scan) finds the lower one in
+        // O(n), one counting pass the upper one -- the bitonic sort it replaces took 78 barrier-separated stages for n = 4096 (44.8 -> ~10 us per launch).  The
         // threshold is formed from the same two floats, so the selected index sets are unchanged bit for bit.
         unsigned* keys = reinterpret_cast<unsigned*>(srt);
         int segc = 0;
@@ -76,10 +76,12 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
         const float rank = q * (float)(n - 1);
         const float lo = floorf(rank), hi = ceilf(rank);
         const int klo = (int)lo, khi = min((int)hi, n - 1);
+        // rank klo by the radix select; rank khi = klo + 1 is then either the same key (a duplicate: more than klo + 1 keys are <= it)
+        // or the smallest key above it -- one counting / min pass instead of four more histogram passes
         unsigned found[2] = {0u, 0u};
-        for (int which = 0; which < (khi != klo ? 2 : 1); ++which) {
+        {
             unsigned prefix = 0u, mask = 0u;
-            int k = which == 0 ? klo : khi;  // 0-based rank among the elements that still match the prefix
+            int k = klo;  // 0-based rank among the elements that still match the prefix
             for (int pass = 3; pass >= 0; --pass) {
                 const int shift = 8 * pass;
                 if (tid < 256) hist[tid] = 0;
@@ -111,7 +113,30 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
                 mask |= 255u << shift;
                 k = s_sel[1];
             }
-            found[which] = prefix;
+            found[0] = found[1] = prefix;
+        }
+        if (khi != klo) {
+            if (tid < 2) hist[tid] = tid == 0 ? 0 : -1;  // hist[0]: #keys <= found[0];  hist[1]: smallest key above it (as unsigned max)
+            __syncthreads();
+            int le = 0;
+            unsigned above = 0xFFFFFFFFu;
+            for (int i = tid; i < n; i += kThreads) {
+                const unsigned key = keys[i];
+                if (key <= found[0]) ++le;
+                else above = min(above, key);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                le += __shfl_xor(le, m, kWave);
+                above = min(above, (unsigned)__shfl_xor((int)above, m, kWave));
+            }
+            if (lane == 0) {
+                atomicAdd(&hist[0], le);
+                atomicMin(reinterpret_cast<unsigned*>(&hist[1]), above);
+            }
+            __syncthreads();
+            if (hist[0] <= khi) found[1] = (unsigned)hist[1];  // no duplicate reaches rank khi: the next distinct key
+            __syncthreads();  // hist is reused by nothing below, but keep the read before any later write
         }
         if (tid == 0) {
             auto unkey = [](unsigned kk) { return __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk); };
