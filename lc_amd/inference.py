@@ -137,8 +137,8 @@ def quiet_capture():
 
 class GraphedSolvePnP:
     """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of 8 short
-    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 145 us
-    eager -> 86 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
+    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 142 us
+    eager -> 85 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
 
         solver = GraphedSolvePnP(cfg, out_dict, gt_dict)      # example inputs fix the shapes; captured on a side stream
         poses = solver(out_dict, gt_dict)                     # copies the tensors into the static buffers, replays
