@@ -322,3 +322,46 @@ def test_shared_poses_batch_equals_separate_solves():
     assert torch.equal(st, torch.cat([st_a, st_b])) and torch.equal(tr, torch.cat([tr_a, tr_b])) and torch.equal(ret, torch.cat([ret_a, ret_b]))
     with pytest.raises(ValueError):
         pnp_ceres.solve_device(d["K"], X2[:P + 1], U2[:P + 1], torch.cat([icov_a, icov_b])[:P + 1], d["start"], None, shared_poses=P, **kw)
+
+
+def test_fused_nan_filter_with_full_information_factor():
+    """LC_PNP_NAN_TO_NUM with a full 2x2 lower factor (B,N,2,2): same bits as torch.nan_to_num on every input followed by the plain
+    solve; a weight mask without point counts; the filter on the in-place form (states = start on entry)."""
+    from lc_amd import _lib, synth
+    from lc_amd.pnp import pnp_ceres
+
+    dev = torch.device("cuda:0")
+    B, N = 19, 96
+    d = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=21, outlier_frac=0.1).items()}
+    g = torch.Generator().manual_seed(2)
+    L = torch.zeros(B, N, 2, 2)
+    L[..., 0, 0] = torch.rand(B, N, generator=g) + 0.5
+    L[..., 1, 1] = torch.rand(B, N, generator=g) + 0.5
+    L[..., 1, 0] = torch.randn(B, N, generator=g) * 0.2
+    L = L.to(dev)
+    pts2d, K = d["pts2d"].clone(), d["K"].clone()
+    pts2d[3, 7, 1] = float("nan"); L[5, 2, 1, 0] = float("inf"); K[6, 0, 2] = float("nan")
+    a = pnp_ceres.solve_device(K, d["pts3d"], pts2d, L, d["start"], nan_to_num=True)
+    Kf, Uf, Lf = torch.nan_to_num(K), torch.nan_to_num(pts2d), torch.nan_to_num(L)
+    b = pnp_ceres.solve_device(Kf, d["pts3d"], Uf, Lf, d["start"])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # mask weights, every row full
+    m = (torch.rand(B, N, generator=g) > 0.2).to(dev)
+    am = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], None, d["start"], weight_mask=m)
+    bm = pnp_ceres.solve_device(d["K"], d["pts3d"], d["pts2d"], m.float().unsqueeze(-1).expand(B, N, 2).contiguous(), d["start"])
+    for x, y in zip(am, bm):
+        assert torch.equal(x, y)
+    # in-place form through the C ABI: an invalid job must end with its FILTERED start in `states`
+    lib = _lib.load()
+    st = d["start"].clone()
+    st[0, 4] = float("nan")
+    counts = torch.full((B,), N, dtype=torch.int32, device=dev)
+    counts[0] = 2  # too few points: invalid
+    tr = torch.empty(B, device=dev); ret = torch.empty(B, device=dev, dtype=torch.int32)
+    P = _lib.ptr
+    rc = lib.lc_pnp_lm2_f32(P(d["K"]), P(d["pts3d"]), P(d["pts2d"]), None, P(d["inv_std"]), None, P(counts), None, P(st), P(tr), P(ret), None,
+                            B, N, 50, 1e-6, pnp_ceres.LC_PNP_NAN_TO_NUM, 0, _lib.stream_ptr(dev))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(ret[0]) == 1 and float(st[0, 4]) == 0.0 and bool(torch.isfinite(st).all())
