@@ -272,10 +272,20 @@ def main():
         torch.cuda.synchronize(dev)
         from lc_amd.inference import quiet_capture  # no Python GC while the stream is capturing
 
-        graph = torch.cuda.CUDAGraph()
-        with quiet_capture(), torch.cuda.graph(graph):
-            for _ in range(args.steps if args.launch == "graph_region" else 1):  # graph_region: the K steps of a region as ONE graph
-                step_eager()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with quiet_capture(), torch.cuda.graph(graph):
+                for _ in range(args.steps if args.launch == "graph_region" else 1):  # graph_region: the K steps of a region as ONE graph
+                    step_eager()
+            graph.replay()
+            torch.cuda.synchronize(dev)
+        except Exception as e:  # noqa: BLE001 -- a runtime that cannot capture still yields the stream-order number, labelled as such
+            if args.launch != "graph_region":
+                raise
+            print(f"bench.py rank {rank}: hipGraph capture of the region failed ({type(e).__name__}: {e}); issuing the launches one by one",
+                  file=sys.stderr)
+            graph, args.launch = None, "fused"
+            torch.cuda.synchronize(dev)
     step = step_eager if graph is None else graph.replay
     steps_per_call = args.steps if args.launch == "graph_region" else 1
 
