@@ -274,7 +274,8 @@ def main():
 
         try:
             graph = torch.cuda.CUDAGraph()
-            with quiet_capture(), torch.cuda.graph(graph):
+            # thread_local: calls of other threads of the process (e.g. the RCCL watchdog of a multi-rank run) neither fail nor invalidate the capture
+            with quiet_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(args.steps if args.launch == "graph_region" else 1):  # graph_region: the K steps of a region as ONE graph
                     step_eager()
             graph.replay()
