@@ -2,20 +2,29 @@
 """Headline benchmark: poses/sec of one "pose unit" = LC-loss forward+backward + one weighted-PnP solve,
 B=256 poses x N=64 correspondences per GPU (BASELINE.json metric, configs[1]), fp32 I/O, synthetic inputs resident in HBM.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N --steps 200 --warmup 20
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a fresh `python -m torch.distributed.run`
+child, before this process has touched the GPU) and relays the child's line and return code; launched by torchrun (WORLD_SIZE
+set) it is one of the ranks, and a WORLD_SIZE that differs from --gpus is an error.
 
 One process per GPU; the batch is sharded by pose (every pose is independent: SURVEY.md 8e), so there is no data-path
-collective -- only the timing barrier/all-reduce.  Scaling is weak: each rank runs its own B=256 batch.
-A step = one launch of the fused loss kernel (loss + d/d pts2d, d/d inv_std, d/d pts3d for the `.mean()` cotangent) and one
-batched LM solve; the two are independent, so by default their workgroups share one grid (see --launch).  Rank 0 prints ONE JSON line.
+collective -- only the timing barrier.  Scaling is weak: each rank runs its own B=256 batch.
+A step = ONE launch of the fused kernel (lc_pose_unit_f32: the loss workgroups -- loss + d/d pts2d, d/d inv_std, d/d pts3d for
+the `.mean()` cotangent -- and the LM-solve workgroups share a grid).  Two launch forms are timed with the same protocol and both
+ride at the top level of the line: `value` (the K steps of a region are K kernel nodes of one hipGraph launch) and
+`value_stream_order` (the same K launches issued one by one from Python).  Rank 0 prints ONE JSON line; it also carries the
+dense configs' hot-path shapes (`dense`: glmo B=32 N=1024, zlmo B=32 N=1849), the keypoint head and the CPU baseline.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import datetime
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +35,12 @@ sys.path.insert(0, ROOT)
 
 METRIC = "poses/sec (cov-loss fwd+bwd + weighted PnP), B=256 N=64, 1/2/4/8 MI355X"  # BASELINE.json:metric
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (non-MFMA) peak; SURVEY.md 8(d) prices the LM against it
+SIMD_CYCLES_PER_S = 1024 * 2.4e9  # 256 CUs x 4 SIMDs x 2.4 GHz (MI355X_MICROARCH.md chip-level parameters)
+
+# the dense configs' per-GPU hot-path shapes (BASELINE.json configs[2]-[4]): reference configs/glmo.yaml (B=32, 64x64 output,
+# dense_sample 2 -> N = 32*32), zlmo (128x128 output, dense_sample 3 -> N = 43*43); losses.py:336-386, test.py:67-136
+DENSE_WORKLOADS = {"glmo_dense": (32, 1024), "zlmo_dense": (32, 1849)}
 
 
 def algorithmic_bytes(N: int, want_pts3d: bool):
@@ -33,6 +48,12 @@ def algorithmic_bytes(N: int, want_pts3d: bool):
     loss = (36 + 28 + 96 + N * (12 + 8 + 8)) + (4 + N * (8 + 8)) + (N * 12 if want_pts3d else 0)
     pnp = (36 + 28 + N * (12 + 8 + 8)) + 36
     return loss, pnp
+
+
+def algorithmic_flops(N: int, lm_evaluations: float):
+    """SURVEY.md 8(d): loss fwd+bwd 115 kflop and 23 kflop per LM evaluation (Jacobian + normal equations + 6x6 solve) at N = 64;
+    both are per-point work up to a few hundred flops of 6x6 algebra, so they are scaled by N / 64 for the dense shapes."""
+    return 115e3 * N / 64.0, 23e3 * N / 64.0 * lm_evaluations
 
 
 def static_counters(kernel: str, B: int, N: int):
@@ -69,9 +90,6 @@ def host_cpu_model():
     except OSError:
         pass
     return "unknown"
-
-
-SIMD_CYCLES_PER_S = 1024 * 2.4e9  # 256 CUs x 4 SIMDs x 2.4 GHz (MI355X_MICROARCH.md chip-level parameters)
 
 
 def valu_bound(sq: dict, B: int):
@@ -132,7 +150,7 @@ def cpu_baseline(B, N, seed, budget_s=15.0):
                        f"{cores} threads = fastest of 4..64), {dt:.1f} s")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -145,79 +163,182 @@ def main():
     ap.add_argument("--slots", type=int, default=4, help="--launch streams: independent batches in flight (own buffers, own stream)")
     ap.add_argument("--launch", default="graph_region", choices=["fused", "eager", "eager2", "graph", "graph2", "graph_fused", "graph_region", "streams"],
                     help="graph_region (default): a step is ONE fused launch (lc_pose_unit_f32: loss and PnP workgroups share a grid) and "
-                         "the K steps of a timed region are K kernel nodes of one hipGraph launch; fused: the same K launches issued one by "
-                         "one from Python; eager: two launches per step on one stream; eager2: LM solve forked onto a second stream; "
-                         "graph / graph2 / graph_fused: one step replayed as a hipGraph")
+                         "the K steps of a timed region are K kernel nodes of one hipGraph launch -- `value`; the stream-order form of the "
+                         "same launches is timed too -- `value_stream_order`; fused: only the stream-order form; eager: two launches per "
+                         "step on one stream; eager2: LM solve forked onto a second stream; graph / graph2 / graph_fused: one step replayed "
+                         "as a hipGraph")
+    ap.add_argument("--workload", default="all", choices=["all", "metric", *DENSE_WORKLOADS],
+                    help="which extra blocks ride on the line next to the headline (which is always the metric's B=256 N=64): the dense "
+                         "configs' hot-path shapes `dense.glmo_dense` (B=32 N=1024) and `dense.zlmo_dense` (B=32 N=1849); metric: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-head", action="store_true", help="skip the keypoint-head measurement attached as out['head']")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def launch_plan(gpus: int, env_world, visible_gpus: int, share_gpu: bool):
+    """What `--gpus N` means for this process (pure; tests/test_host_logic.py):
+    ("self_launch", N)  start N ranks as a child `torch.distributed.run` (N > 1, no WORLD_SIZE yet);
+    ("rank", world)     run as one rank of `world`;
+    ("error", message)  refuse."""
+    if gpus < 1:
+        return "error", f"--gpus {gpus}: need at least one GPU"
+    if env_world is None:
+        if gpus == 1:
+            return "rank", 1
+        if not share_gpu and visible_gpus < gpus:
+            return "error", f"--gpus {gpus} but only {visible_gpus} GPU(s) are visible (one process per GPU; LC_BENCH_SHARE_GPU=1 is the one-GPU test mode)"
+        return "self_launch", gpus
+    world = int(env_world)
+    if world != gpus:
+        return "error", f"--gpus {gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {gpus}, or drop the launcher and let bench.py start the ranks"
+    return "rank", world
+
+
+def self_launch(n: int, argv):
+    """N ranks of this script as a fresh child process (never an exec: this process may not touch the GPU before, and does not)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode  # stdout / stderr are inherited: rank 0's JSON line is this process's line
+
+
+def init_collectives(world: int, dev, share_gpu: bool):
+    """The timing collectives of an N-rank run.  gloo first (cheap, always there: it carries the agreement flags and the
+    per-rank region times); then an RCCL group for the barrier, adopted only if EVERY rank brought it up and passed a probe
+    all-reduce (agreed by a MIN over gloo) -- otherwise every rank uses gloo, together."""
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+    info = {"dist": dist, "barrier_group": None, "backend": "gloo", "rccl_error": None}
+    if share_gpu:
+        return info
+    ok, err, grp = 1, None, None
+    try:  # RCCL over xGMI; one tiny all-reduce proves the communicator works before anything is timed
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe, group=grp)
+        torch.cuda.synchronize(dev)
+        if int(probe.item()) != world:
+            raise RuntimeError(f"probe all-reduce returned {probe.item()} for world {world}")
+    except Exception as e:  # noqa: BLE001 -- the data path has no collective: the backend only carries the timing barrier
+        ok, err = 0, f"{type(e).__name__}: {e}"
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        info.update(barrier_group=grp, backend="nccl")
+    else:
+        info["rccl_error"] = err or "another rank could not bring RCCL up"
+        print(f"bench.py rank {dist.get_rank()}: RCCL unavailable on at least one rank ({info['rccl_error']}); every rank uses gloo "
+              f"for the timing barrier", file=sys.stderr)
+    return info
+
+
+def main():
+    args = parse_args()
+    share_gpu = os.environ.get("LC_BENCH_SHARE_GPU", "0") == "1"
+    # torch.cuda.device_count() does not initialise the GPU on this image; nothing else may touch it before a self-launch
+    kind, val = launch_plan(args.gpus, os.environ.get("WORLD_SIZE"), torch.cuda.device_count(), share_gpu)
+    if kind == "error":
+        print(f"bench.py: {val}", file=sys.stderr)
+        raise SystemExit(2)
+    if kind == "self_launch":
+        raise SystemExit(self_launch(val, sys.argv[1:]))
+    world = val
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     # LC_BENCH_SHARE_GPU=1 (test only): every rank uses GPU 0 and the timing collectives run over gloo, so that the N > 1
     # control flow (barrier, max-over-ranks, aggregation) can be exercised on a one-GPU box; RCCL refuses two ranks per device.
-    share_gpu = os.environ.get("LC_BENCH_SHARE_GPU", "0") == "1"
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    coll = init_collectives(world, dev, share_gpu) if world > 1 else None
+    dist = coll["dist"] if coll else None
 
-        if share_gpu:
-            dist.init_process_group("gloo")
+    def barrier():
+        if coll is None:
+            return
+        if coll["barrier_group"] is not None:
+            dist.barrier(group=coll["barrier_group"], device_ids=[dev_index])
         else:
-            try:  # RCCL over xGMI; one tiny all-reduce proves the communicator works before anything is timed
-                dist.init_process_group("nccl", device_id=dev)
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize(dev)
-                assert int(probe.item()) == world
-            except Exception as e:  # noqa: BLE001 -- the data path has no collective: the backend only carries the timing barrier,
-                # so a node whose RCCL cannot initialise still yields a valid per-N number (reported in collective_backend)
-                print(f"bench.py rank {rank}: RCCL unavailable ({type(e).__name__}: {e}); timing barrier falls back to gloo", file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                dist.init_process_group("gloo")
-                share_gpu = True  # from here on: CPU tensors for the timing collectives (each rank keeps its own GPU)
+            dist.barrier()
+
+    def all_agree(flag: bool) -> bool:
+        """True iff `flag` holds on every rank (MIN over gloo)."""
+        if coll is None:
+            return flag
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     from lc_amd import _lib, synth
 
     lib = _lib.load()
     B, N = args.batch, args.npts
-    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=rank).items()}
-    go = torch.full((B,), 1.0 / B, device=dev)
-    sqrt_diag = b["inv_std"].contiguous()  # icov = inv_std^2 -> sqrt factor = inv_std (cer_solver.py:37-38)
-    loss = torch.empty(B, device=dev)
-    d_u, d_s, d_x = torch.empty_like(b["pts2d"]), torch.empty_like(b["inv_std"]), torch.empty_like(b["pts3d"])
-    states = torch.empty_like(b["start"])
-    tr = torch.empty(B, device=dev)
-    ret = torch.empty(B, device=dev, dtype=torch.int32)
     P = _lib.ptr
 
-    def launch_loss():
-        rc = lib.lc_cov_loss_fwd_bwd_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None,
-                                         P(b["bbox_3d"]), P(go), B, N, 32.0, 3.0, 4.0, P(loss), P(d_u), P(d_s), P(d_x), None,
-                                         _lib.stream_ptr(dev))
-        assert rc == 0
+    class Unit:
+        """Device buffers of one batch of Bq poses x Nq correspondences and the launches over them."""
 
-    def launch_pnp():
-        # start poses are read-only input, states is output: every step solves from the same perturbed pose
-        rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(sqrt_diag), None, P(b["start"]), P(states), P(tr),
-                               P(ret), None, B, N, 50, 1e-6, _lib.stream_ptr(dev))
-        assert rc == 0
+        def __init__(self, Bq, Nq, seed):
+            self.B, self.N = Bq, Nq
+            self.b = b = {k: v.to(dev) for k, v in synth.make_batch(Bq, Nq, seed=seed).items()}
+            self.go = torch.full((Bq,), 1.0 / Bq, device=dev)
+            self.sqrt_diag = b["inv_std"].contiguous()  # icov = inv_std^2 -> sqrt factor = inv_std (cer_solver.py:37-38)
+            self.loss = torch.empty(Bq, device=dev)
+            self.d_u, self.d_s, self.d_x = torch.empty_like(b["pts2d"]), torch.empty_like(b["inv_std"]), torch.empty_like(b["pts3d"])
+            self.states = torch.empty_like(b["start"])
+            self.tr = torch.empty(Bq, device=dev)
+            self.ret = torch.empty(Bq, device=dev, dtype=torch.int32)
+            self.iters = torch.zeros(Bq, device=dev, dtype=torch.int32)
 
+        def launch_loss(self, stream=None):
+            b = self.b
+            rc = lib.lc_cov_loss_fwd_bwd_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None,
+                                             P(b["bbox_3d"]), P(self.go), self.B, self.N, 32.0, 3.0, 4.0, P(self.loss), P(self.d_u),
+                                             P(self.d_s), P(self.d_x), None, stream or _lib.stream_ptr(dev))
+            assert rc == 0
+
+        def launch_pnp(self, stream=None, iters=False):
+            # start poses are read-only input, states is output: every step solves from the same perturbed pose
+            b = self.b
+            rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(self.sqrt_diag), None, P(b["start"]), P(self.states),
+                                   P(self.tr), P(self.ret), P(self.iters) if iters else None, self.B, self.N, 50, 1e-6,
+                                   stream or _lib.stream_ptr(dev))
+            assert rc == 0
+
+        def launch_fused(self, stream=None):
+            # one grid for both halves of the pose unit (lc_amd/csrc/lc_fused.hip)
+            b = self.b
+            rc = lib.lc_pose_unit_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]),
+                                      P(self.go), self.B, self.N, 32.0, 3.0, 4.0, P(self.loss), P(self.d_u), P(self.d_s), P(self.d_x),
+                                      P(self.sqrt_diag), P(b["start"]), P(self.states), P(self.tr), P(self.ret), 50, 1e-6,
+                                      stream or _lib.stream_ptr(dev))
+            assert rc == 0
+
+        def check(self):
+            assert int(self.ret.sum().item()) == 0 and bool(torch.isfinite(self.loss).all())
+
+        def mean_lm_iterations(self):
+            """Trust-region iterations per pose of this batch (the stand-alone solve is bit-identical to the fused grid's half:
+            tests/test_gpu_fused.py), for SURVEY 8(d)'s flop figure."""
+            self.launch_pnp(iters=True)
+            torch.cuda.synchronize(dev)
+            return float(self.iters.float().mean().item()), int(self.iters.max().item())
+
+    main_unit = Unit(B, N, seed=rank)
     side = torch.cuda.Stream(dev)
 
     def step_serial():
-        launch_loss()
-        launch_pnp()
+        main_unit.launch_loss()
+        main_unit.launch_pnp()
 
     def step_forked():
         # the two kernels are independent (the loss linearises at the GT pose, the solve starts from `start`):
@@ -225,16 +346,11 @@ def main():
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            launch_pnp()
-        launch_loss()
+            main_unit.launch_pnp()
+        main_unit.launch_loss()
         main.wait_stream(side)
 
-    def step_fused():
-        # one grid for both halves of the pose unit (lc_amd/csrc/lc_fused.hip)
-        rc = lib.lc_pose_unit_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]),
-                                  P(go), B, N, 32.0, 3.0, 4.0, P(loss), P(d_u), P(d_s), P(d_x), P(sqrt_diag), P(b["start"]),
-                                  P(states), P(tr), P(ret), 50, 1e-6, _lib.stream_ptr(dev))
-        assert rc == 0
+    step_fused = main_unit.launch_fused
 
     # --launch streams (NOT the default, reported separately in DESIGN.md): `slots` independent B-sized batches in flight, each
     # with its own inputs, outputs and stream -- the serving-side picture (independent requests), where a 512-workgroup step
@@ -242,82 +358,89 @@ def main():
     slot_state = []
     if args.launch == "streams":
         for s_i in range(args.slots):
-            bb = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=1000 * (rank + 1) + s_i).items()}
-            outs = dict(loss=torch.empty(B, device=dev), d_u=torch.empty_like(bb["pts2d"]), d_s=torch.empty_like(bb["inv_std"]),
-                        d_x=torch.empty_like(bb["pts3d"]), states=torch.empty_like(bb["start"]), tr=torch.empty(B, device=dev),
-                        ret=torch.empty(B, device=dev, dtype=torch.int32), sd=bb["inv_std"].contiguous())
-            slot_state.append((bb, outs, torch.cuda.Stream(dev)))
+            slot_state.append((Unit(B, N, seed=1000 * (rank + 1) + s_i), torch.cuda.Stream(dev)))
         torch.cuda.synchronize(dev)
     slot_i = [0]
 
     def step_streams():
-        bb, o, stream = slot_state[slot_i[0] % len(slot_state)]
+        u, stream = slot_state[slot_i[0] % len(slot_state)]
         slot_i[0] += 1
-        rc = lib.lc_pose_unit_f32(P(bb["K"]), P(bb["pose"]), P(bb["pts3d"]), P(bb["pts2d"]), P(bb["inv_std"]), None, P(bb["bbox_3d"]),
-                                  P(go), B, N, 32.0, 3.0, 4.0, P(o["loss"]), P(o["d_u"]), P(o["d_s"]), P(o["d_x"]), P(o["sd"]),
-                                  P(bb["start"]), P(o["states"]), P(o["tr"]), P(o["ret"]), 50, 1e-6, ctypes.c_void_p(stream.cuda_stream))
-        assert rc == 0
+        u.launch_fused(ctypes.c_void_p(stream.cuda_stream))
 
     if args.launch in ("fused", "graph_region") and N > 64:
         args.launch = "eager"
     step_eager = {"eager": step_serial, "graph": step_serial, "fused": step_fused, "graph_fused": step_fused, "graph_region": step_fused,
                   "streams": step_streams}.get(args.launch, step_forked)
-    graph = None
-    if args.launch.startswith("graph"):
+
+    def capture(fn, n):
+        """`n` calls of fn as one hipGraph, or None (with the reason on stderr) if the runtime cannot capture them."""
         warm = torch.cuda.Stream(dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(warm):
-            step_eager()
+            fn()
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
         from lc_amd.inference import quiet_capture  # no Python GC while the stream is capturing
 
         try:
-            graph = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             # thread_local: calls of other threads of the process (e.g. the RCCL watchdog of a multi-rank run) neither fail nor invalidate the capture
-            with quiet_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                for _ in range(args.steps if args.launch == "graph_region" else 1):  # graph_region: the K steps of a region as ONE graph
-                    step_eager()
-            graph.replay()
+            with quiet_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for _ in range(n):
+                    fn()
+            g.replay()
             torch.cuda.synchronize(dev)
-        except Exception as e:  # noqa: BLE001 -- a runtime that cannot capture still yields the stream-order number, labelled as such
-            if args.launch != "graph_region":
-                raise
-            print(f"bench.py rank {rank}: hipGraph capture of the region failed ({type(e).__name__}: {e}); issuing the launches one by one",
-                  file=sys.stderr)
-            graph, args.launch = None, "fused"
+            return g
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py rank {rank}: hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
             torch.cuda.synchronize(dev)
-    step = step_eager if graph is None else graph.replay
-    steps_per_call = args.steps if args.launch == "graph_region" else 1
+            return None
 
-    for _ in range(max(1, args.warmup // steps_per_call)):
-        step()
+    graph = None
+    if args.launch.startswith("graph"):
+        graph = capture(step_eager, args.steps if args.launch == "graph_region" else 1)
+        # every rank times the SAME launch form: if one rank could not capture, all of them issue the launches one by one
+        if not all_agree(graph is not None):
+            if args.launch != "graph_region":
+                raise SystemExit(f"bench.py rank {rank}: --launch {args.launch} needs a hipGraph capture on every rank")
+            graph, args.launch = None, "fused"
 
     def fence():
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize(dev)
 
     from lc_amd import dist as lcd
 
-    region_s = []
-    for _ in range(max(1, args.regions)):
-        fence()  # synchronize + barrier + synchronize: every rank starts the region together
-        t0 = time.perf_counter()
-        for _ in range(args.steps // steps_per_call):
+    def timed_regions(step, steps_per_call):
+        """The protocol: W warm-up steps, then R regions of exactly K steps, each bracketed by barrier + synchronize; a region
+        lasts as long as its slowest rank (MAX over ranks), the MEDIAN region is reported."""
+        for _ in range(max(1, args.warmup // steps_per_call)):
             step()
-        torch.cuda.synchronize(dev)  # this rank's K steps are done ...
-        region_s.append(time.perf_counter() - t0)
-        if dist is not None:
-            dist.barrier()  # ... and the region ends when the slowest rank is (MAX over ranks below); the collective's own
+        region_s = []
+        for _ in range(max(1, args.regions)):
+            fence()  # synchronize + barrier + synchronize: every rank starts the region together
+            t0 = time.perf_counter()
+            for _ in range(args.steps // steps_per_call):
+                step()
+            torch.cuda.synchronize(dev)  # this rank's K steps are done ...
+            region_s.append(time.perf_counter() - t0)
+            barrier()  # ... and the region ends when the slowest rank is (MAX over ranks below); the collective's own
             # latency (tens of us over RCCL) is not part of the K steps
-    agg = lcd.aggregate_regions(region_s, args.steps, device="cpu" if (share_gpu or dist is None) else dev)
+        return lcd.aggregate_regions(region_s, args.steps, device="cpu")  # per-rank region times travel over gloo
+
+    if graph is not None:
+        agg = timed_regions(graph.replay, args.steps if args.launch == "graph_region" else 1)
+    else:
+        agg = timed_regions(step_eager, 1)
+    # the stream-order form of the same K launches, same protocol (what a caller pays who issues the launches one by one)
+    agg_so = timed_regions(step_fused, 1) if args.launch == "graph_region" else (agg if args.launch == "fused" else None)
     elapsed = agg["median_region_s"]
     if args.launch == "streams":
-        assert all(int(o["ret"].sum().item()) == 0 and bool(torch.isfinite(o["loss"]).all()) for _, o, _ in slot_state)
+        for u, _ in slot_state:
+            u.check()
     else:
-        assert int(ret.sum().item()) == 0 and bool(torch.isfinite(loss).all())
+        main_unit.check()
 
     # per-kernel launch duration with events on the launch stream (torch's current stream == the kernels' stream)
     def kernel_ms(fn, reps=200, windows=5):
@@ -351,29 +474,61 @@ def main():
 
     def steady_state(Bs):
         """One large batch: every SIMD holds several pose waves, the per-wave latency chain is hidden."""
-        bb = {k: v.to(dev) for k, v in synth.make_batch(Bs, N, seed=977).items()}
-        o_loss = torch.empty(Bs, device=dev)
-        o = [torch.empty_like(bb["pts2d"]), torch.empty_like(bb["inv_std"]), torch.empty_like(bb["pts3d"]), torch.empty_like(bb["start"]),
-             torch.empty(Bs, device=dev), torch.empty(Bs, device=dev, dtype=torch.int32)]
-        gos = torch.full((Bs,), 1.0 / Bs, device=dev)
-        sd = bb["inv_std"].contiguous()
-
-        def one():
-            rc = lib.lc_pose_unit_f32(P(bb["K"]), P(bb["pose"]), P(bb["pts3d"]), P(bb["pts2d"]), P(bb["inv_std"]), None, P(bb["bbox_3d"]),
-                                      P(gos), Bs, N, 32.0, 3.0, 4.0, P(o_loss), P(o[0]), P(o[1]), P(o[2]), P(sd), P(bb["start"]),
-                                      P(o[3]), P(o[4]), P(o[5]), 50, 1e-6, _lib.stream_ptr(dev))
-            assert rc == 0
-        ms = kernel_ms(one, reps=6, windows=5)
-        assert int(o[5].sum().item()) == 0
+        u = Unit(Bs, N, seed=977)
+        ms = kernel_ms(u.launch_fused, reps=6, windows=5)
+        assert int(u.ret.sum().item()) == 0
         return Bs, Bs / (ms * 1e-3), ms
 
+    def dense_block(name, Bd, Nd):
+        """One dense config's per-GPU hot-path shape: LC-loss fwd+bwd (lc_cov_loss_kernel, block-stride form) + one weighted-PnP
+        solve per sample over the same N correspondences (lc_pnp_lm_wide_kernel).  A step = the two launches back to back."""
+        u = Unit(Bd, Nd, seed=4242)
+
+        def step():
+            u.launch_loss()
+            u.launch_pnp()
+        t_loss, t_pnp = kernel_ms(u.launch_loss, reps=50), kernel_ms(u.launch_pnp, reps=50)
+        g = capture(step, 20)
+        t_step = kernel_ms(g.replay, reps=5) / 20 if g is not None else None
+        t_step_so = kernel_ms(step, reps=50)
+        # wall clock, the headline's protocol in small: 11 regions of 20 steps, synchronize around each, median
+        regs = []
+        for _ in range(11):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            if g is not None:
+                g.replay()
+            else:
+                for _ in range(20):
+                    step()
+            torch.cuda.synchronize(dev)
+            regs.append((time.perf_counter() - t0) / 20)
+        wall = sorted(regs)[len(regs) // 2]
+        u.check()
+        it_mean, it_max = u.mean_lm_iterations()
+        by_l, by_p = algorithmic_bytes(Nd, True)
+        fl_l, fl_p = algorithmic_flops(Nd, it_mean + 1.0)
+
+        def roof(t_ms, by, fl):
+            gbs, tf = by * Bd / (t_ms * 1e-3) / 1e9, fl * Bd / (t_ms * 1e-3) / 1e12
+            return {"kernel_us": t_ms * 1e3, "algorithmic_bytes_per_sample": by, "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                    "algorithmic_kflop_per_sample": fl / 1e3, "tflops": tf, "fp64_vector_frac": tf / FP64_VECTOR_PEAK_TFLOPS}
+        return {"workload": f"{name}: B={Bd} samples x N={Nd} correspondences per GPU (fp32 I/O, fp64 inside)",
+                "value": Bd / wall, "unit": "poses/s", "ms_per_step": wall * 1e3,
+                "launch": "graph_region (20 steps per replay)" if g is not None else "stream order",
+                "step_us_events": {"graph": None if t_step is None else t_step * 1e3, "stream_order": t_step_so * 1e3},
+                "lm_iterations": {"mean": it_mean, "max": it_max},
+                "lc_cov_loss_kernel": roof(t_loss, by_l, fl_l), "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p),
+                "bound": "neither HBM nor MFMA: VALU issue / per-workgroup latency (SURVEY.md 8d); both fractions are quoted"}
+
     if rank == 0:
-        t_loss = kernel_ms(launch_loss)
-        t_pnp = kernel_ms(launch_pnp)
+        t_loss = kernel_ms(main_unit.launch_loss)
+        t_pnp = kernel_ms(main_unit.launch_pnp)
         by_loss, by_pnp = algorithmic_bytes(N, True)
         dom = ("lc_cov_loss_kernel", t_loss, by_loss) if t_loss >= t_pnp else ("lc_pnp_lm_kernel", t_pnp, by_pnp)
         kernel_us = {"lc_cov_loss_kernel": t_loss * 1e3, "lc_pnp_lm_kernel": t_pnp * 1e3}
-        if args.launch in ("fused", "graph_fused", "graph_region"):
+        fused_forms = args.launch in ("fused", "graph_fused", "graph_region")
+        if fused_forms:
             t_unit = kernel_ms(step_fused)  # launches issued one by one (stream order)
             kernel_us["lc_pose_unit_kernel"] = t_unit * 1e3
             if args.launch == "graph_region":  # the pattern of the timed region: the kernel as a node of the K-step graph (events around replays)
@@ -382,22 +537,36 @@ def main():
                 kernel_us["lc_pose_unit_kernel"] = t_unit * 1e3
             dom = ("lc_pose_unit_kernel", t_unit, by_loss + by_pnp)
             kernel_us["lc_pose_unit_kernel_p10_p50_p90"] = kernel_percentiles_us(step_fused)
-        hbm_gbs = dom[2] * B / (dom[1] * 1e-3) / 1e9
-        kernel_poses_per_s = B / (dom[1] * 1e-3)
+        # every figure of the roofline block is formed from the PROTOCOL's step (ms_per_step of this rank's line), not from the
+        # event-timed replay; the event-timed launch durations ride along in kernel_us
+        step_s = elapsed / args.steps if fused_forms else dom[1] * 1e-3
+        hbm_gbs = dom[2] * B / step_s / 1e9
+        poses_per_s = B / step_s
+        it_mean, it_max = main_unit.mean_lm_iterations()
+        fl_loss, fl_pnp = algorithmic_flops(N, it_mean + 1.0)
+        tflops = (fl_loss + fl_pnp) * B / step_s / 1e12
+        flops = {"bound": "fp64_vector", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                 "algorithmic_kflop_per_pose": {"loss": fl_loss / 1e3, "pnp": fl_pnp / 1e3},
+                 "lm_iterations": {"mean": it_mean, "max": it_max},
+                 "note": "SURVEY.md 8(d): 115 kflop (loss fwd+bwd) + 23 kflop x (LM iterations + 1 initial evaluation) per pose, the "
+                         "iteration count read from the solve's `iters` output on this batch; peak = fp64 vector (the LM runs in fp64)"}
         ctr, src = static_counters(dom[0], B, N)
         hbm = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                "algorithmic_bytes_per_pose": {"loss": by_loss, "pnp": by_pnp},
                "note": "secondary: 5 KB working set per pose, one wave per pose -- HBM never binds this kernel"}
         if ctr is not None and ctr.get("sq", {}).get("SQ_ACTIVE_INST_VALU"):
             cyc, peak = valu_bound(ctr["sq"], B)
-            roof = {"bound": "valu_issue", "kernel": dom[0], "achieved": kernel_poses_per_s, "peak": peak, "unit": "poses/s",
-                    "frac": kernel_poses_per_s / peak, "traffic": ctr.get("bytes_per_launch"),
+            roof = {"bound": "valu_issue", "kernel": dom[0], "achieved": poses_per_s, "peak": peak, "unit": "poses/s",
+                    "frac": poses_per_s / peak, "traffic": ctr.get("bytes_per_launch"),
                     "valu_insts_per_pose": ctr["sq"]["SQ_INSTS_VALU"] / B, "simd_cycles_per_pose": cyc,
-                    "note": "the bound that binds: 1024 SIMDs x 2.4 GHz / VALU-issue SIMD-cycles per pose (SQ_ACTIVE_INST_VALU); achieved = "
-                            "B / event-timed launch duration of the kernel, measured in this run",
-                    "counters_from": src, "kernel_us": kernel_us, "hbm": hbm}
-        else:  # no committed counter pass for this workload: only the HBM figure can be formed in-run
-            roof = dict(hbm, kernel=dom[0], traffic=None, kernel_us=kernel_us)
+                    "note": "the bound that binds; `peak` is derived from the kernel's OWN instruction count: 1024 SIMDs x 2.4 GHz / "
+                            "VALU-issue SIMD-cycles per pose (SQ_ACTIVE_INST_VALU of the committed counter pass) -- a latency-hiding "
+                            "ratio, not an algorithmic one; the algorithmic rooflines of SURVEY.md 8(d) are `flops` and `hbm` beside "
+                            "it; achieved = B / ms_per_step of the timed protocol",
+                    "counters_from": src, "kernel_us": kernel_us, "flops": flops, "hbm": hbm}
+        else:  # no committed counter pass for this workload: only the algorithmic figures can be formed in-run
+            roof = dict(hbm, kernel=dom[0], traffic=None, kernel_us=kernel_us, flops=flops)
         out = {
             "metric": METRIC,
             "value": B * world * args.steps / elapsed,
@@ -414,22 +583,35 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic B={B} N={N} 2D-3D correspondences per GPU, HIP weighted-PnP + cov-loss",
                        "global_batch": B * world, "n_points": N, "sharding": f"poses over {world} rank(s), no data-path collective",
-                       "launch": args.launch, **({"slots_in_flight": args.slots} if args.launch == "streams" else {})},
+                       "launch": args.launch, "launch_agreed_by_all_ranks": True,
+                       **({"slots_in_flight": args.slots} if args.launch == "streams" else {})},
             "timing": {"protocol": f"{agg['regions']} regions of exactly {args.steps} steps, barrier + synchronize around each, MAX over ranks "
                                    f"per region, MEDIAN region reported"
                                    + ("; the K steps of a region are K kernel nodes of one hipGraph launch" if args.launch == "graph_region" else ""),
                        "region_ms_per_step": agg["region_ms_per_step"]},
-            "ranks_seen": agg["ranks_seen"], "collective_backend": agg["backend"],
-            "rccl_version": rccl_version() if (world > 1 and not share_gpu) else None,
+            "ranks_seen": agg["ranks_seen"], "collective_backend": coll["backend"] if coll else "none",
+            "region_times_gathered_over": agg["backend"],
+            "rccl_version": rccl_version() if (coll and coll["backend"] == "nccl") else None,
             "per_rank_ms_per_step": agg["per_rank_ms_per_step"],
             "roofline": roof,
         }
+        if coll and coll["rccl_error"]:
+            out["rccl_error"] = coll["rccl_error"]
+        if agg_so is not None:
+            out["value_stream_order"] = B * world * args.steps / agg_so["median_region_s"]
+            out["ms_per_step_stream_order"] = agg_so["ms_per_step"]
+            out["timing"]["stream_order"] = {"what": "the same K fused launches per region issued one by one from Python (per-launch host "
+                                                     "cost included), same regions / barrier / MAX-over-ranks / median protocol",
+                                             "region_ms_per_step": agg_so["region_ms_per_step"],
+                                             "per_rank_ms_per_step": agg_so["per_rank_ms_per_step"]}
         if args.steady_batch > 0 and world == 1 and args.launch in ("fused", "graph_region"):
             Bs, pps, ms = steady_state(args.steady_batch)
             ss = {"B": Bs, "poses_per_s": pps, "ms_per_launch": ms}
             if roof.get("bound") == "valu_issue":
                 ss["valu_frac"] = pps / roof["peak"]
             out["steady_state"] = ss
+        if world == 1 and args.workload != "metric":
+            out["dense"] = {k: dense_block(k, *v) for k, v in DENSE_WORKLOADS.items() if args.workload in ("all", k)}
         if world == 1 and not args.no_head:
             # the third kernel family of the path (keypoint head), HBM-bound; its own line: bench_head.py
             from bench_head import measure_head
@@ -437,7 +619,7 @@ def main():
             out["head"] = {"metric": h["metric"], "value": h["value"], "unit": h["unit"], "config": h["config"], "roofline": h["roofline"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, N, seed=rank, budget_s=args.cpu_budget)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

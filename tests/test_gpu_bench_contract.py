@@ -33,6 +33,25 @@ def test_single_gpu_line_has_the_contract_keys():
     assert r["bound"] in ("valu_issue", "hbm") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     if r["bound"] == "valu_issue":
         assert r["hbm"]["bound"] == "hbm" and r["counters_from"]["file"].startswith("profiles/") and r["traffic"] > 0
+    # the survey-defined rooflines ride next to the one that binds, all formed from the protocol's step
+    fl = r["flops"]
+    assert fl["bound"] == "fp64_vector" and 0 < fl["frac"] < 1 and 1.0 <= fl["lm_iterations"]["mean"] <= fl["lm_iterations"]["max"] <= 50
+    per_pose = 115e3 + 23e3 * (fl["lm_iterations"]["mean"] + 1)
+    assert abs(fl["achieved"] - per_pose * 256 / (d["ms_per_step"] * 1e-3) / 1e12) <= 1e-6 * fl["achieved"]
+    hb = r["hbm"] if r["bound"] == "valu_issue" else r
+    assert abs(hb["achieved"] - 5640 * 256 / (d["ms_per_step"] * 1e-3) / 1e9) <= 1e-6 * hb["achieved"]
+    if r["bound"] == "valu_issue":
+        assert abs(r["achieved"] - d["value"]) <= 1e-6 * d["value"]
+    # both launch forms at the top level
+    assert d["config"]["launch"] in ("graph_region", "fused")
+    assert d["value_stream_order"] > 0 and abs(d["value_stream_order"] - 256 / (d["ms_per_step_stream_order"] * 1e-3)) <= 1e-6 * d["value"]
+    # the dense configs' hot-path shapes
+    for name, n in (("glmo_dense", 1024), ("zlmo_dense", 1849)):
+        blk = d["dense"][name]
+        assert f"N={n}" in blk["workload"] and blk["value"] > 0 and blk["unit"] == "poses/s"
+        for k in ("lc_cov_loss_kernel", "lc_pnp_lm_wide_kernel"):
+            assert blk[k]["kernel_us"] > 0 and 0 < blk[k]["hbm_frac"] < 1 and 0 < blk[k]["fp64_vector_frac"] < 1
+        assert blk["ms_per_step"] * 1e3 >= 0.5 * (blk["lc_cov_loss_kernel"]["kernel_us"] + blk["lc_pnp_lm_wide_kernel"]["kernel_us"])
     assert d["steady_state"]["B"] == 4096 and d["steady_state"]["poses_per_s"] > d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
@@ -54,3 +73,34 @@ def test_two_rank_control_flow_on_one_gpu():
     assert d["config"]["global_batch"] == 512 and "cpu_baseline" not in d and "steady_state" not in d
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert d["ms_per_step"] >= max(d["per_rank_ms_per_step"]) * 0.5  # the reported step is a MAX-over-ranks region, not a mean
+    assert d["config"]["launch_agreed_by_all_ranks"] is True and d["value_stream_order"] > 0
+
+
+def test_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts the two ranks itself (the driver's command form)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LC_BENCH_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--regions", "5"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # ONE line, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["config"]["global_batch"] == 512
+    assert d["roofline"]["kernel_us"]["lc_pose_unit_kernel"] > 0  # the N-rank line keeps the per-rank kernel time
+
+
+def test_gpus_1_through_the_launcher_equals_the_plain_run():
+    """N = 1 under torchrun (WORLD_SIZE=1) takes the same in-process path as the plain command."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "3", "--regions", "5", "--no-cpu-baseline", "--no-head", "--workload", "metric",
+            "--steady-batch", "0"]
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900)
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-1500:], b.stderr[-1500:])
+    da, db = _last_json(a.stdout), _last_json(b.stdout)
+    assert da["n_gpus"] == db["n_gpus"] == 1 and da["config"] == db["config"] and set(da) == set(db)
+    assert 0.8 < da["value"] / db["value"] < 1.25
