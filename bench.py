@@ -298,12 +298,16 @@ def main():
             self.tr = torch.empty(Bq, device=dev)
             self.ret = torch.empty(Bq, device=dev, dtype=torch.int32)
             self.iters = torch.zeros(Bq, device=dev, dtype=torch.int32)
+            # dense shapes: the workspace through which the tiles of a sample meet (zeroed once, left zeroed by every launch)
+            nws = int(lib.lc_cov_loss_workspace_bytes(Bq, Nq))
+            self.ws = torch.zeros(nws, dtype=torch.uint8, device=dev) if nws else None
 
         def launch_loss(self, stream=None):
             b = self.b
-            rc = lib.lc_cov_loss_fwd_bwd_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None,
-                                             P(b["bbox_3d"]), P(self.go), self.B, self.N, 32.0, 3.0, 4.0, P(self.loss), P(self.d_u),
-                                             P(self.d_s), P(self.d_x), None, stream or _lib.stream_ptr(dev))
+            rc = lib.lc_cov_loss3_fwd_bwd_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None,
+                                              P(b["bbox_3d"]), P(self.go), self.B, self.N, 32.0, 3.0, 4.0, 0, P(self.loss), P(self.d_u),
+                                              P(self.d_s), P(self.d_x), None, P(self.ws), 0 if self.ws is None else self.ws.numel(),
+                                              stream or _lib.stream_ptr(dev))
             assert rc == 0
 
         def launch_pnp(self, stream=None, iters=False):
@@ -518,7 +522,8 @@ def main():
                 "launch": "graph_region (20 steps per replay)" if g is not None else "stream order",
                 "step_us_events": {"graph": None if t_step is None else t_step * 1e3, "stream_order": t_step_so * 1e3},
                 "lm_iterations": {"mean": it_mean, "max": it_max},
-                "lc_cov_loss_kernel": roof(t_loss, by_l, fl_l), "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p),
+                "lc_cov_loss_kernel": dict(roof(t_loss, by_l, fl_l), form="tiled: one wavefront-sized workgroup per 64 correspondences" if u.ws is not None else "one workgroup per sample"),
+                "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p),
                 "bound": "neither HBM nor MFMA: VALU issue / per-workgroup latency (SURVEY.md 8d); both fractions are quoted"}
 
     if rank == 0:

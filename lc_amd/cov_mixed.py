@@ -12,8 +12,28 @@ from torch import Tensor
 from . import _lib
 
 
+_TILED_WS = {}  # (device index, stream, B, N) -> zeroed workspace of the tiled form (lc_cov_loss3_fwd_bwd_f32)
+
+
+def tiled_workspace(device, B: int, N: int):
+    """The workspace that lets a dense sample (N > 256) spread over many compute units, or None when the shape does not use one.
+    One per (device, stream, shape): launches of one stream are ordered, so they can share it; every launch leaves it zeroed.
+    Allocated through torch's caching allocator, so a first use inside a hipGraph capture lands in the graph's own pool (with its
+    zero-fill as a graph node)."""
+    lib = _lib.load()
+    nbytes = int(lib.lc_cov_loss_workspace_bytes(B, N))
+    if nbytes == 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, B, N)
+    ws = _TILED_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _TILED_WS[key] = ws
+    return ws
+
+
 def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_len, rel_thresh, w_e_thresh,
-                 want_grads: bool, want_pts3d: bool, want_aux: bool = False, cov_2d: bool = False):
+                 want_grads: bool, want_pts3d: bool, want_aux: bool = False, cov_2d: bool = False, tiled: bool = True):
     """One fused launch.  Returns loss (B,), d_pts2d, d_inv_std, d_pts3d, aux (None where not requested)."""
     lib = _lib.load()
     B, N = pts3d.shape[0], pts3d.shape[1]
@@ -23,11 +43,12 @@ def _launch_loss(K, pose, pts3d, pts2d, inv_std, valid, bbox, grad_out, max_err_
     d_x = torch.empty_like(pts3d) if (want_grads and want_pts3d) else None
     aux = torch.empty(B, 40, device=pts3d.device, dtype=torch.float32) if want_aux else None
     with _lib.on_device(pts3d.device):
-        rc = lib.lc_cov_loss2_fwd_bwd_f32(
+        ws = tiled_workspace(pts3d.device, B, N) if (tiled and N > 256) else None  # tiled=False: the one-workgroup form (tests)
+        rc = lib.lc_cov_loss3_fwd_bwd_f32(
             _lib.ptr(K), _lib.ptr(pose), _lib.ptr(pts3d), _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(valid), _lib.ptr(bbox),
             _lib.ptr(grad_out), B, N, float(max_err_len), float(rel_thresh), float(w_e_thresh), int(cov_2d), _lib.ptr(loss), _lib.ptr(d_u),
-            _lib.ptr(d_s), _lib.ptr(d_x), _lib.ptr(aux), _lib.stream_ptr(pts3d.device))
-    _lib.check(rc, "lc_cov_loss2_fwd_bwd_f32")
+            _lib.ptr(d_s), _lib.ptr(d_x), _lib.ptr(aux), _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.stream_ptr(pts3d.device))
+    _lib.check(rc, "lc_cov_loss3_fwd_bwd_f32")
     return loss, d_u, d_s, d_x, aux
 
 
@@ -97,7 +118,7 @@ def Loss_cov_mixed(K_out: Tensor, pose_gt: Tensor, pts3d: Tensor, pts2d_out: Ten
 
 
 def loss_cov_mixed_fused(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out=None, want_pts3d=True, want_aux=False,
-                         max_err_len=32, rel_thresh=3, w_e_thresh=4, cov_2d=False):
+                         max_err_len=32, rel_thresh=3, w_e_thresh=4, cov_2d=False, tiled=True):
     """Non-autograd entry: loss AND input gradients for a known cotangent in ONE launch (bench / training loops that
     know d(total)/d(loss_b) up front, e.g. 1/B for `.mean()`).  Returns (loss, d_pts2d, d_inv_std, d_pts3d, aux)."""
     ts = [_lib.require_hip_f32(n, t) for n, t in (("K", K), ("pose", pose), ("pts3d", pts3d), ("pts2d", pts2d),
@@ -105,4 +126,4 @@ def loss_cov_mixed_fused(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_ou
     valid = None if valid is None else _lib.require_hip_f32("valid", valid)
     grad_out = None if grad_out is None else _lib.require_hip_f32("grad_out", grad_out)
     return _launch_loss(ts[0], ts[1], ts[2], ts[3], ts[4], valid, ts[5], grad_out, max_err_len, rel_thresh, w_e_thresh,
-                        True, want_pts3d, want_aux, cov_2d=cov_2d)
+                        True, want_pts3d, want_aux, cov_2d=cov_2d, tiled=tiled)

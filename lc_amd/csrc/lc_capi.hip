@@ -215,15 +215,28 @@ int lc_cov_loss2_fwd_bwd_f32(const float* K, const float* pose, const float* pts
                              const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
                              float rel_thresh, float w_e_thresh, int cov_2d, float* loss, float* d_pts2d, float* d_inv_std,
                              float* d_pts3d, float* aux, void* stream) {
+    return lc_cov_loss3_fwd_bwd_f32(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, B, N, max_err_len, rel_thresh,
+                                    w_e_thresh, cov_2d, loss, d_pts2d, d_inv_std, d_pts3d, aux, nullptr, 0, stream);
+}
+
+size_t lc_cov_loss_workspace_bytes(int B, int N) { return lc::cov_loss_workspace_bytes(B, N); }
+
+int lc_cov_loss3_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
+                             const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
+                             float rel_thresh, float w_e_thresh, int cov_2d, float* loss, float* d_pts2d, float* d_inv_std,
+                             float* d_pts3d, float* aux, void* workspace, size_t workspace_bytes, void* stream) {
     if (B < 0 || N <= 0) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss) return fail(1, "null pointer");
     if ((d_pts2d == nullptr) != (d_inv_std == nullptr)) return fail(1, "d_pts2d and d_inv_std must both be given or both be NULL");
     if (d_pts3d && !d_pts2d) return fail(1, "d_pts3d needs d_pts2d/d_inv_std");
     LC_REQUIRE_ALIGNED(8, pts2d, inv_std, d_pts2d, d_inv_std);
+    LC_REQUIRE_ALIGNED(256, workspace);
     lc::LossParams p{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, aux,
-                     B, N, max_err_len, rel_thresh, w_e_thresh, cov_2d ? 1 : 0};
-    if (lc::launch_cov_loss(p, static_cast<hipStream_t>(stream))) return fail(11, "loss kernel launch failed");
+                     B, N, max_err_len, rel_thresh, w_e_thresh, cov_2d ? 1 : 0, workspace, workspace ? workspace_bytes : 0};
+    const int rc = lc::launch_cov_loss(p, static_cast<hipStream_t>(stream));
+    if (rc == 3) return fail(3, "workspace smaller than lc_cov_loss_workspace_bytes(B, N)");
+    if (rc) return fail(11, "loss kernel launch failed");
     return 0;
 }
 

@@ -29,8 +29,11 @@ struct LossParams {
     int B, N;
     float max_err_len, rel_thresh, w_e_thresh;
     int cov_2d;  // 0: 3D bbox-corner covariance (every reference call site); 1: projected corners (cov_mixed.py:125-127)
+    void* workspace;         // tiled form (N > 256): cov_loss_workspace_bytes(B, N) bytes, zeroed once by the caller, or null
+    size_t workspace_bytes;
 };
-int launch_cov_loss(const LossParams& p, hipStream_t stream);
+int launch_cov_loss(const LossParams& p, hipStream_t stream);  // 3: workspace too small
+size_t cov_loss_workspace_bytes(int B, int N);  // 0: the shape does not use the tiled form
 
 struct PnpParams {
     const float* K;       // (B,3,3)

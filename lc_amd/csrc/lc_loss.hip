@@ -1,22 +1,97 @@
-// Stand-alone launch of the fused LC-loss forward+backward (device body: lc_loss_body.h).
+// Stand-alone launches of the fused LC-loss forward+backward (device body: lc_loss_body.h).
+//   N <= 256                       one workgroup per sample, one correspondence per thread           lc_cov_loss_kernel<true, .>
+//   N  > 256, workspace given      TILED form: one 256-thread workgroup per 256 correspondences (wave = tile of 64), the
+//                                  workgroups of a sample meet through the workspace (ONE hand-off)  lc_cov_loss_tiled_kernel
+//   N  > 256 otherwise             one 256-thread workgroup per sample walking its tiles             lc_cov_loss_kernel<false, .>
+// All three add the per-sample reductions in the same (tile) order: a sample's results do not depend on the form chosen.
 #include "lc_loss_body.h"
+
+#ifndef LC_GRID_TICKETS
+#define LC_GRID_TICKETS 1  // A/B switch (scripts/ubench/tiled_loss.py): 0 = (sample, tile) from blockIdx (relies on in-order dispatch)
+#endif
 
 namespace lc {
 namespace {
 
 template <bool REG, bool COV2D>
 __global__ __launch_bounds__(256) void lc_cov_loss_kernel(const LossParams p) {
-    __shared__ loss::LossShared sh;
-    loss::sample<REG, COV2D>(p, blockIdx.x, sh);
+    using SH = typename std::conditional<REG, loss::LossShared, loss::LossSharedLoop>::type;
+    __shared__ SH sh;
+    loss::sample<REG, COV2D, false, SH>(p, blockIdx.x, sh);
+}
+
+// Tiled form.  Workgroups take (sample, slice) from a ticket counter as they start (see grid_arrive_wait for why that makes the
+// hand-off deadlock-free); the last workgroup of a sample to finish zeroes the sample's counters, the last sample the header, so
+// the workspace is left as it was found (all zero) for the next launch on the same stream.
+template <bool COV2D>
+__global__ __launch_bounds__(256) void lc_cov_loss_tiled_kernel(const LossParams p, int T, int S) {
+    __shared__ loss::LossSharedLoop sh;
+    __shared__ unsigned ticket_sh;
+    unsigned* head = static_cast<unsigned*>(p.workspace);
+#if LC_GRID_TICKETS
+    if (threadIdx.x == 0) ticket_sh = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = ticket_sh;
+#else
+    const unsigned ticket = blockIdx.x;
+#endif
+    const int b = (int)(ticket / (unsigned)S);
+    loss::GridCtx g;
+    g.head = head;
+    g.ctr = head + 4 + 2 * (size_t)b;
+    g.rows = reinterpret_cast<double*>(static_cast<char*>(p.workspace) + loss::grid_rows_offset_bytes(p.B)) + (size_t)b * T * loss::kGridRow;
+    g.T = T;
+    g.S = S;
+    g.slice = (int)(ticket % (unsigned)S);
+    g.timed_out = 0;
+    loss::sample<true, COV2D, true, loss::LossSharedLoop>(p, b, sh, &g);
+    // retire: relaxed device-scope atomics only (no cache maintenance) -- a workgroup counts itself finished after the hand-off,
+    // the counters it may then zero are touched by nobody else any more
+    if (threadIdx.x == 0) {
+        if (g.timed_out && g.slice == 0) p.loss[b] = __builtin_nanf("");  // never silently wrong
+        const unsigned d = __hip_atomic_fetch_add(g.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == (unsigned)S - 1u) {  // every workgroup of the sample is past the hand-off
+            __hip_atomic_store(g.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned s = __hip_atomic_fetch_add(head + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s == (unsigned)p.B - 1u) {  // every workgroup of the grid has taken its ticket
+                __hip_atomic_store(head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(head + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 }  // namespace
 
+// The tiled form pays while its workgroups find a compute unit each (measured, rocprofv3, B x N: 32 x 1024 20.5 -> 16.0 us,
+// 32 x 1849 35.6 -> 23.7, 16 x 4096 62.6 -> 32.1, 1 x 4096 61.4 -> 24.4; with two workgroups per unit the repeated quarter walk
+// and 6x6 section of every workgroup cost more than the spread buys: 128 x 1024 21.1 -> 25.7, 64 x 4096 64.0 -> 101;
+// profiles/r03/tiled_loss.txt)
+#ifndef LC_TILED_MAX_GROUPS
+#define LC_TILED_MAX_GROUPS 256
+#endif
+
+size_t cov_loss_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 256) return 0;
+    const int T = (N + loss::kTile - 1) / loss::kTile;
+    if ((long long)B * ((T + 3) / 4) > LC_TILED_MAX_GROUPS) return 0;
+    return loss::grid_workspace_bytes(B, T);
+}
+
 int launch_cov_loss(const LossParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     if (p.N <= 0) return 1;
-    const int threads = p.N <= 256 ? ((p.N + 63) / 64) * 64 : 256;
     const bool reg = p.N <= 256;
+    const size_t need = cov_loss_workspace_bytes(p.B, p.N);
+    if (!reg && p.workspace && need) {
+        if (p.workspace_bytes < need) return 3;
+        const int T = (p.N + loss::kTile - 1) / loss::kTile, S = (T + 3) / 4;
+        if (p.cov_2d) hipLaunchKernelGGL(lc_cov_loss_tiled_kernel<true>, dim3(p.B * S), dim3(256), 0, stream, p, T, S);
+        else hipLaunchKernelGGL(lc_cov_loss_tiled_kernel<false>, dim3(p.B * S), dim3(256), 0, stream, p, T, S);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    const int threads = reg ? ((p.N + 63) / 64) * 64 : 256;
     if (p.cov_2d) {
         if (reg) hipLaunchKernelGGL((lc_cov_loss_kernel<true, true>), dim3(p.B), dim3(threads), 0, stream, p);
         else hipLaunchKernelGGL((lc_cov_loss_kernel<false, true>), dim3(p.B), dim3(threads), 0, stream, p);

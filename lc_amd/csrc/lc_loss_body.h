@@ -27,7 +27,7 @@
         __builtin_amdgcn_sched_barrier(0);                                                       \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.aux)[(size_t)b * 20 + (i)] = t_; \
+        if (threadIdx.x == 0 && stamp_ok) reinterpret_cast<unsigned long long*>(p.aux)[(size_t)b * 20 + (i)] = t_; \
     } while (0)
 #else
 #define LC_STAMP(i) do {} while (0)
@@ -45,6 +45,11 @@ struct LossShared {
     double pd[24], cd[24], dl[24], sq[24], isq[24];
     double Hbar[36], Psi[36], mu[6];
     int bad[4];  // [0],[1]: a non-positive diagonal in loss_cov_3d (P, C); [2]: H not SPD
+};
+
+// the one-workgroup loop form adds the per-tile partial rows of the canonical summation order
+struct LossSharedLoop : LossShared {
+    double p3[64][48];   // pass 3 (kLoopTiles rows)
 };
 
 struct PoseConst {
@@ -159,6 +164,111 @@ __device__ __forceinline__ void block_allreduce_small(double (&v)[K], double (*s
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Canonical summation order of the per-sample reductions (the same in every launch form, so a sample's results do not depend
+// on how many workgroups share it): points are cut into TILES of 64 consecutive correspondences.  The 48 sums of pass 3: one
+// wavefront reduces a tile with the cross-lane tree (wave_reduce_scatter16; lanes beyond N contribute exact zeros) and the tile
+// partials are added sequentially in tile order.  The two small sums of passes 1-2: see the quarters at pass 1.
+//   REG  (N <= 256): wave w of the workgroup is tile w, partials meet in LDS;
+//   GRID (tiled form, N > 256): a 256-thread workgroup per FOUR tiles, wave = tile; the pass-3 partials of a sample meet in a
+//        global workspace, ONE arrive-and-wait hand-off on a per-sample counter (below);
+//   loop (!REG, one 256-thread workgroup per sample, for batches that fill the chip anyway): wave q walks quarter q of the tiles,
+//        partials in LDS (up to kLoopTiles tiles; beyond that the per-thread accumulation of round 2 is kept).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTile = 64;
+constexpr int kLoopTiles = 64;  // N <= 4096 in the canonical one-workgroup form
+
+// Workspace of the tiled form (caller-provided, zero-initialised once, left zeroed by every launch):
+//   header: [0] ticket, [1] samples done, [2] spin time-outs (diagnostic), [3] pad;  then 2 counters per sample (tiles arrived at
+//   the hand-off, tiles finished);  then per sample and tile the 48 partial sums of pass 3.
+constexpr int kGridRow = 48;
+__host__ __device__ constexpr size_t grid_counter_words(int B) { return 4 + 2 * (size_t)B; }
+__host__ __device__ constexpr size_t grid_rows_offset_bytes(int B) { return ((grid_counter_words(B) * 4 + 255) / 256) * 256; }
+__host__ __device__ constexpr size_t grid_workspace_bytes(int B, int T) {
+    return grid_rows_offset_bytes(B) + (size_t)B * T * kGridRow * sizeof(double);
+}
+
+struct GridCtx {
+    unsigned* head;   // workspace header
+    unsigned* ctr;    // this sample's two counters
+    double* rows;     // this sample's (T, kGridRow) partials
+    int T, S, slice;  // tiles of the sample; workgroups sharing it (four tiles each); this workgroup's index among them
+    int timed_out;
+};
+
+#ifndef LC_GRID_SPIN_LIMIT
+#define LC_GRID_SPIN_LIMIT (1u << 22)  // ~seconds: a lost sibling (it cannot happen: tickets, below) must not hang the GPU
+#endif
+#ifndef LC_GRID_SLEEP
+#define LC_GRID_SLEEP 2  // s_sleep argument between two polls of the arrival counter (64 cycles each)
+#endif
+
+// Hand-off between the S workgroups of a sample: the workgroup's tile partials have been stored with grid_store(); afterwards
+// every sibling's can be read with grid_load().  No cache maintenance: an agent-scope release / acquire FENCE costs a write-back /
+// invalidate of the whole L2 of the XCD per hand-off and workgroup (measured: the launch then scales with the number of
+// workgroups, ~125 ns each); instead the few values exchanged are written through and read around the non-coherent caches
+// (agent-scope relaxed atomics = sc1 accesses), ordered by the wave's own `s_waitcnt` before the arrival is counted.
+// Deadlock-free without any co-residency assumption: workgroups take their (sample, tile) from a ticket counter when they START,
+// so the tickets handed out are always a prefix 0..t-1 of the grid and every sample whose T tickets are inside the prefix has all
+// its workgroups running; only the last, incomplete sample of the prefix waits for tickets not yet handed out, holds fewer than S
+// workgroup slots, and gets its siblings as soon as any earlier sample retires.
+#ifndef LC_GRID_FENCES
+#define LC_GRID_FENCES 0  // A/B switch (scripts/ubench/tiled_loss.py): 1 = plain accesses + agent-scope fences
+#endif
+__device__ __forceinline__ void grid_store(double* q, double v) {
+#if LC_GRID_FENCES
+    *q = v;
+#else
+    __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ double grid_load(const double* q) {
+#if LC_GRID_FENCES
+    return *q;
+#else
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void grid_arrive_wait(GridCtx& g, int tid) {
+#if LC_GRID_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+#endif
+    __syncthreads();  // ... and so have the other waves' of the workgroup
+    if (tid == 0) {
+        unsigned* c = g.ctr;
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.S) {
+            __builtin_amdgcn_s_sleep(LC_GRID_SLEEP);
+            if (++spins > LC_GRID_SPIN_LIMIT) {
+                __hip_atomic_fetch_add(g.head + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g.timed_out = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();  // no wave loads a sibling's row before the poll has matched
+#if LC_GRID_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+
+// sum over the tiles of column `col` of the sample's partial rows, in tile order
+__device__ __forceinline__ double grid_column_sum(const GridCtx& g, int col) {
+    double s = 0;
+    const double* q = g.rows + col;
+    int t = 0;
+    for (; t + 4 <= g.T; t += 4) {  // four loads in flight, added in order
+        const double a0 = grid_load(q + (size_t)t * kGridRow), a1 = grid_load(q + (size_t)(t + 1) * kGridRow),
+                     a2 = grid_load(q + (size_t)(t + 2) * kGridRow), a3 = grid_load(q + (size_t)(t + 3) * kGridRow);
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; t < g.T; ++t) s += grid_load(q + (size_t)t * kGridRow);
+    return s;
+}
+
 struct Pt {
     double X[3], u[2], s[2], vld;
 };
@@ -175,17 +285,97 @@ __device__ __forceinline__ Pt load_pt(const LossParams& p, size_t base, int n) {
     return o;
 }
 
-// REG: the block has at least N threads, each point's raw inputs and clamped error stay in registers.
-// !REG: block-stride over points; raw inputs are re-read (L1/L2 hits) and e re-derived in every pass.
+// one correspondence as it sits in HBM: the walk below keeps a few of these per thread in registers across the passes
+struct RawPt {
+    float X[3];
+    float2 u, s;
+    float vld;
+};
+__device__ __forceinline__ RawPt load_raw_pt(const LossParams& p, size_t base, int n) {
+    RawPt o;
+    const float* X = p.pts3d + (base + n) * 3;
+    o.u = *reinterpret_cast<const float2*>(p.pts2d + (base + n) * 2);
+    o.s = *reinterpret_cast<const float2*>(p.inv_std + (base + n) * 2);
+    o.X[0] = X[0]; o.X[1] = X[1]; o.X[2] = X[2];
+    o.vld = p.valid ? p.valid[base + n] : 1.f;
+    return o;
+}
+__device__ __forceinline__ Pt to_pt(const RawPt& r) {
+    Pt o;
+    o.X[0] = r.X[0]; o.X[1] = r.X[1]; o.X[2] = r.X[2];
+    o.u[0] = r.u.x; o.u[1] = r.u.y;
+    o.s[0] = r.s.x; o.s[1] = r.s.y;
+    o.vld = r.vld;
+    return o;
+}
+
+// REG, !GRID (N <= 256): the workgroup has one thread per correspondence; raw inputs and clamped error stay in registers.
+// !REG (loop form, N > 256): one 256-thread workgroup per sample; wave q WALKS quarter q of the sample's tiles in every pass.
+// REG, GRID (tiled form, N > 256): a 256-thread workgroup owns FOUR consecutive tiles of a sample (wave w: tile 4 slice + w, its
+//      correspondence in registers like REG); the two small sums come from the same quarter walk over the whole sample as in
+//      the loop form (every workgroup of the sample repeats it: two cheap passes over <= 115 KB that sit in L2, instead of
+//      two more hand-offs), the 48 sums of pass 3 meet the sibling workgroups' in the workspace (ONE hand-off).
+// The walk loads up to kRound tiles per wave at a time into registers, all loads in flight together; a quarter of at most
+// kRound tiles (N <= 1024) is loaded ONCE and serves all passes.
 // COV2D: covariance of the projected bbox corners (cov_mixed.py:125-127) instead of the 3D ones (every reference call site).
-template <bool REG, bool COV2D = false>
-__device__ __forceinline__ void sample(const LossParams& p, const int b, LossShared& sh) {
+// SH: LossShared (REG) or LossSharedLoop (loop form, tiled form)
+template <bool REG, bool COV2D = false, bool GRID = false, typename SH = LossShared>
+__device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh, GridCtx* gc = nullptr) {
+    static_assert(!GRID || REG, "the tiled form keeps its tiles' points in registers");
+    constexpr bool WALK = GRID || !REG;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const int N = p.N;
     const size_t base = (size_t)b * N;
+    const int T = (N + kTile - 1) / kTile;
+    const int my_tile = GRID ? gc->slice * 4 + wave : wave;        // REG / GRID: the tile this wave owns
+    const int my_pt = GRID ? my_tile * kTile + lane : tid;          // ... and the correspondence this thread owns
+    // loop form: canonical tile order while the partials fit the LDS rows; beyond that (N > 4096) per-thread accumulation
+    [[maybe_unused]] const bool tiles = !REG && T <= kLoopTiles;
+    [[maybe_unused]] const bool stamp_ok = !GRID || gc->slice == 0;  // diagnostic build: one workgroup per sample writes the stamps
 
     LC_STAMP(0);
+    // the walk: this wave's quarter of the sample's tiles, kRound tiles per round
+    constexpr int kRound = 4;
+    [[maybe_unused]] RawPt raw[kRound];
+    [[maybe_unused]] const int tq0 = (T * wave) >> 2, tq1 = (T * (wave + 1)) >> 2;  // WALK forms run four waves
+    [[maybe_unused]] const int rounds = (tq1 - tq0 + kRound - 1) / kRound;
+    [[maybe_unused]] const bool cached = T <= 4 * kRound;  // every quarter fits one round: loaded once, kept for all passes
+    [[maybe_unused]] double ce[kRound][2];  // clamped errors of the tiles in registers (valid while `cached`)
+    // branch-free on purpose: indices are clamped into the quarter / the sample, a lane without a correspondence carries a copy
+    // with vld = 0 (exact zeros in the small sums), so the four tiles of a round are one basic block the scheduler can interleave
+    [[maybe_unused]] auto load_round = [&](int r) {
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) {
+            const int t = tq0 + r * kRound + k, n = t * kTile + lane;
+            const bool live = t < tq1 && n < N;
+            raw[k] = load_raw_pt(p, base, live ? n : N - 1);
+            if (!live) raw[k].vld = 0.f;
+        }
+    };
+    // heavy(k, t, n, live): once per tile of the quarter, in tile order; live = this lane has a correspondence in the tile
+    [[maybe_unused]] auto walk = [&](auto&& heavy) {
+        for (int r = 0; r < rounds; ++r) {
+            if (!cached) load_round(r);
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) {
+                const int t = tq0 + r * kRound + k, n = t * kTile + lane;
+                if (t < tq1) heavy(k, t, n, n < N);
+            }
+        }
+    };
+    // light(k): the same for the two small sums, branch-free (tiles beyond the quarter are all-dead copies)
+    [[maybe_unused]] auto walk_light = [&](auto&& light) {
+        for (int r = 0; r < rounds; ++r) {
+            if (!cached) load_round(r);
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) light(k);
+        }
+    };
+    if constexpr (WALK) {
+        if (cached) load_round(0);  // first thing in the kernel: the pose set-up below runs in the loads' shadow
+    }
+
     PoseConst pc;
     {
         const float* Kp = p.K + 9 * (size_t)b;
@@ -215,27 +405,33 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     double re[2];   // REG only: clamped error
     bool active = false;
     if constexpr (REG) {
-        active = tid < N;
-        if (active) rp = load_pt(p, base, tid);
+        active = my_pt < N;  // (a tile beyond T has my_pt >= N)
+        if (active) rp = load_pt(p, base, my_pt);
     }
 
     LC_STAMP(1);
     // ---------------- pass 1: e, sum |e| (robust_weights_cov, cov_mixed.py:27-31) ----------------
+    // The two small reductions (3 and 2 values) in their canonical order: the tiles are cut into four QUARTERS
+    // [T q / 4, T (q+1) / 4); a lane adds its points of a quarter sequentially (tile order), the wave tree reduces the quarter,
+    // the four quarter totals are added in order.  REG: a wave is a tile is a quarter.  Walk forms: wave q walks quarter q.
+    auto huber = [](double v, double d) { return v > d ? d * (2 * v - d) : v * v; };
+    auto clamped_error = [&](const Pt& pt, double e[2]) {
+        const Proj pr = project(pc, pt.X);
+        clamp_err(pt.u, pr.proj, max_len, e);
+    };
     double s1[3] = {0, 0, 0};
     if constexpr (REG) {
         if (active) {
-            const Proj pr = project(pc, rp.X);
-            clamp_err(rp.u, pr.proj, max_len, re);
-            s1[0] = fabs(re[0]) * rp.vld; s1[1] = fabs(re[1]) * rp.vld; s1[2] = rp.vld;
+            clamped_error(rp, re);
+            if constexpr (!GRID) { s1[0] = fabs(re[0]) * rp.vld; s1[1] = fabs(re[1]) * rp.vld; s1[2] = rp.vld; }
         }
-    } else {
-        for (int n = tid; n < N; n += nthr) {
-            const Pt pt = load_pt(p, base, n);
-            const Proj pr = project(pc, pt.X);
-            double e[2];
-            clamp_err(pt.u, pr.proj, max_len, e);
-            s1[0] += fabs(e[0]) * pt.vld; s1[1] += fabs(e[1]) * pt.vld; s1[2] += pt.vld;
-        }
+    }
+    if constexpr (WALK) {
+        walk_light([&](int k) {
+            const Pt pt = to_pt(raw[k]);
+            clamped_error(pt, ce[k]);
+            s1[0] += fabs(ce[k][0]) * pt.vld; s1[1] += fabs(ce[k][1]) * pt.vld; s1[2] += pt.vld;
+        });
     }
     block_allreduce_small<3>(s1, sh.small, lane, wave, nw);
     const double vcnt = p.valid ? s1[2] : (double)N;
@@ -245,26 +441,23 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     LC_STAMP(2);
     // ---------------- pass 2: c, mean(s^2 c) (cov_mixed.py:32-36) ----------------
     double s2[2] = {0, 0};
-    auto huber = [](double v, double d) { return v > d ? d * (2 * v - d) : v * v; };
-    auto load_e = [&](int n, double e[2]) {
-        // !REG: re-derive e in double (the float copy parked in d_pts2d would lose bits)
-        const Pt pt = load_pt(p, base, n);
-        const Proj pr = project(pc, pt.X);
-        clamp_err(pt.u, pr.proj, max_len, e);
+    // e of a walked tile: from the registers while the quarter is cached, else re-derived (in double: a float copy would lose bits)
+    [[maybe_unused]] auto tile_error = [&](int k, const Pt& pt, double e[2]) {
+        if (cached) { e[0] = ce[k][0]; e[1] = ce[k][1]; }
+        else clamped_error(pt, e);
     };
-    if constexpr (REG) {
+    if constexpr (WALK) {
+        walk_light([&](int k) {
+            const Pt pt = to_pt(raw[k]);
+            double e[2];
+            tile_error(k, pt, e);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) s2[c] += pt.s[c] * pt.s[c] * huber(fabs(e[c]), dlt_e[c]) * pt.vld;
+        });
+    } else {
         if (active) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) s2[c] = rp.s[c] * rp.s[c] * huber(fabs(re[c]), dlt_e[c]) * rp.vld;
-        }
-    } else {
-        for (int n = tid; n < N; n += nthr) {
-            double e[2];
-            load_e(n, e);
-            const float2 s = *reinterpret_cast<const float2*>(p.inv_std + (base + n) * 2);
-            const double vld = p.valid ? (double)p.valid[base + n] : 1.0;
-            s2[0] += (double)s.x * s.x * huber(fabs(e[0]), dlt_e[0]) * vld;
-            s2[1] += (double)s.y * s.y * huber(fabs(e[1]), dlt_e[1]) * vld;
         }
     }
     block_allreduce_small<2>(s2, sh.small, lane, wave, nw);
@@ -328,31 +521,84 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
             for (int i = 0; i < 48; ++i) acc[i] = 0;
         }
     } else {
+        if (tiles) {  // a tile's 48 sums by the cross-lane tree, one LDS row per tile
+            walk([&](int k, int t, int, bool live) {
+                if (live) {
+                    const Pt pt = to_pt(raw[k]);
+                    double e[2];
+                    tile_error(k, pt, e);
+                    accumulate(pt, e, std::true_type{});
+                } else {
 #pragma unroll
-        for (int i = 0; i < 48; ++i) acc[i] = 0;
-        for (int n = tid; n < N; n += nthr) {
-            const Pt pt = load_pt(p, base, n);
-            const Proj pr = project(pc, pt.X);
-            double e[2];
-            clamp_err(pt.u, pr.proj, max_len, e);
-            accumulate(pt, e, std::false_type{});
+                    for (int i = 0; i < 48; ++i) acc[i] = 0;
+                }
+                wave_reduce_scatter16<48>(acc, lane);
+                if ((lane & 3) == 0) {
+                    const int bs = scatter16_base(lane, 3);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) sh.p3[t][bs + i] = acc[i];
+                }
+            });
+        } else {
+#pragma unroll
+            for (int i = 0; i < 48; ++i) acc[i] = 0;
+            for (int n = tid; n < N; n += nthr) {
+                const Pt pt = load_pt(p, base, n);
+                double e[2];
+                clamped_error(pt, e);
+                accumulate(pt, e, std::false_type{});
+            }
         }
     }
     LC_STAMP(4);
-    wave_reduce_scatter16<48>(acc, lane);
-    if ((lane & 3) == 0) {
-        const int bs = scatter16_base(lane, 3);
+    if constexpr (GRID) {  // tile partials -> the sample's workspace rows; totals in tile order once every sibling workgroup has arrived
+        wave_reduce_scatter16<48>(acc, lane);
+        if (my_tile < T && (lane & 3) == 0) {
+            const int bs = scatter16_base(lane, 3);
+            double* row = gc->rows + (size_t)my_tile * kGridRow + bs;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) sh.red[wave][bs + i] = acc[i];
-    }
-    wg_sync(nw);
-    if (nw > 1) {  // combine the waves' partials into sh.red[0]
-        if (tid < 48) {
-            double s = 0;
-            for (int w = 0; w < nw; ++w) s += sh.red[w][tid];
-            sh.red[0][tid] = s;
+            for (int i = 0; i < 3; ++i) grid_store(row + i, acc[i]);
+        }
+        grid_arrive_wait(*gc, tid);
+        if (T <= kLoopTiles) {
+            // all T rows in ONE round trip: every thread fetches a few values around the caches into LDS, 48 threads add the columns in tile order
+            for (int i = tid; i < T * kGridRow; i += nthr) (&sh.p3[0][0])[i] = grid_load(gc->rows + i);
+            __syncthreads();
+            if (tid < 48) {
+                double s = 0;
+                for (int t = 0; t < T; ++t) s += sh.p3[t][tid];
+                sh.red[0][tid] = s;
+            }
+        } else if (tid < 48) {
+            sh.red[0][tid] = grid_column_sum(*gc, tid);
+        }
+        __syncthreads();
+    } else if (!REG && tiles) {
+        if constexpr (!REG) {
+            __syncthreads();
+            if (tid < 48) {
+                double s = 0;
+                for (int t = 0; t < T; ++t) s += sh.p3[t][tid];
+                sh.red[0][tid] = s;
+            }
+            __syncthreads();
+        }
+    } else {
+        wave_reduce_scatter16<48>(acc, lane);
+        if ((lane & 3) == 0) {
+            const int bs = scatter16_base(lane, 3);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sh.red[wave][bs + i] = acc[i];
         }
         wg_sync(nw);
+        if (nw > 1) {  // combine the waves' partials into sh.red[0] (wave = tile: the canonical order)
+            if (tid < 48) {
+                double s = 0;
+                for (int w = 0; w < nw; ++w) s += sh.red[w][tid];
+                sh.red[0][tid] = s;
+            }
+            wg_sync(nw);
+        }
     }
     // packed totals (upper triangles, so H and Mc are symmetric by construction: make_sure_symmetric, pnp_utils.py:134-137)
     const double* Hp = &sh.red[0][0];    // H  (21)
@@ -482,7 +728,8 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
     const double iP = fast_rcp(Pm);
     const double loss = log(Pm) + 0.5 * (Cm + Lm) * iP;
     const double gout = p.grad_out ? (double)p.grad_out[b] : 1.0;
-    if (tid == 0) {
+    const bool writer = !GRID || gc->slice == 0;  // tiled form: every workgroup of the sample computes the (identical) sample-level section, the first stores it
+    if (tid == 0 && writer) {
         p.loss[b] = (float)loss;
 #ifndef LC_STAMPS
         if (p.aux) {
@@ -492,7 +739,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
 #endif
     }
 #ifndef LC_STAMPS
-    if (p.aux && tid < 36) p.aux[(size_t)b * kLossAuxStride + 4 + tid] = (float)S[tid];
+    if (p.aux && tid < 36 && writer) p.aux[(size_t)b * kLossAuxStride + 4 + tid] = (float)S[tid];
 #endif
     if (p.d_pts2d == nullptr) return;  // forward only
 
@@ -624,15 +871,16 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, LossSha
         }
     };
     if constexpr (REG) {
-        if (active) backward_point(rp, re, tid);
+        if (active) backward_point(rp, re, my_pt);
     } else {
-        for (int n = tid; n < N; n += nthr) {
-            const Pt pt = load_pt(p, base, n);
-            const Proj pr = project(pc, pt.X);
-            double e[2];
-            clamp_err(pt.u, pr.proj, max_len, e);
-            backward_point(pt, e, n);
-        }
+        walk([&](int k, int, int n, bool live) {
+            if (live) {
+                const Pt pt = to_pt(raw[k]);
+                double e[2];
+                tile_error(k, pt, e);
+                backward_point(pt, e, n);
+            }
+        });
     }
     LC_STAMP(11);
 }

@@ -82,7 +82,7 @@ def test_loss_kernel_vs_oracle_shapes(B, N, seed):
     assert rel_err(gu, ru) <= 3e-4 and rel_err(gs, rs) <= 3e-4 and rel_err(gx, rx) <= 3e-4
 
 
-def test_loss_full_size_properties():
+def test_loss_halves_equal_the_whole_batch():
     """BASELINE size (B=256,N=64) and beyond: size-independent properties of the path.
     (a) per-sample independence: a batch equals the concatenation of its halves, bit for bit;
     (b) the fused cotangent path equals autograd's two-launch path; (c) permutation of the points leaves the loss
@@ -154,3 +154,81 @@ def test_loss_full_size_properties():
     sl = slice(1000, 1037)
     ls, gus, gss, gxs, _ = loss_cov_mixed_fused(*(t[sl].contiguous() for t in args), None, b["bbox_3d"][sl].contiguous(), grad_out=go[sl].contiguous())
     assert torch.equal(ls, loss[sl]) and torch.equal(gus, gu[sl]) and torch.equal(gss, gs[sl]) and torch.equal(gxs, gx[sl])
+
+
+TILED_SHAPES = [(2, 1024, 0), (3, 300, 1), (32, 1024, 2), (5, 1849, 3), (1, 4096, 4), (40, 257, 5)]
+
+
+@pytest.mark.parametrize("B,N,seed", TILED_SHAPES)
+def test_tiled_form_is_bit_identical_to_the_one_workgroup_form(B, N, seed):
+    """Dense shapes (N > 256): one wavefront-sized workgroup per 64 correspondences, the tiles of a sample meeting through the
+    workspace, against one 256-thread workgroup per sample.  Both add the per-sample sums in tile order, so every output --
+    loss, the three gradients, H^-1 -- is bit-identical; the workspace is left zeroed; a second launch over the same workspace
+    and a launch with the sample inside another batch give the same bits again."""
+    from lc_amd import _lib, synth
+    from lc_amd import cov_mixed as cm
+
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=100 + seed, outlier_frac=0.1).items()}
+    g = torch.Generator().manual_seed(seed)
+    valid = (torch.rand(B, N, generator=g) > 0.2).float().to(dev) if seed % 2 else None
+    go = (torch.rand(B, generator=g) + 0.5).to(dev)
+    args = (b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], valid, b["bbox_3d"])
+    assert _lib.load().lc_cov_loss_workspace_bytes(B, N) > 0
+    one = cm.loss_cov_mixed_fused(*args, grad_out=go, want_aux=True, tiled=False)
+    til = cm.loss_cov_mixed_fused(*args, grad_out=go, want_aux=True, tiled=True)
+    for a, c in zip(one, til):
+        assert torch.isfinite(a).all() and torch.equal(a, c)
+    ws = cm.tiled_workspace(dev, B, N)
+    torch.cuda.synchronize()
+    assert int(ws.view(torch.int32)[: 4 + 2 * B].abs().sum().item()) == 0  # ticket, done, time-outs and every sample's counters
+    again = cm.loss_cov_mixed_fused(*args, grad_out=go, want_aux=True, tiled=True)
+    for a, c in zip(til, again):
+        assert torch.equal(a, c)
+    # the sample alone (another grid, another ticket order) gives the same rows
+    k = B // 2
+    solo = cm.loss_cov_mixed_fused(*(None if t is None else t[k:k + 1].contiguous() for t in args), grad_out=go[k:k + 1].contiguous(), want_aux=True)
+    for a, c in zip(til, solo):
+        assert torch.equal(a[k:k + 1], c)
+
+
+def test_tiled_form_under_concurrency_and_replay():
+    """The hand-off is an arrive-and-wait loop between workgroups: exercise it with more workgroups in flight than the chip holds
+    at once (four streams x 240 workgroups, each stream with its own workspace: the tickets keep every sample's workgroups together
+    whatever the dispatcher interleaves) and as a replayed hipGraph."""
+    from lc_amd import _lib, synth
+    from lc_amd import cov_mixed as cm
+
+    dev = torch.device("cuda:0")
+    B, N = 30, 2048
+    assert _lib.load().lc_cov_loss_workspace_bytes(B, N) > 0 and _lib.load().lc_cov_loss_workspace_bytes(200, N) == 0
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=9).items()}
+    args = (b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], None, b["bbox_3d"])
+    ref = cm.loss_cov_mixed_fused(*args, tiled=False)
+    streams = [torch.cuda.Stream(dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(6):
+        for st in streams:
+            with torch.cuda.stream(st):
+                outs.append(cm.loss_cov_mixed_fused(*args))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert all(torch.equal(a, c) for a, c in zip(ref[:4], o[:4]))
+    for st in streams:
+        with torch.cuda.stream(st):
+            ws = cm.tiled_workspace(dev, B, N)
+        assert int(ws.view(torch.int32)[: 4 + 2 * B].abs().sum().item()) == 0
+    small = tuple(None if t is None else t[:, :1024].contiguous() for t in args)
+    want = cm.loss_cov_mixed_fused(*small, tiled=False)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        cm.loss_cov_mixed_fused(*small)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = cm.loss_cov_mixed_fused(*small)
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, c) for a, c in zip(want[:4], got[:4]))
