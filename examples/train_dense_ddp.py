@@ -31,6 +31,7 @@ from lc_amd.config import AttrDict  # noqa: E402
 from lc_amd.losses import Loss_fn  # noqa: E402
 from lc_amd.transforms import gen_uv, quaternion_rep_to_RT  # noqa: E402
 from train_sparse_ddp import KeypointNet  # noqa: E402
+import ddp_common  # noqa: E402
 
 BITS = (7, 7, 6)  # zlmo bit budget
 
@@ -89,33 +90,34 @@ def main():
     ap.add_argument("--bin", action="store_true", help="ZebraPose binary-code head (zlmo/zycbv) instead of the continuous xyz head")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--graphs", action="store_true", help="replay the Loss_fn step as hipGraphs (one per sub-sampling phase; eager inside the warm-up ramp)")
+    ap.add_argument("--np-seed", type=int, default=None, help="seed of the sub-sampling phase draws (losses.py:152); default: the rank")
+    ddp_common.add_args(ap)
     args = ap.parse_args()
-    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    group = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-        group = dist.group.WORLD
+    world, rank, dev, group = ddp_common.init(args)
+    local = dev.index
     torch.manual_seed(0)
-    np.random.seed(rank)
+    np.random.seed(rank if args.np_seed is None else args.np_seed)
     model = DenseNet(sum(BITS) if args.bin else 3, args.width).to(dev).to(memory_format=torch.channels_last)
     cfg = AttrDict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scale_grad=True, clip_pts_grad=not args.bin, dense_sample=2,
                                       max_err_len=32), pose_loss_start_step=4, pose_loss_start_epoch=0, loss_pose_nz_step=0,
                    w_loss_seg=1, w_loss_pose=0.05, seg_loss_type="L1", **({"w_loss_noc_bin": 1} if args.bin else {"w_loss_noc": 1}))
-    loss_fn = Loss_fn(cfg, AttrDict(), sum(BITS) if args.bin else 0, group=group).to(dev)  # group: NormClipper norms over the whole batch
+    # group + 1 / world: the NormClipper norms are those of the whole batch's mean loss (lc_amd/grad.py), as in the reference's single process
+    loss_fn = Loss_fn(cfg, AttrDict(), sum(BITS) if args.bin else 0, group=group, shard_loss_scale=1.0 / world).to(dev)
     model.loss_fn = loss_fn
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    if args.bn_eval:
+        ddp_common.freeze_bn(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     amp = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": None}[args.dtype]
     scaler = torch.amp.GradScaler("cuda", enabled=amp is torch.float16)
-    times = []
+    times, losses, clip_states = [], [], []
+    params_at_start = ddp_common.flat_params(model) if args.dump else None
     graphed = None
     for step in range(args.steps):
-        blob = synthetic_blob(args.batch, dev, seed=1000 * rank + step, binary=args.bin)
+        blob = ddp_common.cat_blobs([synthetic_blob(args.batch, dev, seed=args.seed_offset + 1000 * r + step, binary=args.bin)
+                                     for r in ddp_common.data_ranks(args, world, rank)])
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         with torch.autocast("cuda", dtype=amp or torch.float16, enabled=amp is not None):
@@ -138,6 +140,8 @@ def main():
         scaler.update()
         torch.cuda.synchronize(dev)
         times.append(time.perf_counter() - t0)
+        losses.append(float(loss))
+        clip_states.append({k: float(v) for k, v in loss_fn.state_dict().items() if k.endswith("max_norm")})
         if rank == 0:
             terms = "  ".join(f"{k[5:]} {float(v):8.4f}" for k, v in loss_dict.items())
             print(f"step {step:3d}  loss {float(loss):9.4f}  {terms}  {times[-1] * 1e3:7.1f} ms")
@@ -151,7 +155,9 @@ def main():
         print(f"quartiles of the step time [ms]: min {q(0):.1f}  p25 {q(0.25):.1f}  median {q(0.5):.1f}  p75 {q(0.75):.1f}  max {q(1):.1f}")
         print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), {args.dtype} backbone, "
               f"{'binary-code' if args.bin else 'continuous-xyz'} dense head, N=1024 correspondences per sample")
+    ddp_common.dump(args, rank, model, loss_fn, losses, clip_states, params_at_start)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

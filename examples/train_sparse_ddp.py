@@ -30,6 +30,9 @@ from lc_amd.config import AttrDict  # noqa: E402
 from lc_amd.losses import Loss_fn  # noqa: E402
 from lc_amd.ptnet import sparse_head  # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ddp_common  # noqa: E402
+
 
 class Block(nn.Module):
     def __init__(self, cin, cout, stride):
@@ -90,28 +93,31 @@ def main():
     ap.add_argument("--sparse-cnt", type=int, default=64)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--bf16", action="store_true", default=True)
+    ap.add_argument("--fp32", dest="bf16", action="store_false", help="no autocast (the two-rank parity test: bf16 round-off differs with the batch size)")
     ap.add_argument("--graphs", action="store_true", help="replay the Loss_fn step as hipGraphs once the warm-up ramp is over")
+    ddp_common.add_args(ap)
     args = ap.parse_args()
-    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    world, rank, dev, group = ddp_common.init(args)
+    local = dev.index
     torch.manual_seed(0)
     model = KeypointNet(args.sparse_cnt, args.width).to(dev).to(memory_format=torch.channels_last)
     cfg = AttrDict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True), pose_loss_start_step=4, pose_loss_start_epoch=0,
                    w_loss_kpts=1, w_loss_pose=0.7)
-    loss_fn = Loss_fn(cfg, AttrDict()).to(dev)
+    # group + 1 / world: the NormClipper norms are those of the whole batch's mean loss (lc_amd/grad.py), as in the reference's single process
+    loss_fn = Loss_fn(cfg, AttrDict(), group=group, shard_loss_scale=1.0 / world).to(dev)
     model.loss_fn = loss_fn  # train.py:31: rides in the checkpoint
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    if args.bn_eval:
+        ddp_common.freeze_bn(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    times = []
+    times, losses, clip_states = [], [], []
+    params_at_start = ddp_common.flat_params(model) if args.dump else None
     graphed = None
     for step in range(args.steps):
-        blob = synthetic_blob(args.batch, args.sparse_cnt, dev, seed=1000 * rank + step)
+        blob = ddp_common.cat_blobs([synthetic_blob(args.batch, args.sparse_cnt, dev, seed=args.seed_offset + 1000 * r + step)
+                                     for r in ddp_common.data_ranks(args, world, rank)])
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
@@ -131,6 +137,8 @@ def main():
         opt.step()
         torch.cuda.synchronize(dev)
         times.append(time.perf_counter() - t0)
+        losses.append(float(loss))
+        clip_states.append({k: float(v) for k, v in loss_fn.state_dict().items() if k.endswith("max_norm")})
         if rank == 0:
             print(f"step {step:3d}  loss {float(loss):9.4f}  kpts {float(loss_dict['loss_kpts']):8.4f}  pose {float(loss_dict['loss_pose']):8.4f}"
                   f"  {times[-1] * 1e3:7.1f} ms")
@@ -142,7 +150,9 @@ def main():
         # replay with no host work in it; the quartiles show both modes)
         print(f"quartiles of the step time [ms]: min {q(0):.1f}  p25 {q(0.25):.1f}  median {q(0.5):.1f}  p75 {q(0.75):.1f}  max {q(1):.1f}")
         print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), bf16 backbone, fp32/fp64 LC loss")
+    ddp_common.dump(args, rank, model, loss_fn, losses, clip_states, params_at_start)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -76,11 +76,19 @@ struct PnpHostWorkspace {
         return 0;
     }
 };
-PnpHostWorkspace g_ws;
+// One workspace per DEVICE (pinned staging, device buffer and stream all belong to the device that was current when they were
+// created): a process that drives several GPUs -- one thread per device, or hipSetDevice between calls -- gets the workspace of
+// the device current at the call; calls on the same device serialise on its mutex, calls on different devices do not.
+constexpr int kMaxDevices = 64;
+PnpHostWorkspace g_ws_by_device[kMaxDevices];
 
 int pnp_host_run(float** init_states, float** cam_Ks, float** pts2ds, float** pts3ds, float** icov_sqrtLs, int* ptCnts,
                  int maxIterCnt, float ftol, float* result_trs, int* rets, int B) {
     const int pmax = lc::host::stage_max_points(ptCnts, B);
+    int device = 0;
+    LC_HIP_OK(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) return fail(12, "device ordinal out of range");
+    PnpHostWorkspace& g_ws = g_ws_by_device[device];
     std::lock_guard<std::mutex> lock(g_ws.mu);
     if (int rc = g_ws.ensure(B, pmax)) return rc;
     const size_t P = pmax;

@@ -9,7 +9,11 @@ skip a device->host read of `max_norm <= 0`; with the test evaluated on the devi
 positive once it has been set, so "not started" and "max_norm <= 0" coincide).
 
 Under batch sharding the norm must be taken over the WHOLE batch gradient (grad.py:66-68): pass a process group and the
-squared norm is all-reduced (one float over RCCL) between the two launches.
+squared norm is all-reduced (one float over RCCL) between the two launches.  `shard_loss_scale` is the factor between the loss
+this rank back-propagates and the job's objective: under DistributedDataParallel every rank differentiates the mean over ITS
+shard and DDP averages the parameter gradients, so the gradient the single-process reference would have clipped is this rank's
+times 1 / world_size -- pass that, and `max_norm` (a checkpointed buffer) and the clipping decision are those of the reference on
+the concatenated batch whatever the number of GPUs; 1.0 (default) if the caller already scales its loss by local_B / global_B.
 """
 from __future__ import annotations
 
@@ -57,7 +61,7 @@ def _launch_apply(grads, sq, state_before, state, initial_max_norm, scale, momen
 
 
 class NormClipper(torch.nn.Module):
-    def __init__(self, initial_max_norm=100, rel_thresh=0.7, momentum=0.1, group=None) -> None:
+    def __init__(self, initial_max_norm=100, rel_thresh=0.7, momentum=0.1, group=None, shard_loss_scale=1.0) -> None:
         super().__init__()
         self.initial_max_norm = initial_max_norm
         self.register_buffer("max_norm", torch.tensor(-1, dtype=torch.float))
@@ -65,6 +69,7 @@ class NormClipper(torch.nn.Module):
         self.scale = 1 + rel_thresh
         self.last_norm = 0
         self.group = group
+        self.shard_loss_scale = float(shard_loss_scale)
         self._workspace = {}
 
     def _ws(self, dev):
@@ -94,6 +99,8 @@ class NormClipper(torch.nn.Module):
             import torch.distributed as dist
 
             dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+            if self.shard_loss_scale != 1.0:
+                sq.mul_(self.shard_loss_scale * self.shard_loss_scale)  # the norm of the job's gradient, not of this rank's loss
         clipped, self.last_norm = _launch_apply(tensors, sq, before, self.max_norm, self.initial_max_norm, self.scale, self.momentum)
         clipped = [o if o.dtype == dt else o.to(dt) for o, dt in zip(clipped, in_dtypes)]  # lib/utils/grad.py:78-82 keeps the dtype
         return clipped[0] if single else clipped

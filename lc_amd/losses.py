@@ -181,15 +181,17 @@ def pose_loss_factor(cfg, step, steps_per_epoch) -> float:
 class Loss_fn(nn.Module):
     """Drop-in for `losses.Loss_fn` (`losses.py:239-386`): `forward(gt_dict, out_dict, epoch, step, steps_per_epoch)`
     -> `(loss_dict, w_loss_dict)`.  `group`: optional process group; when the batch is sharded over ranks the
-    NormClippers all-reduce their squared norm over it."""
+    NormClippers all-reduce their squared norm over it; `shard_loss_scale`: lc_amd/grad.py (1 / world_size under
+    DistributedDataParallel)."""
 
-    def __init__(self, cfg, cfg_global, total_bit_cnt=0, group=None) -> None:
+    def __init__(self, cfg, cfg_global, total_bit_cnt=0, group=None, shard_loss_scale=1.0) -> None:
         super().__init__()
         self.cfg = cfg
         pose_cfg = cfg.pose_loss_cfg
-        self.weight_grad_clipper = NormClipper(group=group) if pose_cfg.get("clip_weight_grad", True) else None
-        self.scale_grad_clipper = NormClipper(rel_thresh=2, group=group) if pose_cfg.get("clip_scale_grad", False) else None
-        self.pts_grad_clipper = NormClipper(rel_thresh=2, group=group) if pose_cfg.get("clip_pts_grad", False) else None
+        kw = dict(group=group, shard_loss_scale=shard_loss_scale)
+        self.weight_grad_clipper = NormClipper(**kw) if pose_cfg.get("clip_weight_grad", True) else None
+        self.scale_grad_clipper = NormClipper(rel_thresh=2, **kw) if pose_cfg.get("clip_scale_grad", False) else None
+        self.pts_grad_clipper = NormClipper(rel_thresh=2, **kw) if pose_cfg.get("clip_pts_grad", False) else None
         self.cfg_global = cfg_global
         if total_bit_cnt > 0:
             self.xyz_bin_loss_fn = Loss_xyz_bin(total_bit_cnt)

@@ -68,7 +68,13 @@ def _worker(rank, world, port, B, N, ret):
         lo, hi = lcd.shard_range(4, rank, world)
         clip = NormClipper(initial_max_norm=5.0, group=dist.group.WORLD)
         clipped = clip.clip(g_full[lo:hi])
+        # the DistributedDataParallel form: every rank back-propagates the mean over ITS shard (gradients world x larger than the
+        # job's), shard_loss_scale = 1 / world brings norm, clipping decision and the checkpointed max_norm back to the job's
+        clip_ddp = NormClipper(initial_max_norm=5.0, group=dist.group.WORLD, shard_loss_scale=1.0 / world)
+        clipped_ddp = clip_ddp.clip(world * g_full[lo:hi])
+        clip_ddp.clip(world * 0.5 * g_full[lo:hi])  # second call: the EMA branch
         if rank == 0:
+            ret["ddp"] = (float(clip_ddp.max_norm), (clipped_ddp / world).numpy())
             ret["grads"] = [p.grad.clone().numpy() for p in params]
             ret["max_norm"] = float(clip.max_norm)
             ret["clipped0"] = clipped.numpy()
@@ -105,6 +111,9 @@ def test_two_rank_sharding_equals_full_batch(monkeypatch):
     full_clipped = clip.clip(g_full)
     assert abs(ret["max_norm"] - float(clip.max_norm)) <= 1e-12 * float(clip.max_norm)
     np.testing.assert_allclose(ret["clipped0"], full_clipped[:2].numpy(), rtol=1e-12)
+    clip.clip(0.5 * g_full)
+    assert abs(ret["ddp"][0] - float(clip.max_norm)) <= 1e-12 * float(clip.max_norm)
+    np.testing.assert_allclose(ret["ddp"][1], full_clipped[:2].numpy(), rtol=1e-12)
 
 
 def test_shard_range_covers_everything():

@@ -1,0 +1,70 @@
+"""Two-rank DistributedDataParallel steps on the REAL kernels (both ranks on the one GPU of the test box, collectives over gloo):
+examples/train_sparse_ddp.py and examples/train_dense_ddp.py against the single-process run on the concatenated crops.
+
+What a sharded job must preserve (reference: train.py:57-67 is one process; lib/utils/grad.py:19-30,66-68 takes the clipping norm
+over the whole batch and keeps it in a checkpointed buffer):
+  (i)   finite losses;
+  (ii)  identical parameters on both ranks after the steps (DDP's all-reduced gradients);
+  (iii) NormClipper.max_norm equal on both ranks AND equal to the single-process run on the concatenated batch -- the squared norm
+        is all-reduced and scaled to the job's mean loss (`shard_loss_scale`), so the buffer does not depend on the GPU count;
+  (iv)  the job's loss (mean over ranks) and parameters follow the single-process run (batch-norm statistics frozen: per-rank batch
+        statistics are the one thing a sharded step cannot share without SyncBN)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = 6
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(script, extra, dump, ranks):
+    common = [os.path.join(ROOT, "examples", script), "--steps", str(STEPS), "--batch", "4", "--width", "16", "--bn-eval", "--dump", dump, *extra]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if ranks > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(_port()), *common, "--backend", "gloo", "--share-gpu"]
+    else:
+        cmd = [sys.executable, *common, "--emulate-ranks", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return [torch.load(f"{dump}.rank{r}.pt") for r in range(ranks)]
+
+
+@pytest.mark.parametrize("script,extra", [("train_sparse_ddp.py", ["--sparse-cnt", "16", "--fp32"]),
+                                          ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3"])], ids=["sparse", "dense"])
+def test_two_ranks_match_the_single_process_run(tmp_path, script, extra):
+    r0, r1 = _run(script, extra, str(tmp_path / "two"), 2)
+    (one,) = _run(script, extra, str(tmp_path / "one"), 1)
+    # (i)
+    for d in (r0, r1, one):
+        assert len(d["losses"]) == STEPS and all(map(lambda v: v == v and abs(v) < 1e9, d["losses"]))
+    # (ii) bit for bit
+    assert torch.equal(r0["params"], r1["params"])
+    # (iii)
+    assert r0["clip_states"] == r1["clip_states"]
+    if "dense" in script:
+        assert any(v > 0 for v in r0["final_clip"].values())  # the hooks ran
+    for a, b in zip(r0["clip_states"], one["clip_states"]):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
+    # (iv)
+    job = [(x + y) / 2 for x, y in zip(r0["losses"], r1["losses"])]
+    for x, y in zip(job, one["losses"]):
+        assert abs(x - y) <= 2e-3 * max(abs(y), 1.0), (job, one["losses"])
+    # Adam normalises every gradient entry, so round-off in a near-zero entry moves its weight by up to lr per step in either run:
+    # compare the UPDATES as vectors (same start: torch.manual_seed(0) on every rank and in the single process)
+    assert torch.equal(r0["params_at_start"], one["params_at_start"])
+    u2, u1 = r0["params"] - r0["params_at_start"], one["params"] - one["params_at_start"]
+    assert u1.norm() > 0 and ((u2 - u1).norm() / u1.norm()).item() <= 0.05, ((u2 - u1).norm() / u1.norm()).item()
