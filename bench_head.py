@@ -94,6 +94,13 @@ def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3, dtype="f32"):
         "roofline": {"bound": "hbm", "kernel": "lc_head_bwd_kernel", "achieved": gbs(by_b, t_b), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": gbs(by_b, t_b) / HBM_PEAK_GBS, "traffic": None,
                      "timing": "events around each kernel inside the alternating fwd;bwd loop (median)",
+                     "cache_note": "same-buffer, Infinity-Cache-assisted: the loop re-reads ONE 268 MB logits buffer with a 256 MiB Infinity "
+                                   "Cache behind it (non-temporal gradient stores leave part of it resident), which is how the step gets above "
+                                   "the 6.29 TB/s copy ceiling; inside a training step, where the maps are freshly written by the backbone, "
+                                   "rocprofv3 measured fwd 31.2 / bwd 51.2 us on bf16 maps against 25-26 / 42 us in this loop "
+                                   "(profiles/r02/g1/G1_SUMMARY.md) -- 1.2x: quote that ratio with any use of this figure",
+                     "in_training_rocprof_bf16_us": {"fwd": 31.2, "bwd": 51.2, "this_loop_fwd": [25.0, 26.0], "this_loop_bwd": 42.3,
+                                                     "source": "profiles/r02/g1/G1_SUMMARY.md (sparse head, B=256, bf16 maps)"},
                      "fwd": {"kernel": "lc_head_fwd_wave64_kernel" if (H, W) == (64, 64) else "lc_head_fwd_rows_kernel",
                              "achieved": gbs(by_f, t_f), "frac": gbs(by_f, t_f) / HBM_PEAK_GBS, "ms": t_f},
                      "bwd_ms": t_b,

@@ -27,6 +27,9 @@ extern "C" {
 
 int lc_amd_version(void);
 const char *lc_amd_last_error(void);
+/* sha256 (hex) of the .hip/.h sources this library was compiled from ("unrecorded" for a build that did not pass it): the
+ * loader rebuilds a library whose sources have changed (lc_amd/build.py reads the same string from the file's bytes) */
+const char *lc_amd_source_hash(void);
 
 /* ------------------------------------------------------------------------------------------------
  * (1) Reference ABI -- replaces /root/reference/lib/pnp/cxx/ext.h:2-15 (implemented in

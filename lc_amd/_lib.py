@@ -20,6 +20,7 @@ _FP = ctypes.POINTER(_F)
 _I = ctypes.POINTER(c_int)
 
 _SIGNATURES = {
+    "lc_amd_source_hash": (ctypes.c_char_p, []),
     "lc_amd_version": (c_int, []),
     "lc_amd_last_error": (ctypes.c_char_p, []),
     "pnp_ceres_f32_omp": (None, [_FP, _FP, _FP, _FP, _FP, _I, c_int, c_float, c_int, _F, _I, c_int, c_int]),
@@ -70,15 +71,22 @@ def load(build_if_missing: bool = True):
         return _LIB
     path = lib_path()
     if path == _build.SO_PATH and _build.is_stale():
-        # missing, or built from other .hip/.h contents than the ones on disk: rebuild (hipcc cross-compiles without a GPU);
-        # never load a library that silently ignores edited sources
-        if not build_if_missing:
+        # missing, or built from other .hip/.h contents than the ones on disk (the library carries the hash of its sources):
+        # rebuild (hipcc cross-compiles without a GPU); never silently run a library that ignores edited sources
+        if os.path.exists(path) and not _build.hipcc_available():
+            # a deployed copy on a box without the compiler: it cannot be rebuilt, so say what it is and use it
+            import warnings
+
+            warnings.warn(f"lc_amd: {path} was built from other sources than the ones next to it (embedded hash "
+                          f"{_build.embedded_hash(path)}) and hipcc is not available to rebuild it; loading it as it is")
+        elif not build_if_missing:
             raise RuntimeError(f"lc_amd: {path} is missing or stale; run `python __graft_entry__.py build`")
-        try:
-            _build.build()
-        except Exception as e:  # noqa: BLE001
-            raise RuntimeError(f"lc_amd: {path} is missing or older than lc_amd/csrc and could not be rebuilt ({e}); "
-                               f"run `python __graft_entry__.py build` where hipcc is available") from e
+        else:
+            try:
+                _build.build()
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError(f"lc_amd: {path} is missing or older than lc_amd/csrc and could not be rebuilt ({e}); "
+                                   f"run `python __graft_entry__.py build` where hipcc is available") from e
     elif not os.path.exists(path):
         raise RuntimeError(f"lc_amd: LC_AMD_LIB={path} does not exist")
     lib = ctypes.CDLL(path)

@@ -24,7 +24,7 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-HASH_PATH = SO_PATH + ".srchash"
+HASH_MARKER = b"LC_AMD_SRC_HASH:"  # the library carries the hash of its own sources (lc_capi.hip: lc_amd_source_hash)
 
 
 def _deps():
@@ -44,51 +44,68 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def embedded_hash(path: str = SO_PATH):
+    """The source hash a built library was compiled from, read from its bytes (no dlopen: a stale library must not get loaded
+    just to be asked), or None for a file without the marker."""
+    try:
+        blob = open(path, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(HASH_MARKER)
+    if i < 0:
+        return None
+    j = i + len(HASH_MARKER)
+    return blob[j:j + 64].decode("ascii", "replace")
+
+
 def is_stale() -> bool:
-    """True when liblc_amd.so is missing or was built from other source contents than the ones on disk now."""
-    if not os.path.exists(SO_PATH) or not os.path.exists(HASH_PATH):
+    """True when liblc_amd.so is missing or was built from other source contents than the ones on disk now.  The hash lives INSIDE
+    the library, so a copied library keeps it and there is no window in which library and hash disagree."""
+    return embedded_hash(SO_PATH) != source_hash()
+
+
+def hipcc_available() -> bool:
+    try:
+        _hipcc()
         return True
-    return open(HASH_PATH).read().strip() != source_hash()
+    except RuntimeError:
+        return False
+
+
+def _locked(fn):
+    import fcntl
+
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(SO_PATH + ".lock", "w") as lock:  # one builder at a time (pytest-xdist workers, torchrun ranks, A/B scripts)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return fn()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return SO_PATH
-    os.makedirs(OUT_DIR, exist_ok=True)
-    import fcntl
-
-    with open(SO_PATH + ".lock", "w") as lock:  # one builder at a time (pytest-xdist workers, torchrun ranks)
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and not is_stale():
-            return SO_PATH
-        return _build_locked(verbose)
+    return _locked(lambda: SO_PATH if (not force and not is_stale()) else _compile(SO_PATH, [], verbose))
 
 
-def _build_locked(verbose: bool) -> str:
-    tmp = SO_PATH + f".tmp{os.getpid()}"
-    digest = source_hash()
+def _compile(out: str, flags, verbose: bool) -> str:
+    tmp = out + f".tmp{os.getpid()}"
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           *sources(), "-o", tmp]
+           f'-DLC_AMD_SRC_HASH="{source_hash()}"', *flags, *sources(), "-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, SO_PATH)
-    with open(HASH_PATH, "w") as f:
-        f.write(digest + "\n")
-    return SO_PATH
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)  # atomic: a reader sees the old library or the new one, each with its own hash inside
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    return out
 
 
 def build_variant(name: str, flags, verbose: bool = False) -> str:
     """An experiment build of the same sources with extra compiler flags (-D switches) next to the shipped library:
     lc_amd/_C/liblc_amd_<name>.so; select it with LC_AMD_LIB=<path>.  Used by the A/B scripts under scripts/ only."""
-    os.makedirs(OUT_DIR, exist_ok=True)
-    out = os.path.join(OUT_DIR, f"liblc_amd_{name}.so")
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-function",
-           *flags, *sources(), "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return out
+    return _locked(lambda: _compile(os.path.join(OUT_DIR, f"liblc_amd_{name}.so"), list(flags), verbose))
 
 
 if __name__ == "__main__":

@@ -14,7 +14,14 @@
 #include "lc_host_stage.h"
 #include "lc_kernels.h"
 
+#ifndef LC_AMD_SRC_HASH
+#define LC_AMD_SRC_HASH "unrecorded"
+#endif
+
 namespace {
+
+// sha256 of the sources this library was compiled from, behind a marker lc_amd/build.py finds in the file's bytes (is_stale)
+const char kSrcHash[] = "LC_AMD_SRC_HASH:" LC_AMD_SRC_HASH;
 
 thread_local std::string g_err;
 
@@ -141,6 +148,7 @@ static bool misaligned(size_t bytes, P... ptrs) {
 extern "C" {
 
 int lc_amd_version(void) { return LC_AMD_VERSION; }
+const char* lc_amd_source_hash(void) { return kSrcHash + sizeof("LC_AMD_SRC_HASH:") - 1; }
 const char* lc_amd_last_error(void) { return g_err.c_str(); }
 
 void pnp_ceres_f32_omp(float** init_states, float** cam_Ks, float** pts2ds, float** pts3ds, float** icov_sqrtLs,

@@ -158,9 +158,19 @@ constexpr int sum_bcast_lds_doubles(int K) { return K * 68 * NW + K; }
 #ifndef LC_WAVE_SYNC
 #define LC_WAVE_SYNC 0  // A/B switch (scripts/ubench/pnp_ab.py): 1 restores the drains for one-wave workgroups
 #endif
+// Ordering point between the lanes of ONE wavefront that hand data to each other through LDS.  The wave barrier alone is a
+// scheduling barrier (IntrNoMem); the wavefront-scope release / acquire pair around it makes the hand-off part of the memory
+// model -- the compiler may not move a lane's ds_read above another lane's ds_write across it -- and emits no instruction on
+// gfx950 (a wave's DS operations execute in order; checked: identical instruction counts in the ISA with and without the pair).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int NW>
 __device__ __forceinline__ void block_sum_sync() {
-    if constexpr (NW == 1 && !LC_WAVE_SYNC) __builtin_amdgcn_wave_barrier();  // compiler-only: keeps the DS operations in program order
+    if constexpr (NW == 1 && !LC_WAVE_SYNC) wave_sync();
     else __syncthreads();
 }
 

@@ -141,7 +141,7 @@ __device__ __forceinline__ PointJac point_jac(const PoseConst& pc, const double 
 // Workgroup-wide ordering point of the LDS hand-offs.  One-wave workgroups (N <= 64: the metric's shape) need neither a barrier nor
 // a drain of the LDS queue -- a wave's DS operations execute in program order (lc_common.h: block_sum_sync).
 __device__ __forceinline__ void wg_sync(int nw) {
-    if (nw == 1 && !LC_WAVE_SYNC) __builtin_amdgcn_wave_barrier();
+    if (nw == 1 && !LC_WAVE_SYNC) wave_sync();
     else __syncthreads();
 }
 

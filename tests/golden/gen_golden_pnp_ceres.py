@@ -28,7 +28,7 @@ sys.path.insert(0, REF)
 from tests.pnp_cases import PNP_CASES, pnp_case  # noqa: E402
 
 
-def main():
+def main(out_dir=HERE):
     try:
         from lib.pnp import pnp_ceres  # the reference's cffi binding of ceres.cpp (needs lib/pnp/_ext built against Ceres 2.1.0)
     except Exception as e:  # noqa: BLE001
@@ -44,7 +44,7 @@ def main():
                                                   lists(c["sqrtL"]), [torch.from_numpy(s.copy()) for s in c["start"]],
                                                   [int(v) for v in n], max_iter_count=c["max_iter"], num_workers=1,
                                                   function_tolerance=c["ftol"])
-        out = os.path.join(HERE, f"pnp_ceres_{name}.npz")
+        out = os.path.join(out_dir, f"pnp_ceres_{name}.npz")
         np.savez_compressed(out, **{f"in_{k}": v for k, v in c.items()}, states=np.asarray(states, np.float32),
                             result_tr=np.asarray(result_tr, np.float32), rets=np.asarray(rets, np.int32))
         print(f"{out}: {B} jobs, {int(np.asarray(rets).sum())} invalid")
