@@ -491,7 +491,18 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
             for (int k = 0; k < 3; ++k) t[k] = (float)cand.t[k];
             cnt = 0;
             err = 0.f;
-            for (int i = 0; i < nl; ++i) score_point(R, t, sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], su[2 * i], su[2 * i + 1], thr2, cnt, err);
+            // the inlier error is added in the association of the split form (even / odd points of a 64-point chunk in two sums,
+            // chunk totals in chunk order), so that both launch forms hand the SAME float to the (count, error, id) tie-break and
+            // an object gets the same winner whichever form its batch size selects
+            for (int i0 = 0; i0 < nl; i0 += kWave) {
+                float e0 = 0.f, e1 = 0.f;
+                const int i1 = min(nl, i0 + kWave);
+                for (int i = i0; i < i1; i += 2) {
+                    score_point(R, t, sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], su[2 * i], su[2 * i + 1], thr2, cnt, e0);
+                    if (i + 1 < i1) score_point(R, t, sx[3 * i + 3], sx[3 * i + 4], sx[3 * i + 5], su[2 * i + 2], su[2 * i + 3], thr2, cnt, e1);
+                }
+                err += e0 + e1;
+            }
         }
         if (cnt > best_cnt || (cnt == best_cnt && err < best_err)) {
             best_cnt = cnt; best_err = err; best_hyp = round * kWave + lane;

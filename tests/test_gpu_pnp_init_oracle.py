@@ -54,16 +54,19 @@ def test_ransac_kernel_vs_oracle_fixture(path, split):
         assert decided.sum() >= 0.6 * valid.sum()
 
 
+@pytest.mark.parametrize("noise", [0.7, 0.0], ids=["noisy", "noise-free"])
 @pytest.mark.parametrize("B,N,iters", [(64, 1024, 150), (5, 300, 64), (3, 2500, 200), (40, 64, 150), (7, 129, 150), (6, 700, 300)])
-def test_split_form_equals_single_launch(B, N, iters):
-    """lc_pnp_ransac_init3_f32 (three launches, point chunks spread over the chip) against the one-workgroup-per-pose launch on
-    noisy correspondences with outliers: the per-hypothesis inlier counts are the same integers, so the winner has the same count;
-    where the single launch's winner is unique in (count) the two agree on the hypothesis, the mask and the pose bit for bit."""
+def test_split_form_equals_single_launch(B, N, iters, noise):
+    """lc_pnp_ransac_init3_f32 (three launches, point chunks spread over the chip) against the one-workgroup-per-pose launch: same
+    hypothesis stream, same per-point arithmetic, the same integers in the inlier counts AND the same float in the inlier error
+    (both forms add it as even / odd sums per 64-point chunk, chunks in order), so the (count, error, id) arg-max picks the same
+    hypothesis and an object gets the same initial pose whichever form its batch size selects -- also on noise-free data, where
+    every hypothesis has every inlier and the winner is decided by the error sums alone."""
     from lc_amd import synth
     from lc_amd.pnp import gpu_solver
 
     dev = torch.device("cuda:0")
-    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B + N, outlier_frac=0.3, noise_px=0.7).items()}
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B + N, outlier_frac=0.3 if noise else 0.0, noise_px=noise).items()}
     g = torch.Generator().manual_seed(B)
     counts = torch.randint(max(4, N // 2), N + 1, (B,), generator=g).to(torch.int32)
     counts[0] = 3  # too few -> invalid in both forms
@@ -71,8 +74,5 @@ def test_split_form_equals_single_launch(B, N, iters):
                                     refine=False, return_hypothesis=True, split=s) for s in (True, False)]
     (st_a, in_a, bad_a, hyp_a, n_a), (st_b, in_b, bad_b, hyp_b, n_b) = outs
     assert torch.equal(bad_a, bad_b) and bool(bad_a[0])
-    same = hyp_a == hyp_b
-    assert same.float().mean().item() >= 0.9, same
-    assert torch.equal(in_a[same], in_b[same]) and torch.equal(n_a[same], n_b[same]) and torch.equal(st_a[same], st_b[same])
-    # a different winner can only come from a tie in the inlier count of the scored points (broken by differently associated sums)
-    assert (n_a[~same] - n_b[~same]).abs().max().item() <= 2 if (~same).any() else True
+    assert torch.equal(hyp_a, hyp_b), (hyp_a != hyp_b).nonzero().flatten().tolist()
+    assert torch.equal(in_a, in_b) and torch.equal(n_a, n_b) and torch.equal(st_a, st_b)
