@@ -193,8 +193,13 @@ __device__ __forceinline__ void block_sum_bcast_lds(double (&v)[K], double* lds,
     block_sum_close<K, NW>(v, lds, tid);
 }
 
+// the reduction half alone: afterwards the K totals sit in LDS at block_sum_totals<K, NW>(lds)[0..K-1], where every thread may
+// read them until the next block_sum_open (callers that do not want all K of them in registers at once)
 template <int K, int NW>
-__device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int tid) {
+__device__ __forceinline__ double* block_sum_totals(double* lds) { return lds + K * (68 * NW); }
+
+template <int K, int NW>
+__device__ __forceinline__ void block_sum_reduce(double* lds, int tid) {
     static_assert(K <= 32 && (NW == 1 || NW == 4), "unsupported shape");
     constexpr int LD = 68 * NW, S = 2 * NW;
     block_sum_sync<NW>();
@@ -225,6 +230,12 @@ __device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int
     double* tot = lds + K * LD;
     if (tid < K * S && (tid % S) == 0) tot[tid / S] = s;
     block_sum_sync<NW>();
+}
+
+template <int K, int NW>
+__device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int tid) {
+    block_sum_reduce<K, NW>(lds, tid);
+    const double* tot = block_sum_totals<K, NW>(lds);
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = tot[k];
 }

@@ -13,6 +13,19 @@ __global__ __launch_bounds__(64, WPS) void lc_pnp_lm_kernel(const PnpParams p) {
     pnp::solve_pose<REG, 1, false, OPTS>(p, blockIdx.x, threadIdx.x, bc);
 }
 
+// Large grids (B > kLatencyGridMax), EXPERIMENT kept for the record (profiles/r03/occupancy.txt): the low-register form of the
+// same solve, three waves per SIMD (lc_pnp_body.h: solve_pose_lowreg).  Bit-identical, 168 VGPRs, no scratch -- and 18 % SLOWER
+// at B = 65 536 than the two-waves-per-SIMD register build (450.6 vs 381.1 us): the reads of the LDS-parked state add ~56 waits
+// on the LDS queue per iteration, which a third wave does not buy back.  Not launched unless built with -DLC_BIG_LOWREG=1.
+#ifndef LC_BIG_LOWREG
+#define LC_BIG_LOWREG 0
+#endif
+template <bool OPTS = false>
+__global__ __launch_bounds__(64, 3) void lc_pnp_lm_big_kernel(const PnpParams p) {
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLowregLdsDoubles];
+    pnp::solve_pose_lowreg<OPTS>(p, blockIdx.x, threadIdx.x, bc);
+}
+
 // four wavefronts per pose for N > 64 (dense heads, ragged inference batches)
 template <bool REG, bool OPTS = false>
 __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) {
@@ -44,7 +57,8 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     const bool big = p.B > kLatencyGridMax;
     if (p.options || p.weight_mask || p.pose_mod > 0) {  // input filtering / weight forms folded into the load
         if (p.Nmax <= 64) {
-            if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS, true>), dim3(p.B), dim3(64), 0, stream, p);
+            if (big && LC_BIG_LOWREG) hipLaunchKernelGGL(lc_pnp_lm_big_kernel<true>, dim3(p.B), dim3(64), 0, stream, p);
+            else if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS, true>), dim3(p.B), dim3(64), 0, stream, p);
             else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1, true>), dim3(p.B), dim3(64), 0, stream, p);
         } else if (p.Nmax <= 256) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<true, true>), dim3(p.B), dim3(256), 0, stream, p);
@@ -54,7 +68,8 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     if (p.Nmax <= 64) {
-        if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS>), dim3(p.B), dim3(64), 0, stream, p);
+        if (big && LC_BIG_LOWREG) hipLaunchKernelGGL(lc_pnp_lm_big_kernel<false>, dim3(p.B), dim3(64), 0, stream, p);
+        else if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS>), dim3(p.B), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);
     } else if (p.Nmax <= 256) {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);

@@ -510,5 +510,268 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same solve for LARGE grids (B > kLatencyGridMax poses: several waves per SIMD, throughput matters, not one wave's latency)
+// in at most 168 VGPRs, so that THREE waves fit a SIMD instead of two.  solve_pose keeps every wave-uniform quantity of the solve
+// -- the 21 + 6 entries of the normal equations, pose, candidate, Jacobi scaling and its inverse: ~60 doubles = 120 VGPRs that
+// hold the same value in all 64 lanes -- in registers; here they live in LDS (the block sum's 28 totals stay where the reduction
+// leaves them, x / scale / 1/scale in a 24-double block behind them) and are read (ds_read_b64 of one address: a broadcast) where
+// an expression needs them.  With three waves per SIMD the extra LDS latency is covered by the other waves.
+// The arithmetic is solve_pose<true, 1>'s, expression for expression: same results bit for bit
+// (tests/test_gpu_pnp.py::test_large_grid_build_equals_the_latency_build).
+constexpr int kPnpLowregLdsDoubles = kPnpLdsDoubles<1> + 30;
+
+// (A + diag(dg)) y = g with A (packed upper 21), g and the LM diagonal read from LDS; returns ok, y and the model cost change
+__device__ __forceinline__ bool ldlt_solve6_lds(const double* A, const double* g, double inv_radius, double (&y)[6], double& mcc) {
+    double L[6][6], Ld[6][6], id[6];
+    bool ok = true;
+    auto dgv = [&](int i) { return fmin(fmax(A[tri6(i, i)], 1e-6), 1e32) * inv_radius; };
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double dj = A[tri6(j, j)] + dgv(j);
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * Ld[j][k];
+        ok = ok && (dj > 0) && (dj < DBL_MAX);
+        id[j] = fast_rcp(dj);
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[tri6(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i][k] * Ld[j][k];
+            Ld[i][j] = v;
+            L[i][j] = v * id[j];
+        }
+    }
+    double z[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= L[i][k] * z[k];
+        z[i] = v;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = z[i] * id[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) v -= L[k][i] * y[k];
+        y[i] = v;
+    }
+    mcc = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mcc += y[i] * (g[i] + dgv(i) * y[i]);
+    mcc *= 0.5;
+    return ok;
+}
+
+template <bool OPTS = false>
+__device__ __forceinline__ void solve_pose_lowreg(const PnpParams& p, int b, int lane, double* bc) {
+    const int n = p.counts ? p.counts[b] : p.Nmax;
+    const int bk = (OPTS && p.pose_mod > 0) ? b % p.pose_mod : b;
+    const float* st_in = (p.start ? p.start + 7 * (size_t)bk : p.states + 7 * (size_t)b);
+    const bool filter = OPTS && (p.options & kPnpNanToNum);
+    auto fin = [&](float f) { return filter ? nan_to_num(f) : f; };
+    if (n < 3) {  // ceres.cpp:84-91
+        if (lane == 0) {
+            p.rets[b] = 1;
+            p.result_tr[b] = 1.f;
+            if (p.iters) p.iters[b] = 0;
+        }
+        if ((p.start || filter) && lane < 7) p.states[7 * (size_t)b + lane] = fin(st_in[lane]);
+        return;
+    }
+    const size_t base = (size_t)b * p.Nmax;
+    const bool active = lane < n;
+    const RawPoint raw = load_raw_point<OPTS>(p, base, active ? lane : 0);
+    double cam[6];
+    {
+        const float* Kp = p.K + 9 * (size_t)bk;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cam[i] = fin(Kp[i]);
+    }
+    // LDS: tot[0..20] = H, tot[21..26] = g, tot[27] = r.r of the last evaluation; us: x | scale | iscale | candidate
+    double* const tot = block_sum_totals<28, 1>(bc);
+    double* const ux = bc + kPnpLdsDoubles<1>;
+    double* const uscale = ux + 6;
+    double* const uiscale = ux + 12;
+    double* const uxc = ux + 18;
+    double* const ucam = ux + 24;  // K[0,0], K[0,1], -, K[1,0], K[1,1], - (the principal point is folded into the measurements)
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ucam[i] = cam[i];
+    }
+    {
+        double x[6];
+        const double q0 = fin(st_in[0]), q1 = fin(st_in[1]), q2 = fin(st_in[2]), q3 = fin(st_in[3]);
+        const double s2 = q1 * q1 + q2 * q2 + q3 * q3;
+        double kk = 2.0;
+        if (s2 > 0.0) {
+            const double s = fast_sqrt(s2);
+            const double half = atan_ratio_pos(s, fabs(q0));
+            const double two_theta = 2.0 * ((q0 < 0.0) ? -half : half);
+            kk = two_theta / s;
+        }
+        x[0] = q1 * kk; x[1] = q2 * kk; x[2] = q3 * kk;
+        x[3] = fin(st_in[4]); x[4] = fin(st_in[5]); x[5] = fin(st_in[6]);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { ux[j] = x[j]; uscale[j] = 1.0; }
+        }
+        wave_sync();
+    }
+    Point rp = to_point(raw, cam);
+    if (!active) { rp.a = 0.0; rp.b = 0.0; rp.c = 0.0; }
+
+    // evaluation at xe (6 doubles in LDS) with the column scaling in uscale: the 28 totals stay in LDS; returns the cost, false when non-finite
+    auto evaluate = [&](const double* xe, double& cost) -> bool {
+        double xv[6], sc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { xv[j] = xe[j]; sc[j] = uscale[j]; }
+        Rot rt;
+        make_rot(xv, rt);
+        const double t[3] = {xv[3], xv[4], xv[5]};
+        double acc[28];
+        const int pos = block_sum_open<1>(lane);
+        accumulate_point<true, true, 1>(rp, rt, t, ucam, sc, acc, bc, pos);
+        block_sum_reduce<28, 1>(bc, lane);
+        const double ss = tot[27];
+        cost = 0.5 * ss;
+        double chk = ss;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) chk += tot[tri6(i, i)];
+        return chk <= DBL_MAX;
+    };
+
+    const double ftol = p.ftol, ptol = 1e-8, gtol = 1e-10;
+    double cost;
+    bool failed = !evaluate(ux, cost);
+    {   // Jacobi scaling 1/(1+||J_j||), fixed at iteration 0; the totals become those of the scaled problem
+        double scale[6], iscale[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            iscale[j] = 1.0 + fast_sqrt(tot[tri6(j, j)]);
+            scale[j] = fast_rcp(iscale[j]);
+        }
+        double Hs[21], gs[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) { double h = tot[tri6(i, j)]; h *= scale[i] * scale[j]; Hs[tri6(i, j)] = h; }
+            double gi = tot[21 + i]; gi *= scale[i]; gs[i] = gi;
+        }
+        wave_sync();  // every lane has read the unscaled totals
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 21; ++k) tot[k] = Hs[k];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { tot[21 + j] = gs[j]; uscale[j] = scale[j]; uiscale[j] = iscale[j]; }
+        }
+        wave_sync();
+    }
+    auto grad_max = [&]() {  // max-norm of the UNSCALED gradient J^T r
+        double m = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m = fmax(m, fabs(tot[21 + j]) * uiscale[j]);
+        return m;
+    };
+    auto sqnorm6 = [](const double* v) {
+        double m = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m += v[j] * v[j];
+        return m;
+    };
+    double gmax = grad_max();
+    double xn2 = sqnorm6(ux);
+    double radius = 1e4, dfac = 2.0;
+    int iter = 0, n_invalid = 0;
+    bool converged = false;
+
+    while (uniform(!failed && !converged)) {
+        if (iter >= p.max_iter) break;
+        if (uniform(gmax <= gtol || radius <= 1e-32)) { converged = true; break; }
+        ++iter;
+        double y[6], mcc;
+        const double inv_radius = fast_rcp(radius);
+        bool step_ok = ldlt_solve6_lds(tot, tot + 21, inv_radius, y, mcc);
+        step_ok = step_ok && (mcc > 0.0) && (mcc <= DBL_MAX);
+        if (uniform(!step_ok)) {  // HandleInvalidStep
+            if (++n_invalid >= 5) { failed = true; break; }
+            radius /= dfac; dfac *= 2.0;
+            continue;
+        }
+        n_invalid = 0;
+        double sn2;
+        {
+            double xc[6], delta[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { delta[j] = -y[j] * uscale[j]; xc[j] = ux[j] + delta[j]; }
+            sn2 = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) sn2 += delta[j] * delta[j];
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) uxc[j] = xc[j];
+            }
+            wave_sync();
+        }
+        const bool ptol_in_reach = uniform(!(sn2 > 2.0 * ptol * ptol * (xn2 + ptol * ptol)));
+        bool ptol_hit = false;
+        if (ptol_in_reach) ptol_hit = uniform(fast_sqrt(sn2) <= ptol * (fast_sqrt(xn2) + ptol));
+        double cost_c;
+        const bool cand_ok = evaluate(uxc, cost_c);
+        if (!cand_ok) cost_c = DBL_MAX;
+        if (ptol_hit) { converged = true; break; }  // ParameterToleranceReached
+        const double cost_change = cost - cost_c;
+        if (uniform(fabs(cost_change) <= ftol * cost)) { converged = true; break; }  // FunctionToleranceReached
+        const double rel = cost_change * fast_rcp(mcc);
+        if (uniform(rel > 1e-3)) {  // HandleSuccessfulStep
+            double xn[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) xn[j] = uxc[j];
+            wave_sync();
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) ux[j] = xn[j];
+            }
+            wave_sync();
+            cost = cost_c;
+            xn2 = sqnorm6(ux);
+            gmax = grad_max();
+            const double tq = 2.0 * rel - 1.0;
+            radius = fmin(1e16, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - tq * tq * tq)));
+            dfac = 2.0;
+        } else {
+            radius /= dfac; dfac *= 2.0;
+            double cost_again;
+            if (!evaluate(ux, cost_again)) { failed = true; break; }
+        }
+    }
+    const bool invalid = failed || !converged;
+    if (invalid && (p.start || filter) && lane < 7) p.states[7 * (size_t)b + lane] = fin(st_in[lane]);
+    if (lane == 0) {
+        p.rets[b] = invalid ? 1 : 0;
+        p.result_tr[b] = (float)radius;
+        if (p.iters) p.iters[b] = iter;
+        if (!invalid) {  // ceres.cpp:131-144: AngleAxisToQuaternion, write back in place
+            float* st = p.states + 7 * (size_t)b;
+            double x[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) x[j] = ux[j];
+            const double t2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+            double q0 = 1.0, kk = 0.5;
+            if (t2 > 0.0) {
+                const double th = fast_sqrt(t2), h = 0.5 * th;
+                double sh, ch;
+                sincos_small(h, sh, ch);
+                q0 = ch;
+                kk = sh / th;
+            }
+            st[0] = (float)q0; st[1] = (float)(x[0] * kk); st[2] = (float)(x[1] * kk); st[3] = (float)(x[2] * kk);
+            st[4] = (float)x[3]; st[5] = (float)x[4]; st[6] = (float)x[5];
+        }
+    }
+}
+
 }  // namespace pnp
 }  // namespace lc

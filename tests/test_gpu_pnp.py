@@ -365,3 +365,34 @@ def test_fused_nan_filter_with_full_information_factor():
     assert rc == 0
     torch.cuda.synchronize()
     assert int(ret[0]) == 1 and float(st[0, 4]) == 0.0 and bool(torch.isfinite(st).all())
+
+
+@pytest.mark.parametrize("hard", [False, True], ids=["metric-like", "hard starts + ragged + outliers"])
+def test_large_grid_build_equals_the_latency_build(hard):
+    """Batches of more than 768 poses run the low-register form of the solve (three waves per SIMD, wave-uniform state parked in
+    LDS: lc_pnp_body.h solve_pose_lowreg), smaller ones the register-rich latency build.  Same arithmetic, expression for
+    expression: a pose solved inside a 3000-pose batch returns the same state, trust radius, flag and iteration count, bit for
+    bit, as the same pose solved in a batch of 500 -- through the plain entry point and the one with the input handling fused in."""
+    from lc_amd.pnp import pnp_ceres
+
+    dev = torch.device("cuda:0")
+    B, N = 3000, 64
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=77, outlier_frac=0.3 if hard else 0.05, noise_px=2.0 if hard else 1.0).items()}
+    counts = None
+    if hard:
+        g = torch.Generator().manual_seed(5)
+        counts = torch.randint(0, N + 1, (B,), generator=g).to(torch.int32).to(dev)
+        b["start"] = b["start"] + 0.2 * torch.randn(B, 7, generator=g).to(dev)  # far starts: many iterations, rejected steps, failures
+    big = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"], counts, return_iters=True)
+    for lo in (0, 500, 2500):
+        sl = slice(lo, lo + 500)
+        small = pnp_ceres.solve_device(b["K"][sl], b["pts3d"][sl], b["pts2d"][sl], b["inv_std"][sl], b["start"][sl],
+                                       None if counts is None else counts[sl], return_iters=True)
+        for a, c in zip(big, small):
+            assert torch.equal(a[sl], c)
+    assert int(big[3].max()) > 3 and (not hard or int(big[2].sum()) > 0)
+    big2 = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], b["inv_std"] ** 2, b["start"], counts, weights_are_icov=True, nan_to_num=True)
+    small2 = pnp_ceres.solve_device(b["K"][:500], b["pts3d"][:500], b["pts2d"][:500], b["inv_std"][:500] ** 2, b["start"][:500],
+                                    None if counts is None else counts[:500], weights_are_icov=True, nan_to_num=True)
+    for a, c in zip(big2, small2):
+        assert torch.equal(a[:500], c)
