@@ -27,10 +27,11 @@ __global__ __launch_bounds__(64, 3) void lc_pnp_lm_big_kernel(const PnpParams p)
 }
 
 // four wavefronts per pose for N > 64 (dense heads, ragged inference batches)
-template <bool REG, bool OPTS = false>
+// PPT: correspondences per thread kept in registers (0: block-stride loop over memory, any N)
+template <bool REG, bool OPTS = false, int PPT = 0>
 __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
-    pnp::solve_pose<REG, 4, false, OPTS>(p, blockIdx.x, threadIdx.x, bc);
+    pnp::solve_pose<REG, 4, false, OPTS, PPT>(p, blockIdx.x, threadIdx.x, bc);
 }
 
 // diagnostic twins that also record the per-iteration trace (tests/test_gpu_pnp_trace.py)
@@ -62,6 +63,10 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
             else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1, true>), dim3(p.B), dim3(64), 0, stream, p);
         } else if (p.Nmax <= 256) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<true, true>), dim3(p.B), dim3(256), 0, stream, p);
+        } else if (p.Nmax <= 1024) {
+            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 4>), dim3(p.B), dim3(256), 0, stream, p);
+        } else if (p.Nmax <= 2048) {
+            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 8>), dim3(p.B), dim3(256), 0, stream, p);
         } else {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true>), dim3(p.B), dim3(256), 0, stream, p);
         }
@@ -73,6 +78,10 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
         else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);
     } else if (p.Nmax <= 256) {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);
+    } else if (p.Nmax <= 1024) {
+        hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 4>), dim3(p.B), dim3(256), 0, stream, p);
+    } else if (p.Nmax <= 2048) {
+        hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 8>), dim3(p.B), dim3(256), 0, stream, p);
     } else {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<false>, dim3(p.B), dim3(256), 0, stream, p);
     }

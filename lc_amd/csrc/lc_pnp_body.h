@@ -255,7 +255,10 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 // REG: Nmax <= 64*NW, each thread keeps its correspondence in registers across the whole solve.
 // TRACE: diagnostic instantiation (lc_pnp_lm_trace_f32) that also writes one row per trust-region iteration to p.trace, in the
 // column layout of oracle/pnp_lm_oracle.c's PNP_TRACE_COLS; the shipped kernels are instantiated with TRACE = false.
-template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false>
+// PPT (with !REG): a thread keeps its first PPT correspondences (lane, lane + 64 NW, ...) in registers as they sit in HBM (8 floats
+// each) across the whole solve -- Nmax <= 64 NW PPT; the block-stride loop otherwise re-reads them from L2 in every evaluation,
+// ~1 us of exposed latency each time.  Same accumulation order, same results.
+template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
 #ifdef LC_TRACE_CLOCK
@@ -283,6 +286,12 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     const bool active = lane < n;
     RawPoint raw;
     if constexpr (REG) raw = load_raw_point<OPTS>(p, base, active ? lane : 0);  // n >= 3 here: correspondence 0 exists
+    [[maybe_unused]] RawPoint rawc[PPT > 0 ? PPT : 1];
+    if constexpr (!REG && PPT > 0) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (lane + k * kThreads < n) rawc[k] = load_raw_point<OPTS>(p, base, lane + k * kThreads);
+    }
     double cam[6];
     {
         const float* Kp = p.K + 9 * (size_t)bk;
@@ -337,7 +346,13 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         } else {
 #pragma unroll
             for (int i = 0; i < 28; ++i) acc[i] = 0;
-            for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
+            if constexpr (PPT > 0) {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k)
+                    if (lane + k * kThreads < n) accumulate_point<false>(to_point(rawc[k], cam), rt, t, cam, sc, acc);
+            } else {
+                for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
+            }
             LC_PSTAMP(3);
             block_sum_bcast_lds<28, NW>(acc, bc, lane);
         }
