@@ -75,6 +75,11 @@ def loss_cases():
     b = synth.make_batch(2, 1024, seed=5, dtype=torch.float64, rotate_K=False)
     cases["dense_B2_N1024"] = dict(b, valid=torch.ones(2, 1024, dtype=torch.float64), want_pts3d=True)
 
+    # zlmo's shape (128x128 maps, dense_sample 3 -> 43 x 43 correspondences; 29 tiles of 64, the last one ragged) with a ragged mask
+    b = synth.make_batch(3, 1849, seed=15, dtype=torch.float64, outlier_frac=0.1)
+    g = torch.Generator().manual_seed(35)
+    cases["dense_B3_N1849_mask"] = dict(b, valid=(torch.rand(3, 1849, generator=g) > 0.25).to(torch.float64), want_pts3d=True)
+
     # clamp branch: explicit >32 px outliers; and a different max_err_len
     b = synth.make_batch(3, 32, seed=6, dtype=torch.float64)
     b["pts2d"][:, ::5] += torch.tensor([90.0, -70.0], dtype=torch.float64)
@@ -159,8 +164,10 @@ def run_reference_loss(case, dtype):
     return {k: v.numpy() for k, v in out.items()}
 
 
-def gen_loss():
+def gen_loss(only=None):
     for name, case in loss_cases().items():
+        if only and name not in only:
+            continue
         B = case["K"].shape[0]
         g = torch.Generator().manual_seed(1234)
         case["grad_out"] = torch.rand(B, generator=g, dtype=torch.float64) + 0.5
@@ -322,7 +329,7 @@ if __name__ == "__main__":
     if "errors" in what:
         gen_pose_errors()
     if "loss" in what:
-        gen_loss()
+        gen_loss([w[5:] for w in what if w.startswith("only=")])  # e.g. `gen_golden.py loss only=dense_B3_N1849_mask`
     if "head" in what:
         gen_head()
     if "headc" in what:

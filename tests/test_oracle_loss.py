@@ -32,4 +32,5 @@ def test_oracle_intermediates_f64(path):
     _, inter = orc.loss_cov_mixed(ins["K"], ins["pose"], ins["pts3d"], ins["pts2d"], ins["inv_std"], ins.get("valid"),
                                   bbox_3d=ins["bbox_3d"], return_intermediates=True, **kwargs)
     for k in ("w", "c", "Hinv", "A", "G", "e"):
-        assert rel_err(inter[k], z["f64_" + k]) <= 1e-9, k
+        if "f64_" + k in z.files:  # the largest fixtures keep loss, gradients and Hinv only (gen_golden.py)
+            assert rel_err(inter[k], z["f64_" + k]) <= 1e-9, k
