@@ -2,7 +2,7 @@
 # Copy the judged summaries of the last scripts/profile_round.sh run from gpurun_out/ (scratch) into profiles/<round>/ (tracked).
 #   bash scripts/collect_profiles.sh r02 <git sha the run was taken at>
 set -eu
-TAG=${1:-r02}
+TAG=${1:-r03}
 SHA=${2:-unknown}
 SRC=gpurun_out/prof_$TAG
 DST=profiles/$TAG

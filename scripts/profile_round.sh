@@ -7,7 +7,7 @@
 # --pmc passes carry --kernel-trace only (gpurun refuses --pmc with other trace domains); the program follows `--` directly.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 SHA=${2:-unknown}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

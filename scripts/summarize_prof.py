@@ -15,7 +15,14 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
 
 
-def short(name):
+def short(name, grid=None):
+    import re
+
+    m = re.search(r"lc_pnp_lm_wide_kernel<[^>]*>", name)
+    if m:
+        return m.group(0).replace(" ", "")  # <REG, OPTS, points per thread in registers>: glmo's N = 1024 -> 4, zlmo's N = 1849 -> 8
+    if "lc_cov_loss_tiled_kernel" in name:  # one name for every dense shape: told apart by the grid (workgroups of 256 threads)
+        return "lc_cov_loss_tiled_kernel" + (f"[{int(grid) // 256} workgroups]" if grid else "")
     for key in ("lc_pose_unit_kernel", "lc_cov_loss_kernel", "lc_pnp_lm_kernel", "lc_head_fwd_wave64_kernel", "lc_head_fwd_rows_kernel", "lc_head_fwd_kernel", "lc_head_bwd_kernel",
                 "lc_scale_rows_kernel", "lc_dense"):
         if key in name:
@@ -24,6 +31,34 @@ def short(name):
 
 
 print("# rocprofv3 summary\n")
+
+# what the code object tells the hardware to allocate per kernel (scripts/kernel_resources.py) -- the figure that bounds occupancy;
+# rocprofv3's per-dispatch VGPR_Count column is NOT it (it read 128 for kernels that allocate 256)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kernel_resources import kernel_resources
+
+    RES = kernel_resources()
+except Exception as e:  # noqa: BLE001
+    RES = {}
+    print(f"(kernel resources unavailable: {e})\n")
+if RES:
+    print("## kernel resources (from the code object in liblc_amd.so)\n")
+    print("| kernel | arch VGPRs | AGPRs | SGPRs | LDS B/workgroup | scratch B/lane | waves/SIMD by registers |")
+    print("|---|---|---|---|---|---|---|")
+    for name, d in sorted(RES.items()):
+        if any(k in name for k in ("pose_unit", "pnp_lm", "cov_loss", "head_")):
+            print(f"| `{name}` | {d['arch_vgpr_count']} | {d.get('agpr_count', 0)} | {d.get('sgpr_count', 0)} | {d.get('group_segment_fixed_size', 0)} | "
+                  f"{d.get('private_segment_fixed_size', 0)} | {d['waves_per_simd_by_registers']} |")
+    print()
+
+
+def unit_vgprs(B):
+    """Allocation of the pose-unit instantiation a batch of B poses launches (2 B workgroups; <= 768 -> the latency build)."""
+    for name, d in RES.items():
+        if "lc_pose_unit_kernelILi%dE" % (1 if 2 * B <= 768 else 2) in name:
+            return d.get("vgpr_count")
+    return ""
 for sub, title in (("trace", "bench.py (pose unit, B=256 N=64)"), ("head_trace", "bench_head.py (keypoint head, 256x64x64x64)")):
     for f in find(f"{sub}/**/*kernel_stats.csv"):
         print(f"## kernel stats: {title}\n")
@@ -38,7 +73,7 @@ for sub, title in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("p
     for f in find(f"{sub}/**/*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
-            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[short(r["Kernel_Name"], r.get("Grid_Size"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(f"## {title} (mean per dispatch)\n")
         print("| kernel | counter | dispatches | mean | ")
         print("|---|---|---|---|")
@@ -56,7 +91,7 @@ for sub, key in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("head_pmc_fetc
         acc = defaultdict(list)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+                acc[short(r["Kernel_Name"], r.get("Grid_Size"))].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             if k.startswith("lc_"):
                 traffic.setdefault(k, {})[key + "_kb_raw"] = sum(v) / len(v)
@@ -70,7 +105,7 @@ for k, d in traffic.items():
 for f in find("pmc_sq/**/*counter_collection.csv"):
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
-        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[short(r["Kernel_Name"], r.get("Grid_Size"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         if k.startswith("lc_"):
             traffic.setdefault(k, {})["sq"] = {c: sum(v) / len(v) for c, v in d.items()}
@@ -114,7 +149,7 @@ if sweep or ev:
         act = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else float("nan")
         table[B] = {"avg_us": avg, "poses_per_s": pps, "valu_insts_per_pose": c.get("SQ_INSTS_VALU", float("nan")) / B, "simd_cycles_per_pose": cyc,
                     "valu_bound_poses_per_s": bound, "frac": pps / bound if bound == bound else None, "events_us": ev.get(B, {}).get("us_per_launch")}
-        print(f"| {B} | {sweep.get(B, {}).get('vgpr', '')} | {avg:.1f} | {min(ns) / 1e3 if ns else float('nan'):.1f} | {pps:.3g} | {ev.get(B, {}).get('us_per_launch', float('nan'))} | "
+        print(f"| {B} | {unit_vgprs(B)} | {avg:.1f} | {min(ns) / 1e3 if ns else float('nan'):.1f} | {pps:.3g} | {ev.get(B, {}).get('us_per_launch', float('nan'))} | "
               f"{c.get('SQ_INSTS_VALU', float('nan')) / B:.0f} | {cyc:.0f} | {bound:.3g} | {pps / bound if bound == bound else float('nan'):.3f} | {act:.2f} |")
     json.dump({"_meta": traffic["_meta"], "sweep": table}, open(os.path.join(out, "sweep_pose_unit.json"), "w"), indent=1)
     print()
