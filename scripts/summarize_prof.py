@@ -47,7 +47,7 @@ if RES:
     print("| kernel | arch VGPRs | AGPRs | SGPRs | LDS B/workgroup | scratch B/lane | waves/SIMD by registers |")
     print("|---|---|---|---|---|---|---|")
     for name, d in sorted(RES.items()):
-        if any(k in name for k in ("pose_unit", "pnp_lm", "cov_loss", "head_")):
+        if any(k in name for k in ("pose_unit", "pnp_lm", "cov_loss")):
             print(f"| `{name}` | {d['arch_vgpr_count']} | {d.get('agpr_count', 0)} | {d.get('sgpr_count', 0)} | {d.get('group_segment_fixed_size', 0)} | "
                   f"{d.get('private_segment_fixed_size', 0)} | {d['waves_per_simd_by_registers']} |")
     print()
