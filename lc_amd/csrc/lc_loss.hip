@@ -1,6 +1,6 @@
 // Stand-alone launches of the fused LC-loss forward+backward (device body: lc_loss_body.h).
 //   N <= 256                       one workgroup per sample, one correspondence per thread           lc_cov_loss_kernel<true, .>
-//   N  > 256, workspace given      TILED form: one 256-thread workgroup per 256 correspondences (wave = tile of 64), the
+//   N  > 256, workspace given      TILED form: one 256-thread workgroup per 4, 8 or 16 tiles of 64 correspondences, the
 //                                  workgroups of a sample meet through the workspace (ONE hand-off)  lc_cov_loss_tiled_kernel
 //   N  > 256 otherwise             one 256-thread workgroup per sample walking its tiles             lc_cov_loss_kernel<false, .>
 // All three add the per-sample reductions in the same (tile) order: a sample's results do not depend on the form chosen.
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void lc_cov_loss_kernel(const LossParams p) {
 // hand-off deadlock-free); the last workgroup of a sample to finish zeroes the sample's counters, the last sample the header, so
 // the workspace is left as it was found (all zero) for the next launch on the same stream.
 template <bool COV2D>
-__global__ __launch_bounds__(256) void lc_cov_loss_tiled_kernel(const LossParams p, int T, int S) {
+__global__ __launch_bounds__(256) void lc_cov_loss_tiled_kernel(const LossParams p, int T, int S, int TS) {
     __shared__ loss::LossSharedLoop sh;
     __shared__ unsigned ticket_sh;
     unsigned* head = static_cast<unsigned*>(p.workspace);
@@ -42,9 +42,10 @@ __global__ __launch_bounds__(256) void lc_cov_loss_tiled_kernel(const LossParams
     g.rows = reinterpret_cast<double*>(static_cast<char*>(p.workspace) + loss::grid_rows_offset_bytes(p.B)) + (size_t)b * T * loss::kGridRow;
     g.T = T;
     g.S = S;
+    g.TS = TS;
     g.slice = (int)(ticket % (unsigned)S);
     g.timed_out = 0;
-    loss::sample<true, COV2D, true, loss::LossSharedLoop>(p, b, sh, &g);
+    loss::sample<false, COV2D, true, loss::LossSharedLoop>(p, b, sh, &g);
     // retire: relaxed device-scope atomics only (no cache maintenance) -- a workgroup counts itself finished after the hand-off,
     // the counters it may then zero are touched by nobody else any more
     if (threadIdx.x == 0) {
@@ -64,19 +65,28 @@ __global__ __launch_bounds__(256) void lc_cov_loss_tiled_kernel(const LossParams
 
 }  // namespace
 
-// The tiled form pays while its workgroups find a compute unit each (measured, rocprofv3, B x N: 32 x 1024 20.5 -> 16.0 us,
-// 32 x 1849 35.6 -> 23.7, 16 x 4096 62.6 -> 32.1, 1 x 4096 61.4 -> 24.4; with two workgroups per unit the repeated quarter walk
-// and 6x6 section of every workgroup cost more than the spread buys: 128 x 1024 21.1 -> 25.7, 64 x 4096 64.0 -> 101;
+// The tiled form pays while its workgroups find a compute unit each and a sample is cut at least three ways (measured, rocprofv3,
+// B x N, one-workgroup -> tiled: 32 x 1024 20.5 -> 16.1 us, 32 x 1849 37.7 -> 24.5, 64 x 2048 38.3 -> 26.8, 16 x 4096 66.8 -> 32.4,
+// 64 x 4096 68.6 -> 39.9, 1 x 4096 65.9 -> 24.2; two slices only: 128 x 1024 21.6 -> 23.1; with two workgroups per unit the repeated
+// quarter walk and 6x6 section of every workgroup cost more than the spread buys: 64 x 4096 at four tiles per workgroup 101 us;
 // profiles/r03/tiled_loss.txt)
 #ifndef LC_TILED_MAX_GROUPS
 #define LC_TILED_MAX_GROUPS 256
 #endif
 
+// tiles per workgroup of the tiled form: the smallest of 4, 8, 16 that keeps the grid within LC_TILED_MAX_GROUPS; 0: loop form
+static int tiled_tiles_per_group(int B, int T) {
+    for (int ts = 4; ts <= 16; ts *= 2) {
+        const long long groups = (long long)B * ((T + ts - 1) / ts);
+        if ((T + ts - 1) / ts >= 3 && groups <= LC_TILED_MAX_GROUPS) return ts;
+    }
+    return 0;
+}
+
 size_t cov_loss_workspace_bytes(int B, int N) {
     if (B <= 0 || N <= 256) return 0;
     const int T = (N + loss::kTile - 1) / loss::kTile;
-    if ((long long)B * ((T + 3) / 4) > LC_TILED_MAX_GROUPS) return 0;
-    return loss::grid_workspace_bytes(B, T);
+    return tiled_tiles_per_group(B, T) ? loss::grid_workspace_bytes(B, T) : 0;
 }
 
 int launch_cov_loss(const LossParams& p, hipStream_t stream) {
@@ -86,9 +96,9 @@ int launch_cov_loss(const LossParams& p, hipStream_t stream) {
     const size_t need = cov_loss_workspace_bytes(p.B, p.N);
     if (!reg && p.workspace && need) {
         if (p.workspace_bytes < need) return 3;
-        const int T = (p.N + loss::kTile - 1) / loss::kTile, S = (T + 3) / 4;
-        if (p.cov_2d) hipLaunchKernelGGL(lc_cov_loss_tiled_kernel<true>, dim3(p.B * S), dim3(256), 0, stream, p, T, S);
-        else hipLaunchKernelGGL(lc_cov_loss_tiled_kernel<false>, dim3(p.B * S), dim3(256), 0, stream, p, T, S);
+        const int T = (p.N + loss::kTile - 1) / loss::kTile, TS = tiled_tiles_per_group(p.B, T), S = (T + TS - 1) / TS;
+        if (p.cov_2d) hipLaunchKernelGGL(lc_cov_loss_tiled_kernel<true>, dim3(p.B * S), dim3(256), 0, stream, p, T, S, TS);
+        else hipLaunchKernelGGL(lc_cov_loss_tiled_kernel<false>, dim3(p.B * S), dim3(256), 0, stream, p, T, S, TS);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     const int threads = reg ? ((p.N + 63) / 64) * 64 : 256;

@@ -170,7 +170,7 @@ __device__ __forceinline__ void block_allreduce_small(double (&v)[K], double (*s
 // wavefront reduces a tile with the cross-lane tree (wave_reduce_scatter16; lanes beyond N contribute exact zeros) and the tile
 // partials are added sequentially in tile order.  The two small sums of passes 1-2: see the quarters at pass 1.
 //   REG  (N <= 256): wave w of the workgroup is tile w, partials meet in LDS;
-//   GRID (tiled form, N > 256): a 256-thread workgroup per FOUR tiles, wave = tile; the pass-3 partials of a sample meet in a
+//   GRID (tiled form, N > 256): a 256-thread workgroup per 4, 8 or 16 tiles; the pass-3 partials of a sample meet in a
 //        global workspace, ONE arrive-and-wait hand-off on a per-sample counter (below);
 //   loop (!REG, one 256-thread workgroup per sample, for batches that fill the chip anyway): wave q walks quarter q of the tiles,
 //        partials in LDS (up to kLoopTiles tiles; beyond that the per-thread accumulation of round 2 is kept).
@@ -192,7 +192,7 @@ struct GridCtx {
     unsigned* head;   // workspace header
     unsigned* ctr;    // this sample's two counters
     double* rows;     // this sample's (T, kGridRow) partials
-    int T, S, slice;  // tiles of the sample; workgroups sharing it (four tiles each); this workgroup's index among them
+    int T, S, TS, slice;  // tiles of the sample; workgroups sharing it; tiles per workgroup (4, 8 or 16); this workgroup's index among them
     int timed_out;
 };
 
@@ -309,71 +309,102 @@ __device__ __forceinline__ Pt to_pt(const RawPt& r) {
     return o;
 }
 
-// REG, !GRID (N <= 256): the workgroup has one thread per correspondence; raw inputs and clamped error stay in registers.
-// !REG (loop form, N > 256): one 256-thread workgroup per sample; wave q WALKS quarter q of the sample's tiles in every pass.
-// REG, GRID (tiled form, N > 256): a 256-thread workgroup owns FOUR consecutive tiles of a sample (wave w: tile 4 slice + w, its
-//      correspondence in registers like REG); the two small sums come from the same quarter walk over the whole sample as in
-//      the loop form (every workgroup of the sample repeats it: two cheap passes over <= 115 KB that sit in L2, instead of
-//      two more hand-offs), the 48 sums of pass 3 meet the sibling workgroups' in the workspace (ONE hand-off).
-// The walk loads up to kRound tiles per wave at a time into registers, all loads in flight together; a quarter of at most
-// kRound tiles (N <= 1024) is loaded ONCE and serves all passes.
+// REG (N <= 256): the workgroup has one thread per correspondence; raw inputs and clamped error stay in registers.
+// !REG (N > 256), 256 threads, every pass is a WALK over tiles, four tiles per round, all loads of a round in flight together:
+//   the two small sums walk the STATS range of the wave = quarter `wave` of ALL tiles of the sample (the canonical order above);
+//   pass 3 and the backward pass walk the wave's OWN range:
+//     loop form  (one workgroup per sample): own range = stats range;
+//     tiled form (GRID: a sample shared by S workgroups, each owning TS = 4, 8 or 16 consecutive tiles): own range = quarter `wave`
+//                of the workgroup's slice; every workgroup of the sample repeats the stats walk over the whole sample (two cheap
+//                passes over <= 115 KB that sit in L2, instead of two more hand-offs); the 48 sums of pass 3 meet the sibling
+//                workgroups' in the workspace (ONE hand-off).
+//   A range of at most four tiles per wave is loaded ONCE (raw floats + clamped errors in registers) and serves all passes.
 // COV2D: covariance of the projected bbox corners (cov_mixed.py:125-127) instead of the 3D ones (every reference call site).
-// SH: LossShared (REG) or LossSharedLoop (loop form, tiled form)
+// SH: LossShared (REG) or LossSharedLoop (!REG)
+template <bool C, class A, class B>
+__device__ __forceinline__ auto& pick_ref(A& a, B& b) {
+    if constexpr (C) return a;
+    else return b;
+}
+
 template <bool REG, bool COV2D = false, bool GRID = false, typename SH = LossShared>
 __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh, GridCtx* gc = nullptr) {
-    static_assert(!GRID || REG, "the tiled form keeps its tiles' points in registers");
-    constexpr bool WALK = GRID || !REG;
+    static_assert(!GRID || !REG, "the tiled form is a walk form");
+    constexpr bool WALK = !REG;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const int N = p.N;
     const size_t base = (size_t)b * N;
     const int T = (N + kTile - 1) / kTile;
-    const int my_tile = GRID ? gc->slice * 4 + wave : wave;        // REG / GRID: the tile this wave owns
-    const int my_pt = GRID ? my_tile * kTile + lane : tid;          // ... and the correspondence this thread owns
+    const int my_pt = tid;  // REG: the correspondence this thread owns
     // loop form: canonical tile order while the partials fit the LDS rows; beyond that (N > 4096) per-thread accumulation
-    [[maybe_unused]] const bool tiles = !REG && T <= kLoopTiles;
+    [[maybe_unused]] const bool tiles = !REG && (GRID || T <= kLoopTiles);
     [[maybe_unused]] const bool stamp_ok = !GRID || gc->slice == 0;  // diagnostic build: one workgroup per sample writes the stamps
 
     LC_STAMP(0);
-    // the walk: this wave's quarter of the sample's tiles, kRound tiles per round
     constexpr int kRound = 4;
-    [[maybe_unused]] RawPt raw[kRound];
-    [[maybe_unused]] const int tq0 = (T * wave) >> 2, tq1 = (T * (wave + 1)) >> 2;  // WALK forms run four waves
-    [[maybe_unused]] const int rounds = (tq1 - tq0 + kRound - 1) / kRound;
-    [[maybe_unused]] const bool cached = T <= 4 * kRound;  // every quarter fits one round: loaded once, kept for all passes
-    [[maybe_unused]] double ce[kRound][2];  // clamped errors of the tiles in registers (valid while `cached`)
-    // branch-free on purpose: indices are clamped into the quarter / the sample, a lane without a correspondence carries a copy
+    // stats range (sq0, sq1) and own range (h0, h1) of this wave; WALK forms run four waves
+    [[maybe_unused]] const int sq0 = (T * wave) >> 2, sq1 = (T * (wave + 1)) >> 2;
+    [[maybe_unused]] int h0 = sq0, h1 = sq1;
+    if constexpr (GRID) {
+        const int s0 = gc->slice * gc->TS, len = min(gc->TS, T - s0);
+        h0 = s0 + ((len * wave) >> 2);
+        h1 = s0 + ((len * (wave + 1)) >> 2);
+    }
+    [[maybe_unused]] const bool cachedS = T <= 4 * kRound;               // every stats quarter fits one round
+    [[maybe_unused]] const bool cachedH = GRID ? true : cachedS;         // (the launcher keeps TS <= 16)
+    [[maybe_unused]] RawPt raw[kRound];        // stats range, while cachedS
+    [[maybe_unused]] double ce[kRound][2];     // ... and its clamped errors
+    [[maybe_unused]] RawPt raw_own[GRID ? kRound : 1];
+    [[maybe_unused]] double ce_own[GRID ? kRound : 1][2];
+    auto& rawH = pick_ref<GRID>(raw_own, raw);  // own range: its own registers in the tiled form, the stats range's in the loop form
+    auto& ceH = pick_ref<GRID>(ce_own, ce);
+    // branch-free on purpose: indices are clamped into the range / the sample, a lane without a correspondence carries a copy
     // with vld = 0 (exact zeros in the small sums), so the four tiles of a round are one basic block the scheduler can interleave
-    [[maybe_unused]] auto load_round = [&](int r) {
+    [[maybe_unused]] auto load_round = [&](auto& rw, int t0, int t1, int r) {
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {
-            const int t = tq0 + r * kRound + k, n = t * kTile + lane;
-            const bool live = t < tq1 && n < N;
-            raw[k] = load_raw_pt(p, base, live ? n : N - 1);
-            if (!live) raw[k].vld = 0.f;
+            const int t = t0 + r * kRound + k, n = t * kTile + lane;
+            const bool live = t < t1 && n < N;
+            rw[k] = load_raw_pt(p, base, live ? n : N - 1);
+            if (!live) rw[k].vld = 0.f;
         }
     };
-    // heavy(k, t, n, live): once per tile of the quarter, in tile order; live = this lane has a correspondence in the tile
-    [[maybe_unused]] auto walk = [&](auto&& heavy) {
-        for (int r = 0; r < rounds; ++r) {
-            if (!cached) load_round(r);
-#pragma unroll
+    // heavy(raw, ce, t, n, live): once per tile of the range, in tile order; live = this lane has a correspondence in the tile.
+    // The body is instantiated ONCE: the loop over the round's tiles is not unrolled, the cached tiles ROTATE through slot 0
+    // instead (a full turn after kRound steps: 48 register moves per tile against a body of thousands of cycles) -- four copies of
+    // the pass-3 / backward bodies next to two caches do not fit the register file.
+    [[maybe_unused]] auto walk = [&](auto& rw, auto& cw, int t0, int t1, bool cch, auto&& heavy) {
+        if (t1 - t0 == 1) {  // the usual tiled shape (four tiles per workgroup): one tile per wave, nothing to rotate
+            if (!cch) load_round(rw, t0, t1, 0);
+            heavy(rw[0], cw[0], t0, t0 * kTile + lane, t0 * kTile + lane < N);
+            return;
+        }
+        for (int r = 0; r < (t1 - t0 + kRound - 1) / kRound; ++r) {
+            if (!cch) load_round(rw, t0, t1, r);
+#pragma nounroll
             for (int k = 0; k < kRound; ++k) {
-                const int t = tq0 + r * kRound + k, n = t * kTile + lane;
-                if (t < tq1) heavy(k, t, n, n < N);
+                const int t = t0 + r * kRound + k, n = t * kTile + lane;
+                if (t < t1) heavy(rw[0], cw[0], t, n, n < N);
+                const RawPt r0 = rw[0];
+                const double c0 = cw[0][0], c1 = cw[0][1];
+#pragma unroll
+                for (int j = 0; j + 1 < kRound; ++j) { rw[j] = rw[j + 1]; cw[j][0] = cw[j + 1][0]; cw[j][1] = cw[j + 1][1]; }
+                rw[kRound - 1] = r0; cw[kRound - 1][0] = c0; cw[kRound - 1][1] = c1;
             }
         }
     };
-    // light(k): the same for the two small sums, branch-free (tiles beyond the quarter are all-dead copies)
-    [[maybe_unused]] auto walk_light = [&](auto&& light) {
-        for (int r = 0; r < rounds; ++r) {
-            if (!cached) load_round(r);
+    // light(k): the same for the two small sums, branch-free (tiles beyond the range are all-dead copies)
+    [[maybe_unused]] auto walk_light = [&](auto& rw, int t0, int t1, bool cch, auto&& light) {
+        for (int r = 0; r < (t1 - t0 + kRound - 1) / kRound; ++r) {
+            if (!cch) load_round(rw, t0, t1, r);
 #pragma unroll
             for (int k = 0; k < kRound; ++k) light(k);
         }
     };
-    if constexpr (WALK) {
-        if (cached) load_round(0);  // first thing in the kernel: the pose set-up below runs in the loads' shadow
+    if constexpr (WALK) {  // first thing in the kernel: the pose set-up below runs in the loads' shadow
+        if constexpr (GRID) load_round(rawH, h0, h1, 0);
+        if (cachedS) load_round(raw, sq0, sq1, 0);
     }
 
     PoseConst pc;
@@ -405,7 +436,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
     double re[2];   // REG only: clamped error
     bool active = false;
     if constexpr (REG) {
-        active = my_pt < N;  // (a tile beyond T has my_pt >= N)
+        active = my_pt < N;
         if (active) rp = load_pt(p, base, my_pt);
     }
 
@@ -423,15 +454,18 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
     if constexpr (REG) {
         if (active) {
             clamped_error(rp, re);
-            if constexpr (!GRID) { s1[0] = fabs(re[0]) * rp.vld; s1[1] = fabs(re[1]) * rp.vld; s1[2] = rp.vld; }
+            s1[0] = fabs(re[0]) * rp.vld; s1[1] = fabs(re[1]) * rp.vld; s1[2] = rp.vld;
         }
-    }
-    if constexpr (WALK) {
-        walk_light([&](int k) {
+    } else {
+        walk_light(raw, sq0, sq1, cachedS, [&](int k) {
             const Pt pt = to_pt(raw[k]);
             clamped_error(pt, ce[k]);
             s1[0] += fabs(ce[k][0]) * pt.vld; s1[1] += fabs(ce[k][1]) * pt.vld; s1[2] += pt.vld;
         });
+        if constexpr (GRID) {  // the clamped errors of the own tiles, for pass 3 and the backward pass
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) clamped_error(to_pt(rawH[k]), ceH[k]);
+        }
     }
     block_allreduce_small<3>(s1, sh.small, lane, wave, nw);
     const double vcnt = p.valid ? s1[2] : (double)N;
@@ -441,16 +475,16 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
     LC_STAMP(2);
     // ---------------- pass 2: c, mean(s^2 c) (cov_mixed.py:32-36) ----------------
     double s2[2] = {0, 0};
-    // e of a walked tile: from the registers while the quarter is cached, else re-derived (in double: a float copy would lose bits)
-    [[maybe_unused]] auto tile_error = [&](int k, const Pt& pt, double e[2]) {
-        if (cached) { e[0] = ce[k][0]; e[1] = ce[k][1]; }
+    // e of a walked tile: from the registers while the range is cached, else re-derived (in double: a float copy would lose bits)
+    [[maybe_unused]] auto tile_error = [&](bool cch, const double (&c2)[2], const Pt& pt, double e[2]) {
+        if (cch) { e[0] = c2[0]; e[1] = c2[1]; }
         else clamped_error(pt, e);
     };
     if constexpr (WALK) {
-        walk_light([&](int k) {
+        walk_light(raw, sq0, sq1, cachedS, [&](int k) {
             const Pt pt = to_pt(raw[k]);
             double e[2];
-            tile_error(k, pt, e);
+            tile_error(cachedS, ce[k], pt, e);
 #pragma unroll
             for (int c = 0; c < 2; ++c) s2[c] += pt.s[c] * pt.s[c] * huber(fabs(e[c]), dlt_e[c]) * pt.vld;
         });
@@ -521,12 +555,12 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
             for (int i = 0; i < 48; ++i) acc[i] = 0;
         }
     } else {
-        if (tiles) {  // a tile's 48 sums by the cross-lane tree, one LDS row per tile
-            walk([&](int k, int t, int, bool live) {
+        if (tiles) {  // a tile's 48 sums by the cross-lane tree, one row per tile: LDS (loop form) or the sample's workspace rows (tiled form)
+            walk(rawH, ceH, h0, h1, cachedH, [&](const RawPt& rw, const double (&cw)[2], int t, int, bool live) {
                 if (live) {
-                    const Pt pt = to_pt(raw[k]);
+                    const Pt pt = to_pt(rw);
                     double e[2];
-                    tile_error(k, pt, e);
+                    tile_error(cachedH, cw, pt, e);
                     accumulate(pt, e, std::true_type{});
                 } else {
 #pragma unroll
@@ -535,8 +569,14 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
                 wave_reduce_scatter16<48>(acc, lane);
                 if ((lane & 3) == 0) {
                     const int bs = scatter16_base(lane, 3);
+                    if constexpr (GRID) {
+                        double* row = gc->rows + (size_t)t * kGridRow + bs;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) sh.p3[t][bs + i] = acc[i];
+                        for (int i = 0; i < 3; ++i) grid_store(row + i, acc[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) sh.p3[t][bs + i] = acc[i];
+                    }
                 }
             });
         } else {
@@ -551,14 +591,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
         }
     }
     LC_STAMP(4);
-    if constexpr (GRID) {  // tile partials -> the sample's workspace rows; totals in tile order once every sibling workgroup has arrived
-        wave_reduce_scatter16<48>(acc, lane);
-        if (my_tile < T && (lane & 3) == 0) {
-            const int bs = scatter16_base(lane, 3);
-            double* row = gc->rows + (size_t)my_tile * kGridRow + bs;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) grid_store(row + i, acc[i]);
-        }
+    if constexpr (GRID) {  // totals in tile order once every sibling workgroup's rows have arrived
         grid_arrive_wait(*gc, tid);
         if (T <= kLoopTiles) {
             // all T rows in ONE round trip: every thread fetches a few values around the caches into LDS, 48 threads add the columns in tile order
@@ -873,11 +906,11 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
     if constexpr (REG) {
         if (active) backward_point(rp, re, my_pt);
     } else {
-        walk([&](int k, int, int n, bool live) {
+        walk(rawH, ceH, h0, h1, cachedH, [&](const RawPt& rw, const double (&cw)[2], int, int n, bool live) {
             if (live) {
-                const Pt pt = to_pt(raw[k]);
+                const Pt pt = to_pt(rw);
                 double e[2];
-                tile_error(k, pt, e);
+                tile_error(cachedH, cw, pt, e);
                 backward_point(pt, e, n);
             }
         });

@@ -156,7 +156,8 @@ def test_loss_full_size_properties():
     assert torch.equal(ls, loss[sl]) and torch.equal(gus, gu[sl]) and torch.equal(gss, gs[sl]) and torch.equal(gxs, gx[sl])
 
 
-TILED_SHAPES = [(2, 1024, 0), (3, 300, 1), (32, 1024, 2), (5, 1849, 3), (1, 4096, 4), (40, 257, 5)]
+TILED_SHAPES = [(2, 1024, 0), (3, 300, 1), (32, 1024, 2), (5, 1849, 3), (1, 4096, 4), (40, 257, 5),
+                (64, 4096, 6), (60, 2048, 7), (70, 1500, 8), (3, 5000, 9)]  # 4, 8 and 16 tiles per workgroup; ragged slices; T > 64
 
 
 @pytest.mark.parametrize("B,N,seed", TILED_SHAPES)
