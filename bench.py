@@ -259,7 +259,10 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    coll = init_collectives(world, dev, share_gpu) if world > 1 else None
+    # LC_BENCH_FORCE_COLLECTIVES=1 (test only): bring the timing collectives up even for one rank, so that the RCCL code path of an
+    # N-GPU run (group creation bound to the device, probe all-reduce, barrier on the RCCL group) is exercised on a one-GPU box
+    force_coll = os.environ.get("LC_BENCH_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ
+    coll = init_collectives(world, dev, share_gpu) if (world > 1 or force_coll) else None
     dist = coll["dist"] if coll else None
 
     def barrier():

@@ -27,6 +27,9 @@ def tiled_workspace(device, B: int, N: int):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, B, N)
     ws = _TILED_WS.get(key)
     if ws is None:
+        if len(_TILED_WS) >= 64 and not torch.cuda.is_current_stream_capturing():
+            _TILED_WS.clear()  # a long-running process that walks through many shapes / streams: start over (entries are <= 4 MB each;
+            # tensors a captured graph uses stay alive in the graph's own pool)
         ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         _TILED_WS[key] = ws
     return ws

@@ -104,3 +104,20 @@ def test_gpus_1_through_the_launcher_equals_the_plain_run():
     da, db = _last_json(a.stdout), _last_json(b.stdout)
     assert da["n_gpus"] == db["n_gpus"] == 1 and da["config"] == db["config"] and set(da) == set(db)
     assert 0.8 < da["value"] / db["value"] < 1.25
+
+
+def test_rccl_code_path_with_one_rank():
+    """One rank under a launcher with the timing collectives forced on: group creation bound to the device, the probe all-reduce and
+    the barrier run over RCCL (backend "nccl") exactly as every rank of an 8-GPU run executes them."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LC_BENCH_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3", "--regions", "5",
+                          "--no-cpu-baseline", "--no-head", "--workload", "metric", "--steady-batch", "0"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["rccl_version"] and "rccl_error" not in d, (d.get("rccl_error"), out.stderr[-1500:])
+    assert d["config"]["launch"] == "graph_region"  # the capture coexists with the RCCL group's watchdog thread
