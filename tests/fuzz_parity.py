@@ -43,7 +43,7 @@ def perturbed_start(b, rot, trans, g):
 
 
 def fuzz_pnp(case, rng, g):
-    N = int(rng.choice([3, 4, 6, 12, 33, 64, 65, 100, 300]))
+    N = int(rng.choice([3, 4, 6, 12, 33, 64, 65, 100, 300, 1024]))
     B = 2048 if N <= 64 else 256
     noise, outl = float(rng.choice([0.0, 0.5, 2.0])), float(rng.choice([0.0, 0.05, 0.3]))
     rot, trans = [(0.02, 0.01), (0.08, 0.03), (0.3, 0.1)][int(rng.integers(3))]
@@ -75,7 +75,7 @@ def fuzz_pnp(case, rng, g):
 
 
 def fuzz_loss(case, rng, g):
-    N = int(rng.choice([3, 5, 16, 64, 65, 130, 256, 257, 700]))
+    N = int(rng.choice([3, 5, 16, 64, 65, 130, 256, 257, 700, 1024, 1849]))  # > 256: the tiled form (small B) and the loop form
     B = int(rng.integers(1, 48))
     noise, outl = float(rng.choice([0.2, 1.0, 4.0])), float(rng.choice([0.0, 0.05, 0.3]))
     cov2d = bool(rng.integers(4) == 0)
