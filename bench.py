@@ -525,7 +525,7 @@ def main():
                 "launch": "graph_region (20 steps per replay)" if g is not None else "stream order",
                 "step_us_events": {"graph": None if t_step is None else t_step * 1e3, "stream_order": t_step_so * 1e3},
                 "lm_iterations": {"mean": it_mean, "max": it_max},
-                "lc_cov_loss_kernel": dict(roof(t_loss, by_l, fl_l), form="tiled: one wavefront-sized workgroup per 64 correspondences" if u.ws is not None else "one workgroup per sample"),
+                "lc_cov_loss_kernel": dict(roof(t_loss, by_l, fl_l), form="tiled: the sample's 64-point tiles dealt to 256-thread workgroups (4, 8 or 16 tiles each), one hand-off" if u.ws is not None else "one workgroup per sample"),
                 "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p),
                 "bound": "neither HBM nor MFMA: VALU issue / per-workgroup latency (SURVEY.md 8d); both fractions are quoted"}
 

@@ -121,12 +121,13 @@ int lc_cov_loss2_fwd_bwd_f32(const float *K, const float *pose, const float *pts
                              float *d_pts2d, float *d_inv_std, float *d_pts3d, float *aux, void *stream);
 
 /* (2b'') The same with a caller workspace, which lets the dense shapes (N > 256: configs/glmo.yaml N = 1024, zlmo N = 1849;
- * losses.py:336-386) spread ONE sample over many compute units: every 64 correspondences become their own wavefront-sized
- * workgroup and the tiles of a sample exchange their partial sums through the workspace.  Results are bit-identical to the
- * workspace-less call (all forms add the per-sample sums in the same tile order).
+ * losses.py:336-386) spread ONE sample over several compute units: the sample's 64-correspondence tiles are dealt to 256-thread
+ * workgroups (4, 8 or 16 tiles each) that exchange the partial sums of the normal equations once through the workspace.
+ * Results are bit-identical to the workspace-less call (all forms add the per-sample sums in the same tile order).
  *   lc_cov_loss_workspace_bytes(B, N): bytes needed, 0 when the shape would not use it (N <= 256, or a batch that fills the
- *   chip anyway).  The caller zero-fills the workspace ONCE; every launch leaves it zeroed.  One workspace serves the launches
- *   of ONE stream (or of graphs replayed one at a time); concurrent launches need one each.  workspace == NULL is (2b'). */
+ *   chip anyway).  The caller zero-fills the workspace ONCE per (B, N); every launch leaves it zeroed (re-zero it after a launch
+ *   that returned NaN losses: its hand-off timed out).  One workspace serves the launches of ONE stream (or of graphs replayed
+ *   one at a time); concurrent launches need one each.  workspace == NULL is (2b'). */
 size_t lc_cov_loss_workspace_bytes(int B, int N);
 int lc_cov_loss3_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,
                              const float *inv_std, const float *valid, const float *bbox_3d, const float *grad_out,

@@ -162,7 +162,7 @@ TILED_SHAPES = [(2, 1024, 0), (3, 300, 1), (32, 1024, 2), (5, 1849, 3), (1, 4096
 
 @pytest.mark.parametrize("B,N,seed", TILED_SHAPES)
 def test_tiled_form_is_bit_identical_to_the_one_workgroup_form(B, N, seed):
-    """Dense shapes (N > 256): one wavefront-sized workgroup per 64 correspondences, the tiles of a sample meeting through the
+    """Dense shapes (N > 256): the 64-point tiles of a sample dealt to several 256-thread workgroups that meet once through the
     workspace, against one 256-thread workgroup per sample.  Both add the per-sample sums in tile order, so every output --
     loss, the three gradients, H^-1 -- is bit-identical; the workspace is left zeroed; a second launch over the same workspace
     and a launch with the sample inside another batch give the same bits again."""
