@@ -156,7 +156,7 @@ def test_loss_full_size_properties():
     assert torch.equal(ls, loss[sl]) and torch.equal(gus, gu[sl]) and torch.equal(gss, gs[sl]) and torch.equal(gxs, gx[sl])
 
 
-TILED_SHAPES = [(2, 1024, 0), (3, 300, 1), (32, 1024, 2), (5, 1849, 3), (1, 4096, 4), (40, 257, 5),
+TILED_SHAPES = [(2, 1024, 0), (3, 700, 1), (32, 1024, 2), (5, 1849, 3), (1, 4096, 4), (40, 600, 5),
                 (64, 4096, 6), (60, 2048, 7), (70, 1500, 8), (3, 5000, 9)]  # 4, 8 and 16 tiles per workgroup; ragged slices; T > 64
 
 
@@ -175,7 +175,7 @@ def test_tiled_form_is_bit_identical_to_the_one_workgroup_form(B, N, seed):
     valid = (torch.rand(B, N, generator=g) > 0.2).float().to(dev) if seed % 2 else None
     go = (torch.rand(B, generator=g) + 0.5).to(dev)
     args = (b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], valid, b["bbox_3d"])
-    assert _lib.load().lc_cov_loss_workspace_bytes(B, N) > 0
+    assert _lib.load().lc_cov_loss_workspace_bytes(B, N) > 0  # (a sample is cut at least three ways: N >= 3 slices x 4 tiles - 3 tiles)
     one = cm.loss_cov_mixed_fused(*args, grad_out=go, want_aux=True, tiled=False)
     til = cm.loss_cov_mixed_fused(*args, grad_out=go, want_aux=True, tiled=True)
     for a, c in zip(one, til):
