@@ -59,8 +59,10 @@ def algorithmic_flops(N: int, lm_evaluations: float):
 def static_counters(kernel: str, B: int, N: int):
     """Per-launch PMC counters of `kernel` on the default workload, from the newest committed rocprofv3 --pmc passes
     (profiles/<round>/pmc_traffic.json, written by scripts/profile_round.sh; PMC cannot be collected from inside a run).
-    Returns (entry, source) -- source names the file, the round and the git SHA the passes were taken at -- or (None, None)."""
-    if (B, N) != (256, 64):
+    Returns (entry, source) -- source names the file, the round and the git SHA the passes were taken at -- or (None, None).
+    The passes are taken on the bench's own shapes: the metric's (256, 64) and the dense blocks' (32, 1024) / (32, 1849), whose
+    kernels carry the shape in their key (workgroup count of the tiled loss, points-per-thread template argument of the wide solve)."""
+    if (B, N) not in ((256, 64), (32, 1024), (32, 1849)):
         return None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
@@ -516,17 +518,31 @@ def main():
         by_l, by_p = algorithmic_bytes(Nd, True)
         fl_l, fl_p = algorithmic_flops(Nd, it_mean + 1.0)
 
-        def roof(t_ms, by, fl):
+        def roof(t_ms, by, fl, counter_key=None):
             gbs, tf = by * Bd / (t_ms * 1e-3) / 1e9, fl * Bd / (t_ms * 1e-3) / 1e12
-            return {"kernel_us": t_ms * 1e3, "algorithmic_bytes_per_sample": by, "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-                    "algorithmic_kflop_per_sample": fl / 1e3, "tflops": tf, "fp64_vector_frac": tf / FP64_VECTOR_PEAK_TFLOPS}
+            out = {"kernel_us": t_ms * 1e3, "algorithmic_bytes_per_sample": by, "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                   "algorithmic_kflop_per_sample": fl / 1e3, "tflops": tf, "fp64_vector_frac": tf / FP64_VECTOR_PEAK_TFLOPS}
+            ctr, src = static_counters(counter_key, Bd, Nd) if counter_key else (None, None)
+            if ctr is not None:  # committed counter pass of this very shape: HBM bytes per launch and the issue / wait shares
+                out["traffic"] = ctr.get("bytes_per_launch")
+                out["algorithmic_bytes_per_launch"] = by * Bd
+                sq = ctr.get("sq", {})
+                if sq.get("SQ_WAVE_CYCLES"):
+                    out["valu_active_share_of_wave_cycles"] = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
+                    out["waiting_share_of_wave_cycles"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+                out["counters_from"] = src
+            return out
+        T_ = (Nd + 63) // 64
+        groups = next((Bd * ((T_ + ts - 1) // ts) for ts in (4, 8, 16) if (T_ + ts - 1) // ts >= 3 and Bd * ((T_ + ts - 1) // ts) <= 256), None)
+        loss_key = f"lc_cov_loss_tiled_kernel[{groups} workgroups]" if (u.ws is not None and groups) else None
+        pnp_key = f"lc_pnp_lm_wide_kernel<false,false,{4 if Nd <= 1024 else 8}>" if 256 < Nd <= 2048 else None
         return {"workload": f"{name}: B={Bd} samples x N={Nd} correspondences per GPU (fp32 I/O, fp64 inside)",
                 "value": Bd / wall, "unit": "poses/s", "ms_per_step": wall * 1e3,
                 "launch": "graph_region (20 steps per replay)" if g is not None else "stream order",
                 "step_us_events": {"graph": None if t_step is None else t_step * 1e3, "stream_order": t_step_so * 1e3},
                 "lm_iterations": {"mean": it_mean, "max": it_max},
-                "lc_cov_loss_kernel": dict(roof(t_loss, by_l, fl_l), form="tiled: the sample's 64-point tiles dealt to 256-thread workgroups (4, 8 or 16 tiles each), one hand-off" if u.ws is not None else "one workgroup per sample"),
-                "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p),
+                "lc_cov_loss_kernel": dict(roof(t_loss, by_l, fl_l, loss_key), form="tiled: the sample's 64-point tiles dealt to 256-thread workgroups (4, 8 or 16 tiles each), one hand-off" if u.ws is not None else "one workgroup per sample"),
+                "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p, pnp_key),
                 "bound": "neither HBM nor MFMA: VALU issue / per-workgroup latency (SURVEY.md 8d); both fractions are quoted"}
 
     if rank == 0:
