@@ -157,7 +157,7 @@ def test_loss_full_size_properties():
 
 
 TILED_SHAPES = [(2, 1024, 0), (3, 700, 1), (32, 1024, 2), (5, 1849, 3), (1, 4096, 4), (40, 600, 5),
-                (64, 4096, 6), (60, 2048, 7), (70, 1500, 8), (3, 5000, 9)]  # 4, 8 and 16 tiles per workgroup; ragged slices; T > 64
+                (64, 4096, 6), (60, 2048, 7), (70, 1500, 8), (3, 5000, 9), (4, 1025, 10), (2, 1023, 11)]  # 4, 8 and 16 tiles per workgroup; ragged slices; T > 64; a last tile of one point (17 tiles: uneven quarters, two rounds)
 
 
 @pytest.mark.parametrize("B,N,seed", TILED_SHAPES)
