@@ -16,20 +16,22 @@ _TILED_WS = {}  # (device index, stream, B, N) -> zeroed workspace of the tiled 
 
 
 def tiled_workspace(device, B: int, N: int):
-    """The workspace that lets a dense sample (N > 256) spread over many compute units, or None when the shape does not use one.
-    One per (device, stream, shape): launches of one stream are ordered, so they can share it; every launch leaves it zeroed.
-    Allocated through torch's caching allocator, so a first use inside a hipGraph capture lands in the graph's own pool (with its
-    zero-fill as a graph node)."""
+    """The workspace that lets a dense sample (N > 256) spread over several compute units, or None when the shape does not use one.
+    Eager launches: one per (device, stream, shape), zeroed once -- launches of one stream are ordered, so they can share it, and every
+    launch leaves it zeroed.  Inside a hipGraph capture: a FRESH zeroed tensor per call, never cached -- it lives in the capturing
+    graph's own pool (a cached one would tie later graphs to the first graph's memory), and its zero-fill is a node of the graph, so
+    every replay starts from a clean workspace."""
     lib = _lib.load()
     nbytes = int(lib.lc_cov_loss_workspace_bytes(B, N))
     if nbytes == 0:
         return None
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, B, N)
     ws = _TILED_WS.get(key)
     if ws is None:
-        if len(_TILED_WS) >= 64 and not torch.cuda.is_current_stream_capturing():
-            _TILED_WS.clear()  # a long-running process that walks through many shapes / streams: start over (entries are <= 4 MB each;
-            # tensors a captured graph uses stay alive in the graph's own pool)
+        if len(_TILED_WS) >= 64:
+            _TILED_WS.clear()  # a long-running process that walks through many shapes / streams: start over (entries are <= 4 MB each)
         ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         _TILED_WS[key] = ws
     return ws
