@@ -20,11 +20,13 @@ __global__ __launch_bounds__(64, WPS) void lc_pnp_lm_kernel(const PnpParams p) {
 #ifndef LC_BIG_LOWREG
 #define LC_BIG_LOWREG 0
 #endif
+#if LC_BIG_LOWREG
 template <bool OPTS = false>
 __global__ __launch_bounds__(64, 3) void lc_pnp_lm_big_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLowregLdsDoubles];
     pnp::solve_pose_lowreg<OPTS>(p, blockIdx.x, threadIdx.x, bc);
 }
+#endif
 
 // four wavefronts per pose for N > 64 (dense heads, ragged inference batches)
 // PPT: correspondences per thread kept in registers (0: block-stride loop over memory, any N)
@@ -58,8 +60,11 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     const bool big = p.B > kLatencyGridMax;
     if (p.options || p.weight_mask || p.pose_mod > 0) {  // input filtering / weight forms folded into the load
         if (p.Nmax <= 64) {
-            if (big && LC_BIG_LOWREG) hipLaunchKernelGGL(lc_pnp_lm_big_kernel<true>, dim3(p.B), dim3(64), 0, stream, p);
-            else if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS, true>), dim3(p.B), dim3(64), 0, stream, p);
+#if LC_BIG_LOWREG
+            if (big) hipLaunchKernelGGL(lc_pnp_lm_big_kernel<true>, dim3(p.B), dim3(64), 0, stream, p);
+#else
+            if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS, true>), dim3(p.B), dim3(64), 0, stream, p);
+#endif
             else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1, true>), dim3(p.B), dim3(64), 0, stream, p);
         } else if (p.Nmax <= 256) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<true, true>), dim3(p.B), dim3(256), 0, stream, p);
@@ -73,8 +78,11 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     if (p.Nmax <= 64) {
-        if (big && LC_BIG_LOWREG) hipLaunchKernelGGL(lc_pnp_lm_big_kernel<false>, dim3(p.B), dim3(64), 0, stream, p);
-        else if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS>), dim3(p.B), dim3(64), 0, stream, p);
+#if LC_BIG_LOWREG
+        if (big) hipLaunchKernelGGL(lc_pnp_lm_big_kernel<false>, dim3(p.B), dim3(64), 0, stream, p);
+#else
+        if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS>), dim3(p.B), dim3(64), 0, stream, p);
+#endif
         else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);
     } else if (p.Nmax <= 256) {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);
