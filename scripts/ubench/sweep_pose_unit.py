@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lc_amd import _lib, synth  # noqa: E402
 
-BATCHES = (256, 512, 1024, 2048, 4096, 16384, 65536)
+BATCHES = tuple(int(x) for x in os.environ["LC_SWEEP_BATCHES"].split(",")) if os.environ.get("LC_SWEEP_BATCHES") else (256, 512, 1024, 2048, 4096, 16384, 65536)
 
 
 def main():
