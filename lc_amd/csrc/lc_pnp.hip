@@ -1,17 +1,11 @@
-// Stand-alone launch of the batched weighted-PnP solve (device body: lc_pnp_body.h).
-#include "lc_pnp_body.h"
+// Stand-alone launch of the batched weighted-PnP solve (device body: lc_pnp_body.h).  The one-wave kernels of small grids
+// (B <= kLatencyGridMax: the metric's B = 256) are instantiated in lc_pnp_latency.hip, a translation unit of its own that is compiled
+// with the max-ILP machine scheduler (lc_amd/build.py: PER_FILE_FLAGS).
+#include "lc_pnp_kernels.h"
 
 namespace lc {
 namespace {
 
-// WPS = waves per SIMD the register allocator must allow: 1 for small grids (latency: B <= ~1000 poses leave most SIMDs
-// idle anyway, spilling would only lengthen the lone wave), 2 for large grids (+43 % throughput at B = 16384).
-// OPTS: honours PnpParams::options / weight_mask (lc_pnp_lm2_f32); the plain instantiations are the ones the metric runs
-template <bool REG, int WPS, bool OPTS = false>
-__global__ __launch_bounds__(64, WPS) void lc_pnp_lm_kernel(const PnpParams p) {
-    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<1>];
-    pnp::solve_pose<REG, 1, false, OPTS>(p, blockIdx.x, threadIdx.x, bc);
-}
 
 // Large grids (B > kLatencyGridMax), EXPERIMENT kept for the record (profiles/r03/occupancy.txt): the low-register form of the
 // same solve, three waves per SIMD (lc_pnp_body.h: solve_pose_lowreg).  Bit-identical, 168 VGPRs, no scratch -- and 18 % SLOWER
@@ -65,7 +59,7 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
 #else
             if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS, true>), dim3(p.B), dim3(64), 0, stream, p);
 #endif
-            else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1, true>), dim3(p.B), dim3(64), 0, stream, p);
+            else return launch_pnp_lm_latency(p, stream);
         } else if (p.Nmax <= 256) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<true, true>), dim3(p.B), dim3(256), 0, stream, p);
         } else if (p.Nmax <= 1024) {
@@ -83,7 +77,7 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
 #else
         if (big) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, LC_BIG_WPS>), dim3(p.B), dim3(64), 0, stream, p);
 #endif
-        else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);
+        else return launch_pnp_lm_latency(p, stream);
     } else if (p.Nmax <= 256) {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);
     } else if (p.Nmax <= 1024) {
