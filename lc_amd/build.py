@@ -91,9 +91,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
 # Extra compiler flags of single translation units.  The latency builds of the one-wave pose kernels are scheduled for the shortest
 # dependent chains (a lone wave per SIMD has nobody to hide its latencies behind): -2.8 % on the metric's launch, same bits; every
 # other kernel is faster (or equal) with the default strategy (lc_amd/csrc/lc_pnp_latency.hip has the measurements).
+_LATENCY = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]  # (the register-pressure trackers: -1.3 % more on the fused launch)
 PER_FILE_FLAGS = {
-    "lc_pnp_latency.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-    "lc_fused_latency.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "lc_pnp_latency.hip": _LATENCY,
+    "lc_fused_latency.hip": _LATENCY,
 }
 COMMON_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
