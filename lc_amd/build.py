@@ -92,9 +92,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
 # dependent chains (a lone wave per SIMD has nobody to hide its latencies behind): -2.8 % on the metric's launch, same bits; every
 # other kernel is faster (or equal) with the default strategy (lc_amd/csrc/lc_pnp_latency.hip has the measurements).
 _LATENCY = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]  # (the register-pressure trackers: -1.3 % more on the fused launch)
+_MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 PER_FILE_FLAGS = {
     "lc_pnp_latency.hip": _LATENCY,
     "lc_fused_latency.hip": _LATENCY,
+    # few-waves-per-unit latency chains as well: head forward -2.6 % (fp32) / -2.8 % (bf16), wide solve -1 %, the test-time pipeline
+    # 81.1 -> 79.8 us (scripts/ubench: bench_head.py, pnp_wide_ab.py, graph_inference.py; outputs unchanged)
+    "lc_head.hip": _MAX_ILP,
+    "lc_pnp.hip": _MAX_ILP,
+    "lc_pnp_init.hip": _MAX_ILP,
+    "lc_select.hip": _MAX_ILP,
+    "lc_dense.hip": _MAX_ILP,
+    # NOT lc_loss.hip (the loss kernel alone: +4 %) and NOT lc_fused.hip (the large-grid pose unit: +1.4 %)
 }
 COMMON_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
