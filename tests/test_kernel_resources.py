@@ -51,6 +51,10 @@ def test_dense_kernels_do_not_spill(res):
             assert d["vgpr_count"] <= 512 and d.get("group_segment_fixed_size", 0) <= 64 * 1024, d["name"]
 
 
-def test_head_kernels_keep_full_occupancy(res):
-    for d in _find(res, "lc_head_fwd_wave64_kernel") + _find(res, "lc_head_bwd_kernel"):
+def test_head_kernels_keep_their_occupancy(res):
+    # HBM-bound streams: the backward needs many waves in flight; the one-wave-per-map forward holds 64 values per lane and is
+    # faster under the max-ILP schedule at three waves per SIMD than under the default one at four (bench_head.py: 42.9 -> 41.8 us)
+    for d in _find(res, "lc_head_bwd_kernel"):
         assert d.get("private_segment_fixed_size", 0) == 0 and d["waves_per_simd_by_registers"] >= 4, d["name"]
+    for d in _find(res, "lc_head_fwd_wave64_kernel"):
+        assert d.get("private_segment_fixed_size", 0) == 0 and d["waves_per_simd_by_registers"] >= 3, d["name"]
