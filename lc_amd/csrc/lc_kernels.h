@@ -5,12 +5,17 @@
 namespace lc {
 
 constexpr int kLossAuxStride = 40;
-// up to this many one-wave workgroups use the register-rich 'latency' build (1 wave/SIMD, no spills); beyond it the
-// 2-waves/SIMD build wins (measured: B = 768 -> 19 us, B = 1024 -> 57 us with the latency build vs 19.5 us with the other)
+// up to this many one-wave workgroups use the 'latency' build (one wave per SIMD: 296 registers under the max-ILP schedule, no
+// spills; lc_pnp_latency.hip / lc_fused_latency.hip); beyond it -- more workgroups than SIMDs -- the two-waves-per-SIMD build wins
+// (round 1: 2048 workgroups 57 us with the latency build vs 19.5 us with the other; round 3, threshold 768 -> 1024: 896 workgroups
+// 16.4 -> 15.8 us, 1024 workgroups 18.2 -> 18.0 us)
 #ifndef LC_BIG_WPS
 #define LC_BIG_WPS 2  // waves per SIMD the large-grid builds of the pose kernels are register-limited to (A/B: scripts/ubench/pnp_ab.py)
 #endif
-constexpr int kLatencyGridMax = 768;  // P, C, L, not_spd, Hinv[36]
+#ifndef LC_LATENCY_GRID_MAX
+#define LC_LATENCY_GRID_MAX 1024
+#endif
+constexpr int kLatencyGridMax = LC_LATENCY_GRID_MAX;
 
 struct LossParams {
     const float* K;         // (B,3,3)

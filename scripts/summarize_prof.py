@@ -54,9 +54,9 @@ if RES:
 
 
 def unit_vgprs(B):
-    """Allocation of the pose-unit instantiation a batch of B poses launches (2 B workgroups; <= 768 -> the latency build)."""
+    """Allocation of the pose-unit instantiation a batch of B poses launches (2 B workgroups; <= 1024 -> the latency build)."""
     for name, d in RES.items():
-        if "lc_pose_unit_kernelILi%dE" % (1 if 2 * B <= 768 else 2) in name:
+        if "lc_pose_unit_kernelILi%dE" % (1 if 2 * B <= 1024 else 2) in name:
             return d.get("vgpr_count")
     return ""
 for sub, title in (("trace", "bench.py (pose unit, B=256 N=64)"), ("head_trace", "bench_head.py (keypoint head, 256x64x64x64)")):

@@ -369,10 +369,11 @@ def test_fused_nan_filter_with_full_information_factor():
 
 @pytest.mark.parametrize("hard", [False, True], ids=["metric-like", "hard starts + ragged + outliers"])
 def test_large_grid_build_equals_the_latency_build(hard):
-    """Batches of more than 768 poses run the low-register form of the solve (three waves per SIMD, wave-uniform state parked in
-    LDS: lc_pnp_body.h solve_pose_lowreg), smaller ones the register-rich latency build.  Same arithmetic, expression for
-    expression: a pose solved inside a 3000-pose batch returns the same state, trust radius, flag and iteration count, bit for
-    bit, as the same pose solved in a batch of 500 -- through the plain entry point and the one with the input handling fused in."""
+    """Batches of more than 1024 poses run the two-waves-per-SIMD build of the solve (default instruction schedule; with
+    -DLC_BIG_LOWREG=1 the low-register form of lc_pnp_body.h), smaller ones the latency build (its own translation unit, max-ILP
+    schedule, one wave per SIMD).  Same arithmetic, expression for expression: a pose solved inside a 3000-pose batch returns the
+    same state, trust radius, flag and iteration count, bit for bit, as the same pose solved in a batch of 500 -- through the plain
+    entry point and the one with the input handling fused in."""
     from lc_amd.pnp import pnp_ceres
 
     dev = torch.device("cuda:0")

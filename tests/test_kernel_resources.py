@@ -28,13 +28,13 @@ def _find(res, *parts):
 
 
 def test_pose_kernels_do_not_spill_and_keep_their_occupancy(res):
-    # large-grid builds (more than 768 one-wave workgroups): two waves per SIMD, eight workgroups per CU
+    # large-grid builds (more than 1024 one-wave workgroups): two waves per SIMD, eight workgroups per CU
     for parts in (("lc_pose_unit_kernelILi2E",), ("lc_pnp_lm_kernelILb1ELi2E",), ("lc_cov_loss_kernelILb1ELb0E",)):
         for d in _find(res, *parts):
             assert d.get("private_segment_fixed_size", 0) == 0, (d["name"], "scratch")
             assert d["vgpr_count"] <= 256 and d["waves_per_simd_by_registers"] >= 2, d["name"]
             assert d.get("group_segment_fixed_size", 0) <= 16 * 1024, d["name"]  # eight one-wave workgroups per CU fit the 160 KB of LDS
-    # latency builds (at most 768 workgroups = 3 per CU): one wave per SIMD is all they need, AGPRs may serve the max-ILP schedule,
+    # latency builds (at most 1024 workgroups = one per SIMD): one wave per SIMD is all they need, AGPRs may serve the max-ILP schedule,
     # scratch may not
     for parts in (("lc_pose_unit_kernelILi1E",), ("lc_pnp_lm_kernelILb1ELi1E",)):
         for d in _find(res, *parts):
