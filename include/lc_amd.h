@@ -214,6 +214,26 @@ int lc_pnp_ransac_init3_f32(const float *K, const float *pts3d, const float *pts
                             float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
                             int *valid_counts, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Round 3: init3 plus (a) the inlier re-selection inside the selection step and (b) an optional two-launch split form.
+ *  - sel_w != NULL: second-stage selection by the inlier mask (test.py:129-133, the 'weighted-filtered' solve's input) written by
+ *    the workgroup that writes the mask: the inliers of every pose compacted, order kept, to the front of sel_pts2d (B,Nmax,2),
+ *    sel_w_out (B,Nmax,2) <- sel_w (B,Nmax,2, the weights travelling with the correspondences), sel_pts3d (B,Nmax,3),
+ *    sel_index (B,Nmax)|NULL <- sel_in_index (B,Nmax)|NULL (identity), sel_counts (B); fewer than sel_min_count inliers out of more
+ *    than sel_min_count points are padded as lc_dense_select_f32 pads (test.py:108-113, sel_seed).  Bit for bit what
+ *    lc_dense_select_f32(mode 0, mask = inlier_mask, in_counts = counts, in_index = sel_in_index, square = 0) returns in a launch
+ *    of its own (tests/test_gpu_pnp_init_oracle.py); works with either launch form.
+ *  - ticketed != 0 and workspace != NULL: TWO launches (hypotheses; scoring + selection).  One workgroup per (pose, chunk of 64
+ *    points) scores, counts itself in, and the workgroup that completes the pose's count selects; nobody waits.  The chunk partials
+ *    are still summed in chunk order: every output equals the three launches'.  Same workspace contract as init3 (the arrival
+ *    counters in it are zeroed by the hypotheses launch).  Measured slower than the three launches on MI355X: an
+ *    option for the record, not the default of the Python host side. */
+int lc_pnp_ransac_init4_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
+                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
+                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
+                            int *valid_counts, void *workspace, size_t workspace_bytes, int ticketed, const float *sel_w,
+                            const int *sel_in_index, int sel_min_count, unsigned sel_seed, float *sel_pts2d, float *sel_w_out,
+                            float *sel_pts3d, int *sel_index, int *sel_counts, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (2f) ZebraPose binary surface codes -- floatbits.py.  logits (B,C,H,W), C = n0+n1+n2 code bits
  *      (x,y,z axes back to back, floatbits.py:35-48); black_background as floatbits.py:7-11.

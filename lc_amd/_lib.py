@@ -42,6 +42,8 @@ _SIGNATURES = {
     "lc_pnp_ransac_init2_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6),
     "lc_pnp_ransac_init3_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +
                                 [ctypes.c_size_t, c_void_p]),
+    "lc_pnp_ransac_init4_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +
+                                [ctypes.c_size_t, c_int, c_void_p, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6),
     "lc_pnp_ransac_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "lc_bits_decode_gt_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_gt_bwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),

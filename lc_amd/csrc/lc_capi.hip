@@ -411,6 +411,28 @@ int lc_pnp_ransac_init3_f32(const float* K, const float* pts3d, const float* pts
     return rc ? fail(11, "ransac kernel launch failed") : 0;
 }
 
+int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
+                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
+                            size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
+                            float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, void* stream) {
+    if (B < 0 || Nmax < 0 || iterations <= 0 || sel_min_count < 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
+    if (sel_w && (!sel_pts2d || !sel_w_out || !sel_pts3d || !sel_counts)) return fail(1, "null selection output");
+    LC_REQUIRE_ALIGNED(8, workspace);
+    LC_REQUIRE_ALIGNED(8, sel_w);
+    LC_REQUIRE_ALIGNED(8, sel_w_out);
+    LC_REQUIRE_ALIGNED(8, sel_pts2d);
+    LC_REQUIRE_ALIGNED(8, pts2d);
+    lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
+                       (iterations + 63) / 64, reproj_err, seed, best_hyp, valid_counts, workspace, workspace_bytes,
+                       sel_w, sel_in_index, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, sel_min_count, sel_seed, (workspace && ticketed) ? 1 : 0};
+    const int rc = lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream));
+    if (rc == 3) return fail(1, "workspace smaller than lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)");
+    return rc ? fail(11, "ransac kernel launch failed") : 0;
+}
+
 static int bits_check(int B, int C, int H, int W, int n0, int n1, int n2, int top, int left, int sample) {
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (n0 < 1 || n1 < 1 || n2 < 1 || n0 > 24 || n1 > 24 || n2 > 24 || n0 + n1 + n2 != C) return fail(1, "bad bit counts");

@@ -168,6 +168,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Values handed from one workgroup to another INSIDE a launch (the workgroups may sit on different XCDs, whose L2s are not
+// coherent with each other): written through and read around the caches as agent-scope relaxed atomics (sc1 accesses).  The
+// writer orders them before its arrival count with xcd_stores_done() + a workgroup barrier; no cache-wide fence anywhere
+// (DESIGN.md 4.1 "Tiled form" has the measurements behind this choice).
+template <class T>
+__device__ __forceinline__ void xcd_store(T* q, T v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ T xcd_load(const T* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xcd_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int NW>
 __device__ __forceinline__ void block_sum_sync() {
     if constexpr (NW == 1 && !LC_WAVE_SYNC) wave_sync();

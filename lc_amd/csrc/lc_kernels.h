@@ -113,6 +113,19 @@ struct RansacParams {
     int* valid_counts;     // (B,) out or null: the pose's point count, 0 when invalid -- the `counts` of a refinement that must skip failed poses
     void* workspace;       // null: single launch (one workgroup per pose); else the split form (hypotheses / scoring / selection)
     size_t workspace_bytes;
+    // Optional second-stage selection (test.py:129-133, 'weighted-filtered'): the correspondences the winner calls inliers, compacted
+    // to the front of their rows by the workgroup that writes the inlier mask -- what lc_dense_select_f32 in 'mask' mode would make
+    // of that mask in a launch of its own.  sel_w == null: none.
+    const float* sel_w;        // (B,Nmax,2) the weights that travel with the correspondences
+    const int* sel_in_index;   // (B,Nmax) source index of each input entry, or null (identity)
+    float* sel_pts2d;          // (B,Nmax,2) out
+    float* sel_w_out;          // (B,Nmax,2) out
+    float* sel_pts3d;          // (B,Nmax,3) out
+    int* sel_index;            // (B,Nmax) out or null
+    int* sel_counts;           // (B,) out
+    int sel_min_count;
+    unsigned sel_seed;
+    int ticketed;              // split form only: scoring and selection in ONE launch, the last workgroup of a pose to finish selects
 };
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);  // 3: workspace too small
 size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds);

@@ -23,6 +23,7 @@
 
 #include "lc_common.h"
 #include "lc_kernels.h"
+#include "lc_select_rows.h"
 
 #ifdef LC_P3P_STAMPS
 namespace lc { namespace p3p_diag { __device__ unsigned long long g_p3p_stamp[7]; } }
@@ -123,9 +124,13 @@ struct P3P {
         return l[0] > 0 && l[1] > 0 && l[2] > 0;
     }
 
-    // up to 4 candidates; returns their count
-    template <class Emit>
-    __device__ __forceinline__ int solve(Emit&& emit) const {
+    // Up to four candidates -> L[c] (three depths), ok[c]; c = 2 * (plane of the pair) + (root of that plane's quadratic).
+    // ONE root of the cubic is decomposed: every real solution of the two quadrics lies on the plane pair of any root whose singular
+    // quadric splits into real planes (Persson & Nordberg's Lambda Twist takes one root for the same reason); a root without real
+    // planes is skipped by a cheap scan.  The four candidates are computed WITHOUT branches -- a lane's invalid ones carry a false
+    // flag and whatever arithmetic produced them -- so that their four dependency chains interleave in the one wavefront a SIMD
+    // runs here (the branching form evaluated them one after the other: 7.3 k of the kernel's 13.9 k cycles).
+    __device__ __forceinline__ void solve(double (&L)[4][3], bool (&ok)[4]) const {
         // D1 = a23 M12 - a12 M23,  D2 = a23 M13 - a13 M23
         const Sym3 D1{a23, -a23 * c12, 0.0, a23 - a12, a12 * c23, -a12};
         const Sym3 D2{a23, 0.0, -a23 * c13, -a13, a13 * c23, a23 - a13};
@@ -172,86 +177,62 @@ struct P3P {
             }
         }
         LC_P3P_STAMP(3);
-        // Roots are tried in order until one yields solutions.  A root whose singular quadric has no real plane pair is skipped by a
-        // CHEAP scan (18 flops), so that the lanes of a wavefront enter the expensive decomposition below together: with the skip
-        // inside one loop body the wavefront ran that body once per root position that ANY lane needed (up to three times).
-        int nsol = 0, r = 0;
-        while (nsol == 0) {
-            Sym3 D0;
-            double tr = 0, m2 = 0;
-            bool found = false;
-            for (; r < nroots && !found; ++r) {
-                const double g = r == 0 ? roots[0] : (r == 1 ? roots[1] : roots[2]);
-                D0 = Sym3{D1.a00 + g * D2.a00, D1.a01 + g * D2.a01, D1.a02 + g * D2.a02, D1.a11 + g * D2.a11, D1.a12 + g * D2.a12,
-                          D1.a22 + g * D2.a22};
-                // eigenvalues s1, s2 of the rank-2 matrix: s1 + s2 = trace, s1 s2 = sum of principal 2x2 minors
-                tr = D0.a00 + D0.a11 + D0.a22;
-                m2 = D0.a00 * D0.a11 - D0.a01 * D0.a01 + D0.a00 * D0.a22 - D0.a02 * D0.a02 + D0.a11 * D0.a22 - D0.a12 * D0.a12;
-                found = m2 < 0;  // needs eigenvalues of opposite sign to split into two real planes
-            }
-            if (!found) break;
-            const double sq = fast_sqrt(tr * tr - 4.0 * m2);
-            const double s1 = 0.5 * (tr + sq), s2 = 0.5 * (tr - sq);  // s1 > 0 > s2
-            const Sym3 S1{D0.a00 - s1, D0.a01, D0.a02, D0.a11 - s1, D0.a12, D0.a22 - s1};
-            const V3 e1 = null_vec(S1), e0 = null_vec(D0);
-            const V3 e2 = cross(e0, e1);
-            const double sgm = fast_sqrt(-s2 * fast_rcp(s1));
-            for (int sign = 0; sign < 2; ++sign) {
-                const V3 pl = e1 + ((sign ? -sgm : sgm) * e2);  // plane pl . lambda = 0
-                // eliminate the component with the largest |pl|: lambda_k = u lambda_i + v lambda_j
-                const double ax = fabs(pl.x), ay = fabs(pl.y), az = fabs(pl.z);
-                const int k = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-                const int i = k == 0 ? 1 : 0, j = k == 2 ? 1 : 2;
-                const double pk = k == 0 ? pl.x : (k == 1 ? pl.y : pl.z), pi = i == 0 ? pl.x : pl.y, pj = j == 1 ? pl.y : pl.z;
-                const double ipk = fast_rcp(pk);
-                const double u = -pi * ipk, v = -pj * ipk;
-                auto ent = [&](int r_, int c_) {
-                    const int lo = r_ < c_ ? r_ : c_, hi = r_ < c_ ? c_ : r_;
-                    return lo == 0 ? (hi == 0 ? D1.a00 : (hi == 1 ? D1.a01 : D1.a02)) : (lo == 1 ? (hi == 1 ? D1.a11 : D1.a12) : D1.a22);
-                };
-                const double Dii = ent(i, i), Djj = ent(j, j), Dkk = ent(k, k), Dij = ent(i, j), Dik = ent(i, k), Djk = ent(j, k);
-                const double A = Dii + Dkk * u * u + 2.0 * Dik * u;
-                const double C = Djj + Dkk * v * v + 2.0 * Djk * v;
-                const double Bq = 2.0 * (Dkk * u * v + Dij + Dik * v + Djk * u);
-                // A + Bq tau + C tau^2 = 0, tau = lambda_j / lambda_i
-                double taus[2];
-                int nt = 0;
-                if (fabs(C) > 1e-14 * (fabs(A) + fabs(Bq) + fabs(C))) {
-                    const double disc = Bq * Bq - 4.0 * A * C;
-                    if (disc >= 0) {
-                        const double s = fast_sqrt(disc), qq = -0.5 * (Bq + (Bq >= 0 ? s : -s));
-                        taus[nt++] = qq * fast_rcp(C);
-                        if (qq != 0) taus[nt++] = A * fast_rcp(qq);
-                    }
-                } else if (fabs(Bq) > 0) {
-                    taus[nt++] = -A * fast_rcp(Bq);
-                }
-                const double cij = (i == 0 && j == 1) ? c12 : ((i == 0 && j == 2) ? c13 : c23);
-                const double aij = (i == 0 && j == 1) ? a12 : ((i == 0 && j == 2) ? a13 : a23);
-                for (int tt = 0; tt < nt && nsol < 4; ++tt) {
-                    const double tau = taus[tt];
-                    if (!(tau > 0)) continue;
-                    const double den = 1.0 + tau * tau - 2.0 * cij * tau;
-                    if (!(den > 0)) continue;
-                    const double li = fast_sqrt(aij * fast_rcp(den)), lj = tau * li, lk = u * li + v * lj;
-                    if (!(lk > 0)) continue;
-                    double l[3];
-                    l[i] = li; l[j] = lj; l[k] = lk;
-                    emit(l);
-                    ++nsol;
-                }
+        // the first root whose singular quadric has a real plane pair (18 flops per root)
+        Sym3 D0{0, 0, 0, 0, 0, 0};
+        double tr = 0, m2 = 0;
+        bool found = false;
+        for (int r = 0; r < nroots && !found; ++r) {
+            const double g = r == 0 ? roots[0] : (r == 1 ? roots[1] : roots[2]);
+            D0 = Sym3{D1.a00 + g * D2.a00, D1.a01 + g * D2.a01, D1.a02 + g * D2.a02, D1.a11 + g * D2.a11, D1.a12 + g * D2.a12,
+                      D1.a22 + g * D2.a22};
+            // eigenvalues s1, s2 of the rank-2 matrix: s1 + s2 = trace, s1 s2 = sum of principal 2x2 minors
+            tr = D0.a00 + D0.a11 + D0.a22;
+            m2 = D0.a00 * D0.a11 - D0.a01 * D0.a01 + D0.a00 * D0.a22 - D0.a02 * D0.a02 + D0.a11 * D0.a22 - D0.a12 * D0.a12;
+            found = m2 < 0;  // needs eigenvalues of opposite sign to split into two real planes
+        }
+        const double sq = fast_sqrt(fmax(tr * tr - 4.0 * m2, 0.0));
+        const double s1 = 0.5 * (tr + sq), s2 = 0.5 * (tr - sq);  // s1 > 0 > s2
+        const Sym3 S1{D0.a00 - s1, D0.a01, D0.a02, D0.a11 - s1, D0.a12, D0.a22 - s1};
+        const V3 e1 = null_vec(S1), e0 = null_vec(D0);
+        const V3 e2 = cross(e0, e1);
+        const double sgm = fast_sqrt(fmax(-s2 * fast_rcp(s1), 0.0));
+#pragma unroll
+        for (int sign = 0; sign < 2; ++sign) {
+            const V3 pl = e1 + ((sign ? -sgm : sgm) * e2);  // plane pl . lambda = 0
+            // eliminate the component with the largest |pl|: lambda_k = u lambda_i + v lambda_j, (i, j, k) = (1,2,0) | (0,2,1) | (0,1,2)
+            const double ax = fabs(pl.x), ay = fabs(pl.y), az = fabs(pl.z);
+            const bool k0_ = ax >= ay && ax >= az, k1_ = !k0_ && ay >= az;
+            const double pk = k0_ ? pl.x : (k1_ ? pl.y : pl.z), pi = k0_ ? pl.y : pl.x, pj = (k0_ || k1_) ? pl.z : pl.y;
+            const double ipk = fast_rcp(pk);
+            const double u = -pi * ipk, v = -pj * ipk;
+            const double Dii = k0_ ? D1.a11 : D1.a00, Djj = (k0_ || k1_) ? D1.a22 : D1.a11, Dkk = k0_ ? D1.a00 : (k1_ ? D1.a11 : D1.a22);
+            const double Dij = k0_ ? D1.a12 : (k1_ ? D1.a02 : D1.a01), Dik = k0_ ? D1.a01 : (k1_ ? D1.a01 : D1.a02),
+                         Djk = k0_ ? D1.a02 : D1.a12;
+            const double A = Dii + Dkk * u * u + 2.0 * Dik * u;
+            const double C = Djj + Dkk * v * v + 2.0 * Djk * v;
+            const double Bq = 2.0 * (Dkk * u * v + Dij + Dik * v + Djk * u);
+            // A + Bq tau + C tau^2 = 0, tau = lambda_j / lambda_i
+            const bool quad = fabs(C) > 1e-14 * (fabs(A) + fabs(Bq) + fabs(C));
+            const double disc = Bq * Bq - 4.0 * A * C;
+            const double s = fast_sqrt(fmax(disc, 0.0)), qq = -0.5 * (Bq + (Bq >= 0 ? s : -s));
+            const double tau[2] = {quad ? qq * fast_rcp(C) : -A * fast_rcp(Bq), A * fast_rcp(qq)};
+            const bool have[2] = {found && (quad ? disc >= 0 : fabs(Bq) > 0), found && quad && disc >= 0 && qq != 0};
+            const double cij = k0_ ? c23 : (k1_ ? c13 : c12), aij = k0_ ? a23 : (k1_ ? a13 : a12);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const double den = 1.0 + tau[tt] * tau[tt] - 2.0 * cij * tau[tt];
+                const double li = fast_sqrt(fmax(aij * fast_rcp(den), 0.0)), lj = tau[tt] * li, lk = u * li + v * lj;
+                const int c = 2 * sign + tt;
+                ok[c] = have[tt] && tau[tt] > 0 && den > 0 && lk > 0;
+                L[c][0] = k0_ ? lk : li;
+                L[c][1] = k0_ ? li : (k1_ ? lk : lj);
+                L[c][2] = (k0_ || k1_) ? lj : lk;
             }
         }
-            LC_P3P_STAMP(4);
-            return nsol;
-        }
-    };
+        LC_P3P_STAMP(4);
+    }
+};
 
-
-__device__ __forceinline__ unsigned hash_u32(unsigned a) {  // lowbias32
-    a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16;
-    return a;
-}
 
 // rotation matrix -> quaternion (w,x,y,z), w >= 0
 __device__ void mat_to_quat(const double R[9], float q[4]) {
@@ -317,18 +298,21 @@ __device__ __forceinline__ bool hypothesis_pose(const int (&idx)[4], PointFn&& p
     // The candidate that reprojects the 4th point best (first one on ties) is chosen on its closed-form depths; only the chosen one is
     // Gauss-Newton polished (the closed form is good to ~1e-10, far below the gap between two P3P solutions; polishing all four
     // candidates before the choice was half of this kernel's instructions).
-    geo.solve([&](const double (&l)[3]) {
+    double L[4][3];
+    bool ok[4];
+    geo.solve(L, ok);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
         Pose sol;
-        geo.pose(l, sol);
+        geo.pose(L[c], sol);
         const float X = X4[0], Y = X4[1], Z = X4[2];
         const float cx = (float)sol.R[0] * X + (float)sol.R[1] * Y + (float)sol.R[2] * Z + (float)sol.t[0];
         const float cy = (float)sol.R[3] * X + (float)sol.R[4] * Y + (float)sol.R[5] * Z + (float)sol.t[1];
         const float cz = (float)sol.R[6] * X + (float)sol.R[7] * Y + (float)sol.R[8] * Z + (float)sol.t[2];
-        if (!(cz > 0)) return;
         const float ex = cx / cz - u4[0], ey = cy / cz - u4[1];
         const float e = ex * ex + ey * ey;
-        if (e < pick_e) { pick_e = e; lbest[0] = l[0]; lbest[1] = l[1]; lbest[2] = l[2]; have = true; }
-    });
+        if (ok[c] && cz > 0 && e < pick_e) { pick_e = e; lbest[0] = L[c][0]; lbest[1] = L[c][1]; lbest[2] = L[c][2]; have = true; }
+    }
     if (!have || !geo.polish(lbest)) return false;
     geo.pose(lbest, out);
     return true;
@@ -384,27 +368,67 @@ struct CamInv {
     }
 };
 
-// Winner of pose b -> outputs: inlier mask over ALL n points, their count, the pose as quaternion + translation, flags.
-// Called by every thread of the workgroup; wv_cnt: LDS scratch, one int per wavefront.
+__device__ __forceinline__ RowCopy selection_rows(const RansacParams& p) {
+    return RowCopy{p.pts2d, p.sel_w, p.pts3d, p.sel_in_index, p.sel_pts2d, p.sel_w_out, p.sel_pts3d, p.sel_index, 0};
+}
+
+// Winner of pose b -> outputs: inlier mask over ALL n points, their count, the pose as quaternion + translation, flags and (when
+// asked for) the inliers compacted to the front of the selection rows.  Called by every thread of the workgroup; wv_cnt: LDS scratch,
+// one int per wavefront.
 __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n, bool ok, const double* bp, int win_hyp, float thr2,
                                              const CamInv& kin, int* wv_cnt) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const size_t base = (size_t)b * p.Nmax;
     unsigned char* mask = p.inlier_mask + base;
+    const bool sel = p.sel_w != nullptr;
+    const RowCopy rows = selection_rows(p);
+    int kept = 0;  // inliers in the chunks before this one (same value in every thread; selection only)
     if (ok) {
         float R[9], t[3];
         for (int k = 0; k < 9; ++k) R[k] = (float)bp[k];
         for (int k = 0; k < 3; ++k) t[k] = (float)bp[9 + k];
         int total = 0;
-        for (int i = tid; i < n; i += nthr) {
-            const float X = p.pts3d[(base + i) * 3], Y = p.pts3d[(base + i) * 3 + 1], Z = p.pts3d[(base + i) * 3 + 2];
-            float ux, uy;
-            kin.normalise(p.pts2d[(base + i) * 2], p.pts2d[(base + i) * 2 + 1], ux, uy);
-            const float cz = R[6] * X + R[7] * Y + R[8] * Z + t[2];
-            const float ex = (R[0] * X + R[1] * Y + R[2] * Z + t[0]) / cz - ux, ey = (R[3] * X + R[4] * Y + R[5] * Z + t[1]) / cz - uy;
-            const bool in = cz > 0 && (ex * ex + ey * ey) < thr2;
-            mask[i] = in ? 1 : 0;
-            total += in ? 1 : 0;
+        constexpr int kBatch = 4;  // chunks whose correspondences are requested together: one memory round trip per four chunks
+        for (int i0 = 0; i0 < n; i0 += kBatch * nthr) {
+            float X[kBatch], Y[kBatch], Z[kBatch], pu[kBatch], pv[kBatch];
+            float2 sw[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int i = i0 + k * nthr + tid;
+                const bool have = i < n;
+                X[k] = have ? p.pts3d[(base + i) * 3] : 0.f; Y[k] = have ? p.pts3d[(base + i) * 3 + 1] : 0.f;
+                Z[k] = have ? p.pts3d[(base + i) * 3 + 2] : 0.f;
+                pu[k] = have ? p.pts2d[(base + i) * 2] : 0.f; pv[k] = have ? p.pts2d[(base + i) * 2 + 1] : 0.f;
+                sw[k] = have && sel ? *reinterpret_cast<const float2*>(p.sel_w + (base + i) * 2) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                if (i0 + k * nthr >= n) break;  // uniform
+                const int i = i0 + k * nthr + tid;
+                bool in = false;
+                if (i < n) {
+                    float ux, uy;
+                    kin.normalise(pu[k], pv[k], ux, uy);
+                    const float cz = R[6] * X[k] + R[7] * Y[k] + R[8] * Z[k] + t[2];
+                    const float ex = (R[0] * X[k] + R[1] * Y[k] + R[2] * Z[k] + t[0]) / cz - ux,
+                                ey = (R[3] * X[k] + R[4] * Y[k] + R[5] * Z[k] + t[1]) / cz - uy;
+                    in = cz > 0 && (ex * ex + ey * ey) < thr2;
+                    mask[i] = in ? 1 : 0;
+                    total += in ? 1 : 0;
+                }
+                if (sel) {  // order-preserving compaction: ballot within the wave, prefix over the waves of this chunk
+                    const unsigned long long bal = __ballot(in);
+                    __syncthreads();  // wv_cnt: the caller's arg-max / the previous chunk's prefix may still be reading
+                    if (lane == 0) wv_cnt[wave] = __popcll(bal);
+                    __syncthreads();
+                    int off = kept;
+                    for (int w = 0; w < nwaves; ++w) {
+                        if (w < wave) off += wv_cnt[w];
+                        kept += wv_cnt[w];
+                    }
+                    if (in) rows.entry_from(base, i, off + __popcll(bal & ((1ull << lane) - 1ull)), pu[k], pv[k], sw[k], X[k], Y[k], Z[k]);
+                }
+            }
         }
         for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m, kWave);
         __syncthreads();  // wv_cnt may still be read by the caller's arg-max
@@ -415,6 +439,10 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
             for (int w = 0; w < nwaves; ++w) tot += wv_cnt[w];
             p.n_inliers[b] = tot;
         }
+    }
+    if (sel) {
+        const int cnt = rows.pad(base, b, n, kept, p.sel_min_count, p.sel_seed);
+        if (tid == 0) p.sel_counts[b] = cnt;
     }
     if (tid == 0) {
         float* st = p.states + 7 * (size_t)b;
@@ -432,8 +460,13 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
 }
 
 // fewer than 4 correspondences: cv2.solvePnPRansac needs >= 4 (EPnP: 5 model points); flagged invalid like a failed call
-// (cv2_solver.py:74-80)
-__device__ __forceinline__ void write_too_few(const RansacParams& p, int b) {
+// (cv2_solver.py:74-80).  Called by every thread of the workgroup (the inlier mask is all zero: the selection keeps nothing and pads).
+__device__ __forceinline__ void write_too_few(const RansacParams& p, int b, int n) {
+    if (p.sel_w) {
+        const int cnt = selection_rows(p).pad((size_t)b * p.Nmax, b, n, 0, p.sel_min_count, p.sel_seed);
+        if (threadIdx.x == 0) p.sel_counts[b] = cnt;
+    }
+    if (threadIdx.x != 0) return;
     float* st = p.states + 7 * (size_t)b;
     st[0] = 1; st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0;
     p.invalid[b] = 1;
@@ -456,7 +489,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
     unsigned char* mask = p.inlier_mask + base;
     for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
     if (n < 4) {
-        if (tid == 0) write_too_few(p, b);
+        write_too_few(p, b, max(n, 0));
         return;
     }
     const CamInv kin(p.K + 9 * (size_t)b);
@@ -545,7 +578,10 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
 // Same hypothesis stream, same per-point arithmetic, same ordering as the single launch (the error sums are associated by chunk).
 constexpr int kChunkPts = 64;
 
+__host__ __device__ inline size_t ransac_counter_bytes(int B) { return 8 * (((size_t)B + 1) / 2); }  // keeps the doubles behind it aligned
+
 struct RansacWorkspace {
+    unsigned* arrived;  // (B,) chunks of the pose scored so far (ticketed form; zeroed by the hypotheses launch)
     double* hyp64;   // (B, H, 12)
     float* hyp32;    // (B, H, 12)
     int* part_cnt;   // (B, C, H)
@@ -559,6 +595,7 @@ __host__ __device__ inline RansacWorkspace carve_workspace(void* ws, int B, int 
     w.C = (nl + kChunkPts - 1) / kChunkPts;
     if (w.C < 1) w.C = 1;
     char* q = static_cast<char*>(ws);
+    w.arrived = reinterpret_cast<unsigned*>(q); q += ransac_counter_bytes(B);
     w.hyp64 = reinterpret_cast<double*>(q); q += sizeof(double) * 12 * (size_t)B * w.H;
     w.hyp32 = reinterpret_cast<float*>(q); q += sizeof(float) * 12 * (size_t)B * w.H;
     w.part_cnt = reinterpret_cast<int*>(q); q += sizeof(int) * (size_t)B * w.C * w.H;
@@ -570,8 +607,9 @@ __global__ __launch_bounds__(kWave) void lc_ransac_hypotheses_kernel(const Ransa
     LC_P3P_STAMP(0);
     const int b = blockIdx.x / p.rounds, hyp = (blockIdx.x % p.rounds) * kWave + threadIdx.x;
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
-    if (n < 4) return;  // the selection step flags the pose
     const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    if (hyp == 0) w.arrived[b] = 0;  // the ticketed scoring launch that follows counts the pose's chunks from zero
+    if (n < 4) return;  // the selection step flags the pose
     const CamInv kin(p.K + 9 * (size_t)b);
     const size_t base = (size_t)b * p.Nmax;
     int idx[4];
@@ -663,12 +701,19 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
     w.part_err[o] = err2.x + err2.y;
 }
 
-__global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kernel(const RansacParams p) {
-    __shared__ double best_pose[12];
-    __shared__ int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
-    __shared__ float wv_err[kRansacMaxWaves];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
-    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+// Selection of pose b by the calling workgroup: chunk partials of every hypothesis summed in chunk order (the sums do not depend on
+// which workgroup finished first), arg-max of (count, -error, -hypothesis id), outputs.  XCD: the partials were written by other
+// workgroups of THIS launch (read around the caches), else by an earlier launch.
+struct SelectShared {
+    double best_pose[12];
+    int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
+    float wv_err[kRansacMaxWaves];
+};
+template <bool XCD>
+__device__ __forceinline__ void select_winner(const RansacParams& p, const RansacWorkspace& w, int b, SelectShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
+    auto cnt_at = [&](size_t o) { return XCD ? xcd_load(w.part_cnt + o) : w.part_cnt[o]; };
+    auto err_at = [&](size_t o) { return XCD ? xcd_load(w.part_err + o) : w.part_err[o]; };
     int win_cnt = -1, win_hyp = 0x7fffffff;
     float win_err = INFINITY;
     // the first hypothesis of this thread: its chunk partials are requested together with the point count (rows of chunks the
@@ -679,15 +724,15 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kern
     for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {
         const bool have = c < w.C && tid < w.H;
         const size_t o = ((size_t)b * w.C + c) * w.H + tid;
-        pc0[c] = have ? w.part_cnt[o] : 0;
-        pe0[c] = have ? w.part_err[o] : 0.f;
+        pc0[c] = have ? cnt_at(o) : 0;
+        pe0[c] = have ? err_at(o) : 0.f;
     }
     const CamInv kin(p.K + 9 * (size_t)b);
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
     unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
     for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
     if (n < 4) {
-        if (tid == 0) write_too_few(p, b);
+        write_too_few(p, b, max(n, 0));
         return;
     }
     const int chunks = (min(n, kMaxLdsPts) + kChunkPts - 1) / kChunkPts;
@@ -695,19 +740,19 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kern
         int cnt = 0;
         float err = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {  // chunk order: the sums do not depend on which workgroup finished first
+        for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {
             cnt += c < chunks ? pc0[c] : 0;
             err += c < chunks ? pe0[c] : 0.f;
         }
         win_cnt = cnt; win_err = err; win_hyp = tid;
     }
-    for (int hyp = tid + nthr; hyp < w.H; hyp += nthr) {  // more than 256 hypotheses
+    for (int hyp = tid + nthr; hyp < w.H; hyp += nthr) {  // more hypotheses than threads
         int cnt = 0;
         float err = 0.f;
         for (int c = 0; c < chunks; ++c) {
             const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
-            cnt += w.part_cnt[o];
-            err += w.part_err[o];
+            cnt += cnt_at(o);
+            err += err_at(o);
         }
         if (better_hyp(cnt, err, hyp, win_cnt, win_err, win_hyp)) { win_cnt = cnt; win_err = err; win_hyp = hyp; }
     }
@@ -716,17 +761,114 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kern
         const float oe = __shfl_xor(win_err, m, kWave);
         if (better_hyp(oc, oe, oh, win_cnt, win_err, win_hyp)) { win_cnt = oc; win_err = oe; win_hyp = oh; }
     }
-    if (lane == 0) { wv_cnt[wave] = win_cnt; wv_err[wave] = win_err; wv_hyp[wave] = win_hyp; }
+    if (lane == 0) { sh.wv_cnt[wave] = win_cnt; sh.wv_err[wave] = win_err; sh.wv_hyp[wave] = win_hyp; }
     __syncthreads();
-    win_cnt = wv_cnt[0]; win_err = wv_err[0]; win_hyp = wv_hyp[0];
+    win_cnt = sh.wv_cnt[0]; win_err = sh.wv_err[0]; win_hyp = sh.wv_hyp[0];
     for (int v = 1; v < nwaves; ++v)
-        if (better_hyp(wv_cnt[v], wv_err[v], wv_hyp[v], win_cnt, win_err, win_hyp)) { win_cnt = wv_cnt[v]; win_err = wv_err[v]; win_hyp = wv_hyp[v]; }
+        if (better_hyp(sh.wv_cnt[v], sh.wv_err[v], sh.wv_hyp[v], win_cnt, win_err, win_hyp)) { win_cnt = sh.wv_cnt[v]; win_err = sh.wv_err[v]; win_hyp = sh.wv_hyp[v]; }
     const bool ok = win_cnt >= 4;
-    if (ok && tid < 12) best_pose[tid] = w.hyp64[12 * ((size_t)b * w.H + win_hyp) + tid];
+    if (ok && tid < 12) sh.best_pose[tid] = w.hyp64[12 * ((size_t)b * w.H + win_hyp) + tid];
     __syncthreads();
     const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
     const float thr = thr_px * (float)sqrt(fabs(kin.idet));
-    write_result(p, b, n, ok, best_pose, win_hyp, thr * thr, kin, wv_cnt);
+    write_result(p, b, n, ok, sh.best_pose, win_hyp, thr * thr, kin, sh.wv_cnt);
+}
+
+__global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kernel(const RansacParams p) {
+    __shared__ SelectShared sh;
+    select_winner<false>(p, carve_workspace(p.workspace, p.B, p.Nmax, p.rounds), blockIdx.x, sh);
+}
+
+// Ticketed form (lc_pnp_ransac_init4_f32 with `ticketed`): scoring AND selection in one launch.  One workgroup per (pose, chunk of 64 points), its
+// wavefronts take the rounds of 64 hypotheses; the chunk's partials are written through the caches, the workgroup counts itself
+// in, and the workgroup that completes the pose's count runs the selection -- nobody waits, so no co-residency is assumed, and the
+// partials are still summed in chunk order: same results as the three launches.  Saves the selection launch and its boundary --
+// and MEASURED SLOWER than the three launches on MI355X (64 objects x 1024 points, replayed: 32.0 vs 29.5 us,
+// profiles/r03/ransac_ticketed.txt): write-through stores, their acknowledgement, the arrival atomic and the partials read around the
+// caches cost more than the 1.45 us kernel boundary they replace.  Kept as an option (tests compare it with the three launches);
+// the default is the three launches.
+__global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_select_kernel(const RansacParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[5][kChunkPts];
+    __shared__ SelectShared sh;
+    __shared__ unsigned s_before;
+    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x / w.C, c = blockIdx.x % w.C;
+    float *sX = lds[0], *sY = lds[1], *sZ = lds[2], *sU = lds[3], *sV = lds[4];
+    // requested before the pose's point count is known, as in the scoring kernel above
+    const int i0 = c * kChunkPts, cap = max(0, min(kChunkPts, min(p.Nmax, kMaxLdsPts) - i0));
+    const size_t base = (size_t)b * p.Nmax + i0;
+    const bool in_row = wave == 0 && lane < cap;
+    const float gx = in_row ? p.pts3d[(base + lane) * 3] : 0.f, gy = in_row ? p.pts3d[(base + lane) * 3 + 1] : 0.f,
+                gz = in_row ? p.pts3d[(base + lane) * 3 + 2] : 0.f;
+    const float gu = in_row ? p.pts2d[(base + lane) * 2] : 0.f, gv = in_row ? p.pts2d[(base + lane) * 2 + 1] : 0.f;
+    float R[9], t[3];
+    {
+        const float* h32 = w.hyp32 + 12 * ((size_t)b * w.H + min(wave, p.rounds - 1) * kWave + lane);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = h32[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = h32[9 + k];
+    }
+    const CamInv kin(p.K + 9 * (size_t)b);
+    const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+    if (n < 4) {  // nothing was scored: chunk 0's workgroup flags the pose
+        if (c == 0) {
+            unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
+            for (int i = tid; i < p.Nmax; i += (int)blockDim.x) mask[i] = 0;
+            write_too_few(p, b, max(n, 0));
+        }
+        return;
+    }
+    const int nl = min(n, kMaxLdsPts), chunks = (nl + kChunkPts - 1) / kChunkPts;
+    const int cnt_pts = max(0, min(kChunkPts, nl - i0)), cnt4 = (cnt_pts + 3) & ~3;
+    if (cnt_pts == 0) return;  // a chunk the pose does not have: not counted
+    if (wave == 0) {
+        if (lane < cnt_pts) {
+            float ux, uy;
+            kin.normalise(gu, gv, ux, uy);
+            sU[lane] = -ux; sV[lane] = -uy;
+            sX[lane] = gx; sY[lane] = gy; sZ[lane] = gz;
+        } else if (lane < cnt4) {
+            sX[lane] = sY[lane] = sZ[lane] = 0.f;
+            sU[lane] = sV[lane] = -INFINITY;
+        }
+    }
+    __syncthreads();
+    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr = thr_px * (float)sqrt(fabs(kin.idet));
+    const float thr2 = thr * thr;
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    auto rd = [](const float* a, int i) { return *reinterpret_cast<const v4f_t*>(a + i); };
+    for (int round = wave; round < p.rounds; round += nwaves) {
+        const int hyp = round * kWave + lane;
+        if (round != wave) {
+            const float* h32 = w.hyp32 + 12 * ((size_t)b * w.H + hyp);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = h32[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t[k] = h32[9 + k];
+        }
+        int cnt = 0;
+        v2f_t err2 = {0.f, 0.f};
+        v4f_t X = rd(sX, 0), Y = rd(sY, 0), Z = rd(sZ, 0), U = rd(sU, 0), V = rd(sV, 0);
+        for (int i = 0; i < cnt4; i += 4) {
+            const int nx = i + 4 < cnt4 ? i + 4 : i;
+            const v4f_t Xn = rd(sX, nx), Yn = rd(sY, nx), Zn = rd(sZ, nx), Un = rd(sU, nx), Vn = rd(sV, nx);
+            score_pair(R, t, X.xy, Y.xy, Z.xy, U.xy, V.xy, thr2, cnt, err2);
+            score_pair(R, t, X.zw, Y.zw, Z.zw, U.zw, V.zw, thr2, cnt, err2);
+            X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
+        }
+        const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
+        xcd_store(w.part_cnt + o, cnt);
+        xcd_store(w.part_err + o, err2.x + err2.y);
+    }
+    xcd_stores_done();
+    __syncthreads();  // every wave's partials have been acknowledged
+    if (tid == 0) s_before = __hip_atomic_fetch_add(w.arrived + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_before + 1u != (unsigned)chunks) return;
+    select_winner<true>(p, w, b, sh);
 }
 
 }  // namespace
@@ -736,7 +878,7 @@ size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds) {
     const int H = rounds * kWave;
     const int nl = Nmax < kMaxLdsPts ? Nmax : kMaxLdsPts;
     const int C = nl > 0 ? (nl + kChunkPts - 1) / kChunkPts : 1;
-    return (size_t)B * H * 12 * (sizeof(double) + sizeof(float)) + (size_t)B * C * H * (sizeof(int) + sizeof(float));
+    return ransac_counter_bytes(B) + (size_t)B * H * 12 * (sizeof(double) + sizeof(float)) + (size_t)B * C * H * (sizeof(int) + sizeof(float));
 }
 
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
@@ -750,6 +892,10 @@ int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
     const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
     hipLaunchKernelGGL(lc_ransac_hypotheses_kernel, dim3((unsigned)p.rounds * p.B), dim3(kWave), 0, stream, p);
     const long long units = (long long)p.B * w.C * p.rounds;
+    if (p.ticketed) {
+        hipLaunchKernelGGL(lc_ransac_score_select_kernel, dim3((unsigned)p.B * w.C), dim3(kWave * waves), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     hipLaunchKernelGGL(lc_ransac_score_kernel, dim3((unsigned)((units + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     hipLaunchKernelGGL(lc_ransac_select_kernel, dim3(p.B), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;

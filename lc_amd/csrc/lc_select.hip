@@ -17,17 +17,13 @@
 
 #include "lc_common.h"
 #include "lc_kernels.h"
+#include "lc_select_rows.h"
 
 namespace lc {
 namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / kWave;
-
-__device__ __forceinline__ unsigned hash_u32(unsigned x) {
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
-}
 
 // torch.lerp (aten/src/ATen/native/Lerp.h): the form that is exact at both ends
 __device__ __forceinline__ float torch_lerp(float a, float b, float w) {
@@ -146,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
         __syncthreads();
     }
     const float thr = s_thr;
-    const size_t ob = base;
+    const RowCopy rows{p.pts2d, p.inv_std, p.pts3d, p.in_index, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
     int running = 0;  // survivors in the chunks before this one (same value in every thread)
     for (int i0 = 0; i0 < n; i0 += kThreads) {
         const int i = i0 + tid;
@@ -165,31 +161,11 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
             if (w < wave) off += wave_cnt[w];
             tot += wave_cnt[w];
         }
-        if (keep) {
-            const int o = off + before;
-            const float2 s = *reinterpret_cast<const float2*>(ws + 2 * i);
-            *reinterpret_cast<float2*>(p.o_pts2d + (ob + o) * 2) = *reinterpret_cast<const float2*>(p.pts2d + (base + i) * 2);
-            *reinterpret_cast<float2*>(p.o_w + (ob + o) * 2) = p.square ? make_float2(s.x * s.x, s.y * s.y) : s;
-            const float* X = p.pts3d + (base + i) * 3;
-            float* oX = p.o_pts3d + (ob + o) * 3;
-            oX[0] = X[0]; oX[1] = X[1]; oX[2] = X[2];
-            if (p.o_index) p.o_index[ob + o] = p.in_index ? p.in_index[base + i] : i;
-        }
+        if (keep) rows.entry(base, i, off + before);
         running = tot;
         __syncthreads();  // wave_cnt is rewritten by the next chunk
     }
-    int total = running;
-    if (total < p.min_count && n > p.min_count) {  // test.py:108-113
-        for (int k = total + tid; k < p.min_count; k += kThreads) {
-            const int i = (int)(hash_u32(p.seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)k)) % (unsigned)n);
-            const float2 s = *reinterpret_cast<const float2*>(ws + 2 * i);
-            *reinterpret_cast<float2*>(p.o_pts2d + (ob + k) * 2) = *reinterpret_cast<const float2*>(p.pts2d + (base + i) * 2);
-            *reinterpret_cast<float2*>(p.o_w + (ob + k) * 2) = p.square ? make_float2(s.x * s.x, s.y * s.y) : s;
-            for (int d = 0; d < 3; ++d) p.o_pts3d[(ob + k) * 3 + d] = p.pts3d[(base + i) * 3 + d];
-            if (p.o_index) p.o_index[ob + k] = p.in_index ? p.in_index[base + i] : i;
-        }
-        total = p.min_count;
-    }
+    const int total = rows.pad(base, b, n, running, p.min_count, p.seed);  // test.py:108-113
     if (tid == 0) p.counts[b] = total;
 }
 

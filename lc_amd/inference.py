@@ -102,19 +102,23 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     half = halves.__getitem__
     u, icov, x, counts, index = dense_select(pts2d, inv_std, pts3d, mode, mask=visible, quantile=float(cfg.get("quantile", 0.0)),
                                              square_weights=True, min_count=4, out=half(0))
-    start, inliers, _bad = gpu_solver.solve_device(K, x, u, counts, reprojectionError=_reprojection_threshold(cfg, gt_dict, 3))
+    # test.py:129-133: the selection intersected with the RANSAC inliers -- compacted by the RANSAC's own selection step (the workgroup
+    # that writes the inlier mask), not by a `dense_select(..., 'mask', mask=inliers)` launch behind the refinement
+    filtered = None
+    if "weighted_filtered" in wanted:
+        filtered = dict(weights=icov, index=index, min_count=4, out=half(1) if both else None)
+    start, inliers, _bad = gpu_solver.solve_device(K, x, u, counts, reprojectionError=_reprojection_threshold(cfg, gt_dict, 3),
+                                                   select=filtered)
 
     out = {}
     if "ransac" in wanted:
         out["ransac"] = start
-    if both:  # test.py:129-133: the selection intersected with the RANSAC inliers, next to the unfiltered one
-        dense_select(u, icov, x, "mask", mask=inliers, counts=counts, index=index, square_weights=False, min_count=4, out=half(1))
+    if both:  # the two selections side by side in ONE launch of 2B poses
         states = pnp_ceres.solve_device(K, X2, U2, W2, start, C2, weights_are_icov=True, nan_to_num=True, shared_poses=B)[0]
         out["weighted"], out["weighted-filtered"] = states.chunk(2)
         out = {k: out[k] for k in ("ransac", "weighted-filtered", "weighted") if k in out}  # key order of test.py:129-135
     elif "weighted_filtered" in wanted:
-        fu, ficov, fx, fcounts, _ = dense_select(u, icov, x, "mask", mask=inliers, counts=counts, index=index, square_weights=False,
-                                                 min_count=4)
+        fu, ficov, fx, fcounts, _ = filtered["result"]
         out["weighted-filtered"] = _weighted(K, fx, fu, ficov, start, fcounts)
     elif "weighted" in wanted:
         out["weighted"] = _weighted(K, x, u, icov, start, counts)

@@ -15,9 +15,15 @@ from . import cer_solver, pnp_ceres
 
 
 def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True,
-                 return_hypothesis=False, split=None):
+                 return_hypothesis=False, split=None, ticketed=False, select=None):
     """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool
     [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly].
+
+    select: None, or a dict(weights=(B,N,2), index=(B,N) int32 | None, min_count=4, seed=0, out=None) -- the 'weighted-filtered'
+    re-selection of test.py:129-133 done by the workgroup that writes the inlier mask; the compacted rows
+    (pts2d, weights, pts3d, counts, index), exactly `dense.dense_select(..., 'mask', mask=inliers)`'s, come back as
+    select['result'].  ticketed: the split form with the selection inside the scoring launch (two launches instead of three, same
+    outputs, tests compare the two) -- measured 2.5 us SLOWER per call on MI355X (profiles/r03/ransac_ticketed.txt), hence off.
 
     split: None picks the launch form from the shape -- the single launch keeps a pose on one compute unit (its scoring loop costs
     ~0.07 us per point, times ceil(B/256) when the poses outnumber the compute units), the split form pays ~17 us of extra launches
@@ -43,15 +49,41 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     hyp = torch.empty(B, device=dev, dtype=torch.int32) if return_hypothesis else None
     rows = torch.empty(B, device=dev, dtype=torch.int32) if refine else None  # point count, 0 for the poses RANSAC gave up on
     ws, nbytes = None, 0
+    sel_w = sel_idx = None
+    sel_out = (None,) * 5
+    if select is not None:
+        sel_w = _lib.require_hip_f32("select['weights']", select["weights"])
+        if sel_w.shape != (B, N, 2):
+            raise ValueError(f"select['weights'] must be (B, N, 2) = {(B, N, 2)}, got {tuple(sel_w.shape)}")
+        if select.get("index") is not None:
+            sel_idx = select["index"].to(device=dev, dtype=torch.int32).contiguous()
+        sel_out = select.get("out")
+        if sel_out is None:
+            sel_out = (torch.empty_like(U), torch.empty_like(sel_w), torch.empty_like(X), torch.empty(B, device=dev, dtype=torch.int32),
+                       torch.empty(B, N, device=dev, dtype=torch.int32))
+        o_u, o_w, o_x, o_c, o_i = sel_out
+        if not (o_u.shape == U.shape and o_w.shape == sel_w.shape and o_x.shape == X.shape and o_c.shape == (B,) and o_i.shape == (B, N)
+                and o_u.dtype == o_w.dtype == o_x.dtype == torch.float32 and o_c.dtype == o_i.dtype == torch.int32
+                and all(t.is_contiguous() and t.device == dev for t in sel_out)):
+            raise ValueError("solve_device: select['out'] buffers must be contiguous tensors of the result shapes on the input's device")
     with _lib.on_device(dev):
-        if split:  # hypotheses / scoring / selection as three launches over a workspace: spreads one pose over many compute units
+        if split:  # hypotheses / scoring / selection as launches over a workspace: spreads one pose over many compute units
             nbytes = int(lib.lc_pnp_ransac_workspace_bytes(B, N, int(iterations)))
             ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
-        rc = lib.lc_pnp_ransac_init3_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError),
-                                         _lib.ptr(per_pose), int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask),
-                                         _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp), _lib.ptr(rows), _lib.ptr(ws), nbytes,
-                                         _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_pnp_ransac_init3_f32")
+        head = (_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError), _lib.ptr(per_pose),
+                int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask), _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp),
+                _lib.ptr(rows), _lib.ptr(ws), nbytes)
+        if ticketed or select is not None:
+            name = "lc_pnp_ransac_init4_f32"
+            rc = lib.lc_pnp_ransac_init4_f32(*head, int(bool(ticketed)), _lib.ptr(sel_w), _lib.ptr(sel_idx), int(select.get("min_count", 4)) if select else 0,
+                                             (int(select.get("seed", 0)) if select else 0) & 0xFFFFFFFF, *(_lib.ptr(sel_out[k]) for k in (0, 1, 2, 4, 3)),  # C order: rows, index, counts
+                                             _lib.stream_ptr(dev))
+        else:
+            name = "lc_pnp_ransac_init3_f32"
+            rc = lib.lc_pnp_ransac_init3_f32(*head, _lib.stream_ptr(dev))
+    _lib.check(rc, name)
+    if select is not None:
+        select["result"] = sel_out
     inl = mask.view(torch.bool)  # the kernel writes 0 / 1: same bytes, no launch
     bad = invalid.view(torch.bool).view(B, 4)[:, 0]  # the flag is 0 / 1: its low byte as bool, no launch
     if refine:

@@ -16,7 +16,9 @@ gt, out = dense_inputs(B=64, H=64, W=64, seed=3)
 out["xyz_weight_logits"] = out["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
 out["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
 gt = {k: v.to(dev) for k, v in gt.items()}
-out = {k: v.to(dev) for k, v in out.items()}
+# network outputs are contiguous NCHW tensors (a convolution's output); the synthetic generator hands xyz_noc over as a strided
+# view of a channels-last array, which the front end would first copy (one 6 us torch launch per call that is not the pipeline's)
+out = {k: v.to(dev).contiguous() for k, v in out.items()}
 cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
 
 

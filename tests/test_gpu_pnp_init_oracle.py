@@ -71,8 +71,91 @@ def test_split_form_equals_single_launch(B, N, iters, noise):
     counts = torch.randint(max(4, N // 2), N + 1, (B,), generator=g).to(torch.int32)
     counts[0] = 3  # too few -> invalid in both forms
     outs = [gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], counts, reprojectionError=2.0, iterations=iters, seed=11,
-                                    refine=False, return_hypothesis=True, split=s) for s in (True, False)]
-    (st_a, in_a, bad_a, hyp_a, n_a), (st_b, in_b, bad_b, hyp_b, n_b) = outs
+                                    refine=False, return_hypothesis=True, split=s, ticketed=t) for s, t in ((True, False), (False, False), (True, True))]
+    (st_a, in_a, bad_a, hyp_a, n_a), (st_b, in_b, bad_b, hyp_b, n_b), ticketed = outs
     assert torch.equal(bad_a, bad_b) and bool(bad_a[0])
     assert torch.equal(hyp_a, hyp_b), (hyp_a != hyp_b).nonzero().flatten().tolist()
     assert torch.equal(in_a, in_b) and torch.equal(n_a, n_b) and torch.equal(st_a, st_b)
+    # lc_pnp_ransac_init4_f32: the selection inside the scoring launch (the last workgroup of a pose to finish selects) -- same outputs
+    for x, y in zip(ticketed, outs[0]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("split,ticketed", [(True, False), (True, True), (False, False)], ids=["split", "split_ticketed", "single_launch"])
+@pytest.mark.parametrize("B,N,iters,min_count", [(64, 1024, 150, 4), (5, 300, 64, 4), (3, 2500, 200, 6), (40, 64, 150, 4), (7, 129, 150, 4)])
+def test_fused_inlier_reselection_equals_dense_select(B, N, iters, min_count, split, ticketed):
+    """`select=` of lc_pnp_ransac_init4_f32 (the inliers compacted by the workgroup that writes the inlier mask) against
+    lc_dense_select_f32 in 'mask' mode run on that mask in a launch of its own: rows, counts and source indices bit for bit -- incl. a
+    pose with too few points, poses RANSAC gives up on (nothing kept: padded with min_count pseudo-random entries) and an input that
+    is itself a compacted selection (index != identity)."""
+    from lc_amd import synth
+    from lc_amd.dense import dense_select
+    from lc_amd.pnp import gpu_solver
+
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=3 * B + N, outlier_frac=0.4, noise_px=0.7).items()}
+    g = torch.Generator().manual_seed(N)
+    counts = torch.randint(max(4, N // 2), N + 1, (B,), generator=g).to(torch.int32).to(dev)
+    counts[0] = 3
+    b["pts3d"][1] = 0  # a degenerate object: no hypothesis, RANSAC gives up, nothing is kept
+    w = torch.rand(B, N, 2, generator=g).to(dev) + 0.1
+    index = torch.stack([torch.randperm(4 * N, generator=g)[:N].sort().values for _ in range(B)]).to(torch.int32).to(dev)
+    sel = dict(weights=w, index=index, min_count=min_count, seed=5)
+    st, inl, bad = gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], counts, reprojectionError=2.0, iterations=iters, seed=11,
+                                           refine=False, split=split, ticketed=ticketed, select=sel)
+    assert bool(bad[0]) and bool(bad[1]) and not bool(bad[2:].all())
+    want = dense_select(b["pts2d"], w, b["pts3d"], "mask", mask=inl, counts=counts, index=index, square_weights=False, min_count=min_count, seed=5)
+    got = sel["result"]
+    cnt = want[3]
+    assert torch.equal(got[3], cnt) and int(cnt[0]) == 0 and int(cnt[1]) == min_count and int(cnt.max()) > min_count
+    live = (torch.arange(N, device=dev)[None, :] < cnt[:, None])  # entries behind a row's count are undefined in both
+    for name, x, y in zip(("pts2d", "weights", "pts3d", "", "index"), got, want):
+        if name:
+            m = live if x.dim() == 2 else live[..., None].expand_as(x)
+            assert torch.equal(x[m], y[m]), name
+
+
+def test_ticketed_form_under_concurrency_and_replay():
+    """The arrival counters of the ticketed form: 200 back-to-back launches on two streams with workspaces of their own, and 50 replays
+    of a captured launch, give the outputs of the three-launch form every time."""
+    from lc_amd import synth
+    from lc_amd.pnp import gpu_solver
+
+    dev = torch.device("cuda:0")
+    shapes = [(64, 1024), (33, 700)]
+    data, want = [], []
+    for B, N in shapes:
+        b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B, outlier_frac=0.3, noise_px=0.5).items()}
+        data.append(b)
+        want.append(gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], None, reprojectionError=2.0, seed=3, refine=False,
+                                            return_hypothesis=True, split=True, ticketed=False))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev) for _ in shapes]
+    got = [[] for _ in shapes]
+    for it in range(100):
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                b = data[k]
+                got[k].append(gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], None, reprojectionError=2.0, seed=3, refine=False,
+                                                      return_hypothesis=True, split=True, ticketed=True))
+    torch.cuda.synchronize()
+    for k in range(len(shapes)):
+        for outs in got[k]:
+            for x, y in zip(outs, want[k]):
+                assert torch.equal(x, y)
+    b = data[0]
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], None, reprojectionError=2.0, seed=3, refine=False, split=True, ticketed=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            outs = gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], None, reprojectionError=2.0, seed=3, refine=False,
+                                           return_hypothesis=True, split=True, ticketed=True)
+    for _ in range(50):
+        for t in outs:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for x, y in zip(outs, want[0]):
+            assert torch.equal(x, y)

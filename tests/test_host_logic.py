@@ -30,20 +30,28 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_ransac_workspace_contract():
-    """lc_pnp_ransac_workspace_bytes: (B, H, 12) doubles + floats for the hypotheses and (B, chunks of 64 points, H) count/error
-    partials, H = iterations rounded up to 64; a smaller workspace is refused before anything is launched (no GPU needed)."""
+    """lc_pnp_ransac_workspace_bytes: B arrival counters (padded to 8 bytes), (B, H, 12) doubles + floats for the hypotheses and
+    (B, chunks of 64 points, H) count/error partials, H = iterations rounded up to 64; a smaller workspace is refused before anything
+    is launched (no GPU needed), by both split-form entry points."""
     from lc_amd import _lib
 
     lib = _lib.load()
     assert lib.lc_pnp_ransac_workspace_bytes(0, 10, 150) == 0 and lib.lc_pnp_ransac_workspace_bytes(4, 10, 0) == 0
     B, N, H = 5, 1000, 192
     chunks = (N + 63) // 64
-    assert lib.lc_pnp_ransac_workspace_bytes(B, N, 150) == B * H * 12 * (8 + 4) + B * chunks * H * 8
-    assert lib.lc_pnp_ransac_workspace_bytes(B, 5000, 150) == B * H * 12 * 12 + B * 32 * H * 8  # scoring stops at 2048 points
+    ctr = 8 * ((B + 1) // 2)
+    assert lib.lc_pnp_ransac_workspace_bytes(B, N, 150) == ctr + B * H * 12 * (8 + 4) + B * chunks * H * 8
+    assert lib.lc_pnp_ransac_workspace_bytes(B, 5000, 150) == ctr + B * H * 12 * 12 + B * 32 * H * 8  # scoring stops at 2048 points
     buf = ctypes.create_string_buffer(64)
     p = ctypes.addressof(buf)
     rc = lib.lc_pnp_ransac_init3_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, p, 64, None)
     assert rc != 0 and b"workspace" in lib.lc_amd_last_error()
+    rc = lib.lc_pnp_ransac_init4_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, p, 64, 0, None, None, 4, 0, None, None,
+                                     None, None, None, None)
+    assert rc != 0 and b"workspace" in lib.lc_amd_last_error()
+    rc = lib.lc_pnp_ransac_init4_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, None, 0, 0, p, None, 4, 0, p, p, p, None,
+                                     None, None)  # selection asked for, no counts output
+    assert rc != 0 and b"selection" in lib.lc_amd_last_error()
 
 
 def test_extended_entry_points_reject_bad_arguments_before_launching():
