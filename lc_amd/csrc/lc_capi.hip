@@ -531,5 +531,24 @@ int lc_dense_select_f32(const float* pts2d, const float* inv_std, const float* p
     return rc ? fail(11, "dense select launch failed") : 0;
 }
 
+int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
+                                 float vis_thresh, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
+                                 int square_weights, int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d,
+                                 int* out_index, int* counts, void* stream) {
+    if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    if (mode < 0 || mode > 2 || min_count < 0 || min_count > N) return fail(1, "bad size or mode");
+    if (mode != 0 && !(quantile >= 0.0 && quantile <= 1.0)) return fail(1, "quantile outside [0,1]");
+    if (N > 1024) return fail(1, "more than 1024 sampled pixels per object: use lc_dense_frontend_fwd2_f32 + lc_dense_select_f32");
+    if (B == 0) return 0;
+    if (!xyz || !wlogits || !wscale || !out_pts2d || !out_weights || !out_pts3d || !counts) return fail(1, "null pointer");
+    if (mode != 1 && !vis_logits) return fail(1, "modes 0 (mask) and 2 (quantile_in_mask) need the visibility logits");
+    LC_REQUIRE_ALIGNED(8, out_pts2d, out_weights);
+    lc::SelectParams p{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_pts2d, out_weights, out_pts3d, out_index, counts,
+                       B, N, mode, (float)quantile, (float)(1.0 - quantile), square_weights, min_count, seed};
+    lc::DenseParams d{xyz, wlogits, wscale, noc_scale, nullptr, nullptr, nullptr, nullptr, B, H, W, N, top, left, sample, vis_logits, vis_thresh, nullptr};
+    return lc::launch_dense_frontend_select(p, d, static_cast<hipStream_t>(stream)) ? fail(11, "front end + select launch failed") : 0;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

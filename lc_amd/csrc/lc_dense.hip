@@ -16,51 +16,15 @@
 #include <cstdint>
 
 #include "lc_common.h"
+#include "lc_dense_lse.h"
 #include "lc_kernels.h"
 
 namespace lc {
 namespace {
 
-constexpr int kThreads = 512;
+constexpr int kThreads = kDenseLseThreads;
 constexpr int kWaves = kThreads / kWave;
 constexpr int kMaxSlices = 8;
-
-// (running max, running sum of exp(x - max)) pairs of the online softmax
-__device__ __forceinline__ void ms_push(float& m, float& s, float v) {
-    const float mn = fmaxf(m, v);
-    s = s * __expf(m - mn) + __expf(v - mn);
-    m = mn;
-}
-__device__ __forceinline__ void ms_merge(float& m, float& s, float om, float os) {
-    const float mn = fmaxf(m, om);
-    s = s * __expf(m - mn) + os * __expf(om - mn);
-    m = mn;
-}
-
-// log-sum-exp of lg[0..n), identical in every thread of every workgroup that calls it with the same arguments
-__device__ __forceinline__ float block_lse(const float* __restrict__ lg, int n, float (*red)[2]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float m = -FLT_MAX, s = 0.f;
-    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(lg) & 15) == 0) {
-        const float4* v4 = reinterpret_cast<const float4*>(lg);
-        for (int i = tid; i < (n >> 2); i += kThreads) {
-            const float4 v = v4[i];
-            const float mn = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-            s = s * __expf(m - mn) + ((__expf(v.x - mn) + __expf(v.y - mn)) + (__expf(v.z - mn) + __expf(v.w - mn)));
-            m = mn;
-        }
-    } else {
-        for (int i = tid; i < n; i += kThreads) ms_push(m, s, lg[i]);
-    }
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) ms_merge(m, s, __shfl_xor(m, k, kWave), __shfl_xor(s, k, kWave));
-    if (lane == 0) { red[wave][0] = m; red[wave][1] = s; }
-    __syncthreads();
-    m = red[0][0]; s = red[0][1];
-#pragma unroll
-    for (int w = 1; w < kWaves; ++w) ms_merge(m, s, red[w][0], red[w][1]);
-    return m + __logf(s);
-}
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_fwd_kernel(const D
     const int b = blockIdx.x % p.B, slice = blockIdx.x / p.B, S = gridDim.x / p.B, tid = threadIdx.x;
     const int HW = p.H * p.W, n2 = 2 * HW;
     const float* __restrict__ lg = p.wlogits + (size_t)b * n2;
-    const float lse = block_lse(lg, n2, red);  // joint softmax statistics over both channels (losses.py:355)
+    const float lse = block_lse<kThreads>(lg, n2, red);  // joint softmax statistics over both channels (losses.py:355)
     if (slice == 0 && tid == 0) p.lse[b] = lse;
     const float scale = p.wscale[b];
     const int Wn = (p.W - p.left + p.sample - 1) / p.sample;

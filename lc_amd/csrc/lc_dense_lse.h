@@ -1,0 +1,54 @@
+// Log-sum-exp of a sample's weight logits (the joint softmax of losses.py:355): shared by the dense front end (lc_dense.hip) and the
+// test-time kernel that runs front end and point selection in one launch (lc_select.hip).  NT threads of the workgroup take part
+// (the same NT, stride and merge order everywhere -> the same float everywhere); the workgroup may be larger.
+#pragma once
+#include <cfloat>
+#include <cstdint>
+
+#include "lc_common.h"
+
+namespace lc {
+
+constexpr int kDenseLseThreads = 512;  // the NT every caller uses: the front end's workgroup size
+
+// (running max, running sum of exp(x - max)) pairs of the online softmax
+__device__ __forceinline__ void ms_push(float& m, float& s, float v) {
+    const float mn = fmaxf(m, v);
+    s = s * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+}
+__device__ __forceinline__ void ms_merge(float& m, float& s, float om, float os) {
+    const float mn = fmaxf(m, om);
+    s = s * __expf(m - mn) + os * __expf(om - mn);
+    m = mn;
+}
+
+// log-sum-exp of lg[0..n), identical in every thread of every workgroup that calls it with the same arguments; red: NT / 64 rows of LDS
+template <int NT>
+__device__ __forceinline__ float block_lse(const float* __restrict__ lg, int n, float (*red)[2]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -FLT_MAX, s = 0.f;
+    if (tid < NT) {
+        if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(lg) & 15) == 0) {
+            const float4* v4 = reinterpret_cast<const float4*>(lg);
+            for (int i = tid; i < (n >> 2); i += NT) {
+                const float4 v = v4[i];
+                const float mn = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                s = s * __expf(m - mn) + ((__expf(v.x - mn) + __expf(v.y - mn)) + (__expf(v.z - mn) + __expf(v.w - mn)));
+                m = mn;
+            }
+        } else {
+            for (int i = tid; i < n; i += NT) ms_push(m, s, lg[i]);
+        }
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) ms_merge(m, s, __shfl_xor(m, k, kWave), __shfl_xor(s, k, kWave));
+        if (lane == 0) { red[wave][0] = m; red[wave][1] = s; }
+    }
+    __syncthreads();
+    m = red[0][0]; s = red[0][1];
+#pragma unroll
+    for (int w = 1; w < NT / kWave; ++w) ms_merge(m, s, red[w][0], red[w][1]);
+    return m + __logf(s);
+}
+
+}  // namespace lc

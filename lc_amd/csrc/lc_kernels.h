@@ -241,5 +241,7 @@ struct SelectParams {
     unsigned seed;
 };
 int launch_dense_select(const SelectParams& p, hipStream_t stream);
+// front end + selection in one launch (test time, N <= 1024): the input arrays of `p` are unused (null), `d` names the maps
+int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d, hipStream_t stream);  // 3: N > 1024
 
 }  // namespace lc

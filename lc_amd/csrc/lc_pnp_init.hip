@@ -392,6 +392,7 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
         for (int i0 = 0; i0 < n; i0 += kBatch * nthr) {
             float X[kBatch], Y[kBatch], Z[kBatch], pu[kBatch], pv[kBatch];
             float2 sw[kBatch];
+            int src[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
                 const int i = i0 + k * nthr + tid;
@@ -400,6 +401,7 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
                 Z[k] = have ? p.pts3d[(base + i) * 3 + 2] : 0.f;
                 pu[k] = have ? p.pts2d[(base + i) * 2] : 0.f; pv[k] = have ? p.pts2d[(base + i) * 2 + 1] : 0.f;
                 sw[k] = have && sel ? *reinterpret_cast<const float2*>(p.sel_w + (base + i) * 2) : make_float2(0.f, 0.f);
+                src[k] = (have && sel && p.sel_in_index) ? p.sel_in_index[base + i] : i;
             }
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
@@ -426,7 +428,7 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
                         if (w < wave) off += wv_cnt[w];
                         kept += wv_cnt[w];
                     }
-                    if (in) rows.entry_from(base, i, off + __popcll(bal & ((1ull << lane) - 1ull)), pu[k], pv[k], sw[k], X[k], Y[k], Z[k]);
+                    if (in) rows.entry_from(base, off + __popcll(bal & ((1ull << lane) - 1ull)), pu[k], pv[k], sw[k], X[k], Y[k], Z[k], src[k]);
                 }
             }
         }

@@ -16,6 +16,7 @@
 #include <cfloat>
 
 #include "lc_common.h"
+#include "lc_dense_lse.h"
 #include "lc_kernels.h"
 #include "lc_select_rows.h"
 
@@ -30,22 +31,95 @@ __device__ __forceinline__ float torch_lerp(float a, float b, float w) {
     return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.f - w);
 }
 
-__global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectParams p) {
-    extern __shared__ float srt[];  // n order-preserving integer keys of the weights (modes 1, 2)
+// One count into an LDS histogram per lane that is `active`.  Weights cluster -- a quantile inside a mask zeroes every weight outside
+// it, and the top byte of positive floats of similar size is the same -- so a plain atomicAdd per lane sends hundreds of adds to ONE
+// address, which the LDS serialises.  Two rounds of leader aggregation (the lanes that share the first active lane's bin are counted
+// by one add of their ballot's population) take the crowd off; whoever is left adds for itself.
+__device__ __forceinline__ void hist_add(int* hist, unsigned bin, bool active, int lane) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long act = __ballot(active);
+        if (act == 0ull) return;  // wave-uniform
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned lb = (unsigned)__shfl((int)bin, leader, kWave);
+        const unsigned long long same = __ballot(active && bin == lb);
+        if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+        active = active && bin != lb;
+    }
+    if (active) atomicAdd(&hist[bin], 1);
+}
+
+// One entry of a row: image point, weights, model point, source index, mask bit.
+struct Entry {
+    float2 u, s;
+    float X[3];
+    int src;
+    unsigned char g;
+};
+
+// Rows held in arrays (lc_dense_select_f32)
+struct ArraySource {
+    const SelectParams& p;
+    size_t base;
+    __device__ __forceinline__ Entry load(int i) const {
+        Entry e;
+        e.s = *reinterpret_cast<const float2*>(p.inv_std + (base + i) * 2);
+        e.g = p.mask ? p.mask[base + i] : 0;
+        e.u = *reinterpret_cast<const float2*>(p.pts2d + (base + i) * 2);
+        for (int d = 0; d < 3; ++d) e.X[d] = p.pts3d[(base + i) * 3 + d];
+        e.src = p.in_index ? p.in_index[base + i] : i;
+        return e;
+    }
+};
+
+// Rows that exist only as the network's maps (lc_dense_frontend_select_f32): entry n is sampled pixel n of the dense front end,
+// formed with the front end's own arithmetic (lc_dense.hip: lc_dense_frontend_fwd_kernel)
+struct MapSource {
+    const float* lg;   // (2,H,W) weight logits of the sample
+    const float* xyz;  // (3,H,W)
+    const float* vis;  // (H,W) visibility logits or null
+    float lse, scale, ns[3], vis_thresh;
+    int HW, W, Wn, top, left, sample;
+    __device__ __forceinline__ int pixel(int n, int& x, int& y) const {
+        const int r = n / Wn;
+        y = top + r * sample;
+        x = left + (n - r * Wn) * sample;
+        return y * W + x;
+    }
+    // the part that does not need the log-sum-exp (requested while it is being formed): logits in s, raw xyz in X
+    __device__ __forceinline__ Entry fetch(int n) const {
+        int x, y;
+        const int px = pixel(n, x, y);
+        Entry e;
+        e.u = make_float2((float)x, (float)y);
+        e.s = make_float2(lg[px], lg[HW + px]);
+        for (int d = 0; d < 3; ++d) e.X[d] = xyz[d * HW + px];
+        e.g = vis ? ((1.f / (1.f + expf(-vis[px]))) > vis_thresh ? 1 : 0) : 0;  // torch.sigmoid's own formula
+        e.src = n;
+        return e;
+    }
+    __device__ __forceinline__ Entry finish(Entry e) const {
+        e.s = make_float2(__expf(e.s.x - lse) * scale, __expf(e.s.y - lse) * scale);
+        for (int d = 0; d < 3; ++d) e.X[d] *= ns[d];
+        return e;
+    }
+    __device__ __forceinline__ Entry load(int n) const { return finish(fetch(n)); }
+};
+
+// The selection of row b by the calling workgroup (kThreads threads).  e0: entry `tid` of the row, already in registers -- the only
+// one this thread handles when N <= 1024: its weights feed the threshold search, and its coordinates are there by the time the
+// compaction knows where they go.  srt: n floats of LDS (modes 1, 2).
+template <class Source>
+__device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, const Source& src, const Entry& e0, float* srt) {
     __shared__ int wave_cnt[kWaves];
     __shared__ int s_seg;
     __shared__ float s_thr;
     __shared__ int hist[256];
     __shared__ int s_sel[2];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = min(p.in_counts ? p.in_counts[b] : p.N, p.N);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)b * p.N;
-    const float* ws = p.inv_std + base * 2;
-    const unsigned char* seg = p.mask ? p.mask + base : nullptr;
-    auto weight = [&](int i) {
-        const float2 s = *reinterpret_cast<const float2*>(ws + 2 * i);
-        return (p.mode == 2 && !seg[i]) ? 0.f : s.x + s.y;  // mode 2: (inv_std * seg).sum(-1)
-    };
+    auto entry = [&](int i) { return i == tid ? e0 : src.load(i); };
+    auto weight_of = [&](const Entry& e) { return (p.mode == 2 && !e.g) ? 0.f : e.s.x + e.s.y; };  // mode 2: (inv_std * seg).sum(-1)
     if (tid == 0) { s_seg = 0; s_thr = -FLT_MAX; }
     __syncthreads();
     if (p.mode != 0 && n > 0) {
@@ -56,9 +130,10 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
         unsigned* keys = reinterpret_cast<unsigned*>(srt);
         int segc = 0;
         for (int i = tid; i < n; i += kThreads) {
-            const unsigned u = __float_as_uint(weight(i));
+            const Entry e = entry(i);
+            const unsigned u = __float_as_uint(weight_of(e));
             keys[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending unsigned order == ascending float order
-            if (p.mode == 2 && seg[i]) ++segc;
+            if (p.mode == 2 && e.g) ++segc;
         }
         if (p.mode == 2) {
 #pragma unroll
@@ -82,9 +157,10 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
                 const int shift = 8 * pass;
                 if (tid < 256) hist[tid] = 0;
                 __syncthreads();
-                for (int i = tid; i < n; i += kThreads) {
-                    const unsigned key = keys[i];
-                    if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+                for (int i0 = 0; i0 < n; i0 += kThreads) {
+                    const int i = i0 + tid;
+                    const unsigned key = i < n ? keys[i] : 0u;
+                    hist_add(hist, (key >> shift) & 255u, i < n && (key & mask) == prefix, lane);
                 }
                 __syncthreads();
                 if (wave == 0) {  // lane l owns bins 4l .. 4l+3: exclusive prefix over the lanes, then the bin holding rank k
@@ -142,14 +218,17 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
         __syncthreads();
     }
     const float thr = s_thr;
-    const RowCopy rows{p.pts2d, p.inv_std, p.pts3d, p.in_index, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
+    const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
+    auto put = [&](const Entry& e, int o) { rows.entry_from(base, o, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src); };
     int running = 0;  // survivors in the chunks before this one (same value in every thread)
     for (int i0 = 0; i0 < n; i0 += kThreads) {
         const int i = i0 + tid;
+        Entry e = e0;
         bool keep = false;
         if (i < n) {
-            if (p.mode == 0) keep = seg[i] != 0;
-            else keep = weight(i) >= thr && (p.mode == 1 || seg[i] != 0);
+            if (i0 != 0) e = src.load(i);
+            if (p.mode == 0) keep = e.g != 0;
+            else keep = weight_of(e) >= thr && (p.mode == 1 || e.g != 0);
         }
         const unsigned long long bal = __ballot(keep);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -161,12 +240,49 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
             if (w < wave) off += wave_cnt[w];
             tot += wave_cnt[w];
         }
-        if (keep) rows.entry(base, i, off + before);
+        if (keep) put(e, off + before);
         running = tot;
         __syncthreads();  // wave_cnt is rewritten by the next chunk
     }
-    const int total = rows.pad(base, b, n, running, p.min_count, p.seed);  // test.py:108-113
+    const int total = pad_rows(b, n, running, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
     if (tid == 0) p.counts[b] = total;
+}
+
+__global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectParams p) {
+    extern __shared__ float srt[];  // n order-preserving integer keys of the weights (modes 1, 2)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const ArraySource src{p, (size_t)b * p.N};
+    // requested whole before the row's count is known: one memory round trip at the start instead of three dependent ones
+    Entry e0{};
+    if (tid < p.N) e0 = src.load(tid);
+    const int n = min(p.in_counts ? p.in_counts[b] : p.N, p.N);
+    select_row(p, b, n, src, e0, srt);
+}
+
+// Test time, N <= 1024 sampled pixels per object: the dense front end (joint softmax x scale, strided sub-sampling, visibility mask:
+// test.py:85-92) and the point selection (test.py:94-113) in ONE launch, one workgroup per object.  The front end's (B,N,.) arrays
+// are never written: every thread forms the entry of its own sampled pixel in registers -- the log-sum-exp by the front end's own 512
+// threads in the front end's own order, so every selected value equals what the two launches produce bit for bit -- and hands it to
+// the selection above.
+__global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(const SelectParams p, const DenseParams d) {
+    extern __shared__ float srt[];
+    __shared__ float red[kDenseLseThreads / kWave][2];
+    const int b = blockIdx.x, tid = threadIdx.x, HW = d.H * d.W;
+    MapSource src;
+    src.lg = d.wlogits + (size_t)b * 2 * HW;
+    src.xyz = d.xyz + (size_t)b * 3 * HW;
+    src.vis = d.vis_logits ? d.vis_logits + (size_t)b * HW : nullptr;
+    src.vis_thresh = d.vis_thresh;
+    src.HW = HW; src.W = d.W; src.top = d.top; src.left = d.left; src.sample = d.sample;
+    src.Wn = (d.W - d.left + d.sample - 1) / d.sample;
+    src.lse = 0.f;
+    Entry e0{};
+    if (tid < p.N) e0 = src.fetch(tid);  // in flight while the log-sum-exp is formed
+    src.scale = d.wscale[b];
+    for (int k = 0; k < 3; ++k) src.ns[k] = d.noc_scale ? d.noc_scale[3 * b + k] : 1.f;
+    src.lse = block_lse<kDenseLseThreads>(src.lg, 2 * HW, red);
+    e0 = src.finish(e0);
+    select_row(p, b, p.N, src, e0, srt);
 }
 
 }  // namespace
@@ -181,6 +297,14 @@ int launch_dense_select(const SelectParams& p, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(lc_dense_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return 2;
     hipLaunchKernelGGL(lc_dense_select_kernel, dim3(p.B), dim3(kThreads), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d, hipStream_t stream) {
+    if (p.B <= 0) return 0;
+    if (p.N > kThreads) return 3;
+    const size_t lds = p.mode == 0 ? 0 : (size_t)kThreads * sizeof(float);
+    hipLaunchKernelGGL(lc_dense_frontend_select_kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -12,6 +12,16 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {
     return x;
 }
 
+// test.py:108-113, called by every thread of the workgroup with the same arguments: emit(i, k) copies source entry i to slot k;
+// returns the row's final count
+template <class Emit>
+__device__ __forceinline__ int pad_rows(int b, int n, int total, int min_count, unsigned seed, Emit&& emit) {
+    if (total >= min_count || n <= min_count) return total;
+    for (int k = total + (int)threadIdx.x; k < min_count; k += (int)blockDim.x)
+        emit((int)(hash_u32(seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)k)) % (unsigned)n), k);
+    return min_count;
+}
+
 struct RowCopy {
     const float* pts2d;   // (B,N,2)
     const float* w;       // (B,N,2)
@@ -34,21 +44,17 @@ struct RowCopy {
         if (o_index) o_index[base + o] = in_index ? in_index[base + i] : i;
     }
 
-    // the same for an entry whose values the caller already holds in registers
-    __device__ __forceinline__ void entry_from(size_t base, int i, int o, float u, float v, float2 s, float X, float Y, float Z) const {
+    // the same for an entry whose values the caller already holds in registers (src: its source index, in_index applied)
+    __device__ __forceinline__ void entry_from(size_t base, int o, float u, float v, float2 s, float X, float Y, float Z, int src) const {
         *reinterpret_cast<float2*>(o_pts2d + (base + o) * 2) = make_float2(u, v);
         *reinterpret_cast<float2*>(o_w + (base + o) * 2) = square ? make_float2(s.x * s.x, s.y * s.y) : s;
         float* oX = o_pts3d + (base + o) * 3;
         oX[0] = X; oX[1] = Y; oX[2] = Z;
-        if (o_index) o_index[base + o] = in_index ? in_index[base + i] : i;
+        if (o_index) o_index[base + o] = src;
     }
 
-    // test.py:108-113, called by every thread of the workgroup with the same arguments; returns the row's final count
     __device__ __forceinline__ int pad(size_t base, int b, int n, int total, int min_count, unsigned seed) const {
-        if (total >= min_count || n <= min_count) return total;
-        for (int k = total + (int)threadIdx.x; k < min_count; k += (int)blockDim.x)
-            entry(base, (int)(hash_u32(seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)k)) % (unsigned)n), k);
-        return min_count;
+        return pad_rows(b, n, total, min_count, seed, [&](int i, int k) { entry(base, i, k); });
     }
 };
 

@@ -108,6 +108,49 @@ def dense_front_end_with_visibility(xyz_noc: Tensor, xyz_weight_logits: Tensor, 
 SELECT_MODES = {"mask": 0, "quantile": 1, "quantile_in_mask": 2}
 
 
+FUSED_SELECT_MAX_POINTS = 1024  # lc_dense_frontend_select_f32: one thread per sampled pixel
+
+
+def _select_buffers(out, B, N, dev, what):
+    if out is None:
+        f32, i32 = dict(device=dev, dtype=torch.float32), dict(device=dev, dtype=torch.int32)
+        return (torch.empty(B, N, 2, **f32), torch.empty(B, N, 2, **f32), torch.empty(B, N, 3, **f32), torch.empty(B, **i32),
+                torch.empty(B, N, **i32))
+    o_u, o_w, o_x, o_c, o_i = out
+    if not (o_u.shape == o_w.shape == (B, N, 2) and o_x.shape == (B, N, 3) and o_c.shape == (B,) and o_i.shape == (B, N)
+            and o_u.dtype == o_w.dtype == o_x.dtype == torch.float32 and o_c.dtype == o_i.dtype == torch.int32
+            and all(t.is_contiguous() and t.device == dev for t in out)):
+        raise ValueError(f"{what}: `out` buffers must be contiguous tensors of the result shapes on the input's device")
+    return out
+
+
+@torch.no_grad()
+def dense_front_end_select(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scale: Tensor, noc_scale: Tensor,
+                           msk_vis_logits: Tensor, mode: str, *, seg_thresh: float = 0.5, sample: int = 2, top_left=(0, 0),
+                           quantile: float = 0.0, square_weights: bool = True, min_count: int = 4, seed: int = 0, out=None):
+    """`dense_front_end_with_visibility` followed by `dense_select(..., mask=visible)` as ONE launch (test time, at most
+    FUSED_SELECT_MAX_POINTS sampled pixels per object): the (B,N,.) rows in between are never written.  Returns what `dense_select`
+    returns -- (pts2d, weights, pts3d, counts, index), bit for bit."""
+    lib = _lib.load()
+    top, left = top_left
+    B, _, H, W = xyz_weight_logits.shape
+    xyz = _lib.require_hip_f32("xyz_noc", xyz_noc)
+    wl = _lib.require_hip_f32("xyz_weight_logits", xyz_weight_logits)
+    ws = _lib.require_hip_f32("xyz_weights_scale", xyz_weights_scale.reshape(B))
+    ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
+    vl = None if msk_vis_logits is None else _lib.require_hip_f32("msk_vis_logits", msk_vis_logits.reshape(B, H, W))
+    N = -(-(H - top) // sample) * -(-(W - left) // sample)
+    dev = wl.device
+    o_u, o_w, o_x, o_c, o_i = _select_buffers(out, B, N, dev, "dense_front_end_select")
+    with _lib.on_device(dev):
+        rc = lib.lc_dense_frontend_select_f32(_lib.ptr(xyz), _lib.ptr(wl), _lib.ptr(ws), _lib.ptr(ns), _lib.ptr(vl), float(seg_thresh), B, H, W,
+                                              int(top), int(left), int(sample), SELECT_MODES[mode], float(quantile), int(square_weights),
+                                              int(min_count), int(seed) & 0xFFFFFFFF, _lib.ptr(o_u), _lib.ptr(o_w), _lib.ptr(o_x), _lib.ptr(o_i),
+                                              _lib.ptr(o_c), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_dense_frontend_select_f32")
+    return o_u, o_w, o_x, o_c, o_i
+
+
 @torch.no_grad()
 def dense_select(pts2d: Tensor, inv_std2d: Tensor, pts3d: Tensor, mode: str, *, mask: Tensor = None, quantile: float = 0.0,
                  counts: Tensor = None, index: Tensor = None, square_weights: bool = True, min_count: int = 4, seed: int = 0, out=None):

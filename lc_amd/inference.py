@@ -20,7 +20,7 @@ import gc
 import torch
 from torch import Tensor
 
-from .dense import dense_front_end_with_visibility, dense_select
+from .dense import FUSED_SELECT_MAX_POINTS, dense_front_end_select, dense_front_end_with_visibility, dense_select
 from .losses import nn_out_to_xyz
 from .pnp import gpu_solver, pnp_ceres
 
@@ -70,38 +70,43 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     # joint softmax x scale, the (0,0)-phase stride sub-sampling (test.py:85-92) and the visibility mask of the sampled pixels
     # (test.py:88-90) in one launch
     thr = cfg.get("seg_thresh", 0.5)
-    if "xyz_noc" in out_dict and gt_dict.get("model_transform", None) is None and gt_dict.get("bit_cnt", None) is None:
-        # continuous head: the kernel scales the normalised coordinates itself (losses.py:17-22 is that one multiply)
-        pts2d, inv_std, pts3d, visible = dense_front_end_with_visibility(
-            out_dict["xyz_noc"], out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"], gt_dict["noc_scale"],
-            out_dict["msk_vis_logits"], thr, sample=stride)
-    else:
-        head = out_dict["xyz_noc"] if "xyz_noc" in out_dict else out_dict["xyz_noc_bin"]
-        xyz = nn_out_to_xyz(head, gt_dict["noc_scale"], model_transform=gt_dict.get("model_transform", None),
-                            bit_cnt=gt_dict.get("bit_cnt", None), inference=True)  # (B,H,W,3), object frame
-        pts2d, inv_std, pts3d, visible = dense_front_end_with_visibility(
-            xyz.permute(0, 3, 1, 2), out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"], None, out_dict["msk_vis_logits"], thr,
-            sample=stride)
-
     mode = cfg.dense_point_select
     if mode not in ("mask", "quantile", "quantile_in_mask"):
         raise ValueError(f"unknown dense_point_select {mode!r}")
+    if "xyz_noc" in out_dict and gt_dict.get("model_transform", None) is None and gt_dict.get("bit_cnt", None) is None:
+        # continuous head: the kernel scales the normalised coordinates itself (losses.py:17-22 is that one multiply)
+        xyz_map, noc_scale = out_dict["xyz_noc"], gt_dict["noc_scale"]
+    else:
+        head = out_dict["xyz_noc"] if "xyz_noc" in out_dict else out_dict["xyz_noc_bin"]
+        xyz_map = nn_out_to_xyz(head, gt_dict["noc_scale"], model_transform=gt_dict.get("model_transform", None),
+                                bit_cnt=gt_dict.get("bit_cnt", None), inference=True).permute(0, 3, 1, 2)  # (B,H,W,3), object frame
+        noc_scale = None
+
     # survivors compacted to the front of each row; icov = inv_std^2 (test.py:92); counts stay on the device.
     # 'weighted' and 'weighted-filtered' solve the same objects from the same start on two selections: when both are wanted the two
     # selections are written into the halves of ONE (2B, N, .) batch and solved by ONE launch (K and start shared through
     # `shared_poses`) -- 64 objects fill a quarter of the chip, the two solves side by side cost what one does.
     wanted = cfg.solvers
     both = "weighted_filtered" in wanted and "weighted" in wanted
-    B, N = pts2d.shape[:2]
+    B, _, H, W = out_dict["xyz_weight_logits"].shape
+    N = -(-H // stride) * -(-W // stride)
     rows = 2 * B if both else B
-    f32 = dict(device=pts2d.device, dtype=torch.float32)
-    i32 = dict(device=pts2d.device, dtype=torch.int32)
+    dev = out_dict["xyz_weight_logits"].device
+    f32, i32 = dict(device=dev, dtype=torch.float32), dict(device=dev, dtype=torch.int32)
     U2, W2, X2 = torch.empty(rows, N, 2, **f32), torch.empty(rows, N, 2, **f32), torch.empty(rows, N, 3, **f32)
     C2, I2 = torch.empty(rows, **i32), torch.empty(rows, N, **i32)
     halves = list(zip(*(t.chunk(2) if both else (t,) for t in (U2, W2, X2, C2, I2))))  # [(u, w, x, counts, index) of each half]
     half = halves.__getitem__
-    u, icov, x, counts, index = dense_select(pts2d, inv_std, pts3d, mode, mask=visible, quantile=float(cfg.get("quantile", 0.0)),
-                                             square_weights=True, min_count=4, out=half(0))
+    select_args = dict(quantile=float(cfg.get("quantile", 0.0)), square_weights=True, min_count=4, out=half(0))
+    if N <= FUSED_SELECT_MAX_POINTS:
+        # joint softmax x scale, the (0,0)-phase stride sub-sampling (test.py:85-92), the visibility mask of the sampled pixels
+        # (test.py:88-90) AND the point selection (test.py:94-113) in one launch
+        u, icov, x, counts, index = dense_front_end_select(xyz_map, out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"], noc_scale,
+                                                           out_dict["msk_vis_logits"], mode, seg_thresh=thr, sample=stride, **select_args)
+    else:
+        pts2d, inv_std, pts3d, visible = dense_front_end_with_visibility(xyz_map, out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"],
+                                                                         noc_scale, out_dict["msk_vis_logits"], thr, sample=stride)
+        u, icov, x, counts, index = dense_select(pts2d, inv_std, pts3d, mode, mask=visible, **select_args)
     # test.py:129-133: the selection intersected with the RANSAC inliers -- compacted by the RANSAC's own selection step (the workgroup
     # that writes the inlier mask), not by a `dense_select(..., 'mask', mask=inliers)` launch behind the refinement
     filtered = None

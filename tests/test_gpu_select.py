@@ -87,3 +87,43 @@ def test_select_rejects_bad_arguments():
         dense_select(u.to(DEV), s.to(DEV), x.to(DEV), "quantile_in_mask", quantile=0.5)  # needs a mask
     with pytest.raises(RuntimeError):
         dense_select(u.to(DEV), s.to(DEV), x.to(DEV), "quantile", quantile=1.5)
+
+
+@pytest.mark.parametrize("mode", ["mask", "quantile", "quantile_in_mask"])
+@pytest.mark.parametrize("B,H,W,sample,top_left,min_count", [(64, 64, 64, 2, (0, 0), 4), (5, 32, 32, 1, (0, 0), 4), (3, 37, 45, 2, (1, 0), 4),
+                                                           (4, 64, 64, 3, (2, 1), 6), (2, 16, 16, 4, (0, 0), 12)])
+def test_front_end_and_selection_in_one_launch(B, H, W, sample, top_left, min_count, mode):
+    """lc_dense_frontend_select_f32 against lc_dense_frontend_fwd2_f32 followed by lc_dense_select_f32 on its rows and visibility
+    mask: counts, source indices and every selected value bit for bit (same log-sum-exp reduction, same per-pixel arithmetic) --
+    incl. an object nothing of which is visible (padded with min_count pseudo-random entries) and one that is visible everywhere."""
+    from lc_amd.dense import dense_front_end_select, dense_front_end_with_visibility, dense_select
+
+    g = torch.Generator().manual_seed(B * H + W)
+    xyz = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    wl = (torch.randn(B, 2, H, W, generator=g) * 2).to(DEV)
+    ws = (torch.rand(B, generator=g) * 50 + 1).to(DEV)
+    ns = (torch.rand(B, 3, generator=g) * 100 + 10).to(DEV)
+    vl = (torch.randn(B, 1, H, W, generator=g) * 3).to(DEV)
+    vl[0] = -9.0
+    vl[1] = 9.0
+    kw = dict(quantile=0.35, square_weights=True, min_count=min_count, seed=7)
+    got = dense_front_end_select(xyz, wl, ws, ns, vl, mode, seg_thresh=0.5, sample=sample, top_left=top_left, **kw)
+    u, s, x, vis = dense_front_end_with_visibility(xyz, wl, ws, ns, vl, 0.5, sample=sample, top_left=top_left)
+    want = dense_select(u, s, x, mode, mask=vis, **kw)
+    cnt = want[3]
+    assert torch.equal(got[3], cnt)
+    N = u.shape[1]
+    if mode != "quantile":
+        assert int(cnt[0]) == (min_count if N > min_count else 0) and int(cnt[1]) >= min_count
+    live = torch.arange(N, device=DEV)[None, :] < cnt[:, None]
+    for k, name in ((0, "pts2d"), (1, "weights"), (2, "pts3d"), (4, "index")):
+        m = live if got[k].dim() == 2 else live[..., None].expand_as(got[k])
+        assert torch.equal(got[k][m], want[k][m]), name
+
+
+def test_front_end_select_rejects_more_than_1024_points():
+    from lc_amd.dense import dense_front_end_select
+
+    z = torch.zeros(1, 3, 128, 128, device=DEV)
+    with pytest.raises(RuntimeError, match="1024"):
+        dense_front_end_select(z, z[:, :2], torch.ones(1, device=DEV), None, z[:, :1], "mask", sample=2)
