@@ -26,7 +26,7 @@
 #include "lc_select_rows.h"
 
 #ifdef LC_P3P_STAMPS
-namespace lc { namespace p3p_diag { __device__ unsigned long long g_p3p_stamp[7]; } }
+namespace lc { namespace p3p_diag { __device__ unsigned long long g_p3p_stamp[7]; __device__ unsigned long long g_sel_stamp[8]; } }
 #endif
 
 namespace lc {
@@ -34,8 +34,10 @@ namespace {
 
 #ifdef LC_P3P_STAMPS  // diagnostic build (scripts/ubench/p3p_stamps.py): shader-clock stamps of the hypothesis kernel's phases
 #define LC_P3P_STAMP(i) ::lc::p3p_diag::g_p3p_stamp[i] = __builtin_amdgcn_s_memtime()
+#define LC_SEL_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) ::lc::p3p_diag::g_sel_stamp[i] = __builtin_amdgcn_s_memtime()
 #else
 #define LC_P3P_STAMP(i)
+#define LC_SEL_STAMP(i)
 #endif
 
 struct V3 { double x, y, z; };
@@ -239,19 +241,29 @@ __device__ void mat_to_quat(const double R[9], float q[4]) {
     const double tr = R[0] + R[4] + R[8];
     double w, x, y, z;
     if (tr > 0) {
-        const double s = sqrt(tr + 1.0) * 2.0;
-        w = 0.25 * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s;
+        double s, is;
+        fast_sqrt_rsqrt(tr + 1.0, s, is);
+        s *= 2.0; is *= 0.5;
+        w = 0.25 * s; x = (R[7] - R[5]) * is; y = (R[2] - R[6]) * is; z = (R[3] - R[1]) * is;
     } else if (R[0] > R[4] && R[0] > R[8]) {
-        const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2.0;
-        w = (R[7] - R[5]) / s; x = 0.25 * s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s;
+        double s, is;
+        fast_sqrt_rsqrt(1.0 + R[0] - R[4] - R[8], s, is);
+        s *= 2.0; is *= 0.5;
+        w = (R[7] - R[5]) * is; x = 0.25 * s; y = (R[1] + R[3]) * is; z = (R[2] + R[6]) * is;
     } else if (R[4] > R[8]) {
-        const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2.0;
-        w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = 0.25 * s; z = (R[5] + R[7]) / s;
+        double s, is;
+        fast_sqrt_rsqrt(1.0 + R[4] - R[0] - R[8], s, is);
+        s *= 2.0; is *= 0.5;
+        w = (R[2] - R[6]) * is; x = (R[1] + R[3]) * is; y = 0.25 * s; z = (R[5] + R[7]) * is;
     } else {
-        const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2.0;
-        w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = 0.25 * s;
+        double s, is;
+        fast_sqrt_rsqrt(1.0 + R[8] - R[0] - R[4], s, is);
+        s *= 2.0; is *= 0.5;
+        w = (R[3] - R[1]) * is; x = (R[2] + R[6]) * is; y = (R[5] + R[7]) * is; z = 0.25 * s;
     }
-    const double n = 1.0 / sqrt(w * w + x * x + y * y + z * z), sg = w < 0 ? -n : n;
+    double nn, n;
+    fast_sqrt_rsqrt(w * w + x * x + y * y + z * z, nn, n);
+    const double sg = w < 0 ? -n : n;
     q[0] = (float)(w * sg); q[1] = (float)(x * sg); q[2] = (float)(y * sg); q[3] = (float)(z * sg);
 }
 
@@ -372,81 +384,44 @@ __device__ __forceinline__ RowCopy selection_rows(const RansacParams& p) {
     return RowCopy{p.pts2d, p.sel_w, p.pts3d, p.sel_in_index, p.sel_pts2d, p.sel_w_out, p.sel_pts3d, p.sel_index, 0};
 }
 
+// The correspondences (and, for the re-selection, their weights and source indices) of kBatch consecutive chunks of blockDim.x
+// entries, requested together: one memory round trip per batch.  cap: entries below it exist (rows are padded to Nmax, so a caller
+// that does not know the pose's count yet asks with cap = Nmax and applies the count later).
+constexpr int kBatch = 4;
+struct PointBatch {
+    float X[kBatch], Y[kBatch], Z[kBatch], pu[kBatch], pv[kBatch];
+    float2 sw[kBatch];
+    int src[kBatch];
+};
+__device__ __forceinline__ PointBatch load_batch(const RansacParams& p, size_t base, int i0, int cap) {
+    const bool sel = p.sel_w != nullptr;
+    PointBatch q;
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+        const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
+        const bool have = i < cap;
+        q.X[k] = have ? p.pts3d[(base + i) * 3] : 0.f; q.Y[k] = have ? p.pts3d[(base + i) * 3 + 1] : 0.f;
+        q.Z[k] = have ? p.pts3d[(base + i) * 3 + 2] : 0.f;
+        q.pu[k] = have ? p.pts2d[(base + i) * 2] : 0.f; q.pv[k] = have ? p.pts2d[(base + i) * 2 + 1] : 0.f;
+        q.sw[k] = have && sel ? *reinterpret_cast<const float2*>(p.sel_w + (base + i) * 2) : make_float2(0.f, 0.f);
+        q.src[k] = (have && sel && p.sel_in_index) ? p.sel_in_index[base + i] : i;
+    }
+    return q;
+}
+
 // Winner of pose b -> outputs: inlier mask over ALL n points, their count, the pose as quaternion + translation, flags and (when
-// asked for) the inliers compacted to the front of the selection rows.  Called by every thread of the workgroup; wv_cnt: LDS scratch,
-// one int per wavefront.
+// asked for) the inliers compacted to the front of the selection rows.  Called by every thread of the workgroup; cc: LDS scratch, one
+// int per (chunk of the batch, wavefront); first: load_batch(p, base, 0, cap >= n), which the caller may have requested long before
+// the winner was known.
+typedef int ChunkCounts[kBatch][4];
 __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n, bool ok, const double* bp, int win_hyp, float thr2,
-                                             const CamInv& kin, int* wv_cnt) {
+                                             const CamInv& kin, ChunkCounts& cc, const PointBatch& first) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const size_t base = (size_t)b * p.Nmax;
     unsigned char* mask = p.inlier_mask + base;
     const bool sel = p.sel_w != nullptr;
     const RowCopy rows = selection_rows(p);
-    int kept = 0;  // inliers in the chunks before this one (same value in every thread; selection only)
-    if (ok) {
-        float R[9], t[3];
-        for (int k = 0; k < 9; ++k) R[k] = (float)bp[k];
-        for (int k = 0; k < 3; ++k) t[k] = (float)bp[9 + k];
-        int total = 0;
-        constexpr int kBatch = 4;  // chunks whose correspondences are requested together: one memory round trip per four chunks
-        for (int i0 = 0; i0 < n; i0 += kBatch * nthr) {
-            float X[kBatch], Y[kBatch], Z[kBatch], pu[kBatch], pv[kBatch];
-            float2 sw[kBatch];
-            int src[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int i = i0 + k * nthr + tid;
-                const bool have = i < n;
-                X[k] = have ? p.pts3d[(base + i) * 3] : 0.f; Y[k] = have ? p.pts3d[(base + i) * 3 + 1] : 0.f;
-                Z[k] = have ? p.pts3d[(base + i) * 3 + 2] : 0.f;
-                pu[k] = have ? p.pts2d[(base + i) * 2] : 0.f; pv[k] = have ? p.pts2d[(base + i) * 2 + 1] : 0.f;
-                sw[k] = have && sel ? *reinterpret_cast<const float2*>(p.sel_w + (base + i) * 2) : make_float2(0.f, 0.f);
-                src[k] = (have && sel && p.sel_in_index) ? p.sel_in_index[base + i] : i;
-            }
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                if (i0 + k * nthr >= n) break;  // uniform
-                const int i = i0 + k * nthr + tid;
-                bool in = false;
-                if (i < n) {
-                    float ux, uy;
-                    kin.normalise(pu[k], pv[k], ux, uy);
-                    const float cz = R[6] * X[k] + R[7] * Y[k] + R[8] * Z[k] + t[2];
-                    const float ex = (R[0] * X[k] + R[1] * Y[k] + R[2] * Z[k] + t[0]) / cz - ux,
-                                ey = (R[3] * X[k] + R[4] * Y[k] + R[5] * Z[k] + t[1]) / cz - uy;
-                    in = cz > 0 && (ex * ex + ey * ey) < thr2;
-                    mask[i] = in ? 1 : 0;
-                    total += in ? 1 : 0;
-                }
-                if (sel) {  // order-preserving compaction: ballot within the wave, prefix over the waves of this chunk
-                    const unsigned long long bal = __ballot(in);
-                    __syncthreads();  // wv_cnt: the caller's arg-max / the previous chunk's prefix may still be reading
-                    if (lane == 0) wv_cnt[wave] = __popcll(bal);
-                    __syncthreads();
-                    int off = kept;
-                    for (int w = 0; w < nwaves; ++w) {
-                        if (w < wave) off += wv_cnt[w];
-                        kept += wv_cnt[w];
-                    }
-                    if (in) rows.entry_from(base, off + __popcll(bal & ((1ull << lane) - 1ull)), pu[k], pv[k], sw[k], X[k], Y[k], Z[k], src[k]);
-                }
-            }
-        }
-        for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m, kWave);
-        __syncthreads();  // wv_cnt may still be read by the caller's arg-max
-        if (lane == 0) wv_cnt[wave] = total;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < nwaves; ++w) tot += wv_cnt[w];
-            p.n_inliers[b] = tot;
-        }
-    }
-    if (sel) {
-        const int cnt = rows.pad(base, b, n, kept, p.sel_min_count, p.sel_seed);
-        if (tid == 0) p.sel_counts[b] = cnt;
-    }
-    if (tid == 0) {
+    if (tid == nthr - 1) {  // everything but the inlier count is known: written now, under the loop's memory traffic
         float* st = p.states + 7 * (size_t)b;
         if (ok) {
             mat_to_quat(bp, st);
@@ -458,6 +433,54 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
         p.invalid[b] = ok ? 0 : 1;
         if (p.best_hyp) p.best_hyp[b] = ok ? win_hyp : -1;
         if (p.valid_counts) p.valid_counts[b] = ok ? n : 0;
+    }
+    int kept = 0;  // inliers in the chunks before this one (same value in every thread)
+    if (ok) {
+        float R[9], t[3];
+        for (int k = 0; k < 9; ++k) R[k] = (float)bp[k];
+        for (int k = 0; k < 3; ++k) t[k] = (float)bp[9 + k];
+        for (int i0 = 0; i0 < n; i0 += kBatch * nthr) {
+            const PointBatch q = i0 == 0 ? first : load_batch(p, base, i0, n);
+            bool in[kBatch];
+            unsigned long long bal[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int i = i0 + k * nthr + tid;
+                in[k] = false;
+                if (i < n) {
+                    float ux, uy;
+                    kin.normalise(q.pu[k], q.pv[k], ux, uy);
+                    const float cz = R[6] * q.X[k] + R[7] * q.Y[k] + R[8] * q.Z[k] + t[2];
+                    const float ex = (R[0] * q.X[k] + R[1] * q.Y[k] + R[2] * q.Z[k] + t[0]) / cz - ux,
+                                ey = (R[3] * q.X[k] + R[4] * q.Y[k] + R[5] * q.Z[k] + t[1]) / cz - uy;
+                    in[k] = cz > 0 && (ex * ex + ey * ey) < thr2;
+                    mask[i] = in[k] ? 1 : 0;
+                }
+                bal[k] = __ballot(in[k]);
+            }
+            // inlier counts of the batch's chunks per wavefront through LDS: ONE barrier pair per batch gives every thread the
+            // number of inliers before its own (order-preserving compaction) and the running total (the inlier count itself)
+            __syncthreads();  // cc: the caller's arg-max / the previous batch's prefix may still be reading
+            if (lane < kBatch) cc[lane][wave] = __popcll(lane == 0 ? bal[0] : (lane == 1 ? bal[1] : (lane == 2 ? bal[2] : bal[3])));
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                int off = kept;
+                for (int w = 0; w < nwaves; ++w) {
+                    if (w < wave) off += cc[k][w];
+                    kept += cc[k][w];
+                }
+                if (sel && in[k])
+                    rows.entry_from(base, off + __popcll(bal[k] & ((1ull << lane) - 1ull)), q.pu[k], q.pv[k], q.sw[k], q.X[k], q.Y[k], q.Z[k], q.src[k]);
+            }
+        }
+        LC_SEL_STAMP(4);
+        if (tid == 0) p.n_inliers[b] = kept;
+    }
+    LC_SEL_STAMP(5);
+    if (sel) {
+        const int cnt = rows.pad(base, b, n, kept, p.sel_min_count, p.sel_seed);
+        if (tid == 0) p.sel_counts[b] = cnt;
     }
 }
 
@@ -485,6 +508,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
     __shared__ double best_pose[kRansacMaxWaves][12];
     __shared__ int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
     __shared__ float wv_err[kRansacMaxWaves];
+    __shared__ ChunkCounts chunk_cnt;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
     const size_t base = (size_t)b * p.Nmax;
@@ -564,7 +588,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
     for (int w = 1; w < nwaves; ++w) {
         if (better(wv_cnt[w], wv_err[w], wv_hyp[w], win_cnt, win_err, win_hyp)) { win_cnt = wv_cnt[w]; win_err = wv_err[w]; win_hyp = wv_hyp[w]; ww = w; }
     }
-    write_result(p, b, n, win_cnt >= 4, best_pose[ww], win_hyp, thr2, kin, wv_cnt);
+    write_result(p, b, n, win_cnt >= 4, best_pose[ww], win_hyp, thr2, kin, chunk_cnt, load_batch(p, base, 0, n));
 }
 
 
@@ -580,14 +604,19 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
 // Same hypothesis stream, same per-point arithmetic, same ordering as the single launch (the error sums are associated by chunk).
 constexpr int kChunkPts = 64;
 
+__host__ __device__ inline unsigned long long pack_partial(int cnt, float err) {
+    return (unsigned long long)(unsigned)cnt | ((unsigned long long)__builtin_bit_cast(unsigned, err) << 32);
+}
+__host__ __device__ inline int partial_cnt(unsigned long long v) { return (int)(unsigned)v; }
+__host__ __device__ inline float partial_err(unsigned long long v) { return __builtin_bit_cast(float, (unsigned)(v >> 32)); }
+
 __host__ __device__ inline size_t ransac_counter_bytes(int B) { return 8 * (((size_t)B + 1) / 2); }  // keeps the doubles behind it aligned
 
 struct RansacWorkspace {
     unsigned* arrived;  // (B,) chunks of the pose scored so far (ticketed form; zeroed by the hypotheses launch)
     double* hyp64;   // (B, H, 12)
     float* hyp32;    // (B, H, 12)
-    int* part_cnt;   // (B, C, H)
-    float* part_err; // (B, C, H)
+    unsigned long long* part;  // (B, C, H) chunk partials: inlier count in the low word, the bits of the float error sum in the high word
     int H, C;
 };
 __host__ __device__ inline RansacWorkspace carve_workspace(void* ws, int B, int Nmax, int rounds) {
@@ -600,8 +629,7 @@ __host__ __device__ inline RansacWorkspace carve_workspace(void* ws, int B, int 
     w.arrived = reinterpret_cast<unsigned*>(q); q += ransac_counter_bytes(B);
     w.hyp64 = reinterpret_cast<double*>(q); q += sizeof(double) * 12 * (size_t)B * w.H;
     w.hyp32 = reinterpret_cast<float*>(q); q += sizeof(float) * 12 * (size_t)B * w.H;
-    w.part_cnt = reinterpret_cast<int*>(q); q += sizeof(int) * (size_t)B * w.C * w.H;
-    w.part_err = reinterpret_cast<float*>(q);
+    w.part = reinterpret_cast<unsigned long long*>(q);
     return w;
 }
 
@@ -699,8 +727,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
         X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
     }
     const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
-    w.part_cnt[o] = cnt;
-    w.part_err[o] = err2.x + err2.y;
+    w.part[o] = pack_partial(cnt, err2.x + err2.y);
 }
 
 // Selection of pose b by the calling workgroup: chunk partials of every hypothesis summed in chunk order (the sums do not depend on
@@ -710,51 +737,58 @@ struct SelectShared {
     double best_pose[12];
     int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
     float wv_err[kRansacMaxWaves];
+    ChunkCounts chunk_cnt;
 };
 template <bool XCD>
 __device__ __forceinline__ void select_winner(const RansacParams& p, const RansacWorkspace& w, int b, SelectShared& sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
-    auto cnt_at = [&](size_t o) { return XCD ? xcd_load(w.part_cnt + o) : w.part_cnt[o]; };
-    auto err_at = [&](size_t o) { return XCD ? xcd_load(w.part_err + o) : w.part_err[o]; };
+    auto part_at = [&](size_t o) { return XCD ? xcd_load(w.part + o) : w.part[o]; };
     int win_cnt = -1, win_hyp = 0x7fffffff;
     float win_err = INFINITY;
-    // the first hypothesis of this thread: its chunk partials are requested together with the point count (rows of chunks the
-    // pose does not have hold stale values and are not summed)
-    int pc0[kMaxLdsPts / kChunkPts];
-    float pe0[kMaxLdsPts / kChunkPts];
-#pragma unroll
-    for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {
-        const bool have = c < w.C && tid < w.H;
-        const size_t o = ((size_t)b * w.C + c) * w.H + tid;
-        pc0[c] = have ? cnt_at(o) : 0;
-        pe0[c] = have ? err_at(o) : 0.f;
-    }
-    const CamInv kin(p.K + 9 * (size_t)b);
+    LC_SEL_STAMP(0);
+    // The pose's point count first (one scalar), then everything that does not depend on the winner in ONE memory round trip, and no
+    // more of it than the count asks for (the kernel is bound by the number of its load instructions: 75 per thread with all 16
+    // chunk rows and all four batch slots requested blindly, ~30 this way): the first batch of the pose's correspondences (the
+    // inlier mask below needs them), this thread's own hypothesis in double precision (the winner's is the answer: its thread hands
+    // it over through LDS instead of a dependent load), the chunk partials of this thread's first hypothesis.
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+    const int chunks = n >= 4 ? (min(n, kMaxLdsPts) + kChunkPts - 1) / kChunkPts : 0;
+    const PointBatch first = load_batch(p, (size_t)b * p.Nmax, 0, n);
+    double2 mine[6];
+    {
+        const double2* h = reinterpret_cast<const double2*>(w.hyp64 + 12 * ((size_t)b * w.H + (tid < w.H ? tid : 0)));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) mine[k] = h[k];
+    }
+    unsigned long long pc0[kMaxLdsPts / kChunkPts];
+#pragma unroll
+    for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c)
+        pc0[c] = (c < chunks && tid < w.H) ? part_at(((size_t)b * w.C + c) * w.H + tid) : 0ull;
+    const CamInv kin(p.K + 9 * (size_t)b);
     unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
     for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
     if (n < 4) {
         write_too_few(p, b, max(n, 0));
         return;
     }
-    const int chunks = (min(n, kMaxLdsPts) + kChunkPts - 1) / kChunkPts;
     if (tid < w.H) {
         int cnt = 0;
         float err = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {
-            cnt += c < chunks ? pc0[c] : 0;
-            err += c < chunks ? pe0[c] : 0.f;
+        for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {  // chunk order; rows the pose does not have were not requested (zero)
+            cnt += partial_cnt(pc0[c]);
+            err += c < chunks ? partial_err(pc0[c]) : 0.f;
         }
         win_cnt = cnt; win_err = err; win_hyp = tid;
     }
+    LC_SEL_STAMP(1);
     for (int hyp = tid + nthr; hyp < w.H; hyp += nthr) {  // more hypotheses than threads
         int cnt = 0;
         float err = 0.f;
         for (int c = 0; c < chunks; ++c) {
-            const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
-            cnt += cnt_at(o);
-            err += err_at(o);
+            const unsigned long long v = part_at(((size_t)b * w.C + c) * w.H + hyp);
+            cnt += partial_cnt(v);
+            err += partial_err(v);
         }
         if (better_hyp(cnt, err, hyp, win_cnt, win_err, win_hyp)) { win_cnt = cnt; win_err = err; win_hyp = hyp; }
     }
@@ -769,11 +803,22 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
     for (int v = 1; v < nwaves; ++v)
         if (better_hyp(sh.wv_cnt[v], sh.wv_err[v], sh.wv_hyp[v], win_cnt, win_err, win_hyp)) { win_cnt = sh.wv_cnt[v]; win_err = sh.wv_err[v]; win_hyp = sh.wv_hyp[v]; }
     const bool ok = win_cnt >= 4;
-    if (ok && tid < 12) sh.best_pose[tid] = w.hyp64[12 * ((size_t)b * w.H + win_hyp) + tid];
+    LC_SEL_STAMP(2);
+    if (ok) {
+        if (win_hyp < nthr) {
+            if (tid == win_hyp)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { sh.best_pose[2 * k] = mine[k].x; sh.best_pose[2 * k + 1] = mine[k].y; }
+        } else if (tid < 12) {  // more hypotheses than threads and the winner is one of the later ones
+            sh.best_pose[tid] = w.hyp64[12 * ((size_t)b * w.H + win_hyp) + tid];
+        }
+    }
     __syncthreads();
     const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
     const float thr = thr_px * (float)sqrt(fabs(kin.idet));
-    write_result(p, b, n, ok, sh.best_pose, win_hyp, thr * thr, kin, sh.wv_cnt);
+    LC_SEL_STAMP(3);
+    write_result(p, b, n, ok, sh.best_pose, win_hyp, thr * thr, kin, sh.chunk_cnt, first);
+    LC_SEL_STAMP(6);
 }
 
 __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kernel(const RansacParams p) {
@@ -862,8 +907,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_selec
             X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
         }
         const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
-        xcd_store(w.part_cnt + o, cnt);
-        xcd_store(w.part_err + o, err2.x + err2.y);
+        xcd_store(w.part + o, pack_partial(cnt, err2.x + err2.y));
     }
     xcd_stores_done();
     __syncthreads();  // every wave's partials have been acknowledged
@@ -906,6 +950,9 @@ int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
 }  // namespace lc
 
 #ifdef LC_P3P_STAMPS
+extern "C" __attribute__((visibility("default"))) int lc_debug_sel_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::p3p_diag::g_sel_stamp), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
+}
 extern "C" __attribute__((visibility("default"))) int lc_debug_p3p_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::p3p_diag::g_p3p_stamp), sizeof(unsigned long long) * 7) == hipSuccess ? 0 : 1;
 }

@@ -111,24 +111,27 @@ struct MapSource {
 // compaction knows where they go.  srt: n floats of LDS (modes 1, 2).
 template <class Source>
 __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, const Source& src, const Entry& e0, float* srt) {
-    __shared__ int wave_cnt[kWaves];
-    __shared__ int s_seg;
-    __shared__ float s_thr;
-    __shared__ int hist[256];
-    __shared__ int s_sel[2];
+    __shared__ int wave_cnt[kWaves];    // compaction: survivors per wavefront
+    __shared__ int wave_seg[kWaves];    // mode 2: visible entries per wavefront
+    __shared__ int wave_le[kWaves];     // upper order statistic: keys <= the lower one / smallest key above it, per wavefront
+    __shared__ unsigned wave_above[kWaves];
+    __shared__ int hist[3][256];        // radix passes rotate through three histograms: ONE barrier per pass (see below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)b * p.N;
     auto entry = [&](int i) { return i == tid ? e0 : src.load(i); };
     auto weight_of = [&](const Entry& e) { return (p.mode == 2 && !e.g) ? 0.f : e.s.x + e.s.y; };  // mode 2: (inv_std * seg).sum(-1)
-    if (tid == 0) { s_seg = 0; s_thr = -FLT_MAX; }
-    __syncthreads();
+    float thr = -FLT_MAX;
     if (p.mode != 0 && n > 0) {
         // torch.quantile needs only the two order statistics around q (n - 1): a most-significant-digit RADIX SELECT over the
-        // order-preserving integer image of the weights (4 passes of 8 bits: LDS histogram, one-wave scan) finds the lower one in
-        // O(n), one counting pass the upper one -- the bitonic sort it replaces took 78 barrier-separated stages for n = 4096 (44.8 -> ~10 us per launch).  The
-        // threshold is formed from the same two floats, so the selected index sets are unchanged bit for bit.
+        // order-preserving integer image of the weights (4 passes of 8 bits) finds the lower one in O(n), one counting pass the upper
+        // one -- the bitonic sort it replaces took 78 barrier-separated stages for n = 4096.  The threshold is formed from the same
+        // two floats, so the selected index sets are unchanged bit for bit.
+        // Barriers are what this section costs (16 wavefronts each): every pass has ONE -- the histogram of pass k is scanned by
+        // every wavefront for itself (no broadcast), the histogram of pass k+1 was zeroed while pass k was counting, and with three
+        // of them in rotation the one zeroed during pass k+2 is the one whose scan ended before pass k+1's barrier.
         unsigned* keys = reinterpret_cast<unsigned*>(srt);
         int segc = 0;
+        if (tid < 256) hist[0][tid] = 0;
         for (int i = tid; i < n; i += kThreads) {
             const Entry e = entry(i);
             const unsigned u = __float_as_uint(weight_of(e));
@@ -138,11 +141,16 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
         if (p.mode == 2) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) segc += __shfl_xor(segc, m, kWave);
-            if (lane == 0) atomicAdd(&s_seg, segc);
+            if (lane == 0) wave_seg[wave] = segc;
         }
         __syncthreads();
         float q = p.quantile;
-        if (p.mode == 2) q = 1.f - p.one_minus_q * ((float)s_seg / (float)n);  // test.py:102-103, fp32 like the tensor op
+        if (p.mode == 2) {
+            int seg_total = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) seg_total += wave_seg[w];
+            q = 1.f - p.one_minus_q * ((float)seg_total / (float)n);  // test.py:102-103, fp32 like the tensor op
+        }
         q = fminf(fmaxf(q, 0.f), 1.f);
         const float rank = q * (float)(n - 1);
         const float lo = floorf(rank), hi = ceilf(rank);
@@ -154,42 +162,35 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
             unsigned prefix = 0u, mask = 0u;
             int k = klo;  // 0-based rank among the elements that still match the prefix
             for (int pass = 3; pass >= 0; --pass) {
-                const int shift = 8 * pass;
-                if (tid < 256) hist[tid] = 0;
-                __syncthreads();
+                const int shift = 8 * pass, cur = (3 - pass) % 3, nxt = (cur + 1) % 3;
+                if (tid < 256) hist[nxt][tid] = 0;
                 for (int i0 = 0; i0 < n; i0 += kThreads) {
                     const int i = i0 + tid;
                     const unsigned key = i < n ? keys[i] : 0u;
-                    hist_add(hist, (key >> shift) & 255u, i < n && (key & mask) == prefix, lane);
+                    hist_add(hist[cur], (key >> shift) & 255u, i < n && (key & mask) == prefix, lane);
                 }
                 __syncthreads();
-                if (wave == 0) {  // lane l owns bins 4l .. 4l+3: exclusive prefix over the lanes, then the bin holding rank k
-                    const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
-                    const int mine = c0 + c1 + c2 + c3;
-                    int incl = mine;
+                // every wavefront: lane l owns bins 4l .. 4l+3, exclusive prefix over the lanes, then the bin holding rank k
+                const int c0 = hist[cur][4 * lane], c1 = hist[cur][4 * lane + 1], c2 = hist[cur][4 * lane + 2], c3 = hist[cur][4 * lane + 3];
+                const int mine = c0 + c1 + c2 + c3;
+                int incl = mine;
 #pragma unroll
-                    for (int d = 1; d < kWave; d <<= 1) {
-                        const int up = __shfl_up(incl, d, kWave);
-                        if (lane >= d) incl += up;
-                    }
-                    const int excl = incl - mine;
-                    if (k >= excl && k < incl) {  // exactly one lane
-                        int r = k - excl, bin = 4 * lane;
-                        if (r >= c0) { r -= c0; ++bin; if (r >= c1) { r -= c1; ++bin; if (r >= c2) { r -= c2; ++bin; } } }
-                        s_sel[0] = bin;
-                        s_sel[1] = r;
-                    }
+                for (int d = 1; d < kWave; d <<= 1) {
+                    const int up = __shfl_up(incl, d, kWave);
+                    if (lane >= d) incl += up;
                 }
-                __syncthreads();
-                prefix |= (unsigned)s_sel[0] << shift;
+                const int excl = incl - mine;
+                const bool hit = k >= excl && k < incl;  // exactly one lane
+                int r = k - excl, bin = 4 * lane;
+                if (r >= c0) { r -= c0; ++bin; if (r >= c1) { r -= c1; ++bin; if (r >= c2) { r -= c2; ++bin; } } }
+                const int owner = __ffsll((long long)__ballot(hit)) - 1;
+                prefix |= (unsigned)__shfl(bin, owner, kWave) << shift;
                 mask |= 255u << shift;
-                k = s_sel[1];
+                k = __shfl(r, owner, kWave);
             }
             found[0] = found[1] = prefix;
         }
-        if (khi != klo) {
-            if (tid < 2) hist[tid] = tid == 0 ? 0 : -1;  // hist[0]: #keys <= found[0];  hist[1]: smallest key above it (as unsigned max)
-            __syncthreads();
+        if (khi != klo) {  // uniform
             int le = 0;
             unsigned above = 0xFFFFFFFFu;
             for (int i = tid; i < n; i += kThreads) {
@@ -202,22 +203,18 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
                 le += __shfl_xor(le, m, kWave);
                 above = min(above, (unsigned)__shfl_xor((int)above, m, kWave));
             }
-            if (lane == 0) {
-                atomicAdd(&hist[0], le);
-                atomicMin(reinterpret_cast<unsigned*>(&hist[1]), above);
-            }
+            if (lane == 0) { wave_le[wave] = le; wave_above[wave] = above; }
             __syncthreads();
-            if (hist[0] <= khi) found[1] = (unsigned)hist[1];  // no duplicate reaches rank khi: the next distinct key
-            __syncthreads();  // hist is reused by nothing below, but keep the read before any later write
+            int le_total = 0;
+            unsigned above_min = 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) { le_total += wave_le[w]; above_min = min(above_min, wave_above[w]); }
+            if (le_total <= khi) found[1] = above_min;  // no duplicate reaches rank khi: the next distinct key
         }
-        if (tid == 0) {
-            auto unkey = [](unsigned kk) { return __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk); };
-            const float vlo = unkey(found[0]), vhi = khi != klo ? unkey(found[1]) : vlo;
-            s_thr = torch_lerp(vlo, vhi, rank - lo);
-        }
-        __syncthreads();
+        auto unkey = [](unsigned kk) { return __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk); };
+        const float vlo = unkey(found[0]), vhi = khi != klo ? unkey(found[1]) : vlo;
+        thr = torch_lerp(vlo, vhi, rank - lo);  // every thread forms it from the same two floats
     }
-    const float thr = s_thr;
     const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
     auto put = [&](const Entry& e, int o) { rows.entry_from(base, o, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src); };
     int running = 0;  // survivors in the chunks before this one (same value in every thread)
@@ -242,7 +239,7 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
         }
         if (keep) put(e, off + before);
         running = tot;
-        __syncthreads();  // wave_cnt is rewritten by the next chunk
+        if (i0 + kThreads < n) __syncthreads();  // wave_cnt is rewritten by the next chunk
     }
     const int total = pad_rows(b, n, running, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
     if (tid == 0) p.counts[b] = total;

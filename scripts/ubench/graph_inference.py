@@ -49,4 +49,5 @@ torch.cuda.synchronize()
 same = all(torch.equal(res[k], eager[k]) for k in eager)
 print(f"captured: results equal to eager: {same}")
 print(f"eager  {timeit(lambda: solve_pnp(cfg, out, gt)):7.1f} us per call (64 objects)")
-print(f"replay {timeit(graph.replay):7.1f} us per call")
+runs = sorted(timeit(graph.replay, 200) for _ in range(9))
+print(f"replay {runs[4]:7.1f} us per call (median of 9 x 200 replays; min {runs[0]:.1f}, max {runs[-1]:.1f})")

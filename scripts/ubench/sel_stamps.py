@@ -1,0 +1,46 @@
+"""Phase clock of lc_ransac_select_kernel (workgroup 0, thread 0): diagnostic build -DLC_P3P_STAMPS, shader cycles (s_memtime)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from lc_amd import build  # noqa: E402
+
+LIB = os.path.join(ROOT, "lc_amd", "_C", "liblc_amd_p3pstamps.so")
+if "--build" in sys.argv or not os.path.exists(LIB):
+    build.build_variant("p3pstamps", ["-DLC_P3P_STAMPS"])
+    if "--build" in sys.argv:
+        sys.exit(0)
+os.environ["LC_AMD_LIB"] = LIB
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from lc_amd import _lib, synth  # noqa: E402
+from lc_amd.pnp import gpu_solver  # noqa: E402
+
+NAMES = ["requests issued .. partial sums", "(more hypotheses)", "arg-max over lanes and waves", "winner's pose through LDS", "inlier mask + compaction",
+         "inlier count", "padding + outputs"]
+dev = torch.device("cuda:0")
+lib = _lib.load()
+fn = lib.lc_debug_sel_stamps
+fn.argtypes = [ctypes.c_void_p]
+rows = []
+B, N = 64, 1024
+g = torch.Generator().manual_seed(0)
+w = (torch.rand(B, N, 2, generator=g) + 0.1).to(dev)
+for seed in range(24):
+    bt = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=seed, outlier_frac=0.3, noise_px=0.7).items()}
+    counts = torch.randint(300, 560, (B,), generator=g).to(torch.int32).to(dev)
+    for _ in range(2):
+        gpu_solver.solve_device(bt["K"], bt["pts3d"], bt["pts2d"], counts, reprojectionError=3.0, refine=False, split=True, select=dict(weights=w))
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 8)()
+    assert fn(out) == 0
+    rows.append(np.diff(np.array(list(out)[:7], dtype=np.float64)))
+d = np.median(np.array(rows), axis=0)
+print("# scripts/ubench/sel_stamps.py: lc_ransac_select_kernel, workgroup 0, median over 24 batches of 64 x 1024 (300-560 used), s_memtime counts")
+for n_, v in zip(NAMES, d):
+    print(f"  {n_:40s} {v:9.0f}  {100 * v / d.sum():5.1f} %")
+print(f"  {'total':40s} {d.sum():9.0f}")
