@@ -545,6 +545,48 @@ def main():
                 "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p, pnp_key),
                 "bound": "neither HBM nor MFMA: VALU issue / per-workgroup latency (SURVEY.md 8d); both fractions are quoted"}
 
+    def test_time_block(objects=64, size=64):
+        """SURVEY.md 8f rows f1 + f2 + a24 chained -- the reference's test.py:67-136 for one batch of detections: dense front end +
+        point selection, P3P RANSAC (three launches), inlier refinement, the 'weighted' and 'weighted-filtered' solves as one launch of
+        2B poses; six launches, no host synchronisation, replayed as ONE hipGraph.  Timed like the headline in small: 11 regions of 20
+        replays, synchronize around each, median; the eager call (launches issued from Python) beside it."""
+        from lc_amd.config import AttrDict
+        from lc_amd.inference import GraphedSolvePnP, solve_pnp
+        from tests.golden.gen_golden_lossfn import dense_inputs  # synthetic network outputs looking at a synthetic surface
+
+        gt, net = dense_inputs(B=objects, H=size, W=size, seed=3)
+        net["xyz_weight_logits"] = net["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
+        net["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
+        gt = {k: v.to(dev) for k, v in gt.items()}
+        net = {k: v.to(dev).contiguous() for k, v in net.items()}  # a convolution's output is contiguous NCHW
+        cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
+        eager = solve_pnp(cfg, net, gt)
+        solver = GraphedSolvePnP(cfg, net, gt)
+        solver.graph.replay()
+        torch.cuda.synchronize(dev)
+        same = all(torch.equal(solver._res[k], eager[k]) for k in eager)
+
+        def regions(fn, reps=20, n=11):
+            out = []
+            for _ in range(n):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(dev)
+                out.append((time.perf_counter() - t0) / reps)
+            return sorted(out)[n // 2]
+        t_replay = regions(solver.graph.replay)
+        t_eager = regions(lambda: solve_pnp(cfg, net, gt))
+        from lc_amd.transforms import quaternion_rep_to_RT  # pose error of the 'weighted' solve against the synthetic ground truth
+        Rg, tg = quaternion_rep_to_RT(gt["pose_best"].double())
+        Re, te = quaternion_rep_to_RT(eager["weighted"].double())
+        return {"workload": f"{objects} objects x {size}x{size} maps, stride 2 ({(size // 2) ** 2} candidates each), quantile_in_mask 0.5, 150 hypotheses, "
+                            "solvers weighted + weighted_filtered",
+                "launches": 6, "us_per_call_replayed": t_replay * 1e6, "us_per_call_eager": t_eager * 1e6,
+                "objects_per_s_replayed": objects / t_replay, "replay_equals_eager": bool(same),
+                "max_translation_error_mm": float((te - tg).norm(dim=-1).max()), "max_rotation_error": float((Re - Rg).abs().max())}
+
     if rank == 0:
         t_loss = kernel_ms(main_unit.launch_loss)
         t_pnp = kernel_ms(main_unit.launch_pnp)
@@ -636,6 +678,8 @@ def main():
             out["steady_state"] = ss
         if world == 1 and args.workload != "metric":
             out["dense"] = {k: dense_block(k, *v) for k, v in DENSE_WORKLOADS.items() if args.workload in ("all", k)}
+        if world == 1 and args.workload == "all":
+            out["test_time"] = test_time_block()
         if world == 1 and not args.no_head:
             # the third kernel family of the path (keypoint head), HBM-bound; its own line: bench_head.py
             from bench_head import measure_head

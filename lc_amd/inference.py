@@ -67,8 +67,6 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     """Dense heads (`test.py:67-136`)."""
     K = gt_dict["out_K"]
     stride = cfg.get("dense_sample", 2)
-    # joint softmax x scale, the (0,0)-phase stride sub-sampling (test.py:85-92) and the visibility mask of the sampled pixels
-    # (test.py:88-90) in one launch
     thr = cfg.get("seg_thresh", 0.5)
     mode = cfg.dense_point_select
     if mode not in ("mask", "quantile", "quantile_in_mask"):
@@ -145,9 +143,9 @@ def quiet_capture():
 
 
 class GraphedSolvePnP:
-    """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of 8 short
-    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 142 us
-    eager -> 85 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
+    """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of 6 short
+    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 105 us
+    eager -> 65 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
 
         solver = GraphedSolvePnP(cfg, out_dict, gt_dict)      # example inputs fix the shapes; captured on a side stream
         poses = solver(out_dict, gt_dict)                     # copies the tensors into the static buffers, replays
@@ -157,8 +155,11 @@ class GraphedSolvePnP:
 
     def __init__(self, cfg, out_dict, gt_dict, warmup: int = 2):
         self.cfg = cfg
-        self._out = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in out_dict.items()}
-        self._gt = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in gt_dict.items()}
+        # static input buffers, contiguous whatever the example's layout: a strided network output would otherwise be copied into
+        # shape by a torch launch INSIDE every replay
+        own = lambda v: v.detach().clone(memory_format=torch.contiguous_format) if isinstance(v, Tensor) else v  # noqa: E731
+        self._out = {k: own(v) for k, v in out_dict.items()}
+        self._gt = {k: own(v) for k, v in gt_dict.items()}
         dev = next(v.device for v in self._out.values() if isinstance(v, Tensor))
         if dev.type != "cuda":
             raise RuntimeError("lc_amd: GraphedSolvePnP needs tensors on the MI355X (there is no CPU fallback in the product path)")
