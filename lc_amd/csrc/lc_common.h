@@ -250,6 +250,33 @@ __device__ __forceinline__ void block_sum_close(double (&v)[K], double* lds, int
     for (int k = 0; k < K; ++k) v[k] = tot[k];
 }
 
+// The same sum for FOUR wavefronts without sending every thread's K values through LDS (4 x 64 x K doubles each way: the LDS form
+// above is bandwidth-bound there, ~2.0 k cycles per sum of 28): each wavefront reduce-scatters its K values in registers
+// (permlane / DPP exchanges, the data halves at every step), 16 of its lanes put its 32 wave totals into LDS, 32 threads add the four
+// rows in wave order, every thread reads the totals.  Two barriers per sum: the totals alternate between two LDS rows (`phase`,
+// toggled by the call), so a wave still reading the previous totals is never overwritten.  lds: at least 4 * 32 + 2 * 32 doubles.
+#ifndef LC_WIDE_SUM_REGS
+#define LC_WIDE_SUM_REGS 1  // A/B switch (scripts/ubench/wide_stamps.py): 0 = every thread's values through LDS
+#endif
+template <int K>
+__device__ __forceinline__ void block_sum_waves4(double (&v)[K], double* lds, int tid, int& phase) {
+    static_assert(K <= 32, "one reduce-scatter of 32");
+    const int lane = tid & 63, wave = tid >> 6;
+    double w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = k < K ? v[k] : 0.0;
+    wave_reduce_scatter16<32>(w, lane);
+    double* part = lds;                      // [4][32]
+    double* tot = lds + 128 + 32 * phase;    // [2][32]
+    phase ^= 1;
+    if ((lane & 3) == 0) *reinterpret_cast<double2*>(part + 32 * wave + scatter16_base(lane, 2)) = make_double2(w[0], w[1]);
+    __syncthreads();
+    if (tid < 32) tot[tid] = ((part[tid] + part[32 + tid]) + part[64 + tid]) + part[96 + tid];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = tot[k];
+}
+
 #ifndef LC_HORNER_ASM
 #define LC_HORNER_ASM 1  // A/B switch (scripts/ubench/pnp_ab.py)
 #endif

@@ -325,6 +325,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         if (!active) { rp.a = 0.0; rp.b = 0.0; rp.c = 0.0; }
     }
 
+    [[maybe_unused]] int sum_phase = 0;  // block_sum_waves4: which of its two rows of totals the next sum writes
     // full evaluation at xe with column scaling sc: H = Js^T Js (21), g = Js^T r (6), cost; false when anything is non-finite
     auto evaluate = [&](const double (&xe)[6], const double (&sc)[6], double (&H)[21], double (&g)[6], double& cost) -> bool {
         LC_PSTAMP(1);
@@ -354,7 +355,8 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
                 for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
             }
             LC_PSTAMP(3);
-            block_sum_bcast_lds<28, NW>(acc, bc, lane);
+            if constexpr (NW == 4 && LC_WIDE_SUM_REGS) block_sum_waves4<28>(acc, bc, lane, sum_phase);
+            else block_sum_bcast_lds<28, NW>(acc, bc, lane);
         }
         LC_PSTAMP(4);
 #pragma unroll

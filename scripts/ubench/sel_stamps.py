@@ -20,8 +20,8 @@ import torch  # noqa: E402
 from lc_amd import _lib, synth  # noqa: E402
 from lc_amd.pnp import gpu_solver  # noqa: E402
 
-NAMES = ["requests issued .. partial sums", "(more hypotheses)", "arg-max over lanes and waves", "winner's pose through LDS", "inlier mask + compaction",
-         "inlier count", "padding + outputs"]
+NAMES = ["count, then all requests .. partial sums", "arg-max over lanes and waves (barrier)", "winner's pose through LDS (barrier)",
+         "inlier mask + compaction + state outputs", "inlier count", "padding + selection count"]
 dev = torch.device("cuda:0")
 lib = _lib.load()
 fn = lib.lc_debug_sel_stamps
