@@ -830,8 +830,8 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kern
 // wavefronts take the rounds of 64 hypotheses; the chunk's partials are written through the caches, the workgroup counts itself
 // in, and the workgroup that completes the pose's count runs the selection -- nobody waits, so no co-residency is assumed, and the
 // partials are still summed in chunk order: same results as the three launches.  Saves the selection launch and its boundary --
-// and MEASURED SLOWER than the three launches on MI355X (64 objects x 1024 points, replayed: 32.0 vs 29.5 us,
-// profiles/r03/ransac_ticketed.txt): write-through stores, their acknowledgement, the arrival atomic and the partials read around the
+// and MEASURED SLOWER than the three launches on MI355X (64 objects x 1024 points, replayed: 29.8 vs 26.9 us,
+// profiles/r03/test_time/ransac_forms.txt): write-through stores, their acknowledgement, the arrival atomic and the partials read around the
 // caches cost more than the 1.45 us kernel boundary they replace.  Kept as an option (tests compare it with the three launches);
 // the default is the three launches.
 __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_select_kernel(const RansacParams p) {

@@ -23,7 +23,7 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     re-selection of test.py:129-133 done by the workgroup that writes the inlier mask; the compacted rows
     (pts2d, weights, pts3d, counts, index), exactly `dense.dense_select(..., 'mask', mask=inliers)`'s, come back as
     select['result'].  ticketed: the split form with the selection inside the scoring launch (two launches instead of three, same
-    outputs, tests compare the two) -- measured 2.5 us SLOWER per call on MI355X (profiles/r03/ransac_ticketed.txt), hence off.
+    outputs, tests compare the two) -- measured 2.9 us SLOWER per call on MI355X (profiles/r03/test_time/ransac_forms.txt), hence off.
 
     split: None picks the launch form from the shape -- the single launch keeps a pose on one compute unit (its scoring loop costs
     ~0.07 us per point, times ceil(B/256) when the poses outnumber the compute units), the split form pays ~17 us of extra launches
