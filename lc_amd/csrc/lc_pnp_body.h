@@ -45,6 +45,9 @@
 #define LC_PSTAMP(i) do {} while (0)
 #endif
 
+#ifndef LC_WIDE_REG_SUM_REGS
+#define LC_WIDE_REG_SUM_REGS 1  // A/B switch: the four-wave register block sum also on the one-correspondence-per-thread path (N <= 256: 12.4 -> 11.6 us at 64 x 256; 0 = sums streamed through LDS)
+#endif
 #ifndef LC_PNP_STREAM_SUM
 #define LC_PNP_STREAM_SUM 1  // A/B switch of the streamed block sum (scripts/ubench/pnp_ab.py); 1 in the shipped library
 #endif
@@ -334,7 +337,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         LC_PSTAMP(2);
         const double t[3] = {xe[3], xe[4], xe[5]};
         double acc[28];
-        if constexpr (REG && LC_PNP_STREAM_SUM) {
+        if constexpr (REG && LC_PNP_STREAM_SUM && !(NW == 4 && LC_WIDE_REG_SUM_REGS)) {
             // lanes beyond n hold zero-weight copies (exact zeros); the 28 partial sums go to LDS as they are produced
             const int pos = block_sum_open<NW>(lane);
             accumulate_point<true, true, NW>(rp, rt, t, cam, sc, acc, bc, pos);
@@ -343,7 +346,8 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         } else if constexpr (REG) {
             accumulate_point<true>(rp, rt, t, cam, sc, acc);
             LC_PSTAMP(3);
-            block_sum_bcast_lds<28, NW>(acc, bc, lane);
+            if constexpr (NW == 4 && LC_WIDE_SUM_REGS) block_sum_waves4<28>(acc, bc, lane, sum_phase);
+            else block_sum_bcast_lds<28, NW>(acc, bc, lane);
         } else {
 #pragma unroll
             for (int i = 0; i < 28; ++i) acc[i] = 0;

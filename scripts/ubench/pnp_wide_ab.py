@@ -13,7 +13,7 @@ from lc_amd import _lib, synth
 lib = _lib.load(); P = _lib.ptr
 dev = torch.device("cuda:0")
 res = {}
-for B, N, frac in ((64, 1024, 0.5), (128, 1024, 0.5), (32, 1024, 1.0), (32, 1849, 1.0), (64, 300, 1.0), (16, 4096, 1.0)):
+for B, N, frac in ((64, 1024, 0.5), (128, 1024, 0.5), (32, 1024, 1.0), (32, 1849, 1.0), (64, 300, 1.0), (16, 4096, 1.0), (64, 256, 1.0), (256, 256, 1.0), (256, 128, 1.0)):
     b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=0).items()}
     cnt = torch.full((B,), int(N * frac), dtype=torch.int32, device=dev)
     st = torch.empty_like(b["start"]); tr = torch.empty(B, device=dev); ret = torch.empty(B, device=dev, dtype=torch.int32)
