@@ -89,6 +89,16 @@ def main():
              note="one workgroup per sample; quantile modes radix-select the two order statistics from keys staged in LDS; the time here is "
                   "the Python call (output allocation included), the kernel alone is in next_kernel_stats.csv", B=B, N=N, mode=mode)
 
+    # ---- f1, test time at 64x64 maps (1024 sampled pixels per object): front end + selection in ONE launch ----
+    Hs = Ws = 64
+    xyz_s, wl_s = torch.randn(B, 3, Hs, Ws, generator=g).to(dev), torch.randn(B, 2, Hs, Ws, generator=g).to(dev)
+    vl_s = torch.randn(B, 1, Hs, Ws, generator=g).to(dev)
+    for mode in ("mask", "quantile_in_mask"):
+        us = ev(lambda: dense.dense_front_end_select(xyz_s, wl_s, ws, ns, vl_s, mode, quantile=0.5, sample=2), dev, a.reps)
+        line("lc_dense_frontend_select_kernel (%s)" % mode, us, B * (6 * Hs * Ws * 4 + 512 * 32), B, "samples",
+             note="front end + point selection of test.py:85-113 in one launch, one workgroup per object; replaces lc_dense_frontend_fwd_kernel + "
+                  "lc_dense_select_kernel when an object has at most 1024 sampled pixels", B=B, H=Hs, W=Ws, sample=2, mode=mode)
+
     # ---- f3: ZebraPose codes: 3x7-bit logits over 128x128 ----
     C, bits = 21, 7
     lg = torch.randn(B, C, H, W, generator=g).to(dev)
@@ -146,7 +156,7 @@ def main():
     out_d["xyz_weight_logits"] = out_d["xyz_weight_logits"] + 3 * gt_d["msk_vis"][:, None]
     out_d["msk_vis_logits"] = (gt_d["msk_vis"][:, None] * 2 - 1) * 4
     gt_d = {k: v.to(dev) for k, v in gt_d.items()}
-    out_d = {k: v.to(dev) for k, v in out_d.items()}
+    out_d = {k: v.to(dev).contiguous() for k, v in out_d.items()}  # a network's output is contiguous NCHW (the generator's xyz map is a strided view)
     cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
     for _ in range(3):
         solve_pnp(cfg, out_d, gt_d)
@@ -156,7 +166,7 @@ def main():
         solve_pnp(cfg, out_d, gt_d)
     torch.cuda.synchronize(dev)
     us = (time.perf_counter() - t0) / a.reps * 1e6
-    line("inference.solve_pnp_dense (front end + select + RANSAC + 2 weighted solves + inlier re-selection)", us,
+    line("inference.solve_pnp_dense (front end + select, RANSAC + inlier re-selection, refinement, 2 weighted solves: 6 launches)", us,
          64 * 6 * 64 * 64 * 4, 64, "objects", note="wall clock per call incl. Python; no host synchronisation inside the pipeline",
          B=64, H=64, W=64, N=1024, select="quantile_in_mask")
 

@@ -2,7 +2,8 @@
 # Kernel-trace profile of bench_next.py (the SURVEY 8f rows); run through gpurun from the repo root.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_next
+TAG=${1:-r03}
+OUT=$ROOT/gpurun_out/prof_next_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o next -- python3 $ROOT/bench_next.py > "$OUT/bench_next.log" 2>&1
