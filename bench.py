@@ -547,8 +547,8 @@ def main():
 
     def test_time_block(objects=64, size=64):
         """SURVEY.md 8f rows f1 + f2 + a24 chained -- the reference's test.py:67-136 for one batch of detections: dense front end +
-        point selection, P3P RANSAC (three launches), inlier refinement, the 'weighted' and 'weighted-filtered' solves as one launch of
-        2B poses; six launches, no host synchronisation, replayed as ONE hipGraph.  Timed like the headline in small: 11 regions of 20
+        point selection (one launch), P3P RANSAC (three), inlier refinement chained with the 'weighted' and 'weighted-filtered' solves of
+        2B poses (one); five launches, no host synchronisation, replayed as ONE hipGraph.  Timed like the headline in small: 11 regions of 20
         replays, synchronize around each, median; the eager call (launches issued from Python) beside it."""
         from lc_amd.config import AttrDict
         from lc_amd.inference import GraphedSolvePnP, solve_pnp
@@ -583,7 +583,7 @@ def main():
         Re, te = quaternion_rep_to_RT(eager["weighted"].double())
         return {"workload": f"{objects} objects x {size}x{size} maps, stride 2 ({(size // 2) ** 2} candidates each), quantile_in_mask 0.5, 150 hypotheses, "
                             "solvers weighted + weighted_filtered",
-                "launches": 6, "us_per_call_replayed": t_replay * 1e6, "us_per_call_eager": t_eager * 1e6,
+                "launches": 5, "us_per_call_replayed": t_replay * 1e6, "us_per_call_eager": t_eager * 1e6,
                 "objects_per_s_replayed": objects / t_replay, "replay_equals_eager": bool(same),
                 "max_translation_error_mm": float((te - tg).norm(dim=-1).max()), "max_rotation_error": float((Re - Rg).abs().max())}
 
@@ -679,7 +679,10 @@ def main():
         if world == 1 and args.workload != "metric":
             out["dense"] = {k: dense_block(k, *v) for k, v in DENSE_WORKLOADS.items() if args.workload in ("all", k)}
         if world == 1 and args.workload == "all":
-            out["test_time"] = test_time_block()
+            try:  # an auxiliary block: whatever happens in it, the headline above is printed
+                out["test_time"] = test_time_block()
+            except Exception as e:  # noqa: BLE001
+                out["test_time"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_head:
             # the third kernel family of the path (keypoint head), HBM-bound; its own line: bench_head.py
             from bench_head import measure_head

@@ -166,7 +166,7 @@ def main():
         solve_pnp(cfg, out_d, gt_d)
     torch.cuda.synchronize(dev)
     us = (time.perf_counter() - t0) / a.reps * 1e6
-    line("inference.solve_pnp_dense (front end + select, RANSAC + inlier re-selection, refinement, 2 weighted solves: 6 launches)", us,
+    line("inference.solve_pnp_dense (front end + select, RANSAC + inlier re-selection, refinement + 2 weighted solves: 5 launches)", us,
          64 * 6 * 64 * 64 * 4, 64, "objects", note="wall clock per call incl. Python; no host synchronisation inside the pipeline",
          B=64, H=64, W=64, N=1024, select="quantile_in_mask")
 

@@ -79,6 +79,28 @@ int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const
                    int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod,
                    void *stream);
 
+/* Two solves, the second starting where the first ends -- the RANSAC inlier refinement followed by the weighted solve(s) of
+ * test.py:120,133 -- as ONE call.  A job is the argument list of lc_pnp_lm2_f32; the call is defined as
+ *     lc_pnp_lm2_f32(first ...);  lc_pnp_lm2_f32(second ...);      on `stream`
+ * and returns what those return.  Where the shapes allow (both 256 < Nmax <= 1024, second->B a multiple of first->B, and
+ * second->start either unrelated to first->states or reading its row b % first->B: pose_mod == first->B, or pose_mod == 0 with equal
+ * B) it is ONE launch: workgroup b solves pose b % first->B of the first job, then pose b of the second -- a pose of the first job
+ * that several second-stage poses start from is solved by each of them (same inputs, same arithmetic, same bits; its outputs are
+ * written by each with identical values).  Same results as the two calls bit for bit (tests/test_gpu_pnp.py).  Apart from
+ * second->start == first->states the buffers of the two jobs must not overlap. */
+typedef struct lc_pnp_lm_job {
+    const float *K, *pts3d, *pts2d, *sqrtL, *weights_diag;
+    const unsigned char *weight_mask;
+    const int *counts;
+    const float *start;
+    float *states, *result_tr;
+    int *rets, *iters;
+    int B, Nmax, max_iter;
+    float function_tolerance;
+    int options, pose_mod;
+} lc_pnp_lm_job;
+int lc_pnp_lm_chain_f32(const lc_pnp_lm_job *first, const lc_pnp_lm_job *second, void *stream);
+
 /* (2a') Parity diagnostics of (2a): the same solve (same template body, so the same arithmetic) that also records the
  *      trust-region schedule -- what `Solver::Summary::iterations` holds after ceres::Solve (ceres.cpp:126-130) --
  *      into trace (B,trace_rows,8) doubles, one row per iteration i < trace_rows:

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "lc_dense_frontend_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 5),
     "lc_dense_frontend_fwd2_f32": (c_int, [c_void_p] * 5 + [c_float] + [c_int] * 6 + [c_void_p] * 6),
     "lc_dense_frontend_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p] * 4),
+    "lc_pnp_lm_chain_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lc_pnp_ransac_init_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 5),
     "lc_pnp_ransac_init2_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6),
     "lc_pnp_ransac_init3_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +

@@ -185,11 +185,15 @@ int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const 
     return 0;
 }
 
-int lc_pnp_lm2_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
-                   const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
-                   int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod, void* stream) {
+// argument checks of lc_pnp_lm2_f32 -> kernel parameters; 0 / 1 (lc_amd_last_error says why)
+static int pnp_params(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
+                      const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
+                      int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod, lc::PnpParams& p) {
     if (B < 0 || Nmax < 0 || pose_mod < 0) return fail(1, "negative size");
-    if (B == 0) return 0;
+    if (B == 0) {  // an empty batch is a no-op whatever else is passed
+        p = lc::PnpParams{};
+        return 0;
+    }
     if ((sqrtL != nullptr) + (weights_diag != nullptr) + (weight_mask != nullptr) != 1)
         return fail(1, "exactly one of sqrtL / weights_diag / weight_mask must be given");
     if (options & ~(LC_PNP_WEIGHTS_ARE_ICOV | LC_PNP_NAN_TO_NUM)) return fail(1, "unknown option bit");
@@ -198,9 +202,35 @@ int lc_pnp_lm2_f32(const float* K, const float* pts3d, const float* pts2d, const
     if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, pts2d, weights_diag);
     LC_REQUIRE_ALIGNED(16, sqrtL);
-    lc::PnpParams p{K, pts2d, pts3d, sqrtL, weights_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
-                    B, Nmax, max_iter, function_tolerance, nullptr, 0, options, weight_mask, pose_mod};
+    p = lc::PnpParams{K, pts2d, pts3d, sqrtL, weights_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
+                      B, Nmax, max_iter, function_tolerance, nullptr, 0, options, weight_mask, pose_mod};
+    return 0;
+}
+
+int lc_pnp_lm2_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
+                   const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
+                   int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod, void* stream) {
+    lc::PnpParams p;
+    if (int rc = pnp_params(K, pts3d, pts2d, sqrtL, weights_diag, weight_mask, counts, start, states, result_tr, rets, iters, B, Nmax, max_iter,
+                            function_tolerance, options, pose_mod, p))
+        return rc;
+    if (B == 0) return 0;
     if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
+    return 0;
+}
+
+int lc_pnp_lm_chain_f32(const lc_pnp_lm_job* first, const lc_pnp_lm_job* second, void* stream) {
+    if (!first || !second) return fail(1, "null job");
+    lc::PnpParams a, b;
+    const lc_pnp_lm_job* jobs[2] = {first, second};
+    lc::PnpParams* ps[2] = {&a, &b};
+    for (int k = 0; k < 2; ++k) {
+        const lc_pnp_lm_job& j = *jobs[k];
+        if (int rc = pnp_params(j.K, j.pts3d, j.pts2d, j.sqrtL, j.weights_diag, j.weight_mask, j.counts, j.start, j.states, j.result_tr, j.rets,
+                                j.iters, j.B, j.Nmax, j.max_iter, j.function_tolerance, j.options, j.pose_mod, *ps[k]))
+            return rc;
+    }
+    if (lc::launch_pnp_lm_chain(a, b, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
     return 0;
 }
 

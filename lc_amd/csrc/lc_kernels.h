@@ -63,6 +63,8 @@ struct PnpParams {
 enum PnpOptions { kPnpWeightsAreIcov = 1,  // sqrt_diag holds inverse VARIANCES: take the square root at the load (cer_solver.py:33-36)
                   kPnpNanToNum = 2 };      // torch.nan_to_num on K, points, weights and start at the load (cer_solver.py:29-31)
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream);
+// launch_pnp_lm(a) then launch_pnp_lm(b) -- as one launch where the shapes allow (include/lc_amd.h: lc_pnp_lm_chain_f32)
+int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stream);
 int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream);  // same solve + p.trace rows (parity diagnostics, not a hot path)
 // both of the above in one grid (N <= 64 only; returns 3 otherwise)
 int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stream);

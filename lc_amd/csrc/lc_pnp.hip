@@ -30,6 +30,18 @@ __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) 
     pnp::solve_pose<REG, 4, false, OPTS, PPT>(p, blockIdx.x, threadIdx.x, bc);
 }
 
+// Two dependent solves in one launch (lc_pnp_lm_chain_f32): workgroup b runs pose b % a.B of the first job, then pose b of the second,
+// whose start may be the first's result.  Between the two: the first solve's outputs were written by this workgroup's own threads
+// (and, identically, by the other workgroups that solve the same first-stage pose); a workgroup-scope fence + barrier orders them
+// before the second solve's loads.
+__global__ __launch_bounds__(256) void lc_pnp_lm_chain_kernel(const PnpParams a, const PnpParams b) {
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
+    pnp::solve_pose<false, 4, false, true, 4>(a, (int)(blockIdx.x % (unsigned)a.B), threadIdx.x, bc);
+    __threadfence_block();
+    __syncthreads();
+    pnp::solve_pose<false, 4, false, true, 4>(b, blockIdx.x, threadIdx.x, bc);
+}
+
 // diagnostic twins that also record the per-iteration trace (tests/test_gpu_pnp_trace.py)
 __global__ __launch_bounds__(64, 1) void lc_pnp_lm_trace_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<1>];
@@ -47,6 +59,18 @@ int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream) {
     if (p.Nmax <= 64) hipLaunchKernelGGL(lc_pnp_lm_trace_kernel, dim3(p.B), dim3(64), 0, stream, p);
     else hipLaunchKernelGGL(lc_pnp_lm_wide_trace_kernel, dim3(p.B), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stream) {
+    const auto wide4 = [](const PnpParams& p) { return p.Nmax > 256 && p.Nmax <= 1024; };
+    const float* b_start = b.start ? b.start : b.states;
+    const bool rows_match = b_start != a.states || b.pose_mod == a.B || (b.pose_mod == 0 && b.B == a.B);
+    if (a.B > 0 && b.B > 0 && wide4(a) && wide4(b) && b.B % a.B == 0 && rows_match) {
+        hipLaunchKernelGGL(lc_pnp_lm_chain_kernel, dim3(b.B), dim3(256), 0, stream, a, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    if (int rc = launch_pnp_lm(a, stream)) return rc;
+    return launch_pnp_lm(b, stream);
 }
 
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {

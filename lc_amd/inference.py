@@ -110,22 +110,28 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     filtered = None
     if "weighted_filtered" in wanted:
         filtered = dict(weights=icov, index=index, min_count=4, out=half(1) if both else None)
-    start, inliers, _bad = gpu_solver.solve_device(K, x, u, counts, reprojectionError=_reprojection_threshold(cfg, gt_dict, 3),
-                                                   select=filtered)
-
+    start, inliers, _bad, refine = gpu_solver.solve_device(K, x, u, counts, reprojectionError=_reprojection_threshold(cfg, gt_dict, 3),
+                                                           select=filtered, refine="defer")
+    # The RANSAC's inlier refinement and the weighted solve(s) that start from its result: ONE launch (`lc_pnp_lm_chain_f32`), each
+    # workgroup refines its object's pose and goes on with its own weighted solve.
+    weighted = dict(weights_are_icov=True, nan_to_num=True, start="first")  # `_weighted` above, chained
     out = {}
-    if "ransac" in wanted:
-        out["ransac"] = start
-    if both:  # the two selections side by side in ONE launch of 2B poses
-        states = pnp_ceres.solve_device(K, X2, U2, W2, start, C2, weights_are_icov=True, nan_to_num=True, shared_poses=B)[0]
+    if both:  # the two selections side by side: 2B poses
+        (start, _, _), (states, _, _) = pnp_ceres.solve_chain_device(
+            refine, dict(cam_mat=K, pts3d=X2, pts2d=U2, sqrtL=W2, n_points=C2, shared_poses=B, **weighted))
         out["weighted"], out["weighted-filtered"] = states.chunk(2)
-        out = {k: out[k] for k in ("ransac", "weighted-filtered", "weighted") if k in out}  # key order of test.py:129-135
     elif "weighted_filtered" in wanted:
         fu, ficov, fx, fcounts, _ = filtered["result"]
-        out["weighted-filtered"] = _weighted(K, fx, fu, ficov, start, fcounts)
+        (start, _, _), (out["weighted-filtered"], _, _) = pnp_ceres.solve_chain_device(
+            refine, dict(cam_mat=K, pts3d=fx, pts2d=fu, sqrtL=ficov, n_points=fcounts, **weighted))
     elif "weighted" in wanted:
-        out["weighted"] = _weighted(K, x, u, icov, start, counts)
-    return out
+        (start, _, _), (out["weighted"], _, _) = pnp_ceres.solve_chain_device(
+            refine, dict(cam_mat=K, pts3d=x, pts2d=u, sqrtL=icov, n_points=counts, **weighted))
+    else:
+        start = pnp_ceres.solve_device(**refine)[0]
+    if "ransac" in wanted:
+        out["ransac"] = start
+    return {k: out[k] for k in ("ransac", "weighted-filtered", "weighted") if k in out}  # key order of test.py:129-135
 
 
 @contextlib.contextmanager
@@ -143,9 +149,9 @@ def quiet_capture():
 
 
 class GraphedSolvePnP:
-    """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of 6 short
-    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 105 us
-    eager -> 65 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
+    """`solve_pnp` captured once as a hipGraph and replayed (fixed shapes): the pipeline above is a chain of 5 short
+    launches with no host synchronisation, so a replay removes the per-launch host cost (64 objects of 64x64 maps: 104 us
+    eager -> 64 us replayed on one MI355X, identical results; `scripts/ubench/graph_inference.py`).
 
         solver = GraphedSolvePnP(cfg, out_dict, gt_dict)      # example inputs fix the shapes; captured on a side stream
         poses = solver(out_dict, gt_dict)                     # copies the tensors into the static buffers, replays

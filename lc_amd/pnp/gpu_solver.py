@@ -19,6 +19,9 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool
     [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly].
 
+    refine: True runs the inlier refinement (an unweighted LM solve on the inliers, the role EPnP-on-inliers plays inside
+    cv2.solvePnPRansac); 'defer' returns (ransac states, inlier_mask, invalid, job) with `job` the keyword arguments of that solve for
+    `pnp_ceres.solve_chain_device` -- a caller that continues with a weighted solve runs both as one launch.
     select: None, or a dict(weights=(B,N,2), index=(B,N) int32 | None, min_count=4, seed=0, out=None) -- the 'weighted-filtered'
     re-selection of test.py:129-133 done by the workgroup that writes the inlier mask; the compacted rows
     (pts2d, weights, pts3d, counts, index), exactly `dense.dense_select(..., 'mask', mask=inliers)`'s, come back as
@@ -89,7 +92,10 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     if refine:
         # unit information on the inliers (weight_mask); the poses RANSAC gave up on are skipped through their zero point count: the
         # solver returns its start for them and for the solves it flags invalid -- no element-wise launches around the solve
-        states, _, _ = pnp_ceres.solve_device(K, X, U, None, states, rows, max_iter_count=20, weight_mask=mask)
+        job = dict(cam_mat=K, pts3d=X, pts2d=U, sqrtL=None, start=states, n_points=rows, max_iter_count=20, weight_mask=mask)
+        if refine == "defer":  # the caller chains the refinement with its own solve (pnp_ceres.solve_chain_device: one launch)
+            return states, inl, bad, job
+        states, _, _ = pnp_ceres.solve_device(**job)
     if return_hypothesis:
         return states, inl, bad, hyp, n_in
     return states, inl, bad

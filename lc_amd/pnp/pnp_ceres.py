@@ -79,6 +79,65 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     return (state, tr, ret, iters) if return_iters else (state, tr, ret)
 
 
+class _Job(ctypes.Structure):  # include/lc_amd.h: lc_pnp_lm_job
+    _fields_ = [(n, ctypes.c_void_p) for n in ("K", "pts3d", "pts2d", "sqrtL", "weights_diag", "weight_mask", "counts", "start", "states",
+                                               "result_tr", "rets", "iters")] + \
+               [("B", ctypes.c_int), ("Nmax", ctypes.c_int), ("max_iter", ctypes.c_int), ("function_tolerance", ctypes.c_float),
+                ("options", ctypes.c_int), ("pose_mod", ctypes.c_int)]
+
+
+def _job(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6, weights_are_icov=False,
+         nan_to_num=False, weight_mask=None, shared_poses=0):
+    """The arguments of `solve_device` as an lc_pnp_lm_job + its output tensors (state, tr, ret) + the tensors the job points into."""
+    K = _lib.require_hip_f32("cam_mat", cam_mat)
+    X = _lib.require_hip_f32("pts3d", pts3d)
+    U = _lib.require_hip_f32("pts2d", pts2d)
+    B, N = X.shape[:2]
+    dev = X.device
+    L = M = None
+    if weight_mask is not None:
+        M = weight_mask.view(torch.uint8) if weight_mask.dtype == torch.bool else weight_mask
+        if M.dtype != torch.uint8 or not M.is_cuda or tuple(M.shape) != (B, N):
+            raise TypeError("weight_mask must be a (B,N) uint8/bool tensor on the GPU")
+        M = M.contiguous()
+    else:
+        L = _lib.require_hip_f32("pts2d_icov_sqrtL", sqrtL)
+    full = L is not None and L.dim() == 4
+    start = _lib.require_hip_f32("start", start)
+    if shared_poses and (start.shape[0] != shared_poses or K.shape[0] != shared_poses or B % shared_poses):
+        raise ValueError("shared_poses: cam_mat and start need that many rows and B must be a multiple of it")
+    state = torch.empty(B, 7, device=dev, dtype=torch.float32)
+    counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
+    tr = torch.empty(B, device=dev, dtype=torch.float32)
+    ret = torch.empty(B, device=dev, dtype=torch.int32)
+    opts = (LC_PNP_WEIGHTS_ARE_ICOV if weights_are_icov else 0) | (LC_PNP_NAN_TO_NUM if nan_to_num else 0)
+    P = _lib.ptr
+    job = _Job(P(K), P(X), P(U), P(L) if full else None, P(L) if (L is not None and not full) else None, P(M), P(counts), P(start), P(state),
+               P(tr), P(ret), None, B, N, int(max_iter_count), float(function_tolerance), opts, int(shared_poses))
+    return job, (state, tr, ret), (K, X, U, L, M, counts, start), dev
+
+
+def solve_chain_device(first: dict, second: dict):
+    """Two solves as one call (`lc_pnp_lm_chain_f32`): `first` and `second` are keyword arguments of `solve_device`; second['start'] may be
+    the string 'first' -- the states the first solve returns (with shared_poses = the first job's batch when the second holds several
+    selections of the same objects).  One launch where the shapes allow (both 256 < N <= 1024), else the two launches; the same
+    results as `solve_device(**first)` followed by `solve_device(**second)` bit for bit.  Returns ((state, tr, ret), (state, tr, ret))."""
+    lib = _lib.load()
+    j1, out1, keep1, dev = _job(**first)
+    if isinstance(second.get("start"), str):
+        if second["start"] != "first":
+            raise ValueError("second['start'] is a tensor or the string 'first'")
+        second = dict(second, start=out1[0])
+    j2, out2, keep2, dev2 = _job(**second)
+    if dev2 != dev:
+        raise ValueError("solve_chain_device: both jobs on one device")
+    with _lib.on_device(dev):
+        rc = lib.lc_pnp_lm_chain_f32(ctypes.byref(j1), ctypes.byref(j2), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_lm_chain_f32")
+    del keep1, keep2
+    return out1, out2
+
+
 def _solve_host_lists(state, pts3d, pts2d, sqrtL, cam_mat, point_counts, worker_count=1, max_iter_count=300, **kwargs):
     """`_pnp_ceres_omp_f32` (pnp_ceres.py:74-140): per-job contiguous float32 arrays -> `pnp_ceres_f32_omp`."""
     lib = _lib.load()

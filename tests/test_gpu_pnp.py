@@ -397,3 +397,38 @@ def test_large_grid_build_equals_the_latency_build(hard):
                                     None if counts is None else counts[:500], weights_are_icov=True, nan_to_num=True)
     for a, c in zip(big2, small2):
         assert torch.equal(a[:500], c)
+
+
+@pytest.mark.parametrize("B1,k,N,used", [(16, 2, 700, 400), (24, 1, 1024, 1024), (8, 3, 300, 260), (16, 2, 64, 64), (16, 2, 1500, 900)])
+def test_chained_solves_equal_the_two_calls(B1, k, N, used):
+    """lc_pnp_lm_chain_f32 (refinement on a mask, then k weighted solves per object that start from its result -- one launch where
+    256 < N <= 1024) against lc_pnp_lm2_f32 twice: states, radii and flags of BOTH jobs bit for bit; incl. an object the first job skips
+    (zero point count: the second starts from the first's start) and shapes that fall back to two launches."""
+    from lc_amd import synth
+    from lc_amd.pnp import pnp_ceres
+
+    dev = torch.device("cuda:0")
+    B2 = B1 * k
+    a = {key: v.to(dev) for key, v in synth.make_batch(B1, N, seed=N + B1, outlier_frac=0.1, noise_px=1.0).items()}
+    g = torch.Generator().manual_seed(B2)
+    mask = (torch.rand(B1, N, generator=g) > 0.3).to(torch.uint8).to(dev)
+    rows = torch.full((B1,), used, dtype=torch.int32, device=dev)
+    rows[1] = 0  # a pose RANSAC gave up on
+    first = dict(cam_mat=a["K"], pts3d=a["pts3d"], pts2d=a["pts2d"], sqrtL=None, start=a["start"], n_points=rows, max_iter_count=20,
+                 weight_mask=mask)
+    X2, U2 = a["pts3d"].repeat(k, 1, 1), a["pts2d"].repeat(k, 1, 1)
+    W2 = (torch.rand(B2, N, 2, generator=g) * 4 + 0.05).to(dev)
+    C2 = torch.randint(max(4, used // 2), used + 1, (B2,), generator=g).to(torch.int32).to(dev)
+    second = dict(cam_mat=a["K"], pts3d=X2, pts2d=U2, sqrtL=W2, n_points=C2, weights_are_icov=True, nan_to_num=True,
+                  shared_poses=B1 if k > 1 else 0)
+    want1 = pnp_ceres.solve_device(**first)
+    want2 = pnp_ceres.solve_device(**dict(second, start=want1[0]))
+    got1, got2 = pnp_ceres.solve_chain_device(first, dict(second, start="first"))
+    for x, y in zip(got1 + got2, want1 + want2):
+        assert torch.equal(x, y)
+    assert int(want2[2].sum()) < B2  # most second-stage solves converge
+    # a second job that does not depend on the first
+    got1, got2 = pnp_ceres.solve_chain_device(first, dict(second, start=a["start"]))
+    want2 = pnp_ceres.solve_device(**dict(second, start=a["start"]))
+    for x, y in zip(got1 + got2, want1 + want2):
+        assert torch.equal(x, y)
