@@ -331,8 +331,8 @@ int lc_dense_select_f32(const float *pts2d, const float *inv_std, const float *p
                         float *out_pts3d, int *out_index, int *counts, void *stream);
 
 /* Round 3: the dense front end (2d, lc_dense_frontend_fwd2_f32) and the selection above in ONE launch for the test-time pipeline,
- * one workgroup per object, for N = ceil((H-top)/sample) * ceil((W-left)/sample) <= 1024 sampled pixels (64x64 maps at stride 2;
- * more: an error, use the two launches).  The front end's (B,N,.) rows are never written; every selected value, count and index
+ * one workgroup per object, for N = ceil((H-top)/sample) * ceil((W-left)/sample) <= 8192 sampled pixels (128x128 maps at stride 2:
+ * 4096; more: an error, use the two launches).  The front end's (B,N,.) rows are never written; every selected value, count and index
  * equals what lc_dense_frontend_fwd2_f32 followed by lc_dense_select_f32(mask = the visibility mask) returns, bit for bit
  * (tests/test_gpu_select.py).  xyz (B,3,H,W) required; vis_logits (B,H,W) required by modes 0 and 2. */
 int lc_dense_frontend_select_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale,

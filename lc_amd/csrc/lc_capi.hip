@@ -569,7 +569,7 @@ int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const f
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     if (mode < 0 || mode > 2 || min_count < 0 || min_count > N) return fail(1, "bad size or mode");
     if (mode != 0 && !(quantile >= 0.0 && quantile <= 1.0)) return fail(1, "quantile outside [0,1]");
-    if (N > 1024) return fail(1, "more than 1024 sampled pixels per object: use lc_dense_frontend_fwd2_f32 + lc_dense_select_f32");
+    if (N > 8192) return fail(1, "more than 8192 sampled pixels per object: use lc_dense_frontend_fwd2_f32 + lc_dense_select_f32");
     if (B == 0) return 0;
     if (!xyz || !wlogits || !wscale || !out_pts2d || !out_weights || !out_pts3d || !counts) return fail(1, "null pointer");
     if (mode != 1 && !vis_logits) return fail(1, "modes 0 (mask) and 2 (quantile_in_mask) need the visibility logits");

@@ -24,6 +24,7 @@ namespace lc {
 namespace {
 
 constexpr int kThreads = 1024;
+constexpr int kFusedSelectMaxPoints = 8192;  // lc_dense_frontend_select_f32: keys in 32 KB of LDS; entries beyond the thread's first are re-formed from the maps
 constexpr int kWaves = kThreads / kWave;
 
 // torch.lerp (aten/src/ATen/native/Lerp.h): the form that is exact at both ends
@@ -256,9 +257,10 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
     select_row(p, b, n, src, e0, srt);
 }
 
-// Test time, N <= 1024 sampled pixels per object: the dense front end (joint softmax x scale, strided sub-sampling, visibility mask:
+// Test time, N <= 8192 sampled pixels per object: the dense front end (joint softmax x scale, strided sub-sampling, visibility mask:
 // test.py:85-92) and the point selection (test.py:94-113) in ONE launch, one workgroup per object.  The front end's (B,N,.) arrays
-// are never written: every thread forms the entry of its own sampled pixel in registers -- the log-sum-exp by the front end's own 512
+// are never written: every thread forms the entry of its own sampled pixel in registers (beyond 1024 pixels per object: the further
+// ones again from the maps where the selection needs them) -- the log-sum-exp by the front end's own 512
 // threads in the front end's own order, so every selected value equals what the two launches produce bit for bit -- and hands it to
 // the selection above.
 __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(const SelectParams p, const DenseParams d) {
@@ -299,8 +301,10 @@ int launch_dense_select(const SelectParams& p, hipStream_t stream) {
 
 int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d, hipStream_t stream) {
     if (p.B <= 0) return 0;
-    if (p.N > kThreads) return 3;
-    const size_t lds = p.mode == 0 ? 0 : (size_t)kThreads * sizeof(float);
+    if (p.N > kFusedSelectMaxPoints) return 3;
+    int P = kThreads;
+    while (P < p.N) P <<= 1;
+    const size_t lds = p.mode == 0 ? 0 : (size_t)P * sizeof(float);
     hipLaunchKernelGGL(lc_dense_frontend_select_kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
