@@ -341,6 +341,25 @@ int lc_dense_frontend_select_f32(const float *xyz, const float *wlogits, const f
                                  float *out_pts2d, float *out_weights, float *out_pts3d, int *out_index, int *counts,
                                  void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (2h) The dense heads' auxiliary losses of Loss_fn.forward (losses.py:281-316), one launch each way:
+ *        losses[0] loss_noc        = mean |xyz * msk_noc - noc_tgt|                        (F.l1_loss, losses.py:293-295)
+ *        losses[1] loss_seg        = mean seg(seg_logits, msk_vis)                         (losses.py:296)
+ *        losses[2] loss_weight_seg = mean seg(wlogits, msk_vis broadcast over 2 channels)  (warm-up blend, losses.py:303-306)
+ *      seg_type 0 = F.binary_cross_entropy_with_logits, 1 = Loss_seg_L1 (|sigmoid(x) - t|, losses.py:219-236).
+ *      xyz (B,3,HW)|NULL with noc_tgt and the object mask as bool bytes (msk_noc_u8) or floats (msk_noc_f32), both (B,HW);
+ *      seg_logits, msk_vis (B,HW); wlogits (B,2,HW)|NULL.  Forward: partials = 3 * 1024 doubles of workspace, ticket = one unsigned,
+ *      zero before the first call (the kernel leaves it zero); sums in double precision, block partials added in block order.
+ *      Backward: g_* = device scalars (the cotangents of the three means, NULL = none), d_* (same shapes as the inputs)|NULL.
+ * ------------------------------------------------------------------------------------------------ */
+int lc_dense_aux_fwd_f32(const float *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
+                         const float *seg_logits, const float *msk_vis, const float *wlogits, int B, int HW, int seg_type,
+                         float *losses, double *partials, unsigned *ticket, void *stream);
+int lc_dense_aux_bwd_f32(const float *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
+                         const float *seg_logits, const float *msk_vis, const float *wlogits, int B, int HW, int seg_type,
+                         const float *g_noc, const float *g_seg, const float *g_wseg, float *d_xyz, float *d_seg,
+                         float *d_wlogits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -580,5 +580,31 @@ int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const f
     return lc::launch_dense_frontend_select(p, d, static_cast<hipStream_t>(stream)) ? fail(11, "front end + select launch failed") : 0;
 }
 
+int lc_dense_aux_fwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
+                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type, float* losses,
+                         double* partials, unsigned* ticket, void* stream) {
+    if (B < 0 || HW <= 0 || seg_type < 0 || seg_type > 1) return fail(1, "bad size or loss type");
+    if (B == 0) return 0;
+    if (!seg_logits || !msk_vis || !losses || !partials || !ticket) return fail(1, "null pointer");
+    if (xyz && (!noc_tgt || (msk_noc_u8 != nullptr) == (msk_noc_f32 != nullptr))) return fail(1, "xyz needs its target and exactly one mask form");
+    LC_REQUIRE_ALIGNED(8, partials);
+    lc::DenseAuxParams p{xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, seg_type, losses, partials, ticket,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, HW};
+    return lc::launch_dense_aux_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense aux loss launch failed") : 0;
+}
+
+int lc_dense_aux_bwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
+                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type,
+                         const float* g_noc, const float* g_seg, const float* g_wseg, float* d_xyz, float* d_seg, float* d_wlogits,
+                         void* stream) {
+    if (B < 0 || HW <= 0 || seg_type < 0 || seg_type > 1) return fail(1, "bad size or loss type");
+    if (B == 0) return 0;
+    if (!msk_vis || (d_seg && !seg_logits) || (d_wlogits && !wlogits)) return fail(1, "null pointer");
+    if (d_xyz && (!xyz || !noc_tgt || (msk_noc_u8 != nullptr) == (msk_noc_f32 != nullptr))) return fail(1, "d_xyz needs xyz, its target and exactly one mask form");
+    lc::DenseAuxParams p{xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, seg_type, nullptr, nullptr, nullptr,
+                         g_noc, g_seg, g_wseg, d_xyz, d_seg, d_wlogits, B, HW};
+    return lc::launch_dense_aux_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense aux loss backward launch failed") : 0;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -38,20 +38,21 @@ __global__ __launch_bounds__(kThreads) void lc_sqnorm_kernel(const ClipParams p)
     for (long long i = (n4 << 2) + tid; i < p.n; i += stride) a0 = fmaf(p.x[i], p.x[i], a0);
     const double part = block_sum_d(((double)a0 + (double)a1) + ((double)a2 + (double)a3), red);
     if (threadIdx.x == 0) {
-        p.partials[blockIdx.x] = part;
-        __threadfence();
-        last = atomicAdd(p.ticket, 1u) == gridDim.x - 1;
+        // written through the caches and acknowledged before the block counts itself in, read around them by the last block: no
+        // agent-scope fence (an L2 write-back per block; lc_common.h: xcd_store)
+        xcd_store(p.partials + blockIdx.x, part);
+        xcd_stores_done();
+        last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();
     double s = 0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads) s += p.partials[i];
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads) s += xcd_load(p.partials + i);
     s = block_sum_d(s, red);
     if (threadIdx.x == 0) {
         *p.sq = (p.accumulate ? *p.sq : 0.f) + (float)s;
         if (p.state_snapshot) *p.state_snapshot = *p.state_in;  // lets lc_clip_apply update the state in place (hipGraph-safe)
-        *p.ticket = 0;  // ready for the next call on this stream
+        xcd_store(p.ticket, 0u);  // ready for the next call on this stream
     }
 }
 

@@ -190,6 +190,30 @@ struct DenseBwdParams {
 };
 int launch_dense_bwd(const DenseBwdParams& p, hipStream_t stream);
 
+constexpr int kDenseAuxMaxBlocks = 1024;  // rows of the caller-provided `partials` workspace of lc_dense_aux_fwd_f32 (3 doubles each)
+struct DenseAuxParams {
+    const float* xyz;                 // (B,3,HW) xyz head, or null (binary-code heads have no loss_noc)
+    const unsigned char* msk_noc_u8;  // (B,HW) object mask as bool bytes, or
+    const float* msk_noc_f32;         // (B,HW) the same as floats (exactly one of the two with xyz)
+    const float* noc_tgt;             // (B,3,HW)
+    const float* seg_logits;          // (B,HW) msk_vis_logits
+    const float* msk_vis;             // (B,HW) visibility target
+    const float* wlogits;             // (B,2,HW) xyz_weight_logits, or null (no warm-up blend)
+    int seg_type;                     // 0: binary_cross_entropy_with_logits, 1: Loss_seg_L1
+    float* losses;                    // (3) out: loss_noc, loss_seg, loss_weight_seg (forward)
+    double* partials;                 // (kDenseAuxMaxBlocks,3) workspace (forward)
+    unsigned* ticket;                 // zero between launches (forward)
+    const float* g_noc;               // upstream cotangents: device scalars or null (backward)
+    const float* g_seg;
+    const float* g_wseg;
+    float* d_xyz;                     // (B,3,HW) or null (backward)
+    float* d_seg;                     // (B,HW) or null
+    float* d_wlogits;                 // (B,2,HW) or null
+    int B, HW;
+};
+int launch_dense_aux_fwd(const DenseAuxParams& p, hipStream_t stream);
+int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream);
+
 constexpr int kClipMaxBlocks = 512;  // length of the caller-provided `partials` workspace of lc_sqnorm_f32
 struct ClipParams {
     const float* x;      // gradient

@@ -1,0 +1,96 @@
+"""The dense heads' auxiliary losses of `Loss_fn.forward` (`losses.py:281-316`) as ONE HIP launch each way
+(`lc_amd/csrc/lc_dense_aux.hip`): loss_noc (L1 of the masked xyz head), loss_seg (visibility mask) and, during the pose loss's
+warm-up, loss_weight_seg (the weight logits against the visibility mask) -- ~25 element-wise / reduction torch launches and their
+autograd twins in the reference."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+SEG_TYPES = {"bce": 0, "l1": 1}
+_WS = {}  # (device index, stream) -> (partials, ticket): the forward's reduction workspace (launches of one stream are ordered)
+
+
+def _workspace(dev):
+    if torch.cuda.is_current_stream_capturing():  # a graph owns its workspace (its zero-fill is a node of the graph)
+        return torch.zeros(3 * 1024, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        if len(_WS) >= 64:
+            _WS.clear()
+        ws = _WS[key] = (torch.zeros(3 * 1024, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32))
+    return ws
+
+
+def fused_path_ok(*tensors) -> bool:
+    """fp32 maps on the GPU take the fused launch; half-precision heads keep the torch formulas (same device, no CPU path)."""
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
+
+
+class _DenseAux(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, msk_noc, noc_tgt, seg_logits, msk_vis, wlogits, seg_type: int):
+        lib = _lib.load()
+        seg = _lib.require_hip_f32("msk_vis_logits", seg_logits)
+        B = seg.shape[0]
+        HW = seg.numel() // B
+        dev = seg.device
+        vis = _lib.require_hip_f32("msk_vis", msk_vis.reshape(B, HW))
+        x = tgt = m8 = mf = w = None
+        if xyz is not None:
+            x = _lib.require_hip_f32("xyz_noc", xyz)
+            tgt = _lib.require_hip_f32("xyz_noc_tgt", noc_tgt)
+            m = msk_noc.reshape(B, HW).contiguous()
+            if m.dtype == torch.bool:
+                m8 = m.view(torch.uint8)
+            elif m.dtype == torch.uint8:
+                m8 = m
+            else:
+                mf = _lib.require_hip_f32("msk_noc", m)
+        if wlogits is not None:
+            w = _lib.require_hip_f32("xyz_weight_logits", wlogits)
+        losses = torch.empty(3, device=dev, dtype=torch.float32)
+        partials, ticket = _workspace(dev)
+        P = _lib.ptr
+        with _lib.on_device(dev):
+            rc = lib.lc_dense_aux_fwd_f32(P(x), P(m8), P(mf), P(tgt), P(seg), P(vis), P(w), B, HW, int(seg_type), P(losses), P(partials),
+                                          P(ticket), _lib.stream_ptr(dev))
+        _lib.check(rc, "lc_dense_aux_fwd_f32")
+        ctx.save_for_backward(*(t for t in (x, m8, mf, tgt, seg, vis, w) if t is not None))
+        ctx.have = tuple(t is not None for t in (x, m8, mf, tgt, seg, vis, w))
+        ctx.seg_type, ctx.shapes = int(seg_type), (None if xyz is None else xyz.shape, seg_logits.shape, None if wlogits is None else wlogits.shape)
+        l0, l1, l2 = losses.unbind(0)
+        return l0, l1, l2
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        lib = _lib.load()
+        it = iter(ctx.saved_tensors)
+        x, m8, mf, tgt, seg, vis, w = (next(it) if h else None for h in ctx.have)
+        B = seg.shape[0]
+        HW = seg.numel() // B
+        dev = seg.device
+        need_x, _, _, need_seg, _, need_w, _ = ctx.needs_input_grad
+        d_x = torch.empty_like(x) if (need_x and x is not None) else None
+        d_s = torch.empty_like(seg) if need_seg else None
+        d_w = torch.empty_like(w) if (need_w and w is not None) else None
+        gs = [None if g is None else g.to(dtype=torch.float32).contiguous() for g in (g0, g1, g2)]
+        P = _lib.ptr
+        with _lib.on_device(dev):
+            rc = lib.lc_dense_aux_bwd_f32(P(x), P(m8), P(mf), P(tgt), P(seg), P(vis), P(w), B, HW, ctx.seg_type, P(gs[0]), P(gs[1]), P(gs[2]),
+                                          P(d_x), P(d_s), P(d_w), _lib.stream_ptr(dev))
+        _lib.check(rc, "lc_dense_aux_bwd_f32")
+        sx, ss, sw = ctx.shapes
+        return (None if d_x is None else d_x.view(sx), None, None, None if d_s is None else d_s.view(ss), None,
+                None if d_w is None else d_w.view(sw), None)
+
+
+def dense_aux_losses(xyz_noc: Tensor, msk_noc: Tensor, xyz_noc_tgt: Tensor, msk_vis_logits: Tensor, msk_vis: Tensor,
+                     xyz_weight_logits: Tensor = None, seg_loss_type: str = "bce"):
+    """-> (loss_noc, loss_seg, loss_weight_seg) as 0-dim tensors (the first / last are zero constants when their input is None):
+    `F.l1_loss(xyz_noc * msk_noc[:, None], xyz_noc_tgt)`, `seg(msk_vis_logits, msk_vis[:, None])` and
+    `seg(xyz_weight_logits, msk_vis[:, None].expand_as(xyz_weight_logits))`, seg = BCE-with-logits or `Loss_seg_L1`."""
+    return _DenseAux.apply(xyz_noc, msk_noc, xyz_noc_tgt, msk_vis_logits, msk_vis, xyz_weight_logits, SEG_TYPES[seg_loss_type.lower()])

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import floatbits
+from . import dense_aux, floatbits
 from . import transforms as xforms
 from .cov_mixed import Loss_cov_mixed
 from .dense import dense_front_end
@@ -196,6 +196,7 @@ class Loss_fn(nn.Module):
         if total_bit_cnt > 0:
             self.xyz_bin_loss_fn = Loss_xyz_bin(total_bit_cnt)
         seg_loss_type = cfg.get("seg_loss_type", "BCE")
+        self.seg_loss_type = seg_loss_type.lower()
         if seg_loss_type.lower() == "bce":
             self.seg_loss_fn = F.binary_cross_entropy_with_logits
         elif seg_loss_type.lower() == "l1":
@@ -220,17 +221,28 @@ class Loss_fn(nn.Module):
         if "xyz_noc_bin" in out_dict:  # zebra-pose structure (losses.py:289-291)
             loss_dict["loss_noc_bin"] = self.xyz_bin_loss_fn(out_dict["xyz_noc_bin"], gt_dict["xyz_noc_bin_tgt"],
                                                              out_dict["msk_vis_logits"])
-        if "xyz_noc" in out_dict:
-            noc_msked, noc_gt = out_dict["xyz_noc"] * msk_noc.unsqueeze(-3), gt_dict["xyz_noc_tgt"]
-            loss_dict["loss_noc"] = F.l1_loss(noc_msked, noc_gt, reduction="mean")
-        loss_dict["loss_seg"] = self.seg_loss_fn(out_dict["msk_vis_logits"], msk_vis.unsqueeze(-3), reduction="mean")
+        factor = pose_loss_factor(cfg, step, steps_per_epoch)
+        xyz_noc = out_dict.get("xyz_noc")
+        weight_logits = out_dict["xyz_weight_logits"] if factor != 1 else None
+        if dense_aux.fused_path_ok(xyz_noc, out_dict["msk_vis_logits"], weight_logits, msk_vis, gt_dict.get("xyz_noc_tgt") if xyz_noc is not None else None):
+            # loss_noc, loss_seg and (during the warm-up) loss_weight_seg: one launch each way (lc_amd/dense_aux.py)
+            loss_noc, loss_seg, loss_weight_seg = dense_aux.dense_aux_losses(
+                xyz_noc, msk_noc if xyz_noc is not None else None, gt_dict["xyz_noc_tgt"] if xyz_noc is not None else None,
+                out_dict["msk_vis_logits"], msk_vis, weight_logits, self.seg_loss_type)
+            if xyz_noc is not None:
+                loss_dict["loss_noc"] = loss_noc
+            loss_dict["loss_seg"] = loss_seg
+        else:  # half-precision heads: the reference's torch formulas
+            if xyz_noc is not None:
+                noc_msked, noc_gt = xyz_noc * msk_noc.unsqueeze(-3), gt_dict["xyz_noc_tgt"]
+                loss_dict["loss_noc"] = F.l1_loss(noc_msked, noc_gt, reduction="mean")
+            loss_dict["loss_seg"] = self.seg_loss_fn(out_dict["msk_vis_logits"], msk_vis.unsqueeze(-3), reduction="mean")
+            if factor != 1:
+                msk_vis_tgt = msk_vis.unsqueeze(-3).expand_as(weight_logits)
+                loss_weight_seg = self.seg_loss_fn(weight_logits, msk_vis_tgt, reduction="mean")
 
         loss_pose = self.dense_pose_loss(cfg.pose_loss_cfg, gt_dict, out_dict)
-        factor = pose_loss_factor(cfg, step, steps_per_epoch)
         if factor != 1:
-            weight_logits = out_dict["xyz_weight_logits"]
-            msk_vis_tgt = msk_vis.unsqueeze(-3).expand_as(weight_logits)
-            loss_weight_seg = self.seg_loss_fn(weight_logits, msk_vis_tgt, reduction="mean")
             loss_pose = factor * loss_pose + (1 - factor) * loss_weight_seg
         loss_dict["loss_pose"] = loss_pose
 

@@ -19,8 +19,8 @@ def run(kind, make, cfg, reps=50):
     dev = torch.device("cuda:0")
     fn = Loss_fn(AttrDict(cfg), AttrDict(), 17 if kind.startswith("bin") else 0).to(dev)
     gt, out = make()
-    gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
-    out = {k: v.to(dev) for k, v in out.items()}
+    gt = {k: (v.to(dev).contiguous() if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}  # loader tensors are contiguous (the generator hands out strided views)
+    out = {k: v.to(dev).contiguous() for k, v in out.items()}
 
     def step(i):
         np.random.seed(i)
@@ -31,12 +31,15 @@ def run(kind, make, cfg, reps=50):
 
     for i in range(5):
         step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(reps):
-        step(i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    win = []
+    for _ in range(5):  # median of 5 windows (the shared pool shows occasional ~55 ms stalls)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            step(i)
+        torch.cuda.synchronize()
+        win.append((time.perf_counter() - t0) / reps)
+    dt = sorted(win)[2]
     print(f"{kind}: {dt * 1e3:.3f} ms per Loss_fn step (forward + backward)")
 
 

@@ -8,8 +8,8 @@ from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda:0")
 fn = Loss_fn(AttrDict(DENSE_CFG), AttrDict(), 0).to(dev)
 gt, out = dense_inputs(B=32, H=64, W=64)
-gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
-out = {k: v.to(dev) for k, v in out.items()}
+gt = {k: (v.to(dev).contiguous() if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}  # loader tensors are contiguous (the generator hands out strided views)
+out = {k: v.to(dev).contiguous() for k, v in out.items()}
 def step(i):
     np.random.seed(i)
     leaves = {k: v.detach().requires_grad_(True) for k, v in out.items()}

@@ -112,3 +112,50 @@ def test_front_end_visibility_mask_equals_torch(thr):
     assert torch.equal(p2, q2) and torch.equal(w2, v2) and torch.equal(x3, y3)
     want = (torch.sigmoid(vl) > thr).squeeze(1)[..., 0::s, 0::s].flatten(-2)
     assert vis.dtype == torch.bool and torch.equal(vis, want) and 0 < int(want.sum()) < want.numel()
+
+
+@pytest.mark.parametrize("seg_type", ["bce", "l1"])
+@pytest.mark.parametrize("B,H,W,with_xyz,with_w,mask_dtype", [(32, 64, 64, True, True, torch.bool), (3, 17, 23, True, False, torch.float32),
+                                                               (5, 32, 32, False, True, torch.bool), (2, 128, 128, True, True, torch.uint8)])
+def test_dense_aux_losses_equal_the_torch_formulas(B, H, W, with_xyz, with_w, mask_dtype, seg_type):
+    """lc_dense_aux_{fwd,bwd}_f32 (loss_noc, loss_seg, loss_weight_seg of losses.py:281-316 in one launch each way) against the
+    reference's torch formulas in float64: values to 2e-6, gradients to 2e-6 of their largest entry, with non-trivial upstream
+    cotangents, exact zeros of the L1 difference (sign(0) = 0) and saturated logits."""
+    import torch.nn.functional as F
+
+    from lc_amd.dense_aux import dense_aux_losses
+    from lc_amd.losses import Loss_seg_L1
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * H + W)
+    xyz = torch.randn(B, 3, H, W, generator=g) if with_xyz else None
+    msk = torch.rand(B, H, W, generator=g) > 0.4
+    tgt = torch.randn(B, 3, H, W, generator=g) * msk[:, None] if with_xyz else None
+    if with_xyz:
+        xyz[0, :, :2] = tgt[0, :, :2]  # exact zeros of the difference where the mask is set
+    seg = torch.randn(B, 1, H, W, generator=g) * 4
+    seg[0, 0, 0, :4] = torch.tensor([60.0, -60.0, 0.0, 100.0])[:min(4, W)]
+    vis = (torch.rand(B, H, W, generator=g) > 0.5).float()
+    wl = torch.randn(B, 2, H, W, generator=g) * 2 if with_w else None
+    up = torch.tensor([0.7, 1.3, 0.4])
+
+    def leaves(dt, d):
+        return [None if t is None else t.to(device=d, dtype=dt).requires_grad_(True) for t in (xyz, seg, wl)]
+
+    # reference formulas, float64 on the CPU
+    x64, s64, w64 = leaves(torch.float64, "cpu")
+    seg_fn = F.binary_cross_entropy_with_logits if seg_type == "bce" else Loss_seg_L1()
+    want = [F.l1_loss(x64 * msk[:, None], tgt.double()) if with_xyz else None, seg_fn(s64, vis[:, None].double(), reduction="mean"),
+            seg_fn(w64, vis[:, None].double().expand_as(w64), reduction="mean") if with_w else None]
+    sum(u * v for u, v in zip(up.double(), want) if v is not None).backward()
+    # fused launches
+    xg, sg, wg = leaves(torch.float32, dev)
+    m = msk.to(dev) if mask_dtype == torch.bool else msk.to(device=dev, dtype=mask_dtype)
+    got = dense_aux_losses(xg, m if with_xyz else None, tgt.to(dev) if with_xyz else None, sg, vis.to(dev), wg, seg_type)
+    sum(u * v for u, v, w_ in zip(up.to(dev), got, want) if w_ is not None).backward()
+    for a, b in zip(got, want):
+        if b is not None:
+            assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, abs(float(b))), (float(a), float(b))
+    for a, b in ((xg, x64), (sg, s64), (wg, w64)):
+        if b is not None:
+            assert (a.grad.cpu().double() - b.grad).abs().max() <= 2e-6 * b.grad.abs().max(), float((a.grad.cpu().double() - b.grad).abs().max())
