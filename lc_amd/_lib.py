@@ -56,6 +56,8 @@ _SIGNATURES = {
     "lc_kpt_nll_fwd_bwd_f32": (c_int, [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 4),
     "lc_dense_frontend_select_f32": (c_int, [c_void_p] * 5 + [c_float] + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint] +
                                      [c_void_p] * 6),
+    "lc_xyz_bin_loss_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float] + [c_void_p] * 6),
+    "lc_xyz_bin_loss_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 2),
     "lc_dense_aux_fwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p] * 4),
     "lc_dense_aux_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p] * 7),
     "lc_dense_select_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, ctypes.c_double, c_int, c_int, ctypes.c_uint] + [c_void_p] * 6),

@@ -606,5 +606,26 @@ int lc_dense_aux_bwd_f32(const float* xyz, const unsigned char* msk_noc_u8, cons
     return lc::launch_dense_aux_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense aux loss backward launch failed") : 0;
 }
 
+int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, int B, int C, int HW,
+                            float momentum, float* histogram, float* loss, float* bin_weights, double* partials, unsigned* ticket,
+                            void* stream) {
+    if (B < 0 || C <= 0 || HW <= 0) return fail(1, "bad size");
+    if (C > lc::kBinMaxChannels) return fail(1, "more than 128 code bits");
+    if (B == 0) return 0;
+    if (!logits || !gt_bits || !msk_vis_logits || !histogram || !loss || !bin_weights || !partials || !ticket) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, partials);
+    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, histogram, momentum, loss, bin_weights, partials, ticket, nullptr, nullptr, B, C, HW};
+    return lc::launch_xyz_bin_loss_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss launch failed") : 0;
+}
+
+int lc_xyz_bin_loss_bwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, const float* bin_weights,
+                            const float* g_loss, int B, int C, int HW, float* d_logits, void* stream) {
+    if (B < 0 || C <= 0 || HW <= 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!logits || !gt_bits || !msk_vis_logits || !bin_weights || !g_loss || !d_logits) return fail(1, "null pointer");
+    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, nullptr, 0.f, nullptr, const_cast<float*>(bin_weights), nullptr, nullptr, g_loss, d_logits, B, C, HW};
+    return lc::launch_xyz_bin_loss_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss backward launch failed") : 0;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

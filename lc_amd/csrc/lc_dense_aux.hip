@@ -114,6 +114,85 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
     }
 }
 
+// ---- Loss_xyz_bin (losses.py:196-216): per-bit weighted BCE on the binary surface-code logits with an EMA histogram of per-bit
+// Hamming errors.  The reference walks the (B,C,H,W) logits ~12 times (compare, xor, and, two integer reductions, mask multiply,
+// log-sigmoid, BCE, mean, ...); here one pass: grid (C, chunks), a workgroup reduces its share of ONE code channel -- Hamming errors
+// inside the hard visibility mask, the BCE sum, and (channel 0) the mask's population -- partials in a fixed order, and the last
+// workgroup to arrive finishes: histogram EMA in place, soft histogram, softmax bit weights, the loss.  Backward: one element-wise pass.
+constexpr int kBinChunks = 8;  // workgroups per code channel
+
+__device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - log1pf(expf(-fabsf(z)))); }
+
+__global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const BinLossParams p) {
+    __shared__ double red[4][3];
+    __shared__ bool last;
+    __shared__ float zs[kBinMaxChannels], ws[kBinMaxChannels];
+    const int c = blockIdx.x / kBinChunks, chunk = blockIdx.x % kBinChunks;
+    const long long n = (long long)p.B * p.HW;
+    double acc[3] = {0, 0, 0};  // Hamming errors, BCE sum, visible pixels (channel 0 only)
+    for (long long i = (long long)chunk * kThreads + threadIdx.x; i < n; i += (long long)kBinChunks * kThreads) {
+        const long long b = i / p.HW, px = i - b * p.HW;
+        const size_t e = ((size_t)b * p.C + c) * p.HW + px;
+        const float x = p.logits[e];
+        const bool t = p.gt_bits[e] != 0, vis = p.msk_vis_logits[i] > 0.f;
+        acc[0] += (vis && ((x > 0.f) != t)) ? 1.0 : 0.0;
+        acc[1] += (double)bce_logits(vis ? x : 0.f * x, t ? 1.f : 0.f);  // logits * msk_hard (keeps a NaN / inf logit visible like the product)
+        if (c == 0) acc[2] += vis ? 1.0 : 0.0;
+    }
+    block_sum3(acc, red);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; ++k) xcd_store(p.partials + 3 * blockIdx.x + k, acc[k]);
+        xcd_stores_done();
+        last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    const int tid = threadIdx.x;
+    double vis_total = 0;
+    for (int k = 0; k < kBinChunks; ++k) vis_total += xcd_load(p.partials + 3 * k + 2);  // channel 0's chunks, in order
+    for (int ch = tid; ch < p.C; ch += kThreads) {
+        double hamm = 0, bce = 0;
+        for (int k = 0; k < kBinChunks; ++k) {
+            hamm += xcd_load(p.partials + 3 * (ch * kBinChunks + k));
+            bce += xcd_load(p.partials + 3 * (ch * kBinChunks + k) + 1);
+        }
+        // losses.py:205-210 in the reference's fp32 operation order
+        const float hist = (float)(long long)hamm / (float)((long long)vis_total + 1);
+        float h = p.histogram[ch];
+        h = h * (1.f - p.momentum);
+        h = h + hist * p.momentum;
+        p.histogram[ch] = h;
+        zs[ch] = fminf(h, 0.51f - h) * 3.f;
+        ws[ch] = (float)(bce / (double)n);  // loss_raw.mean([0, 2, 3]) of this bit, parked until the weights exist
+    }
+    __syncthreads();
+    if (tid == 0) {  // C <= 128 values: softmax and the weighted sum by one thread, in index order
+        float m = -INFINITY, s = 0.f, loss = 0.f;
+        for (int ch = 0; ch < p.C; ++ch) m = fmaxf(m, zs[ch]);
+        for (int ch = 0; ch < p.C; ++ch) s += expf(zs[ch] - m);
+        for (int ch = 0; ch < p.C; ++ch) {
+            const float w = expf(zs[ch] - m) / s;
+            loss += ws[ch] * w;
+            p.bin_weights[ch] = w;
+        }
+        *p.loss = loss;
+        xcd_store(p.ticket, 0u);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const BinLossParams p) {
+    const long long n = (long long)p.B * p.C * p.HW;
+    const float g = *p.g_loss / (float)((long long)p.B * p.HW);
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long long)gridDim.x * kThreads) {
+        const long long bc = e / p.HW, px = e - bc * p.HW, b = bc / p.C;
+        const int c = (int)(bc - b * p.C);
+        const bool vis = p.msk_vis_logits[b * p.HW + px] > 0.f;
+        const float x = p.logits[e], t = p.gt_bits[e] ? 1.f : 0.f;
+        // d/dx BCE(x * m, t) = (sigmoid(x m) - t) m
+        p.d_logits[e] = vis ? g * p.bin_weights[c] * (sigmoidf_(x) - t) : 0.f;
+    }
+}
+
 int grid_for(long long n) {
     long long g = (n + kThreads - 1) / kThreads;
     return (int)(g < 1 ? 1 : (g > kDenseAuxMaxBlocks ? kDenseAuxMaxBlocks : g));
@@ -133,6 +212,21 @@ int launch_dense_aux_fwd(const DenseAuxParams& p, hipStream_t stream) {
 int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     hipLaunchKernelGGL(lc_dense_aux_bwd_kernel, dim3(grid_for((long long)p.B * p.HW)), dim3(kThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.C <= 0) return 0;
+    if (p.C > kBinMaxChannels) return 3;
+    hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel, dim3(p.C * kBinChunks), dim3(kThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_xyz_bin_loss_bwd(const BinLossParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.C <= 0) return 0;
+    const long long n = (long long)p.B * p.C * p.HW;
+    const int grid = (int)std::min<long long>(2048, std::max<long long>(1, (n + 4 * kThreads - 1) / (4 * kThreads)));
+    hipLaunchKernelGGL(lc_xyz_bin_loss_bwd_kernel, dim3(grid), dim3(kThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -214,6 +214,24 @@ struct DenseAuxParams {
 int launch_dense_aux_fwd(const DenseAuxParams& p, hipStream_t stream);
 int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream);
 
+constexpr int kBinMaxChannels = 128;  // code bits of Loss_xyz_bin (3 axes x up to 24 bits)
+struct BinLossParams {
+    const float* logits;            // (B,C,HW) code logits
+    const unsigned char* gt_bits;   // (B,C,HW) target bits as bool bytes
+    const float* msk_vis_logits;    // (B,HW)
+    float* histogram;               // (C) EMA of the per-bit Hamming error rate: read AND updated (forward)
+    float momentum;
+    float* loss;                    // (1) out (forward)
+    float* bin_weights;             // (C) out (forward), in (backward)
+    double* partials;               // (C * 8, 3) workspace (forward)
+    unsigned* ticket;               // zero between launches (forward)
+    const float* g_loss;            // device scalar (backward)
+    float* d_logits;                // (B,C,HW) (backward)
+    int B, C, HW;
+};
+int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream);  // 3: more than kBinMaxChannels bits
+int launch_xyz_bin_loss_bwd(const BinLossParams& p, hipStream_t stream);
+
 constexpr int kClipMaxBlocks = 512;  // length of the caller-provided `partials` workspace of lc_sqnorm_f32
 struct ClipParams {
     const float* x;      // gradient

@@ -94,3 +94,50 @@ def dense_aux_losses(xyz_noc: Tensor, msk_noc: Tensor, xyz_noc_tgt: Tensor, msk_
     `F.l1_loss(xyz_noc * msk_noc[:, None], xyz_noc_tgt)`, `seg(msk_vis_logits, msk_vis[:, None])` and
     `seg(xyz_weight_logits, msk_vis[:, None].expand_as(xyz_weight_logits))`, seg = BCE-with-logits or `Loss_seg_L1`."""
     return _DenseAux.apply(xyz_noc, msk_noc, xyz_noc_tgt, msk_vis_logits, msk_vis, xyz_weight_logits, SEG_TYPES[seg_loss_type.lower()])
+
+
+class _XyzBinLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, gt_bits, msk_vis_logits, histogram, momentum: float):
+        lib = _lib.load()
+        x = _lib.require_hip_f32("xyz_noc_bin", logits)
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        dev = x.device
+        t = gt_bits.contiguous()
+        t = t.view(torch.uint8) if t.dtype == torch.bool else (t if t.dtype == torch.uint8 else (t != 0).view(torch.uint8))
+        v = _lib.require_hip_f32("msk_vis_logits", msk_vis_logits.reshape(B, HW))
+        if not (histogram.is_cuda and histogram.dtype == torch.float32 and histogram.is_contiguous() and histogram.numel() == C):
+            raise ValueError("Loss_xyz_bin: the histogram buffer is a contiguous float32 tensor of one entry per code bit on the GPU")
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        weights = torch.empty(C, device=dev, dtype=torch.float32)
+        partials, ticket = _workspace(dev)
+        if partials.numel() < C * 8 * 3:
+            raise ValueError("Loss_xyz_bin: more than 128 code bits")
+        P = _lib.ptr
+        with _lib.on_device(dev):
+            rc = lib.lc_xyz_bin_loss_fwd_f32(P(x), P(t), P(v), B, C, HW, float(momentum), P(histogram), P(loss), P(weights), P(partials),
+                                             P(ticket), _lib.stream_ptr(dev))
+        _lib.check(rc, "lc_xyz_bin_loss_fwd_f32")
+        ctx.save_for_backward(x, t, v, weights)
+        ctx.shape = logits.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, t, v, weights = ctx.saved_tensors
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        d = torch.empty_like(x)
+        g = g.to(dtype=torch.float32).contiguous()
+        P = _lib.ptr
+        with _lib.on_device(x.device):
+            rc = lib.lc_xyz_bin_loss_bwd_f32(P(x), P(t), P(v), P(weights), P(g), B, C, HW, P(d), _lib.stream_ptr(x.device))
+        _lib.check(rc, "lc_xyz_bin_loss_bwd_f32")
+        return d.view(ctx.shape), None, None, None, None
+
+
+def xyz_bin_loss(noc_xyz_bin_logits: Tensor, noc_xyz_bin_gt: Tensor, msk_vis_logits: Tensor, histogram: Tensor, momentum: float) -> Tensor:
+    """`Loss_xyz_bin.forward` (`losses.py:196-216`) as one launch each way; `histogram` (the module's buffer) is updated in place."""
+    return _XyzBinLoss.apply(noc_xyz_bin_logits, noc_xyz_bin_gt, msk_vis_logits, histogram, momentum)

@@ -130,6 +130,9 @@ class Loss_xyz_bin(nn.Module):
         self.momentum = momentum
 
     def forward(self, noc_xyz_bin_logits: Tensor, noc_xyz_bin_gt: Tensor, msk_vis_logits: Tensor):
+        if dense_aux.fused_path_ok(noc_xyz_bin_logits, msk_vis_logits, self.histogram) and self.histogram.numel() <= 128:
+            # one pass over the logits instead of ~12 (lc_amd/csrc/lc_dense_aux.hip); the histogram buffer is updated in place
+            return dense_aux.xyz_bin_loss(noc_xyz_bin_logits, noc_xyz_bin_gt, msk_vis_logits, self.histogram, self.momentum)
         msk_hard = msk_vis_logits > 0
         hamm = (noc_xyz_bin_logits > 0).logical_xor(noc_xyz_bin_gt.to(torch.bool)).logical_and(msk_hard)
         hist = hamm.sum([0, 2, 3]) / (msk_hard.sum() + 1)

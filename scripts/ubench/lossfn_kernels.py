@@ -9,15 +9,18 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lc_amd.config import AttrDict  # noqa: E402
 from lc_amd.losses import Loss_fn  # noqa: E402
-from tests.golden.gen_golden_lossfn import DENSE_CFG, SPARSE_CFG, dense_inputs, sparse_inputs  # noqa: E402
+from tests.golden.gen_golden_lossfn import BIN_CFG, DENSE_CFG, SPARSE_CFG, bin_inputs, dense_inputs, sparse_inputs  # noqa: E402
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
 
 dev = torch.device("cuda:0")
-for kind, cfg, make in (("dense B=32 64x64", DENSE_CFG, lambda: dense_inputs(B=32, H=64, W=64)), ("sparse B=256 N=64", SPARSE_CFG, lambda: sparse_inputs(B=256, N=64))):
-    fn = Loss_fn(AttrDict(cfg), AttrDict(), 0).to(dev)
+for kind, cfg, make in (("dense B=32 64x64", DENSE_CFG, lambda: dense_inputs(B=32, H=64, W=64)), ("sparse B=256 N=64", SPARSE_CFG, lambda: sparse_inputs(B=256, N=64)),
+                        ("bin B=32 64x64", BIN_CFG, lambda: bin_inputs(B=32, H=64, W=64)), ("bin B=32 128x128", BIN_CFG, lambda: bin_inputs(B=32, H=128, W=128))):
+    fn = Loss_fn(AttrDict(cfg), AttrDict(), 17 if kind.startswith("bin") else 0).to(dev)
     gt, out = make()
     gt = {k: (v.to(dev).contiguous() if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}  # loader tensors are contiguous (the generator hands out strided views)
     out = {k: v.to(dev).contiguous() for k, v in out.items()}
+    if len(sys.argv) > 1 and sys.argv[1] not in kind:
+        continue
 
     def step(i):
         np.random.seed(i)

@@ -159,3 +159,28 @@ def test_dense_aux_losses_equal_the_torch_formulas(B, H, W, with_xyz, with_w, ma
     for a, b in ((xg, x64), (sg, s64), (wg, w64)):
         if b is not None:
             assert (a.grad.cpu().double() - b.grad).abs().max() <= 2e-6 * b.grad.abs().max(), float((a.grad.cpu().double() - b.grad).abs().max())
+
+
+@pytest.mark.parametrize("B,C,H,W", [(32, 17, 64, 64), (3, 21, 37, 29), (2, 72, 16, 16), (4, 5, 128, 128)])
+def test_xyz_bin_loss_equals_the_torch_formulas(B, C, H, W):
+    """lc_xyz_bin_loss_{fwd,bwd}_f32 against Loss_xyz_bin's torch formulas (losses.py:196-216) over three steps of the EMA histogram:
+    loss to 2e-6, histogram to 1e-6, gradient to 2e-6 of its largest entry (float64 torch on the CPU as the reference)."""
+    from lc_amd.losses import Loss_xyz_bin
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C * H)
+    fused, plain = Loss_xyz_bin(C).to(dev), Loss_xyz_bin(C).double()
+    for step in range(3):
+        logits = torch.randn(B, C, H, W, generator=g) * 3
+        logits[0, 0, 0, :3] = torch.tensor([0.0, 50.0, -50.0])[:min(3, W)]
+        bits = (logits > 0) ^ (torch.rand(B, C, H, W, generator=g) < 0.2)  # a head that is right four times out of five
+        vis = torch.randn(B, 1, H, W, generator=g)
+        a = logits.to(dev).requires_grad_(True)
+        b = logits.double().requires_grad_(True)
+        la, lb = fused(a, bits.to(dev), vis.to(dev)), plain(b, bits, vis.double())
+        (la * 1.7).backward()
+        (lb * 1.7).backward()
+        assert abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb))), (step, float(la), float(lb))
+        assert (fused.histogram.cpu().double() - plain.histogram).abs().max() <= 1e-6
+        assert (a.grad.cpu().double() - b.grad).abs().max() <= 2e-6 * b.grad.abs().max()
+    assert float((fused.histogram - 0.5).abs().max()) > 1e-3  # the EMA moved
