@@ -363,7 +363,7 @@ int lc_dense_aux_bwd_f32(const float *xyz, const unsigned char *msk_noc_u8, cons
 /* Loss_xyz_bin (losses.py:196-216), the ZebraPose heads' code loss: per-bit BCE-with-logits on logits * (msk_vis_logits > 0),
  * weighted by softmax(3 * min(h, 0.51 - h)) of the EMA histogram h of per-bit Hamming error rates inside that mask.  logits (B,C,HW),
  * gt_bits (B,C,HW) bool bytes, msk_vis_logits (B,HW), C <= 128.  Forward (one pass over the logits): histogram (C) is read and updated in
- * place (h <- h (1 - momentum) + rate momentum), loss (1), bin_weights (C) for the backward pass; partials = C * 8 * 3 doubles, ticket =
+ * place (h <- h (1 - momentum) + rate momentum), loss (1), bin_weights (C) for the backward pass; partials = C * 32 * 3 doubles, ticket =
  * one unsigned, zero before the first call (left zero).  Backward: d_logits = g_loss (device scalar) * d loss / d logits. */
 int lc_xyz_bin_loss_fwd_f32(const float *logits, const unsigned char *gt_bits, const float *msk_vis_logits, int B, int C, int HW,
                             float momentum, float *histogram, float *loss, float *bin_weights, double *partials,

@@ -614,7 +614,8 @@ int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, c
     if (B == 0) return 0;
     if (!logits || !gt_bits || !msk_vis_logits || !histogram || !loss || !bin_weights || !partials || !ticket) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, partials);
-    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, histogram, momentum, loss, bin_weights, partials, ticket, nullptr, nullptr, B, C, HW};
+    const int vec = HW % 4 == 0 && !misaligned(16, logits, msk_vis_logits) && !misaligned(4, gt_bits);
+    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, histogram, momentum, loss, bin_weights, partials, ticket, nullptr, nullptr, B, C, HW, vec, 0};
     return lc::launch_xyz_bin_loss_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss launch failed") : 0;
 }
 
@@ -623,7 +624,8 @@ int lc_xyz_bin_loss_bwd_f32(const float* logits, const unsigned char* gt_bits, c
     if (B < 0 || C <= 0 || HW <= 0) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!logits || !gt_bits || !msk_vis_logits || !bin_weights || !g_loss || !d_logits) return fail(1, "null pointer");
-    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, nullptr, 0.f, nullptr, const_cast<float*>(bin_weights), nullptr, nullptr, g_loss, d_logits, B, C, HW};
+    const int vec = HW % 4 == 0 && !misaligned(16, logits, msk_vis_logits, d_logits) && !misaligned(4, gt_bits);
+    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, nullptr, 0.f, nullptr, const_cast<float*>(bin_weights), nullptr, nullptr, g_loss, d_logits, B, C, HW, vec, 0};
     return lc::launch_xyz_bin_loss_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss backward launch failed") : 0;
 }
 

@@ -119,26 +119,66 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
 // log-sigmoid, BCE, mean, ...); here one pass: grid (C, chunks), a workgroup reduces its share of ONE code channel -- Hamming errors
 // inside the hard visibility mask, the BCE sum, and (channel 0) the mask's population -- partials in a fixed order, and the last
 // workgroup to arrive finishes: histogram EMA in place, soft histogram, softmax bit weights, the loss.  Backward: one element-wise pass.
-constexpr int kBinChunks = 8;  // workgroups per code channel
+constexpr int kBinChunks = 32;  // at most that many workgroups per code channel (their partials are added in chunk order)
 
-__device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - log1pf(expf(-fabsf(z)))); }
+// (1 - t) z - log_sigmoid(z), log_sigmoid(z) = min(z, 0) - log1p(exp(-|z|)); the hardware exp / log (v_exp_f32, v_log_f32) are good
+// to ~1e-7 absolute on log1p(e), e in (0, 1] -- terms of a MEAN of order 0.1-1 that is compared at 1e-6
+__device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - __logf(1.f + __expf(-fabsf(z)))); }
 
 __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const BinLossParams p) {
     __shared__ double red[4][3];
     __shared__ bool last;
     __shared__ float zs[kBinMaxChannels], ws[kBinMaxChannels];
-    const int c = blockIdx.x / kBinChunks, chunk = blockIdx.x % kBinChunks;
+    const int chunks = p.chunks, c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
     const long long n = (long long)p.B * p.HW;
-    double acc[3] = {0, 0, 0};  // Hamming errors, BCE sum, visible pixels (channel 0 only)
-    for (long long i = (long long)chunk * kThreads + threadIdx.x; i < n; i += (long long)kBinChunks * kThreads) {
-        const long long b = i / p.HW, px = i - b * p.HW;
-        const size_t e = ((size_t)b * p.C + c) * p.HW + px;
-        const float x = p.logits[e];
-        const bool t = p.gt_bits[e] != 0, vis = p.msk_vis_logits[i] > 0.f;
-        acc[0] += (vis && ((x > 0.f) != t)) ? 1.0 : 0.0;
-        acc[1] += (double)bce_logits(vis ? x : 0.f * x, t ? 1.f : 0.f);  // logits * msk_hard (keeps a NaN / inf logit visible like the product)
-        if (c == 0) acc[2] += vis ? 1.0 : 0.0;
+    // Hamming errors and visible pixels (channel 0 only) are counted in integers; the BCE terms of the four pixels of a request are
+    // added in fp32 and that sum goes into a double (one conversion + one fp64 add per request: the kernel is VALU-bound)
+    int n_err = 0, n_vis = 0;
+    double bce_sum = 0;
+    float bce4 = 0.f;
+    auto one = [&](float x, bool t, bool vis) {
+        n_err += (vis && ((x > 0.f) != t)) ? 1 : 0;
+        bce4 += bce_logits(vis ? x : 0.f * x, t ? 1.f : 0.f);  // logits * msk_hard (keeps a NaN / inf logit visible like the product)
+        n_vis += (c == 0 && vis) ? 1 : 0;
+    };
+    if (p.vec) {  // HW % 4 == 0, 16-byte aligned maps: four pixels per thread and request
+        const long long n4 = n >> 2;
+        const int hw4 = p.HW >> 2;
+        constexpr int kAhead = 4;  // requests in flight per thread: the loop is a latency chain otherwise (one round trip per iteration)
+        const long long stride = (long long)chunks * kThreads;
+        for (long long i0 = (long long)chunk * kThreads + threadIdx.x; i0 < n4; i0 += kAhead * stride) {
+            float4 x[kAhead], v[kAhead];
+            uchar4 t[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const long long i = i0 + u * stride;
+                if (i < n4) {
+                    const long long b = i / hw4, q = i - b * hw4;
+                    const size_t e = (((size_t)b * p.C + c) * p.HW >> 2) + q;
+                    x[u] = reinterpret_cast<const float4*>(p.logits)[e];
+                    t[u] = reinterpret_cast<const uchar4*>(p.gt_bits)[e];
+                    v[u] = reinterpret_cast<const float4*>(p.msk_vis_logits)[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                if (i0 + u * stride >= n4) break;
+                one(x[u].x, t[u].x != 0, v[u].x > 0.f); one(x[u].y, t[u].y != 0, v[u].y > 0.f);
+                one(x[u].z, t[u].z != 0, v[u].z > 0.f); one(x[u].w, t[u].w != 0, v[u].w > 0.f);
+                bce_sum += (double)bce4;
+                bce4 = 0.f;
+            }
+        }
+    } else {
+        for (long long i = (long long)chunk * kThreads + threadIdx.x; i < n; i += (long long)chunks * kThreads) {
+            const long long b = i / p.HW, px = i - b * p.HW;
+            const size_t e = ((size_t)b * p.C + c) * p.HW + px;
+            one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[i] > 0.f);
+            bce_sum += (double)bce4;
+            bce4 = 0.f;
+        }
     }
+    double acc[3] = {(double)n_err, bce_sum, (double)n_vis};
     block_sum3(acc, red);
     if (threadIdx.x == 0) {
         for (int k = 0; k < 3; ++k) xcd_store(p.partials + 3 * blockIdx.x + k, acc[k]);
@@ -147,23 +187,32 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
     }
     __syncthreads();
     if (!last) return;
+    // The last workgroup: every partial is fetched around the caches ONCE, many requests in flight per thread (a thread adding its
+    // channel's chunks one dependent load after the other spent ~0.7 us per load), staged in LDS and added in chunk order.
     const int tid = threadIdx.x;
-    double vis_total = 0;
-    for (int k = 0; k < kBinChunks; ++k) vis_total += xcd_load(p.partials + 3 * k + 2);  // channel 0's chunks, in order
-    for (int ch = tid; ch < p.C; ch += kThreads) {
-        double hamm = 0, bce = 0;
-        for (int k = 0; k < kBinChunks; ++k) {
-            hamm += xcd_load(p.partials + 3 * (ch * kBinChunks + k));
-            bce += xcd_load(p.partials + 3 * (ch * kBinChunks + k) + 1);
+    __shared__ double stage[32][2][kBinChunks];
+    __shared__ double vis_part[kBinChunks];
+    if (tid < chunks) vis_part[tid] = xcd_load(p.partials + 3 * tid + 2);  // channel 0's chunks
+    for (int g0 = 0; g0 < p.C; g0 += 32) {
+        for (int v = tid; v < 32 * 2 * chunks; v += kThreads) {
+            const int ch = v / (2 * chunks), r = v % (2 * chunks), which = r / chunks, k = r % chunks;
+            if (g0 + ch < p.C) stage[ch][which][k] = xcd_load(p.partials + 3 * ((g0 + ch) * chunks + k) + which);
         }
-        // losses.py:205-210 in the reference's fp32 operation order
-        const float hist = (float)(long long)hamm / (float)((long long)vis_total + 1);
-        float h = p.histogram[ch];
-        h = h * (1.f - p.momentum);
-        h = h + hist * p.momentum;
-        p.histogram[ch] = h;
-        zs[ch] = fminf(h, 0.51f - h) * 3.f;
-        ws[ch] = (float)(bce / (double)n);  // loss_raw.mean([0, 2, 3]) of this bit, parked until the weights exist
+        __syncthreads();
+        if (tid < 32 && g0 + tid < p.C) {
+            const int ch = g0 + tid;
+            double hamm = 0, bce = 0, vis_total = 0;
+            for (int k = 0; k < chunks; ++k) { hamm += stage[tid][0][k]; bce += stage[tid][1][k]; vis_total += vis_part[k]; }
+            // losses.py:205-210 in the reference's fp32 operation order
+            const float hist = (float)(long long)hamm / (float)((long long)vis_total + 1);
+            float h = p.histogram[ch];
+            h = h * (1.f - p.momentum);
+            h = h + hist * p.momentum;
+            p.histogram[ch] = h;
+            zs[ch] = fminf(h, 0.51f - h) * 3.f;
+            ws[ch] = (float)(bce / (double)n);  // loss_raw.mean([0, 2, 3]) of this bit, parked until the weights exist
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (tid == 0) {  // C <= 128 values: softmax and the weighted sum by one thread, in index order
@@ -183,13 +232,24 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
 __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const BinLossParams p) {
     const long long n = (long long)p.B * p.C * p.HW;
     const float g = *p.g_loss / (float)((long long)p.B * p.HW);
+    // d/dx BCE(x * m, t) = (sigmoid(x m) - t) m
+    auto one = [&](float x, bool t, bool vis, float w) { return vis ? g * w * (sigmoidf_(x) - (t ? 1.f : 0.f)) : 0.f; };
+    if (p.vec) {
+        const int hw4 = p.HW >> 2;
+        for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < (n >> 2); e += (long long)gridDim.x * kThreads) {
+            const long long bc = e / hw4, q = e - bc * hw4, b = bc / p.C;
+            const float w = p.bin_weights[(int)(bc - b * p.C)];
+            const float4 x = reinterpret_cast<const float4*>(p.logits)[e];
+            const uchar4 t = reinterpret_cast<const uchar4*>(p.gt_bits)[e];
+            const float4 v = reinterpret_cast<const float4*>(p.msk_vis_logits)[b * hw4 + q];
+            reinterpret_cast<float4*>(p.d_logits)[e] = make_float4(one(x.x, t.x != 0, v.x > 0.f, w), one(x.y, t.y != 0, v.y > 0.f, w),
+                                                                   one(x.z, t.z != 0, v.z > 0.f, w), one(x.w, t.w != 0, v.w > 0.f, w));
+        }
+        return;
+    }
     for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long long)gridDim.x * kThreads) {
         const long long bc = e / p.HW, px = e - bc * p.HW, b = bc / p.C;
-        const int c = (int)(bc - b * p.C);
-        const bool vis = p.msk_vis_logits[b * p.HW + px] > 0.f;
-        const float x = p.logits[e], t = p.gt_bits[e] ? 1.f : 0.f;
-        // d/dx BCE(x * m, t) = (sigmoid(x m) - t) m
-        p.d_logits[e] = vis ? g * p.bin_weights[c] * (sigmoidf_(x) - t) : 0.f;
+        p.d_logits[e] = one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[b * p.HW + px] > 0.f, p.bin_weights[(int)(bc - b * p.C)]);
     }
 }
 
@@ -218,7 +278,12 @@ int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream) {
 int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.C <= 0) return 0;
     if (p.C > kBinMaxChannels) return 3;
-    hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel, dim3(p.C * kBinChunks), dim3(kThreads), 0, stream, p);
+    // every workgroup ends with one counted arrival (~11 ns each on the one counter): no more of them than keep a thread at
+    // about eight requests of four pixels
+    BinLossParams q = p;
+    const long long req = ((long long)p.B * p.HW + 3) / 4;
+    q.chunks = (int)std::min<long long>(kBinChunks, std::max<long long>(4, (req + 8 * kThreads - 1) / (8 * kThreads)));
+    hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel, dim3(q.C * q.chunks), dim3(kThreads), 0, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

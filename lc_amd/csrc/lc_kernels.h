@@ -223,11 +223,13 @@ struct BinLossParams {
     float momentum;
     float* loss;                    // (1) out (forward)
     float* bin_weights;             // (C) out (forward), in (backward)
-    double* partials;               // (C * 8, 3) workspace (forward)
+    double* partials;               // (C * 32, 3) workspace (forward)
     unsigned* ticket;               // zero between launches (forward)
     const float* g_loss;            // device scalar (backward)
     float* d_logits;                // (B,C,HW) (backward)
     int B, C, HW;
+    int vec;                        // HW % 4 == 0 and all maps 16-byte (bits: 4-byte) aligned: four pixels per request
+    int chunks;                     // workgroups per code channel (set by the launcher)
 };
 int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream);  // 3: more than kBinMaxChannels bits
 int launch_xyz_bin_loss_bwd(const BinLossParams& p, hipStream_t stream);

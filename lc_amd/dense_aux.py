@@ -15,13 +15,13 @@ _WS = {}  # (device index, stream) -> (partials, ticket): the forward's reductio
 
 def _workspace(dev):
     if torch.cuda.is_current_stream_capturing():  # a graph owns its workspace (its zero-fill is a node of the graph)
-        return torch.zeros(3 * 1024, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32)
+        return torch.zeros(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         if len(_WS) >= 64:
             _WS.clear()
-        ws = _WS[key] = (torch.zeros(3 * 1024, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32))
+        ws = _WS[key] = (torch.zeros(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32))
     return ws
 
 
@@ -112,7 +112,7 @@ class _XyzBinLoss(torch.autograd.Function):
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         weights = torch.empty(C, device=dev, dtype=torch.float32)
         partials, ticket = _workspace(dev)
-        if partials.numel() < C * 8 * 3:
+        if partials.numel() < C * 32 * 3:
             raise ValueError("Loss_xyz_bin: more than 128 code bits")
         P = _lib.ptr
         with _lib.on_device(dev):
