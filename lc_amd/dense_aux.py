@@ -14,8 +14,10 @@ _WS = {}  # (device index, stream) -> (partials, ticket): the forward's reductio
 
 
 def _workspace(dev):
-    if torch.cuda.is_current_stream_capturing():  # a graph owns its workspace (its zero-fill is a node of the graph)
-        return torch.zeros(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32)
+    if torch.cuda.is_current_stream_capturing():
+        # a graph owns its workspace; only the arrival counter has to start from zero (its zero-fill is a node of the graph), the
+        # partials are written before they are read
+        return torch.empty(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
