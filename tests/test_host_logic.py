@@ -268,3 +268,36 @@ def test_label_prep_names_pass_through_to_the_reference(monkeypatch):
               msk_noc=torch.ones(B, H, W))
     Rt_best, pose_best, xyz_gt = L.selete_best_pose(gt, {}, False)
     assert Rt_best.shape == (B, 3, 4) and pose_best.shape == (B, 7) and torch.allclose(xyz_gt, want, atol=1e-5)
+
+
+def test_chain_and_round3_entry_points_check_their_arguments_before_launching():
+    """lc_pnp_lm_chain_f32 (plain C struct jobs), lc_dense_frontend_select_f32, lc_dense_aux_fwd_f32, lc_xyz_bin_loss_fwd_f32: argument
+    errors come back as return code + lc_amd_last_error and empty batches are no-ops, all without touching a GPU."""
+    from lc_amd import _lib
+    from lc_amd.pnp.pnp_ceres import _Job
+
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.addressof(buf)
+    empty = _Job(None, None, None, None, None, None, None, None, None, None, None, None, 0, 700, 20, 1e-6, 0, 0)
+    assert lib.lc_pnp_lm_chain_f32(ctypes.byref(empty), ctypes.byref(empty), None) == 0  # two empty batches
+    assert lib.lc_pnp_lm_chain_f32(None, ctypes.byref(empty), None) != 0 and b"null job" in lib.lc_amd_last_error()
+    bad = _Job(p, p, p, None, p, None, None, None, p, p, p, None, 4, 700, 20, 1e-6, 8, 0)  # unknown option bit
+    assert lib.lc_pnp_lm_chain_f32(ctypes.byref(empty), ctypes.byref(bad), None) != 0 and b"option" in lib.lc_amd_last_error()
+    two = _Job(p, p, p, p, p, None, None, None, p, p, p, None, 4, 700, 20, 1e-6, 0, 0)  # two weight forms at once
+    assert lib.lc_pnp_lm_chain_f32(ctypes.byref(two), ctypes.byref(empty), None) != 0 and b"exactly one" in lib.lc_amd_last_error()
+    # front end + selection: more sampled pixels than the one launch takes; a mask mode without visibility logits
+    rc = lib.lc_dense_frontend_select_f32(p, p, p, None, p, 0.5, 1, 256, 256, 0, 0, 2, 0, 0.5, 1, 4, 0, p, p, p, None, p, None)
+    assert rc != 0 and b"8192" in lib.lc_amd_last_error()
+    rc = lib.lc_dense_frontend_select_f32(p, p, p, None, None, 0.5, 1, 64, 64, 0, 0, 2, 2, 0.5, 1, 4, 0, p, p, p, None, p, None)
+    assert rc != 0 and b"visibility" in lib.lc_amd_last_error()
+    assert lib.lc_dense_frontend_select_f32(p, p, p, None, p, 0.5, 0, 64, 64, 0, 0, 2, 0, 0.5, 1, 4, 0, p, p, p, None, p, None) == 0
+    # dense auxiliary losses: xyz without exactly one mask form; unknown loss type; empty batch
+    rc = lib.lc_dense_aux_fwd_f32(p, None, None, p, p, p, None, 2, 64, 0, p, p, p, None)
+    assert rc != 0 and b"mask" in lib.lc_amd_last_error()
+    assert lib.lc_dense_aux_fwd_f32(None, None, None, None, p, p, None, 2, 64, 7, p, p, p, None) != 0
+    assert lib.lc_dense_aux_fwd_f32(None, None, None, None, p, p, None, 0, 64, 0, p, p, p, None) == 0
+    # code loss: more bits than the kernel's per-bit tables hold
+    rc = lib.lc_xyz_bin_loss_fwd_f32(p, p, p, 2, 200, 64, 0.05, p, p, p, p, p, None)
+    assert rc != 0 and b"128" in lib.lc_amd_last_error()
+    assert lib.lc_xyz_bin_loss_fwd_f32(p, p, p, 0, 17, 64, 0.05, p, p, p, p, p, None) == 0
