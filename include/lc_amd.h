@@ -271,6 +271,16 @@ int lc_bits_decode_gt_fwd_f32(const float *logits, const unsigned char *gt_bits,
 int lc_bits_decode_gt_bwd_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
                               const float *g_noc, int B, int C, int H, int W, int n0, int n1, int n2, int black_background,
                               int top, int left, int sample, float *d_logits, void *stream);
+/* Round 3: the training decode with the callers' coordinate map folded in (nn_out_to_xyz, losses.py:17-47,163-184): out (B,N,3) =
+ * noc * out_scale (B,3), and with out_xform (B,4,4) = the model transform T: (noc * out_scale - T[:3,3]) @ T[:3,:3]; the backward form
+ * takes the cotangent of `out`.  out_scale = out_xform = NULL is lc_bits_decode_gt_{fwd,bwd}_f32. */
+int lc_bits_decode_gt_fwd2_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
+                               const float *out_scale, const float *out_xform, int B, int C, int H, int W, int n0, int n1, int n2,
+                               int black_background, int top, int left, int sample, float *out, void *stream);
+int lc_bits_decode_gt_bwd2_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
+                               const float *out_scale, const float *out_xform, const float *g_out, int B, int C, int H, int W,
+                               int n0, int n1, int n2, int black_background, int top, int left, int sample, float *d_logits,
+                               void *stream);
 int lc_bits_decode_f32(const float *logits, int B, int C, int H, int W, int n0, int n1, int n2, int black_background,
                        float *noc, void *stream);
 

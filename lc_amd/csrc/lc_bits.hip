@@ -125,6 +125,30 @@ __device__ __forceinline__ void decode_gray(const float* lg, size_t stride, int 
 }
 
 // forward of the training decode.  V == 4 needs sample == 1 (the pixel subset is the whole map), W % 4 == 0
+// normalised coordinates -> object coordinates of sample b (nn_out_to_xyz): x = (n * s - t) @ R, R = T[:3,:3], t = T[:3,3]; and the
+// cotangent's way back, g_n[i] = s[i] * sum_j g_x[j] R[i][j].  Identity where the pointers are null.
+struct OutMap {
+    float s[3], t[3], R[3][3];
+    bool scale, xform;
+    __device__ OutMap(const BitsParams& p, int b) : scale(p.out_scale != nullptr), xform(p.out_xform != nullptr) {
+        for (int i = 0; i < 3; ++i) {
+            s[i] = scale ? p.out_scale[3 * b + i] : 1.f;
+            t[i] = xform ? p.out_xform[16 * b + 4 * i + 3] : 0.f;
+            for (int j = 0; j < 3; ++j) R[i][j] = xform ? p.out_xform[16 * b + 4 * i + j] : (i == j ? 1.f : 0.f);
+        }
+    }
+    __device__ __forceinline__ void apply(float (&v)[3]) const {
+        if (!scale && !xform) return;
+        const float w0 = v[0] * s[0] - t[0], w1 = v[1] * s[1] - t[1], w2 = v[2] * s[2] - t[2];
+        if (!xform) { v[0] = w0; v[1] = w1; v[2] = w2; return; }
+        for (int j = 0; j < 3; ++j) v[j] = w0 * R[0][j] + w1 * R[1][j] + w2 * R[2][j];
+    }
+    __device__ __forceinline__ float pull(const float* g, int i) const {  // g: the three cotangents of one point
+        if (!xform) return g[i] * s[i];
+        return s[i] * (g[0] * R[i][0] + g[1] * R[i][1] + g[2] * R[i][2]);
+    }
+};
+
 template <int V>
 __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_fwd_kernel(const BitsParams p) {
     const int Wn = (p.W - p.left + p.sample - 1) / p.sample;
@@ -154,6 +178,9 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_fwd_kernel(const B
             for (int v = 0; v < V; ++v) res[v][a] = st[v].finish(nb, in_msk[v]).val / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
         }
+        const OutMap om(p, b);  // the V pixels of a request belong to one sample (N % V == 0 on this path)
+#pragma unroll
+        for (int v = 0; v < V; ++v) om.apply(res[v]);
         float* o = p.out + i0 * 3;
         if constexpr (V == 4) {  // 12 contiguous floats
             *reinterpret_cast<float4*>(o) = make_float4(res[0][0], res[0][1], res[0][2], res[1][0]);
@@ -197,6 +224,7 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const B
             n[v] = live[v] ? (size_t)(dy / p.sample) * Wn + dx / p.sample : 0;
             any = any || live[v];
         }
+        const OutMap om(p, b);
         int c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const B
                     if (live[v]) {
                         const AxisDecode d = st[v].finish(nb, true);
                         idx[v] = d.idx;
-                        g[v] = p.g_out[((size_t)b * p.N + n[v]) * 3 + a] * d.dval / ((float)((1 << nb) - 1) * 0.5f);
+                        g[v] = om.pull(p.g_out + ((size_t)b * p.N + n[v]) * 3, a) * d.dval / ((float)((1 << nb) - 1) * 0.5f);
                     }
                 }
             }

@@ -493,6 +493,32 @@ int lc_bits_decode_gt_bwd_f32(const float* logits, const unsigned char* gt_bits,
     return lc::launch_bits_decode_gt_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode backward launch failed") : 0;
 }
 
+int lc_bits_decode_gt_fwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
+                               const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top,
+                               int left, int sample, float* out, void* stream) {
+    if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
+    if (B == 0) return 0;
+    if (!logits || !gt_bits || !out) return fail(1, "null pointer");
+    if (out_xform && !out_scale) return fail(1, "the model transform applies to scaled coordinates: out_scale is needed with out_xform");
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    lc::BitsParams p{logits, gt_bits, gt_msk, nullptr, out, nullptr, B, C, H, W, N, top, left, sample, {n0, n1, n2},
+                     black_background ? -1 : 1, out_scale, out_xform};
+    return lc::launch_bits_decode_gt_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
+}
+
+int lc_bits_decode_gt_bwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
+                               const float* out_xform, const float* g_out, int B, int C, int H, int W, int n0, int n1, int n2,
+                               int black_background, int top, int left, int sample, float* d_logits, void* stream) {
+    if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
+    if (B == 0) return 0;
+    if (!logits || !gt_bits || !g_out || !d_logits) return fail(1, "null pointer");
+    if (out_xform && !out_scale) return fail(1, "the model transform applies to scaled coordinates: out_scale is needed with out_xform");
+    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
+    lc::BitsParams p{logits, gt_bits, gt_msk, g_out, nullptr, d_logits, B, C, H, W, N, top, left, sample, {n0, n1, n2},
+                     black_background ? -1 : 1, out_scale, out_xform};
+    return lc::launch_bits_decode_gt_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode backward launch failed") : 0;
+}
+
 int lc_bits_decode_f32(const float* logits, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, float* noc,
                        void* stream) {
     if (int rc = bits_check(B, C, H, W, n0, n1, n2, 0, 0, 1)) return rc;

@@ -41,53 +41,61 @@ def _as_u8(name, t):
     return (t != 0).to(torch.uint8).contiguous() if t.dtype != torch.uint8 else t.contiguous()
 
 
-def _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample):
+def _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample, out_scale=None, out_xform=None):
     lib = _lib.load()
     B, C, H, W = logits.shape
     N = ((H - top + sample - 1) // sample) * ((W - left + sample - 1) // sample)
-    noc = torch.empty(B, N, 3, device=logits.device, dtype=torch.float32)
+    out = torch.empty(B, N, 3, device=logits.device, dtype=torch.float32)
     with _lib.on_device(logits.device):
-        rc = lib.lc_bits_decode_gt_fwd_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), B, C, H, W, *bits, int(_black_background),
-                                           top, left, sample, _lib.ptr(noc), _lib.stream_ptr(logits.device))
-    _lib.check(rc, "lc_bits_decode_gt_fwd_f32")
-    return noc
+        rc = lib.lc_bits_decode_gt_fwd2_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(out_scale), _lib.ptr(out_xform),
+                                            B, C, H, W, *bits, int(_black_background), top, left, sample, _lib.ptr(out),
+                                            _lib.stream_ptr(logits.device))
+    _lib.check(rc, "lc_bits_decode_gt_fwd2_f32")
+    return out
 
 
-def _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g_noc, bits, top, left, sample, black):
+def _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g_out, bits, top, left, sample, black, out_scale=None, out_xform=None):
     lib = _lib.load()
     B, C, H, W = logits.shape
     d = torch.empty_like(logits)
     with _lib.on_device(logits.device):
-        rc = lib.lc_bits_decode_gt_bwd_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(g_noc), B, C, H, W, *bits, int(black),
-                                           top, left, sample, _lib.ptr(d), _lib.stream_ptr(logits.device))
-    _lib.check(rc, "lc_bits_decode_gt_bwd_f32")
+        rc = lib.lc_bits_decode_gt_bwd2_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(out_scale), _lib.ptr(out_xform),
+                                            _lib.ptr(g_out), B, C, H, W, *bits, int(black), top, left, sample, _lib.ptr(d),
+                                            _lib.stream_ptr(logits.device))
+    _lib.check(rc, "lc_bits_decode_gt_bwd2_f32")
     return d
 
 
 class _DecodeGtFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, gt_bits, gt_msk, bits, top, left, sample):
-        noc = _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample)
-        ctx.save_for_backward(logits, gt_bits, gt_msk)
+    def forward(ctx, logits, gt_bits, gt_msk, bits, top, left, sample, out_scale=None, out_xform=None):
+        out = _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample, out_scale, out_xform)
+        ctx.save_for_backward(logits, gt_bits, gt_msk, out_scale, out_xform)
         ctx.cfg = (tuple(bits), top, left, sample, _black_background)
-        return noc
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        logits, gt_bits, gt_msk = ctx.saved_tensors
+        logits, gt_bits, gt_msk, out_scale, out_xform = ctx.saved_tensors
         bits, top, left, sample, black = ctx.cfg
-        d = _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g.contiguous().to(torch.float32), list(bits), top, left, sample, black)
-        return d, None, None, None, None, None, None
+        d = _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g.contiguous().to(torch.float32), list(bits), top, left, sample, black, out_scale,
+                                  out_xform)
+        return d, None, None, None, None, None, None, None, None
 
 
-def decode_with_gt_strided(logits: Tensor, gt_raw_bits: Tensor, bit_cnt, gt_msk: Tensor, sample: int = 1, top_left=(0, 0)) -> Tensor:
+def decode_with_gt_strided(logits: Tensor, gt_raw_bits: Tensor, bit_cnt, gt_msk: Tensor, sample: int = 1, top_left=(0, 0), *,
+                           out_scale: Tensor = None, out_xform: Tensor = None) -> Tensor:
     """(B,C,H,W) logits -> (B,N,3) normalised coordinates of the strided pixel subset (losses.py:163-184 order:
-    sub-sample first, decode second)."""
+    sub-sample first, decode second).  out_scale (B,3) / out_xform (B,4,4): the callers' `noc * noc_scale` and
+    `(xyz - T[:, :3, 3]) @ T[:, :3, :3]` (losses.py:17-47) applied by the same launch (and undone by the backward launch); neither
+    takes a gradient."""
     lg = _lib.require_hip_f32("logits", logits)
     bits = _bits3(bit_cnt, lg.shape[1])
     gb = _as_u8("gt_raw_bits", gt_raw_bits)
     gm = None if gt_msk is None else _as_u8("gt_msk", gt_msk)
-    return _DecodeGtFn.apply(lg, gb, gm, bits, int(top_left[0]), int(top_left[1]), int(sample))
+    sc = None if out_scale is None else _lib.require_hip_f32("out_scale", out_scale.detach().reshape(lg.shape[0], 3))
+    xf = None if out_xform is None else _lib.require_hip_f32("out_xform", out_xform.detach().reshape(lg.shape[0], 4, 4))
+    return _DecodeGtFn.apply(lg, gb, gm, bits, int(top_left[0]), int(top_left[1]), int(sample), sc, xf)
 
 
 def nn_logits2noc_with_gt(logits: Tensor, gt_raw_bits: Tensor, bit_cnt: Union[int, List[int]], gt_msk: Tensor) -> Tensor:

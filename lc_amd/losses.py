@@ -112,9 +112,13 @@ def dense_pnp_matching_from_noc_bin(noc_bin_out_logits: Tensor, noc_bin_gt_raw: 
 
 
 def _decode_bin_points(logits, raw_bits, noc_mask, noc_scale, gt_dict, sample, top_left):
+    T = gt_dict.get("model_transform", None)
+    if logits.is_cuda and logits.dtype == torch.float32 and noc_scale.dtype == torch.float32 and (T is None or T.dtype == torch.float32):
+        # decode, `noc * noc_scale` and the model transform `(xyz - T[:, :3, 3]) @ T[:, :3, :3]` in ONE launch each way
+        return floatbits.decode_with_gt_strided(logits, raw_bits, gt_dict["bit_cnt"], noc_mask, sample=sample, top_left=top_left,
+                                                out_scale=noc_scale, out_xform=T)
     noc = floatbits.decode_with_gt_strided(logits, raw_bits, gt_dict["bit_cnt"], noc_mask, sample=sample, top_left=top_left)  # (B,N,3)
     xyz = noc * noc_scale.unsqueeze(-2)
-    T = gt_dict.get("model_transform", None)
     if T is not None:
         xyz = (xyz - T[:, None, :3, 3]) @ T[:, :3, :3]
     return xyz

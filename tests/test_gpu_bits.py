@@ -77,3 +77,41 @@ def test_bits_odd_widths_take_the_scalar_path(H, W, sample, tl):
     assert rel_err(gk.cpu(), go) <= 5e-6
     inf = fb.nn_logits2noc(lg.to(dev), bits)
     assert rel_err(inf.cpu(), orc.nn_logits2noc(lg.double(), bits)) <= 2e-6
+
+
+@pytest.mark.parametrize("H,W,sample,tl,with_T", [(64, 64, 2, (1, 0), True), (32, 32, 1, (0, 0), True), (21, 30, 2, (0, 1), False), (16, 16, 1, (0, 0), False)])
+def test_decode_with_the_coordinate_map_folded_in(H, W, sample, tl, with_T):
+    """lc_bits_decode_gt_{fwd,bwd}2_f32: `noc * noc_scale` and the model transform `(xyz - T[:, :3, 3]) @ T[:, :3, :3]` of
+    nn_out_to_xyz (losses.py:17-47) applied by the decode launches, against the plain decode followed by the torch ops (float64 on the
+    oracle's decode): values and logit gradients."""
+    from lc_amd import floatbits as fb
+    from oracle import floatbits_oracle as orc
+
+    g = torch.Generator().manual_seed(H + W)
+    B, bits = 3, [6, 6, 5]
+    noc = torch.rand(B, H, W, 3, generator=g) * 2 - 1
+    mod, raw = fb.nn_noc2target(noc, bits)
+    lg = (mod.float() * 2 - 1) * (torch.rand(B, sum(bits), H, W, generator=g) * 3 + 0.1)
+    lg = torch.where(torch.rand(lg.shape, generator=g) < 0.1, -lg, lg)
+    msk = torch.rand(B, H, W, generator=g) > 0.2
+    scale = torch.rand(B, 3, generator=g) * 100 + 20
+    T = None
+    if with_T:
+        q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+        T = torch.eye(4).repeat(B, 1, 1)
+        T[:, :3, :3] = q
+        T[:, :3, 3] = torch.randn(B, 3, generator=g) * 5
+    dev = torch.device("cuda:0")
+    x = lg.to(dev).requires_grad_(True)
+    out = fb.decode_with_gt_strided(x, raw.to(dev), bits, msk.to(dev), sample=sample, top_left=tl, out_scale=scale.to(dev),
+                                    out_xform=None if T is None else T.to(dev))
+    x64 = lg.double().requires_grad_(True)
+    sl = (Ellipsis, slice(tl[0], None, sample), slice(tl[1], None, sample))
+    ref = orc.nn_logits2noc_with_gt(x64[sl], raw[sl], bits, msk[sl]).flatten(1, 2) * scale.double()[:, None]
+    if T is not None:
+        ref = (ref - T.double()[:, None, :3, 3]) @ T.double()[:, :3, :3]
+    assert out.shape == ref.shape and rel_err(out.detach().cpu(), ref.detach()) <= 2e-6
+    ct = torch.randn(out.shape, generator=g)
+    (gk,) = torch.autograd.grad(out, x, ct.to(dev))
+    (go,) = torch.autograd.grad(ref, x64, ct.double())
+    assert rel_err(gk.cpu(), go) <= 5e-6
