@@ -271,6 +271,12 @@ int lc_bits_decode_gt_fwd_f32(const float *logits, const unsigned char *gt_bits,
 int lc_bits_decode_gt_bwd_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
                               const float *g_noc, int B, int C, int H, int W, int n0, int n1, int n2, int black_background,
                               int top, int left, int sample, float *d_logits, void *stream);
+/* Round 3: the inference decode with the callers' coordinate map folded in (nn_out_to_xyz(..., inference=True), losses.py:17-47) and,
+ * with planar != 0, written as (B,3,H,W) planes -- what lc_dense_frontend_*_f32 read -- instead of (B,H,W,3): out = noc * out_scale
+ * (B,3)|NULL, then (. - T[:3,3]) @ T[:3,:3] with out_xform (B,4,4)|NULL. */
+int lc_bits_decode2_f32(const float *logits, const float *out_scale, const float *out_xform, int B, int C, int H, int W, int n0,
+                        int n1, int n2, int black_background, int planar, float *out, void *stream);
+
 /* Round 3: the training decode with the callers' coordinate map folded in (nn_out_to_xyz, losses.py:17-47,163-184): out (B,N,3) =
  * noc * out_scale (B,3), and with out_xform (B,4,4) = the model transform T: (noc * out_scale - T[:3,3]) @ T[:3,:3]; the backward form
  * takes the cotangent of `out`.  out_scale = out_xform = NULL is lc_bits_decode_gt_{fwd,bwd}_f32. */

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "lc_bits_decode_gt_fwd2_f32": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_gt_bwd2_f32": (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_f32": (c_int, [c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
+    "lc_bits_decode2_f32": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_void_p]),
     "lc_pose_errors_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     "lc_sqnorm_f32": (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "lc_norm_clip_apply_f32": (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_float, c_float, ctypes.c_double,

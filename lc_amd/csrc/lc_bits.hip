@@ -276,6 +276,19 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_kernel(const BitsPara
             for (int v = 0; v < V; ++v) res[v][a] = val[v] / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
         }
+        const OutMap om(p, b);
+#pragma unroll
+        for (int v = 0; v < V; ++v) om.apply(res[v]);
+        if (p.out_planar) {  // (B,3,H,W): one coalesced store per coordinate plane
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float o[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) o[v] = res[v][a];
+                store_px<V>(p.out + ((size_t)b * 3 + a) * HW + px, o);
+            }
+            continue;
+        }
         float* o = p.out + i0 * 3;
         if constexpr (V == 4) {
             *reinterpret_cast<float4*>(o) = make_float4(res[0][0], res[0][1], res[0][2], res[1][0]);

@@ -528,6 +528,17 @@ int lc_bits_decode_f32(const float* logits, int B, int C, int H, int W, int n0, 
     return lc::launch_bits_decode(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
 }
 
+int lc_bits_decode2_f32(const float* logits, const float* out_scale, const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2,
+                        int black_background, int planar, float* out, void* stream) {
+    if (int rc = bits_check(B, C, H, W, n0, n1, n2, 0, 0, 1)) return rc;
+    if (B == 0) return 0;
+    if (!logits || !out) return fail(1, "null pointer");
+    if (out_xform && !out_scale) return fail(1, "the model transform applies to scaled coordinates: out_scale is needed with out_xform");
+    lc::BitsParams p{logits, nullptr, nullptr, nullptr, out, nullptr, B, C, H, W, H * W, 0, 0, 1, {n0, n1, n2}, black_background ? -1 : 1,
+                     out_scale, out_xform, planar ? 1 : 0};
+    return lc::launch_bits_decode(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
+}
+
 int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt, const float* t_gt, const float* pts,
                        const int* pts_off, const int* pts_cnt, int B, int M, int want_adi, float* out, void* stream) {
     if (B < 0 || M < 0) return fail(1, "bad size");

@@ -145,6 +145,7 @@ struct BitsParams {
     // training decode only: normalised coordinates -> object coordinates in the kernel (losses.py:17-47 nn_out_to_xyz, :163-184):
     const float* out_scale;       // (B,3) noc_scale, or null: out = noc * scale
     const float* out_xform;       // (B,4,4) model transform T, or null: out = (noc * scale - T[:3,3]) @ T[:3,:3]
+    int out_planar;               // inference decode only: write (B,3,H,W) planes (what the dense front end reads) instead of (B,H,W,3)
 };
 int launch_bits_decode_gt_fwd(const BitsParams& p, hipStream_t stream);
 int launch_bits_decode_gt_bwd(const BitsParams& p, hipStream_t stream);

@@ -121,6 +121,25 @@ def nn_logits2noc(logits: Tensor, bit_cnt: Union[int, List[int]], nearest_lut: T
 
 
 @torch.no_grad()
+def nn_logits2xyz_planes(logits: Tensor, bit_cnt: Union[int, List[int]], noc_scale: Tensor = None, model_transform: Tensor = None) -> Tensor:
+    """Inference decode straight to object coordinates as (B,3,H,W) planes -- `nn_out_to_xyz(..., inference=True).permute(0, 3, 1, 2)`
+    (losses.py:17-47) in one launch: Gray decode, `* noc_scale`, `(. - T[:, :3, 3]) @ T[:, :3, :3]`, channel-first layout (what the
+    dense front end reads)."""
+    lib = _lib.load()
+    lg = _lib.require_hip_f32("logits", logits)
+    B, C, H, W = lg.shape
+    bits = _bits3(bit_cnt, C)
+    sc = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale.reshape(B, 3))
+    xf = None if model_transform is None else _lib.require_hip_f32("model_transform", model_transform.reshape(B, 4, 4))
+    out = torch.empty(B, 3, H, W, device=lg.device, dtype=torch.float32)
+    with _lib.on_device(lg.device):
+        rc = lib.lc_bits_decode2_f32(_lib.ptr(lg), _lib.ptr(sc), _lib.ptr(xf), B, C, H, W, *bits, int(_black_background), 1, _lib.ptr(out),
+                                     _lib.stream_ptr(lg.device))
+    _lib.check(rc, "lc_bits_decode2_f32")
+    return out
+
+
+@torch.no_grad()
 def mod_noc2bits_bb(numbers: Tensor, N: int, black_background=True):
     """floatbits.py:77-97 (label prep): normalised coordinate (-1,1) -> Gray-coded bits + raw bits, (*,N) bool."""
     max_num = 2 ** N - 1

@@ -20,6 +20,7 @@ import gc
 import torch
 from torch import Tensor
 
+from . import floatbits
 from .dense import FUSED_SELECT_MAX_POINTS, dense_front_end_select, dense_front_end_with_visibility, dense_select
 from .losses import nn_out_to_xyz
 from .pnp import gpu_solver, pnp_ceres
@@ -74,6 +75,11 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     if "xyz_noc" in out_dict and gt_dict.get("model_transform", None) is None and gt_dict.get("bit_cnt", None) is None:
         # continuous head: the kernel scales the normalised coordinates itself (losses.py:17-22 is that one multiply)
         xyz_map, noc_scale = out_dict["xyz_noc"], gt_dict["noc_scale"]
+    elif "xyz_noc_bin" in out_dict and out_dict["xyz_noc_bin"].dtype == torch.float32:
+        # binary-code head: Gray decode, noc_scale, model transform and the channel-first layout in one launch
+        xyz_map = floatbits.nn_logits2xyz_planes(out_dict["xyz_noc_bin"], gt_dict["bit_cnt"], gt_dict["noc_scale"],
+                                                 gt_dict.get("model_transform", None))
+        noc_scale = None
     else:
         head = out_dict["xyz_noc"] if "xyz_noc" in out_dict else out_dict["xyz_noc_bin"]
         xyz_map = nn_out_to_xyz(head, gt_dict["noc_scale"], model_transform=gt_dict.get("model_transform", None),

@@ -115,3 +115,32 @@ def test_decode_with_the_coordinate_map_folded_in(H, W, sample, tl, with_T):
     (gk,) = torch.autograd.grad(out, x, ct.to(dev))
     (go,) = torch.autograd.grad(ref, x64, ct.double())
     assert rel_err(gk.cpu(), go) <= 5e-6
+
+
+@pytest.mark.parametrize("H,W,with_T", [(64, 64, True), (30, 21, True), (128, 128, False)])
+def test_inference_decode_straight_to_xyz_planes(H, W, with_T):
+    """lc_bits_decode2_f32 (Gray decode + noc_scale + model transform, written as (B,3,H,W) planes) against
+    `nn_out_to_xyz(..., inference=True).permute(0, 3, 1, 2)`: the decode itself bit for bit (same kernel body), the coordinate map to
+    fp32 rounding of a 3-term product sum."""
+    from lc_amd import floatbits as fb
+    from lc_amd.losses import nn_out_to_xyz
+
+    g = torch.Generator().manual_seed(H * W)
+    B, bits = 3, [7, 6, 6]
+    dev = torch.device("cuda:0")
+    lg = (torch.randn(B, sum(bits), H, W, generator=g) * 2).to(dev)
+    scale = (torch.rand(B, 3, generator=g) * 100 + 20).to(dev)
+    T = None
+    if with_T:
+        q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+        T = torch.eye(4).repeat(B, 1, 1)
+        T[:, :3, :3] = q
+        T[:, :3, 3] = torch.randn(B, 3, generator=g) * 5
+        T = T.to(dev)
+    got = fb.nn_logits2xyz_planes(lg, bits, scale, T)
+    want = nn_out_to_xyz(lg, scale, model_transform=T, bit_cnt=bits, inference=True).permute(0, 3, 1, 2)
+    assert got.shape == want.shape == (B, 3, H, W) and got.is_contiguous()
+    if T is None:
+        assert torch.equal(got, want.contiguous())
+    else:
+        assert (got - want).abs().max() <= 2e-5 * want.abs().max()
