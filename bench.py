@@ -324,12 +324,12 @@ def main():
             assert rc == 0
 
         def launch_fused(self, stream=None):
-            # one grid for both halves of the pose unit (lc_amd/csrc/lc_fused.hip)
+            # one grid for both halves of the pose unit (lc_amd/csrc/lc_fused.hip; dense shapes: lc_fused_dense.hip)
             b = self.b
-            rc = lib.lc_pose_unit_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]),
-                                      P(self.go), self.B, self.N, 32.0, 3.0, 4.0, P(self.loss), P(self.d_u), P(self.d_s), P(self.d_x),
-                                      P(self.sqrt_diag), P(b["start"]), P(self.states), P(self.tr), P(self.ret), 50, 1e-6,
-                                      stream or _lib.stream_ptr(dev))
+            rc = lib.lc_pose_unit2_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]),
+                                       P(self.go), self.B, self.N, 32.0, 3.0, 4.0, P(self.loss), P(self.d_u), P(self.d_s), P(self.d_x),
+                                       P(self.sqrt_diag), P(b["start"]), P(self.states), P(self.tr), P(self.ret), None, 50, 1e-6,
+                                       P(self.ws), 0 if self.ws is None else self.ws.numel(), stream or _lib.stream_ptr(dev))
             assert rc == 0
 
         def check(self):
@@ -489,31 +489,47 @@ def main():
         return Bs, Bs / (ms * 1e-3), ms
 
     def dense_block(name, Bd, Nd):
-        """One dense config's per-GPU hot-path shape: LC-loss fwd+bwd (lc_cov_loss_kernel, block-stride form) + one weighted-PnP
-        solve per sample over the same N correspondences (lc_pnp_lm_wide_kernel).  A step = the two launches back to back."""
+        """One dense config's per-GPU hot-path shape: LC-loss fwd+bwd (tiled form) + one weighted-PnP solve per sample over the same N
+        correspondences (four wavefronts per pose).  A step = one pose-unit launch over the batch (lc_pose_unit2_f32: the two kernels'
+        workgroups in one grid), with the two stand-alone launches back to back timed beside it (`two_launches`)."""
         u = Unit(Bd, Nd, seed=4242)
 
         def step():
             u.launch_loss()
             u.launch_pnp()
         t_loss, t_pnp = kernel_ms(u.launch_loss, reps=50), kernel_ms(u.launch_pnp, reps=50)
-        g = capture(step, 20)
-        t_step = kernel_ms(g.replay, reps=5) / 20 if g is not None else None
-        t_step_so = kernel_ms(step, reps=50)
-        # wall clock, the headline's protocol in small: 11 regions of 20 steps, synchronize around each, median
-        regs = []
-        for _ in range(11):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            if g is not None:
-                g.replay()
-            else:
-                for _ in range(20):
-                    step()
-            torch.cuda.synchronize(dev)
-            regs.append((time.perf_counter() - t0) / 20)
-        wall = sorted(regs)[len(regs) // 2]
+
+        def wall_clock(step_fn):
+            """the headline's protocol in small: 11 regions of 20 steps (one graph replay where it captures), synchronize around
+            each, median; also the event-timed step inside the graph and in stream order"""
+            g = capture(step_fn, 20)
+            t_graph = kernel_ms(g.replay, reps=5) / 20 if g is not None else None
+            t_so = kernel_ms(step_fn, reps=50)
+            regs = []
+            for _ in range(11):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                if g is not None:
+                    g.replay()
+                else:
+                    for _ in range(20):
+                        step_fn()
+                torch.cuda.synchronize(dev)
+                regs.append((time.perf_counter() - t0) / 20)
+            return sorted(regs)[len(regs) // 2], t_graph, t_so, g is not None
+        wall, t_step, t_step_so, graphed = wall_clock(step)
         u.check()
+        # the same unit as ONE launch (tiled loss workgroups + four-wave solve workgroups in one grid: lc_pose_unit2_f32)
+        fused = None
+        if u.ws is not None and Nd <= 2048:
+            u.loss.fill_(float("nan"))
+            u.states.fill_(float("nan"))
+            wall_f, t_f, t_f_so, graphed_f = wall_clock(u.launch_fused)
+            u.check()
+            fused = {"value": Bd / wall_f, "unit": "poses/s", "ms_per_step": wall_f * 1e3,
+                     "launch": "graph_region (20 steps per replay)" if graphed_f else "stream order",
+                     "step_us_events": {"graph": None if t_f is None else t_f * 1e3, "stream_order": t_f_so * 1e3},
+                     "what": "lc_pose_unit_dense_kernel: the loss's and the solve's workgroups in one grid, results bit for bit the two launches'"}
         it_mean, it_max = u.mean_lm_iterations()
         by_l, by_p = algorithmic_bytes(Nd, True)
         fl_l, fl_p = algorithmic_flops(Nd, it_mean + 1.0)
@@ -536,10 +552,16 @@ def main():
         groups = next((Bd * ((T_ + ts - 1) // ts) for ts in (4, 8, 16) if (T_ + ts - 1) // ts >= 3 and Bd * ((T_ + ts - 1) // ts) <= 256), None)
         loss_key = f"lc_cov_loss_tiled_kernel[{groups} workgroups]" if (u.ws is not None and groups) else None
         pnp_key = f"lc_pnp_lm_wide_kernel<false,false,{4 if Nd <= 1024 else 8}>" if 256 < Nd <= 2048 else None
+        two = {"value": Bd / wall, "unit": "poses/s", "ms_per_step": wall * 1e3,
+               "launch": "graph_region (20 steps per replay)" if graphed else "stream order",
+               "step_us_events": {"graph": None if t_step is None else t_step * 1e3, "stream_order": t_step_so * 1e3},
+               "what": "the loss launch and the solve launch back to back"}
+        top = fused if fused is not None else two  # like the headline: a step is ONE launch over the batch where that form exists
         return {"workload": f"{name}: B={Bd} samples x N={Nd} correspondences per GPU (fp32 I/O, fp64 inside)",
-                "value": Bd / wall, "unit": "poses/s", "ms_per_step": wall * 1e3,
-                "launch": "graph_region (20 steps per replay)" if g is not None else "stream order",
-                "step_us_events": {"graph": None if t_step is None else t_step * 1e3, "stream_order": t_step_so * 1e3},
+                "value": top["value"], "unit": "poses/s", "ms_per_step": top["ms_per_step"], "launch": top["launch"],
+                "step_us_events": top["step_us_events"],
+                "step": "one launch (lc_pose_unit2_f32)" if fused is not None else "two launches",
+                "two_launches": two,
                 "lm_iterations": {"mean": it_mean, "max": it_max},
                 "lc_cov_loss_kernel": dict(roof(t_loss, by_l, fl_l, loss_key), form="tiled: the sample's 64-point tiles dealt to 256-thread workgroups (4, 8 or 16 tiles each), one hand-off" if u.ws is not None else "one workgroup per sample"),
                 "lc_pnp_lm_wide_kernel": roof(t_pnp, by_p, fl_p, pnp_key),

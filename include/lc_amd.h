@@ -135,6 +135,18 @@ int lc_pose_unit_f32(const float *K, const float *pose, const float *pts3d, cons
                      const float *pnp_sqrt_diag, const float *pnp_start, float *pnp_states, float *pnp_result_tr,
                      int *pnp_rets, int pnp_max_iter, float pnp_function_tolerance, void *stream);
 
+/* Round 3: the pose unit for the dense shapes as well.  N <= 64: lc_pose_unit_f32 (workspace unused).  256 < N <= 2048 with
+ * workspace = lc_cov_loss_workspace_bytes(B, N) > 0 bytes (8-byte aligned, zero-filled once, left zero): the tiled loss's
+ * workgroups and the four-wave solve's share one grid (B = 32, N = 1024: 128 + 32 workgroups at the same time instead of two launches
+ * back to back).  Other shapes: return code 3 -- launch lc_cov_loss3_fwd_bwd_f32 and lc_pnp_lm_f32 separately.  pnp_iters (B)|NULL.
+ * Results bit for bit those of the two stand-alone launches. */
+int lc_pose_unit2_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d, const float *inv_std,
+                      const float *valid, const float *bbox_3d, const float *grad_out, int B, int N, float max_err_len,
+                      float rel_thresh, float w_e_thresh, float *loss, float *d_pts2d, float *d_inv_std, float *d_pts3d,
+                      const float *pnp_sqrt_diag, const float *pnp_start, float *pnp_states, float *pnp_result_tr,
+                      int *pnp_rets, int *pnp_iters, int pnp_max_iter, float pnp_function_tolerance, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
 /* same with the cov_2d switch of cov_mixed.py:111,125-130 (covariance of the PROJECTED bbox corners; no reference call site
  * enables it, losses.py:333,383) */
 int lc_cov_loss2_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,

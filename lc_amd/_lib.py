@@ -33,6 +33,8 @@ _SIGNATURES = {
     "lc_cov_loss_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "lc_pose_unit_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 9 +
                          [c_int, c_float, c_void_p]),
+    "lc_pose_unit2_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 10 +
+                          [c_int, c_float, c_void_p, ctypes.c_size_t, c_void_p]),
     "lc_scale_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_int, c_void_p]),
     "lc_dense_frontend_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 5),

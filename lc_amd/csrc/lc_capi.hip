@@ -306,6 +306,28 @@ int lc_pose_unit_f32(const float* K, const float* pose, const float* pts3d, cons
     return 0;
 }
 
+int lc_pose_unit2_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
+                      const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
+                      float rel_thresh, float w_e_thresh, float* loss, float* d_pts2d, float* d_inv_std, float* d_pts3d,
+                      const float* pnp_sqrt_diag, const float* pnp_start, float* pnp_states, float* pnp_result_tr, int* pnp_rets,
+                      int* pnp_iters, int pnp_max_iter, float pnp_function_tolerance, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B < 0 || N <= 0) return fail(1, "bad size");
+    if (B == 0) return 0;
+    if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss || !d_pts2d || !d_inv_std || !pnp_sqrt_diag ||
+        !pnp_start || !pnp_states || !pnp_result_tr || !pnp_rets)
+        return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, pts2d, inv_std, d_pts2d, d_inv_std, pnp_sqrt_diag, workspace);
+    lc::LossParams lp{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, nullptr,
+                      B, N, max_err_len, rel_thresh, w_e_thresh, 0, workspace, workspace_bytes};
+    lc::PnpParams pp{K, pts2d, pts3d, nullptr, pnp_sqrt_diag, nullptr, pnp_start == pnp_states ? nullptr : pnp_start, pnp_states,
+                     pnp_result_tr, pnp_rets, pnp_iters, B, N, pnp_max_iter, pnp_function_tolerance};
+    const int rc = N <= 64 ? lc::launch_pose_unit(lp, pp, static_cast<hipStream_t>(stream)) : lc::launch_pose_unit_dense(lp, pp, static_cast<hipStream_t>(stream));
+    if (rc == 3) return fail(3, "lc_pose_unit2_f32 takes N <= 64, or 256 < N <= 2048 with the workspace of lc_cov_loss_workspace_bytes(B, N) "
+                                "where that is non-zero; launch the two kernels separately otherwise");
+    if (rc) return fail(11, "pose-unit kernel launch failed");
+    return 0;
+}
+
 int lc_scale_rows_f32(const float* scale, int B, const float* src0, float* dst0, int len0, const float* src1, float* dst1,
                       int len1, const float* src2, float* dst2, int len2, void* stream) {
     if (B <= 0) return 0;

@@ -39,6 +39,9 @@ struct LossParams {
 };
 int launch_cov_loss(const LossParams& p, hipStream_t stream);  // 3: workspace too small
 size_t cov_loss_workspace_bytes(int B, int N);  // 0: the shape does not use the tiled form
+// tiles, workgroups per sample, tiles per workgroup of the tiled form; reserved_groups: compute units to leave to other workgroups of
+// the same grid (the dense pose unit's solves) where a coarser slicing allows it -- any slicing adds in the same tile order
+bool cov_loss_tiled_shape(int B, int N, int* T, int* S, int* TS, int reserved_groups = 0);
 
 struct PnpParams {
     const float* K;       // (B,3,3)
@@ -68,6 +71,9 @@ int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stre
 int launch_pnp_lm_trace(const PnpParams& p, hipStream_t stream);  // same solve + p.trace rows (parity diagnostics, not a hot path)
 // both of the above in one grid (N <= 64 only; returns 3 otherwise)
 int launch_pose_unit(const LossParams& lp, const PnpParams& pp, hipStream_t stream);
+// the same for dense shapes (256 < N <= 2048, lp.workspace given): tiled loss workgroups and four-wave solve workgroups in one grid;
+// 3: shape not supported / workspace too small
+int launch_pose_unit_dense(const LossParams& lp, const PnpParams& pp, hipStream_t stream);
 
 enum HeadDtype { kHeadF32 = 0, kHeadF16 = 1, kHeadBF16 = 2 };  // element type of the (M,H,W) maps (input and its gradient)
 

@@ -4,11 +4,7 @@
 //                                  workgroups of a sample meet through the workspace (ONE hand-off)  lc_cov_loss_tiled_kernel
 //   N  > 256 otherwise             one 256-thread workgroup per sample walking its tiles             lc_cov_loss_kernel<false, .>
 // All three add the per-sample reductions in the same (tile) order: a sample's results do not depend on the form chosen.
-#include "lc_loss_body.h"
-
-#ifndef LC_GRID_TICKETS
-#define LC_GRID_TICKETS 1  // A/B switch (scripts/ubench/tiled_loss.py): 0 = (sample, tile) from blockIdx (relies on in-order dispatch)
-#endif
+#include "lc_loss_tiled.h"
 
 namespace lc {
 namespace {
@@ -20,47 +16,12 @@ __global__ __launch_bounds__(256) void lc_cov_loss_kernel(const LossParams p) {
     loss::sample<REG, COV2D, false, SH>(p, blockIdx.x, sh);
 }
 
-// Tiled form.  Workgroups take (sample, slice) from a ticket counter as they start (see grid_arrive_wait for why that makes the
-// hand-off deadlock-free); the last workgroup of a sample to finish zeroes the sample's counters, the last sample the header, so
-// the workspace is left as it was found (all zero) for the next launch on the same stream.
+// Tiled form (lc_loss_tiled.h)
 template <bool COV2D>
 __global__ __launch_bounds__(256) void lc_cov_loss_tiled_kernel(const LossParams p, int T, int S, int TS) {
     __shared__ loss::LossSharedLoop sh;
     __shared__ unsigned ticket_sh;
-    unsigned* head = static_cast<unsigned*>(p.workspace);
-#if LC_GRID_TICKETS
-    if (threadIdx.x == 0) ticket_sh = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned ticket = ticket_sh;
-#else
-    const unsigned ticket = blockIdx.x;
-#endif
-    const int b = (int)(ticket / (unsigned)S);
-    loss::GridCtx g;
-    g.head = head;
-    g.ctr = head + 4 + 2 * (size_t)b;
-    g.rows = reinterpret_cast<double*>(static_cast<char*>(p.workspace) + loss::grid_rows_offset_bytes(p.B)) + (size_t)b * T * loss::kGridRow;
-    g.T = T;
-    g.S = S;
-    g.TS = TS;
-    g.slice = (int)(ticket % (unsigned)S);
-    g.timed_out = 0;
-    loss::sample<false, COV2D, true, loss::LossSharedLoop>(p, b, sh, &g);
-    // retire: relaxed device-scope atomics only (no cache maintenance) -- a workgroup counts itself finished after the hand-off,
-    // the counters it may then zero are touched by nobody else any more
-    if (threadIdx.x == 0) {
-        if (g.timed_out && g.slice == 0) p.loss[b] = __builtin_nanf("");  // never silently wrong
-        const unsigned d = __hip_atomic_fetch_add(g.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == (unsigned)S - 1u) {  // every workgroup of the sample is past the hand-off
-            __hip_atomic_store(g.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned s = __hip_atomic_fetch_add(head + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (s == (unsigned)p.B - 1u) {  // every workgroup of the grid has taken its ticket
-                __hip_atomic_store(head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(head + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+    loss::tiled_workgroup<COV2D>(p, T, S, TS, sh, ticket_sh, blockIdx.x);
 }
 
 }  // namespace
@@ -75,12 +36,22 @@ __global__ __launch_bounds__(256) void lc_cov_loss_tiled_kernel(const LossParams
 #endif
 
 // tiles per workgroup of the tiled form: the smallest of 4, 8, 16 that keeps the grid within LC_TILED_MAX_GROUPS; 0: loop form
-static int tiled_tiles_per_group(int B, int T) {
+static int tiled_tiles_per_group(int B, int T, int max_groups = LC_TILED_MAX_GROUPS) {
     for (int ts = 4; ts <= 16; ts *= 2) {
         const long long groups = (long long)B * ((T + ts - 1) / ts);
-        if ((T + ts - 1) / ts >= 3 && groups <= LC_TILED_MAX_GROUPS) return ts;
+        if ((T + ts - 1) / ts >= 3 && groups <= max_groups) return ts;
     }
     return 0;
+}
+
+bool cov_loss_tiled_shape(int B, int N, int* T, int* S, int* TS, int reserved_groups) {
+    if (B <= 0 || N <= 256) return false;
+    *T = (N + loss::kTile - 1) / loss::kTile;
+    *TS = tiled_tiles_per_group(B, *T, LC_TILED_MAX_GROUPS - reserved_groups);
+    if (!*TS) *TS = tiled_tiles_per_group(B, *T);  // no slicing leaves that many compute units free: the stand-alone launch's
+    if (!*TS) return false;
+    *S = (*T + *TS - 1) / *TS;
+    return true;
 }
 
 size_t cov_loss_workspace_bytes(int B, int N) {

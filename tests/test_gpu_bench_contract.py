@@ -51,7 +51,12 @@ def test_single_gpu_line_has_the_contract_keys():
         assert f"N={n}" in blk["workload"] and blk["value"] > 0 and blk["unit"] == "poses/s"
         for k in ("lc_cov_loss_kernel", "lc_pnp_lm_wide_kernel"):
             assert blk[k]["kernel_us"] > 0 and 0 < blk[k]["hbm_frac"] < 1 and 0 < blk[k]["fp64_vector_frac"] < 1
-        assert blk["ms_per_step"] * 1e3 >= 0.5 * (blk["lc_cov_loss_kernel"]["kernel_us"] + blk["lc_pnp_lm_wide_kernel"]["kernel_us"])
+        two = blk["two_launches"]
+        assert two["ms_per_step"] * 1e3 >= 0.5 * (blk["lc_cov_loss_kernel"]["kernel_us"] + blk["lc_pnp_lm_wide_kernel"]["kernel_us"])
+        # the step itself is ONE launch: not slower than the two, not faster than the longer of its halves
+        assert blk["step"].startswith("one launch") and blk["value"] > two["value"]
+        assert blk["ms_per_step"] * 1e3 >= 0.8 * max(blk["lc_cov_loss_kernel"]["kernel_us"], blk["lc_pnp_lm_wide_kernel"]["kernel_us"])
+        assert abs(blk["value"] - 32 / (blk["ms_per_step"] * 1e-3)) <= 1e-6 * blk["value"]
         for k in ("lc_cov_loss_kernel", "lc_pnp_lm_wide_kernel"):  # the committed counter pass of this very shape rides along
             assert blk[k]["traffic"] > 0 and blk[k]["counters_from"]["file"].startswith("profiles/") and 0 < blk[k]["valu_active_share_of_wave_cycles"] < 1
     # the test-time chain (8f rows f1 + f2 + a24), replayed as one graph

@@ -24,11 +24,39 @@ def test_pose_unit_equals_separate_kernels(B, N):
         assert torch.equal(a, c)
 
 
-def test_pose_unit_rejects_large_n():
+def test_pose_unit_rejects_shapes_without_a_fused_form():
     from lc_amd.fused import PoseUnit
 
-    with pytest.raises(ValueError):
-        PoseUnit(2, 65, torch.device("cuda:0"))
+    for B, N in ((2, 65), (2, 256), (300, 1024), (2, 4096)):  # between the forms; more loss workgroups than the tiled form takes; too wide
+        with pytest.raises(ValueError):
+            PoseUnit(B, N, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("B,N", [(32, 1024), (32, 1849), (5, 700), (64, 1024), (3, 2048)])
+def test_dense_pose_unit_equals_separate_kernels(B, N):
+    """lc_pose_unit2_f32 for the dense shapes (tiled loss workgroups + four-wave solve workgroups in one grid) against the two
+    stand-alone launches: loss, gradients, poses, radii, flags, iteration counts bit for bit -- twice in a row (the workspace is left
+    as found)."""
+    from lc_amd import synth
+    from lc_amd.cov_mixed import loss_cov_mixed_fused
+    from lc_amd.fused import PoseUnit
+    from lc_amd.pnp import pnp_ceres
+
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B + N).items()}
+    go = torch.rand(B, device=dev) + 0.5
+    loss, du, ds, dx, _ = loss_cov_mixed_fused(b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], None, b["bbox_3d"], grad_out=go)
+    st, tr, ret, it = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"], return_iters=True)
+    unit = PoseUnit(B, N, dev)
+    for _ in range(2):
+        for t in (unit.loss, unit.d_pts2d, unit.d_inv_std, unit.d_pts3d, unit.states):
+            t.fill_(float("nan"))
+        unit(b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], b["bbox_3d"], b["start"], grad_out=go)
+        torch.cuda.synchronize()
+        for a, c in ((unit.loss, loss), (unit.d_pts2d, du), (unit.d_inv_std, ds), (unit.d_pts3d, dx), (unit.states, st),
+                     (unit.trust_radius, tr), (unit.invalid, ret), (unit.iters, it)):
+            assert torch.equal(a, c)
+        assert int(unit.ws[:4 * (4 + 2 * B)].count_nonzero()) == 0  # the hand-off's counters are back at zero (the tile rows behind them are scratch)
 
 
 def test_pose_unit_options_equal_separate_kernels():
