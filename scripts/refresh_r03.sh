@@ -1,6 +1,6 @@
 set -u
 cd $GRAFT_REPO_ROOT
-bash scripts/profile_round.sh r03 a9aa86b > gpurun_out/profile_round.log 2>&1 < /dev/null
+bash scripts/profile_round.sh r03 0b84899 > gpurun_out/profile_round.log 2>&1 < /dev/null
 O=gpurun_out/prof_r03
 timeout 600 python3 bench.py 2>/dev/null < /dev/null | tail -1 > $O/bench_default.json
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null < /dev/null | tail -1 > $O/bench_k20.json
