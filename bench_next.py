@@ -113,6 +113,41 @@ def main():
     us = ev(lambda: floatbits._launch_decode_gt_bwd(lg, gb, gm, gn, b3, 0, 0, 1, True), dev, a.reps)
     line("lc_bits_decode_gt_bwd_kernel", us, B * H * W * (2 * C * 4 + C + 1 + 12), B, "samples", B=B, C=C, H=H, W=W)
 
+    # the same decodes with the callers' coordinate map applied in the kernel (noc_scale, model transform; the inference form writes planes)
+    scl = (torch.rand(B, 3, generator=g) * 100 + 20).to(dev)
+    Tm = torch.eye(4).repeat(B, 1, 1).to(dev)
+    us = ev(lambda: floatbits.nn_logits2xyz_planes(lg, bits, scl, Tm), dev, a.reps)
+    line("lc_bits_decode_kernel (planes, scale + model transform)", us, B * H * W * (C * 4 + 12), B, "samples", B=B, C=C, H=H, W=W,
+         note="replaces decode + broadcast multiply + subtract + batched GEMM + permute-copy")
+
+    # ---- a19, dense heads: the auxiliary losses of Loss_fn (one launch each way) and the code loss (one pass over the logits) ----
+    from lc_amd import dense_aux
+    xyz_a = torch.randn(B, 3, H, W, generator=g).to(dev)
+    tgt_a = torch.randn(B, 3, H, W, generator=g).to(dev)
+    mn_a = (torch.rand(B, H, W, generator=g) > 0.4).to(dev)
+    sl_a = torch.randn(B, 1, H, W, generator=g).to(dev)
+    mv_a = (torch.rand(B, H, W, generator=g) > 0.5).float().to(dev)
+    wl_a = torch.randn(B, 2, H, W, generator=g).to(dev)
+    us = ev(lambda: dense_aux.dense_aux_losses(xyz_a, mn_a, tgt_a, sl_a, mv_a, wl_a, "bce"), dev, a.reps)
+    line("lc_dense_aux_fwd_kernel", us, B * H * W * (3 * 4 + 3 * 4 + 1 + 4 + 4 + 2 * 4), B, "samples", B=B, H=H, W=W,
+         note="loss_noc + loss_seg + loss_weight_seg (losses.py:281-316) from one pass; ~12 torch launches in the reference")
+    xg, sg, wg = xyz_a.clone().requires_grad_(True), sl_a.clone().requires_grad_(True), wl_a.clone().requires_grad_(True)
+    l3 = dense_aux.dense_aux_losses(xg, mn_a, tgt_a, sg, mv_a, wg, "bce")
+    tot = l3[0] + l3[1] + l3[2]
+    us = ev(lambda: torch.autograd.grad(tot, (xg, sg, wg), retain_graph=True), dev, a.reps)
+    line("lc_dense_aux_bwd_kernel", us, B * H * W * (2 * (3 * 4 + 4 + 2 * 4) + 3 * 4 + 1 + 4), B, "samples", B=B, H=H, W=W,
+         note="timed through autograd (three scalar adds' backward included)")
+    hist = torch.full((C,), 0.5, device=dev)
+    gbb = gb.view(torch.bool)
+    us = ev(lambda: dense_aux.xyz_bin_loss(lg, gbb, sl_a, hist, 0.05), dev, a.reps)
+    line("lc_xyz_bin_loss_fwd_kernel", us, B * H * W * (C * 4 + C + 4), B, "samples", B=B, C=C, H=H, W=W,
+         note="Loss_xyz_bin (losses.py:196-216) in one pass over the code logits; ~12 passes in the reference; VALU-bound (one exp + one log per logit) "
+              "with a serial tail (per-channel partials -> histogram EMA -> softmax weights)")
+    lgg = lg.clone().requires_grad_(True)
+    lb = dense_aux.xyz_bin_loss(lgg, gbb, sl_a, hist, 0.05)
+    us = ev(lambda: torch.autograd.grad(lb, lgg, retain_graph=True), dev, a.reps)
+    line("lc_xyz_bin_loss_bwd_kernel", us, B * H * W * (2 * C * 4 + C + 4), B, "samples", B=B, C=C, H=H, W=W)
+
     # ---- f4: pose errors over a test set: 1024 poses x 2048 model points (ADI is an all-pairs nearest neighbour) ----
     Bp, M = 1024, 2048
     bt = synth.make_batch(Bp, 8, seed=1)
