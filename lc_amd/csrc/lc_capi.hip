@@ -643,6 +643,7 @@ int lc_dense_aux_fwd_f32(const float* xyz, const unsigned char* msk_noc_u8, cons
                          const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type, float* losses,
                          double* partials, unsigned* ticket, void* stream) {
     if (B < 0 || HW <= 0 || seg_type < 0 || seg_type > 1) return fail(1, "bad size or loss type");
+    if ((long long)B * HW * 3 >= (1ll << 31)) return fail(1, "maps of 2^31 elements or more");
     if (B == 0) return 0;
     if (!seg_logits || !msk_vis || !losses || !partials || !ticket) return fail(1, "null pointer");
     if (xyz && (!noc_tgt || (msk_noc_u8 != nullptr) == (msk_noc_f32 != nullptr))) return fail(1, "xyz needs its target and exactly one mask form");
@@ -657,6 +658,7 @@ int lc_dense_aux_bwd_f32(const float* xyz, const unsigned char* msk_noc_u8, cons
                          const float* g_noc, const float* g_seg, const float* g_wseg, float* d_xyz, float* d_seg, float* d_wlogits,
                          void* stream) {
     if (B < 0 || HW <= 0 || seg_type < 0 || seg_type > 1) return fail(1, "bad size or loss type");
+    if ((long long)B * HW * 3 >= (1ll << 31)) return fail(1, "maps of 2^31 elements or more");
     if (B == 0) return 0;
     if (!msk_vis || (d_seg && !seg_logits) || (d_wlogits && !wlogits)) return fail(1, "null pointer");
     if (d_xyz && (!xyz || !noc_tgt || (msk_noc_u8 != nullptr) == (msk_noc_f32 != nullptr))) return fail(1, "d_xyz needs xyz, its target and exactly one mask form");
@@ -670,6 +672,7 @@ int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, c
                             void* stream) {
     if (B < 0 || C <= 0 || HW <= 0) return fail(1, "bad size");
     if (C > lc::kBinMaxChannels) return fail(1, "more than 128 code bits");
+    if ((long long)B * C * HW >= (1ll << 31)) return fail(1, "logits of 2^31 elements or more");
     if (B == 0) return 0;
     if (!logits || !gt_bits || !msk_vis_logits || !histogram || !loss || !bin_weights || !partials || !ticket) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, partials);
@@ -681,6 +684,7 @@ int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, c
 int lc_xyz_bin_loss_bwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, const float* bin_weights,
                             const float* g_loss, int B, int C, int HW, float* d_logits, void* stream) {
     if (B < 0 || C <= 0 || HW <= 0) return fail(1, "bad size");
+    if ((long long)B * C * HW >= (1ll << 31)) return fail(1, "logits of 2^31 elements or more");
     if (B == 0) return 0;
     if (!logits || !gt_bits || !msk_vis_logits || !bin_weights || !g_loss || !d_logits) return fail(1, "null pointer");
     const int vec = HW % 4 == 0 && !misaligned(16, logits, msk_vis_logits, d_logits) && !misaligned(4, gt_bits);

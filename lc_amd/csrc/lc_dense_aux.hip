@@ -81,10 +81,12 @@ template <int V>
 __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseAuxParams p) {
     __shared__ double red[4][3];
     __shared__ bool last;
-    const long long n = (long long)p.B * p.HW, nv = n / V;
+    // 32-bit index arithmetic throughout (the entry points refuse maps of 2^31 elements or more): a 64-bit division per request costs
+    // more instructions than the request's arithmetic
+    const unsigned HW = (unsigned)p.HW, n = (unsigned)p.B * HW, nv = n / V;
     double acc[3] = {0, 0, 0};
-    for (long long j = (long long)blockIdx.x * kThreads + threadIdx.x; j < nv; j += (long long)gridDim.x * kThreads) {
-        const long long i = j * V, b = i / p.HW, px = i - b * p.HW;
+    for (unsigned j = blockIdx.x * kThreads + threadIdx.x; j < nv; j += gridDim.x * kThreads) {
+        const unsigned i = j * V, b = i / HW, px = i - b * HW;
         const Px<V> t = ld<V>(p.msk_vis + i);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;  // the V pixels' terms in fp32, one fp64 add per request and loss
         if (p.xyz) {
@@ -131,12 +133,12 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseA
 
 template <int V>
 __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseAuxParams p) {
-    const long long n = (long long)p.B * p.HW, nv = n / V;
+    const unsigned HW = (unsigned)p.HW, n = (unsigned)p.B * HW, nv = n / V;
     const float g0 = (p.g_noc && p.d_xyz) ? *p.g_noc / (3.f * (float)n) : 0.f;
     const float g1 = p.g_seg ? *p.g_seg / (float)n : 0.f;
     const float g2 = (p.g_wseg && p.d_wlogits) ? *p.g_wseg / (2.f * (float)n) : 0.f;
-    for (long long j = (long long)blockIdx.x * kThreads + threadIdx.x; j < nv; j += (long long)gridDim.x * kThreads) {
-        const long long i = j * V, b = i / p.HW, px = i - b * p.HW;
+    for (unsigned j = blockIdx.x * kThreads + threadIdx.x; j < nv; j += gridDim.x * kThreads) {
+        const unsigned i = j * V, b = i / HW, px = i - b * HW;
         const Px<V> t = ld<V>(p.msk_vis + i);
         if (p.d_xyz) {
             const Px<V> m = mask_at<V>(p, (size_t)i);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
     __shared__ bool last;
     __shared__ float zs[kBinMaxChannels], ws[kBinMaxChannels];
     const int chunks = p.chunks, c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-    const long long n = (long long)p.B * p.HW;
+    const unsigned n = (unsigned)p.B * (unsigned)p.HW;  // 32-bit index arithmetic (see lc_dense_aux_fwd_kernel)
     // Hamming errors and visible pixels (channel 0 only) are counted in integers; the BCE terms of the four pixels of a request are
     // added in fp32 and that sum goes into a double (one conversion + one fp64 add per request: the kernel is VALU-bound)
     int n_err = 0, n_vis = 0;
@@ -200,19 +202,18 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
         n_vis += (c == 0 && vis) ? 1 : 0;
     };
     if (p.vec) {  // HW % 4 == 0, 16-byte aligned maps: four pixels per thread and request
-        const long long n4 = n >> 2;
-        const int hw4 = p.HW >> 2;
+        const unsigned n4 = n >> 2, hw4 = (unsigned)p.HW >> 2;
         constexpr int kAhead = 4;  // requests in flight per thread: the loop is a latency chain otherwise (one round trip per iteration)
-        const long long stride = (long long)chunks * kThreads;
-        for (long long i0 = (long long)chunk * kThreads + threadIdx.x; i0 < n4; i0 += kAhead * stride) {
+        const unsigned stride = (unsigned)chunks * kThreads;
+        for (unsigned i0 = (unsigned)chunk * kThreads + threadIdx.x; i0 < n4; i0 += kAhead * stride) {
             float4 x[kAhead], v[kAhead];
             uchar4 t[kAhead];
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                const long long i = i0 + u * stride;
+                const unsigned i = i0 + u * stride;
                 if (i < n4) {
-                    const long long b = i / hw4, q = i - b * hw4;
-                    const size_t e = (((size_t)b * p.C + c) * p.HW >> 2) + q;
+                    const unsigned b = i / hw4, q = i - b * hw4;
+                    const unsigned e = (b * (unsigned)p.C + (unsigned)c) * hw4 + q;
                     x[u] = reinterpret_cast<const float4*>(p.logits)[e];
                     t[u] = reinterpret_cast<const uchar4*>(p.gt_bits)[e];
                     v[u] = reinterpret_cast<const float4*>(p.msk_vis_logits)[i];
@@ -228,9 +229,9 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
             }
         }
     } else {
-        for (long long i = (long long)chunk * kThreads + threadIdx.x; i < n; i += (long long)chunks * kThreads) {
-            const long long b = i / p.HW, px = i - b * p.HW;
-            const size_t e = ((size_t)b * p.C + c) * p.HW + px;
+        for (unsigned i = (unsigned)chunk * kThreads + threadIdx.x; i < n; i += (unsigned)chunks * kThreads) {
+            const unsigned b = i / (unsigned)p.HW, px = i - b * (unsigned)p.HW;
+            const unsigned e = (b * (unsigned)p.C + (unsigned)c) * (unsigned)p.HW + px;
             one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[i] > 0.f);
             bce_sum += (double)bce4;
             bce4 = 0.f;
@@ -288,15 +289,15 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
 }
 
 __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const BinLossParams p) {
-    const long long n = (long long)p.B * p.C * p.HW;
-    const float g = *p.g_loss / (float)((long long)p.B * p.HW);
+    const unsigned n = (unsigned)p.B * (unsigned)p.C * (unsigned)p.HW, C = (unsigned)p.C;
+    const float g = *p.g_loss / (float)((unsigned)p.B * (unsigned)p.HW);
     // d/dx BCE(x * m, t) = (sigmoid(x m) - t) m
     auto one = [&](float x, bool t, bool vis, float w) { return vis ? g * w * (sigmoidf_(x) - (t ? 1.f : 0.f)) : 0.f; };
     if (p.vec) {
-        const int hw4 = p.HW >> 2;
-        for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < (n >> 2); e += (long long)gridDim.x * kThreads) {
-            const long long bc = e / hw4, q = e - bc * hw4, b = bc / p.C;
-            const float w = p.bin_weights[(int)(bc - b * p.C)];
+        const unsigned hw4 = (unsigned)p.HW >> 2;
+        for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < (n >> 2); e += gridDim.x * kThreads) {
+            const unsigned bc = e / hw4, q = e - bc * hw4, b = bc / C;
+            const float w = p.bin_weights[bc - b * C];
             const float4 x = reinterpret_cast<const float4*>(p.logits)[e];
             const uchar4 t = reinterpret_cast<const uchar4*>(p.gt_bits)[e];
             const float4 v = reinterpret_cast<const float4*>(p.msk_vis_logits)[b * hw4 + q];
@@ -305,9 +306,9 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const Bin
         }
         return;
     }
-    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long long)gridDim.x * kThreads) {
-        const long long bc = e / p.HW, px = e - bc * p.HW, b = bc / p.C;
-        p.d_logits[e] = one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[b * p.HW + px] > 0.f, p.bin_weights[(int)(bc - b * p.C)]);
+    for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < n; e += gridDim.x * kThreads) {
+        const unsigned bc = e / (unsigned)p.HW, px = e - bc * (unsigned)p.HW, b = bc / C;
+        p.d_logits[e] = one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[b * (unsigned)p.HW + px] > 0.f, p.bin_weights[bc - b * C]);
     }
 }
 
