@@ -8,7 +8,9 @@
 //   * lc_pnp_ransac_kernel: one workgroup per pose, its rounds on separate wavefronts, points staged in LDS -- for batches that fill
 //     the chip with one workgroup per pose (or few points);
 //   * lc_ransac_{hypotheses,score,select}_kernel: three launches over a workspace that spread the points of one pose over the chip
-//     (further down).
+//     (further down; lc_ransac_score_select_kernel: scoring and selection as one launch, an option that measured slower).
+// Either form can also write the 'weighted-filtered' re-selection of test.py:129-133 (the winner's inliers compacted to the front of
+// their rows: lc_pnp_ransac_init4_f32), which the workgroup that writes the inlier mask does on the way.
 // OpenCV's RNG/EPnP cannot be reproduced bit for bit (and OpenCV is absent here: parity at this boundary is unpinned and outside the
 // metric); the contract kept is the role: a pose inside the LM basin of convergence plus an inlier set for
 // `weighted_filtered` (test.py:129-134); the kernels' own contract is pinned by oracle/p3p_ransac_oracle.py.
@@ -17,7 +19,7 @@
 // constant-free quadrics is made singular by a root g of a cubic (coefficients from 3x3 determinants), the singular quadric
 // splits into two planes through its eigen-decomposition, each plane cuts D1 in <= 2 rays (a quadratic), the scale comes
 // from one distance constraint; the candidate that reprojects a fourth correspondence best is Gauss-Newton polished and R,t follow
-// from the three point pairs.  (Divisions and square roots are the Newton-refined v_rcp_f64 / v_rsq_f64 forms of lc_common.h,
+// from the three point pairs.  ONE root is decomposed and its up-to-four candidates are formed without branches (P3P::solve).  (Divisions and square roots are the Newton-refined v_rcp_f64 / v_rsq_f64 forms of lc_common.h,
 // 2-4e-15 relative: the result is polished and compared at 1e-4.)
 #include <cfloat>
 
@@ -600,7 +602,8 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
 //   2. scoring: one wavefront per (pose, chunk of 64 points, round of 64 hypotheses): the chunk is staged in LDS, every lane scores
 //      its hypothesis on it and writes (count, error) of the chunk -- no atomics: the chunk partials are summed in chunk order by
 //      step 3, so results do not depend on scheduling;
-//   3. selection: grid B: arg-max of (count, -error, -hypothesis id), inlier mask of the winner over all points, outputs.
+//   3. selection: grid B: arg-max of (count, -error, -hypothesis id), inlier mask of the winner over all points, outputs (and the
+//      inlier re-selection).  Bound by its load instructions: the pose's count first, then one round trip sized by it (select_winner).
 // Same hypothesis stream, same per-point arithmetic, same ordering as the single launch (the error sums are associated by chunk).
 constexpr int kChunkPts = 64;
 

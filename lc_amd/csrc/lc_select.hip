@@ -13,6 +13,10 @@
 //   5. fewer than min_count survivors (and more than min_count candidates): pad with pseudo-random source indices, the
 //      role np.random.choice plays in test.py:108-113 (seeded hash instead of the host RNG)
 // The outputs feed lc_pnp_ransac_init_f32 / lc_pnp_lm_f32 directly through their `counts` argument.
+// Two kernels over the same body (select_row): lc_dense_select_kernel reads the rows the dense front end wrote (ArraySource);
+// lc_dense_frontend_select_kernel forms them itself from the network's maps (MapSource: front end + selection in one launch, the rows
+// in between never exist).  The body is bound by barriers of 16 wavefronts and by LDS atomics on clustered keys: one barrier per radix
+// pass (three histograms in rotation, every wavefront scans), wave-aggregated histogram adds, the thread's own entry held in registers.
 #include <cfloat>
 
 #include "lc_common.h"
