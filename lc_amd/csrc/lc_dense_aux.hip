@@ -32,13 +32,19 @@ __device__ __forceinline__ float seg_grad(float x, float t, int type) {
     return (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (s * (1.f - s));  // sign(s - t) * sigmoid'(x)
 }
 
+template <int NWAVES = kThreads / 64>
 __device__ __forceinline__ void block_sum3(double (&v)[3], double (*red)[3]) {
     wave_allreduce<3>(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0)
         for (int k = 0; k < 3; ++k) red[threadIdx.x >> 6][k] = v[k];
     __syncthreads();
-    for (int k = 0; k < 3; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    for (int k = 0; k < 3; ++k) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; w += 4) s += (red[w][k] + red[w + 1][k]) + (red[w + 2][k] + red[w + 3][k]);  // fixed order
+        v[k] = s;
+    }
 }
 
 // V consecutive pixels of one map row per thread and request (V = 4: 16-byte loads / stores; HW % 4 == 0 and aligned maps)
@@ -179,14 +185,15 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
 // log-sigmoid, BCE, mean, ...); here one pass: grid (C, chunks), a workgroup reduces its share of ONE code channel -- Hamming errors
 // inside the hard visibility mask, the BCE sum, and (channel 0) the mask's population -- partials in a fixed order, and the last
 // workgroup to arrive finishes: histogram EMA in place, soft histogram, softmax bit weights, the loss.  Backward: one element-wise pass.
-constexpr int kBinChunks = 32;  // at most that many workgroups per code channel (their partials are added in chunk order)
+constexpr int kBinChunks = 32;   // at most that many workgroups per code channel (their partials are added in chunk order)
+constexpr int kBinThreads = 1024;  // of 1024 threads each: every workgroup ends with ONE counted arrival on the one counter
 
 // (1 - t) z - log_sigmoid(z), log_sigmoid(z) = min(z, 0) - log1p(exp(-|z|)); the hardware exp / log (v_exp_f32, v_log_f32) are good
 // to ~1e-7 absolute on log1p(e), e in (0, 1] -- terms of a MEAN of order 0.1-1 that is compared at 1e-6
 __device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - __logf(1.f + __expf(-fabsf(z)))); }
 
-__global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const BinLossParams p) {
-    __shared__ double red[4][3];
+__global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const BinLossParams p) {
+    __shared__ double red[kBinThreads / 64][3];
     __shared__ bool last;
     __shared__ float zs[kBinMaxChannels], ws[kBinMaxChannels];
     const int chunks = p.chunks, c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
@@ -204,8 +211,8 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
     if (p.vec) {  // HW % 4 == 0, 16-byte aligned maps: four pixels per thread and request
         const unsigned n4 = n >> 2, hw4 = (unsigned)p.HW >> 2;
         constexpr int kAhead = 4;  // requests in flight per thread: the loop is a latency chain otherwise (one round trip per iteration)
-        const unsigned stride = (unsigned)chunks * kThreads;
-        for (unsigned i0 = (unsigned)chunk * kThreads + threadIdx.x; i0 < n4; i0 += kAhead * stride) {
+        const unsigned stride = (unsigned)chunks * kBinThreads;
+        for (unsigned i0 = (unsigned)chunk * kBinThreads + threadIdx.x; i0 < n4; i0 += kAhead * stride) {
             float4 x[kAhead], v[kAhead];
             uchar4 t[kAhead];
 #pragma unroll
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
             }
         }
     } else {
-        for (unsigned i = (unsigned)chunk * kThreads + threadIdx.x; i < n; i += (unsigned)chunks * kThreads) {
+        for (unsigned i = (unsigned)chunk * kBinThreads + threadIdx.x; i < n; i += (unsigned)chunks * kBinThreads) {
             const unsigned b = i / (unsigned)p.HW, px = i - b * (unsigned)p.HW;
             const unsigned e = (b * (unsigned)p.C + (unsigned)c) * (unsigned)p.HW + px;
             one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[i] > 0.f);
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
         }
     }
     double acc[3] = {(double)n_err, bce_sum, (double)n_vis};
-    block_sum3(acc, red);
+    block_sum3<kBinThreads / 64>(acc, red);
     if (threadIdx.x == 0) {
         for (int k = 0; k < 3; ++k) xcd_store(p.partials + 3 * blockIdx.x + k, acc[k]);
         xcd_stores_done();
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
     __shared__ double vis_part[kBinChunks];
     if (tid < chunks) vis_part[tid] = xcd_load(p.partials + 3 * tid + 2);  // channel 0's chunks
     for (int g0 = 0; g0 < p.C; g0 += 32) {
-        for (int v = tid; v < 32 * 2 * chunks; v += kThreads) {
+        for (int v = tid; v < 32 * 2 * chunks; v += kBinThreads) {
             const int ch = v / (2 * chunks), r = v % (2 * chunks), which = r / chunks, k = r % chunks;
             if (g0 + ch < p.C) stage[ch][which][k] = xcd_load(p.partials + 3 * ((g0 + ch) * chunks + k) + which);
         }
@@ -274,15 +281,24 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_fwd_kernel(const Bin
         __syncthreads();
     }
     __syncthreads();
-    if (tid == 0) {  // C <= 128 values: softmax and the weighted sum by one thread, in index order
-        float m = -INFINITY, s = 0.f, loss = 0.f;
-        for (int ch = 0; ch < p.C; ++ch) m = fmaxf(m, zs[ch]);
-        for (int ch = 0; ch < p.C; ++ch) s += expf(zs[ch] - m);
-        for (int ch = 0; ch < p.C; ++ch) {
-            const float w = expf(zs[ch] - m) / s;
-            loss += ws[ch] * w;
-            p.bin_weights[ch] = w;
-        }
+    // softmax over the C <= 128 bits and the weighted sum: one thread per bit for the exponentials, sums in index order (every
+    // thread forms them for itself from LDS): the one-thread version cost ~3 us of serial expf at the very end of the launch
+    __shared__ float es[kBinMaxChannels];
+    float m = -INFINITY;
+    for (int ch = 0; ch < p.C; ++ch) m = fmaxf(m, zs[ch]);
+    if (tid < p.C) es[tid] = expf(zs[tid] - m);
+    __syncthreads();
+    float sum = 0.f;
+    for (int ch = 0; ch < p.C; ++ch) sum += es[ch];
+    if (tid < p.C) {
+        const float w = es[tid] / sum;
+        p.bin_weights[tid] = w;
+        ws[tid] *= w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float loss = 0.f;
+        for (int ch = 0; ch < p.C; ++ch) loss += ws[ch];
         *p.loss = loss;
         xcd_store(p.ticket, 0u);
     }
@@ -347,12 +363,12 @@ int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream) {
 int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.C <= 0) return 0;
     if (p.C > kBinMaxChannels) return 3;
-    // every workgroup ends with one counted arrival (~11 ns each on the one counter): no more of them than keep a thread at
-    // about eight requests of four pixels
+    // every workgroup ends with one counted arrival (~11 ns each on the one counter): 1024-thread workgroups, and no more of them
+    // than keep a thread at about eight requests of four pixels
     BinLossParams q = p;
     const long long req = ((long long)p.B * p.HW + 3) / 4;
-    q.chunks = (int)std::min<long long>(kBinChunks, std::max<long long>(4, (req + 8 * kThreads - 1) / (8 * kThreads)));
-    hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel, dim3(q.C * q.chunks), dim3(kThreads), 0, stream, q);
+    q.chunks = (int)std::min<long long>(16, std::max<long long>(1, (req + 8 * kBinThreads - 1) / (8 * kBinThreads)));
+    hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel, dim3(q.C * q.chunks), dim3(kBinThreads), 0, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
