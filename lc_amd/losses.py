@@ -296,7 +296,7 @@ class Loss_fn(nn.Module):
             den_pts2d, den_inv_std2d, _ = dense_front_end(None, xyz_weight_logits, xyz_weights_scale, None, sample=sample, top_left=top_left)
             den_pts3d = _decode_bin_points(out_dict["xyz_noc_bin"], gt_dict["xyz_noc_bin_raw"], gt_dict["msk_noc"], noc_scale, gt_dict,
                                            sample, top_left)
-        den_valid_msk = torch.ones_like(den_pts3d[..., 0])
+        den_valid_msk = None  # losses.py:370 passes a mask of ones: every correspondence valid, which is what no mask means to the kernel
         if self.pts_grad_clipper is not None and den_pts3d.requires_grad:
             den_pts3d.register_hook(lambda grad: self.pts_grad_clipper.clip(grad))
 
