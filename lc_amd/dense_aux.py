@@ -29,7 +29,7 @@ def _workspace(dev):
 
 def fused_path_ok(*tensors) -> bool:
     """fp32 maps on the GPU take the fused launch; half-precision heads keep the torch formulas (same device, no CPU path)."""
-    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() > 0) for t in tensors)
 
 
 class _DenseAux(torch.autograd.Function):
