@@ -65,7 +65,10 @@ int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stre
     const auto wide4 = [](const PnpParams& p) { return p.Nmax > 256 && p.Nmax <= 1024; };
     const float* b_start = b.start ? b.start : b.states;
     const bool rows_match = b_start != a.states || b.pose_mod == a.B || (b.pose_mod == 0 && b.B == a.B);
-    if (a.B > 0 && b.B > 0 && wide4(a) && wide4(b) && b.B % a.B == 0 && rows_match) {
+    // a first job in the in-place form (its states are both start and result) solved by SEVERAL second-stage workgroups would let one of
+    // them read a start the other has already overwritten: one launch only when every first-stage pose has one solver, or a separate start
+    const bool first_is_safe = a.start != nullptr || b.B == a.B;
+    if (a.B > 0 && b.B > 0 && wide4(a) && wide4(b) && b.B % a.B == 0 && rows_match && first_is_safe) {
         hipLaunchKernelGGL(lc_pnp_lm_chain_kernel, dim3(b.B), dim3(256), 0, stream, a, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
@@ -88,10 +91,8 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<true, true>), dim3(p.B), dim3(256), 0, stream, p);
         } else if (p.Nmax <= 1024) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 4>), dim3(p.B), dim3(256), 0, stream, p);
-        } else if (p.Nmax <= 2048) {
+        } else {  // rows wider than 2048: the first 2048 correspondences of a pose in registers, the rest (if its count gets there) from memory
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 8>), dim3(p.B), dim3(256), 0, stream, p);
-        } else {
-            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true>), dim3(p.B), dim3(256), 0, stream, p);
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
@@ -106,10 +107,8 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);
     } else if (p.Nmax <= 1024) {
         hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 4>), dim3(p.B), dim3(256), 0, stream, p);
-    } else if (p.Nmax <= 2048) {
-        hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 8>), dim3(p.B), dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<false>, dim3(p.B), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 8>), dim3(p.B), dim3(256), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

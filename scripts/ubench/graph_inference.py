@@ -12,10 +12,15 @@ from lc_amd.inference import solve_pnp  # noqa: E402
 from tests.golden.gen_golden_lossfn import dense_inputs  # noqa: E402
 
 dev = torch.device("cuda:0")
-gt, out = dense_inputs(B=64, H=64, W=64, seed=3)
+B, S = int(os.environ.get("B", 64)), int(os.environ.get("SIZE", 64))
+if os.environ.get("HEAD", "xyz") == "bin":  # ZebraPose structure: binary surface codes + a model transform (zlmo: SIZE=128)
+    from tests.golden.gen_golden_lossfn import bin_inputs
+    gt, out = bin_inputs(B=B, H=S, W=S, seed=3)
+else:
+    gt, out = dense_inputs(B=B, H=S, W=S, seed=3)
 out["xyz_weight_logits"] = out["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
 out["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
-gt = {k: v.to(dev) for k, v in gt.items()}
+gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
 # network outputs are contiguous NCHW tensors (a convolution's output); the synthetic generator hands xyz_noc over as a strided
 # view of a channels-last array, which the front end would first copy (one 6 us torch launch per call that is not the pipeline's)
 out = {k: v.to(dev).contiguous() for k, v in out.items()}
@@ -48,6 +53,6 @@ graph.replay()
 torch.cuda.synchronize()
 same = all(torch.equal(res[k], eager[k]) for k in eager)
 print(f"captured: results equal to eager: {same}")
-print(f"eager  {timeit(lambda: solve_pnp(cfg, out, gt)):7.1f} us per call (64 objects)")
+print(f"eager  {timeit(lambda: solve_pnp(cfg, out, gt)):7.1f} us per call ({B} objects, {S}x{S} maps)")
 runs = sorted(timeit(graph.replay, 200) for _ in range(9))
 print(f"replay {runs[4]:7.1f} us per call (median of 9 x 200 replays; min {runs[0]:.1f}, max {runs[-1]:.1f})")

@@ -44,8 +44,8 @@ def test_pose_kernels_do_not_spill_and_keep_their_occupancy(res):
 
 def test_dense_kernels_do_not_spill(res):
     # 256-thread workgroups, one per compute unit: AGPRs may serve as spill space (cheap), scratch memory may not
-    for parts in (("lc_cov_loss_tiled_kernelILb0E",), ("lc_cov_loss_kernelILb0ELb0E",), ("lc_pnp_lm_wide_kernel", "Lb0ELi0E"), ("lc_pnp_lm_wide_kernel", "Lb0ELi4E"),
-                  ("lc_pnp_lm_wide_kernel", "Lb0ELi8E"), ("lc_pnp_lm_wide_kernelILb1E",)):
+    for parts in (("lc_cov_loss_tiled_kernelILb0E",), ("lc_cov_loss_kernelILb0ELb0E",), ("lc_pnp_lm_wide_kernel", "Lb0ELi4E"), ("lc_pnp_lm_wide_kernel", "Lb0ELi8E"),
+                  ("lc_pnp_lm_wide_kernelILb1E",), ("lc_pnp_lm_chain_kernel",), ("lc_pose_unit_dense_kernel",)):
         for d in _find(res, *parts):
             assert d.get("private_segment_fixed_size", 0) == 0, (d["name"], "scratch")
             assert d["vgpr_count"] <= 512 and d.get("group_segment_fixed_size", 0) <= 64 * 1024, d["name"]
