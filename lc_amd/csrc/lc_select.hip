@@ -111,11 +111,13 @@ struct MapSource {
     __device__ __forceinline__ Entry load(int n) const { return finish(fetch(n)); }
 };
 
-// The selection of row b by the calling workgroup (kThreads threads).  e0: entry `tid` of the row, already in registers -- the only
-// one this thread handles when N <= 1024: its weights feed the threshold search, and its coordinates are there by the time the
+// The selection of row b by the calling workgroup (kThreads threads).  ec: entries tid + k * 1024 of the row, already in registers -- all
+// this thread handles when N <= 4096: their weights feed the threshold search, and their coordinates are there by the time the
 // compaction knows where they go.  srt: n floats of LDS (modes 1, 2).
+constexpr int kCache = 4;  // entries tid, tid + 1024, ... a thread keeps in registers (rows of up to 4096 candidates never re-read one)
+
 template <class Source>
-__device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, const Source& src, const Entry& e0, float* srt) {
+__device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, const Source& src, const Entry (&ec)[kCache], float* srt) {
     __shared__ int wave_cnt[kWaves];    // compaction: survivors per wavefront
     __shared__ int wave_seg[kWaves];    // mode 2: visible entries per wavefront
     __shared__ int wave_le[kWaves];     // upper order statistic: keys <= the lower one / smallest key above it, per wavefront
@@ -123,7 +125,6 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
     __shared__ int hist[3][256];        // radix passes rotate through three histograms: ONE barrier per pass (see below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)b * p.N;
-    auto entry = [&](int i) { return i == tid ? e0 : src.load(i); };
     auto weight_of = [&](const Entry& e) { return (p.mode == 2 && !e.g) ? 0.f : e.s.x + e.s.y; };  // mode 2: (inv_std * seg).sum(-1)
     float thr = -FLT_MAX;
     if (p.mode != 0 && n > 0) {
@@ -137,12 +138,15 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
         unsigned* keys = reinterpret_cast<unsigned*>(srt);
         int segc = 0;
         if (tid < 256) hist[0][tid] = 0;
-        for (int i = tid; i < n; i += kThreads) {
-            const Entry e = entry(i);
+        auto stage = [&](const Entry& e, int i) {
             const unsigned u = __float_as_uint(weight_of(e));
             keys[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending unsigned order == ascending float order
             if (p.mode == 2 && e.g) ++segc;
-        }
+        };
+#pragma unroll
+        for (int k = 0; k < kCache; ++k)
+            if (tid + k * kThreads < n) stage(ec[k], tid + k * kThreads);
+        for (int i = tid + kCache * kThreads; i < n; i += kThreads) stage(src.load(i), i);
         if (p.mode == 2) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) segc += __shfl_xor(segc, m, kWave);
@@ -223,12 +227,9 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
     const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
     auto put = [&](const Entry& e, int o) { rows.entry_from(base, o, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src); };
     int running = 0;  // survivors in the chunks before this one (same value in every thread)
-    for (int i0 = 0; i0 < n; i0 += kThreads) {
-        const int i = i0 + tid;
-        Entry e = e0;
+    auto chunk = [&](int i0, const Entry& e, bool mine) {  // mine: this thread has an entry in the chunk (e)
         bool keep = false;
-        if (i < n) {
-            if (i0 != 0) e = src.load(i);
+        if (mine) {
             if (p.mode == 0) keep = e.g != 0;
             else keep = weight_of(e) >= thr && (p.mode == 1 || e.g != 0);
         }
@@ -245,6 +246,15 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
         if (keep) put(e, off + before);
         running = tot;
         if (i0 + kThreads < n) __syncthreads();  // wave_cnt is rewritten by the next chunk
+    };
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) {
+        if (k * kThreads >= n) break;  // uniform
+        chunk(k * kThreads, ec[k], tid + k * kThreads < n);
+    }
+    for (int i0 = kCache * kThreads; i0 < n; i0 += kThreads) {
+        const bool mine = i0 + tid < n;
+        chunk(i0, mine ? src.load(i0 + tid) : ec[0], mine);
     }
     const int total = pad_rows(b, n, running, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
     if (tid == 0) p.counts[b] = total;
@@ -255,10 +265,12 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
     const int b = blockIdx.x, tid = threadIdx.x;
     const ArraySource src{p, (size_t)b * p.N};
     // requested whole before the row's count is known: one memory round trip at the start instead of three dependent ones
-    Entry e0{};
-    if (tid < p.N) e0 = src.load(tid);
+    Entry ec[kCache] = {};
+#pragma unroll
+    for (int k = 0; k < kCache; ++k)
+        if (tid + k * kThreads < p.N) ec[k] = src.load(tid + k * kThreads);
     const int n = min(p.in_counts ? p.in_counts[b] : p.N, p.N);
-    select_row(p, b, n, src, e0, srt);
+    select_row(p, b, n, src, ec, srt);
 }
 
 // Test time, N <= 8192 sampled pixels per object: the dense front end (joint softmax x scale, strided sub-sampling, visibility mask:
@@ -279,13 +291,16 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
     src.HW = HW; src.W = d.W; src.top = d.top; src.left = d.left; src.sample = d.sample;
     src.Wn = (d.W - d.left + d.sample - 1) / d.sample;
     src.lse = 0.f;
-    Entry e0{};
-    if (tid < p.N) e0 = src.fetch(tid);  // in flight while the log-sum-exp is formed
+    Entry ec[kCache] = {};
+#pragma unroll
+    for (int k = 0; k < kCache; ++k)
+        if (tid + k * kThreads < p.N) ec[k] = src.fetch(tid + k * kThreads);  // in flight while the log-sum-exp is formed
     src.scale = d.wscale[b];
     for (int k = 0; k < 3; ++k) src.ns[k] = d.noc_scale ? d.noc_scale[3 * b + k] : 1.f;
     src.lse = block_lse<kDenseLseThreads>(src.lg, 2 * HW, red);
-    e0 = src.finish(e0);
-    select_row(p, b, p.N, src, e0, srt);
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) ec[k] = src.finish(ec[k]);
+    select_row(p, b, p.N, src, ec, srt);
 }
 
 }  // namespace
