@@ -41,7 +41,8 @@ def source_hash() -> str:
         if os.path.exists(d):
             h.update(os.path.basename(d).encode())
             h.update(open(d, "rb").read())
-    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())  # a change of the per-file compiler flags is a change of the build
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())  # a change of the compiler flags is a change of the build
+    h.update(repr(COMMON_FLAGS).encode())
     return h.hexdigest()
 
 
@@ -105,7 +106,13 @@ PER_FILE_FLAGS = {
     "lc_dense.hip": _MAX_ILP,
     # NOT lc_loss.hip (the loss kernel alone: +4 %) and NOT lc_fused.hip (the large-grid pose unit: +1.4 %)
 }
-COMMON_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# -ffp-contract=on: a multiply and an add are fused where the SOURCE writes them in one expression, and nowhere else.  hipcc's default
+# (fast) also fuses across statements, and decides that per inlined copy of a function: the LC loss's walk body exists in a one-tile
+# and a many-tiles copy, and under `fast` the two contracted differently -- two slicings of the same sample then differed in the last
+# bit of an fp32 gradient for about 4 outputs in 10^8 (scripts/ubench/forms_ulp.py).  With `on` every form, slicing and translation
+# unit evaluates the same expressions the same way: "bit for bit" is a property of the build, not of the inputs tried.  Cost on the
+# headline launch: within the run-to-run noise (13.13 vs 13.07 us).
+COMMON_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-ffp-contract=on"]
 
 
 def _compile(out: str, flags, verbose: bool) -> str:

@@ -14,7 +14,7 @@ def test_pose_unit_equals_separate_kernels(B, N):
 
     dev = torch.device("cuda:0")
     b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B + N).items()}
-    go = torch.rand(B, device=dev) + 0.5
+    go = (torch.rand(B, generator=torch.Generator().manual_seed(B + N)) + 0.5).to(dev)  # seeded: a test's inputs are part of the test
     unit = PoseUnit(B, N, dev)(b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], b["bbox_3d"], b["start"], grad_out=go)
     loss, du, ds, dx, _ = loss_cov_mixed_fused(b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], None, b["bbox_3d"], grad_out=go)
     st, tr, ret = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"])
@@ -44,7 +44,7 @@ def test_dense_pose_unit_equals_separate_kernels(B, N):
 
     dev = torch.device("cuda:0")
     b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B + N).items()}
-    go = torch.rand(B, device=dev) + 0.5
+    go = (torch.rand(B, generator=torch.Generator().manual_seed(B + N)) + 0.5).to(dev)  # seeded: a test's inputs are part of the test
     loss, du, ds, dx, _ = loss_cov_mixed_fused(b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"], None, b["bbox_3d"], grad_out=go)
     st, tr, ret, it = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"], return_iters=True)
     unit = PoseUnit(B, N, dev)

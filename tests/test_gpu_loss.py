@@ -99,11 +99,11 @@ def test_loss_halves_equal_the_whole_batch():
     l1, du1, _, _, _ = loss_cov_mixed_fused(*[a[:h] if a is not None else None for a in args])
     l2, du2, _, _, _ = loss_cov_mixed_fused(*[a[h:] if a is not None else None for a in args])
     assert torch.equal(torch.cat((l1, l2)), loss) and torch.equal(torch.cat((du1, du2)), du)
-    go = torch.rand(4096, device=dev) + 0.5
+    go = (torch.rand(4096, generator=torch.Generator().manual_seed(4096)) + 0.5).to(dev)
     _, du_g, ds_g, dx_g, _ = loss_cov_mixed_fused(*args, grad_out=go)
     assert torch.allclose(du_g, du * go[:, None, None], rtol=1e-5, atol=1e-12)
     assert torch.allclose(dx_g, dx * go[:, None, None], rtol=1e-5, atol=1e-12)
-    perm = torch.randperm(64, device=dev)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(64)).to(dev)
     lp, dup, _, _, _ = loss_cov_mixed_fused(b["K"], b["pose"], b["pts3d"][:, perm], b["pts2d"][:, perm], b["inv_std"][:, perm],
                                             None, b["bbox_3d"])
     assert (lp - loss).abs().max().item() <= 1e-5
@@ -131,7 +131,7 @@ def test_loss_full_size_properties():
     dev = torch.device("cuda:0")
     B, N = 4096, 64
     b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=123, outlier_frac=0.1).items()}
-    go = torch.rand(B, device=dev) + 0.5
+    go = (torch.rand(B, generator=torch.Generator().manual_seed(B)) + 0.5).to(dev)
     args = (b["K"], b["pose"], b["pts3d"], b["pts2d"], b["inv_std"])
     loss, gu, gs, gx, _ = loss_cov_mixed_fused(*args, None, b["bbox_3d"], grad_out=go)
     assert torch.isfinite(loss).all() and torch.isfinite(gu).all() and torch.isfinite(gs).all() and torch.isfinite(gx).all()
