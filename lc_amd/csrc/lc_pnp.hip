@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64, 3) void lc_pnp_lm_big_kernel(const PnpParams p)
 template <bool REG, bool OPTS = false, int PPT = 0>
 __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
-    pnp::solve_pose<REG, 4, false, OPTS, PPT>(p, blockIdx.x, threadIdx.x, bc);
+    pnp::solve_pose<REG, 4, false, OPTS, PPT, (PPT >= 8)>(p, blockIdx.x, threadIdx.x, bc);  // PPT 8 serves every Nmax > 1024
 }
 
 // Two dependent solves in one launch (lc_pnp_lm_chain_f32): workgroup b runs pose b % a.B of the first job, then pose b of the second,

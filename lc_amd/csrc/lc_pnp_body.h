@@ -260,8 +260,9 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 // column layout of oracle/pnp_lm_oracle.c's PNP_TRACE_COLS; the shipped kernels are instantiated with TRACE = false.
 // PPT (with !REG): a thread keeps its first PPT correspondences (lane, lane + 64 NW, ...) in registers as they sit in HBM (8 floats
 // each) across the whole solve; the block-stride loop otherwise re-reads them from L2 in every evaluation, ~1 us of exposed latency
-// each time.  Correspondences behind the cached prefix (n > 64 NW PPT) are read from memory.  Same accumulation order, same results.
-template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0>
+// each time.  TAIL: correspondences behind the cached prefix (n > 64 NW PPT) are read from memory; instantiations whose rows always fit
+// the prefix leave it out (the never-taken loop cost the test-time chain 1 us).  Same accumulation order, same results.
+template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0, bool TAIL = false>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
 #ifdef LC_TRACE_CLOCK
@@ -357,7 +358,8 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
                     if (lane + k * kThreads < n) accumulate_point<false>(to_point(rawc[k], cam), rt, t, cam, sc, acc);
                 // rows wider than the cached prefix (Nmax > 64 NW PPT): the correspondences behind it from memory, in the same per-thread
                 // order as the plain loop below -- same sums bit for bit; empty when the pose's count fits the prefix
-                for (int i = lane + PPT * kThreads; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
+                if constexpr (TAIL)
+                    for (int i = lane + PPT * kThreads; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
             } else {
                 for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
             }

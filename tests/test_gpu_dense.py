@@ -184,3 +184,57 @@ def test_xyz_bin_loss_equals_the_torch_formulas(B, C, H, W):
         assert (fused.histogram.cpu().double() - plain.histogram).abs().max() <= 1e-6
         assert (a.grad.cpu().double() - b.grad).abs().max() <= 2e-6 * b.grad.abs().max()
     assert float((fused.histogram - 0.5).abs().max()) > 1e-3  # the EMA moved
+
+
+@pytest.mark.parametrize("vis_sign", [-1.0, 1.0])
+def test_xyz_bin_loss_with_an_empty_and_a_full_visibility_mask(vis_sign):
+    """Edge cases of Loss_xyz_bin (losses.py:203-216): no visible pixel at all (the histogram update divides by `msk_hard.sum() + 1`
+    = 1, every masked logit is 0 so each pixel costs log 2) and every pixel visible; same tolerances as the seeded cases."""
+    from lc_amd.losses import Loss_xyz_bin
+
+    dev = torch.device("cuda:0")
+    B, C, H, W = 3, 9, 24, 40
+    g = torch.Generator().manual_seed(7)
+    fused, plain = Loss_xyz_bin(C).to(dev), Loss_xyz_bin(C).double()
+    for step in range(2):
+        logits = torch.randn(B, C, H, W, generator=g) * 3
+        bits = torch.rand(B, C, H, W, generator=g) < 0.5
+        vis = vis_sign * (torch.rand(B, 1, H, W, generator=g) + 0.1)
+        a, b = logits.to(dev).requires_grad_(True), logits.double().requires_grad_(True)
+        la, lb = fused(a, bits.to(dev), vis.to(dev)), plain(b, bits, vis.double())
+        la.backward()
+        lb.backward()
+        assert abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb))), (step, float(la), float(lb))
+        assert (fused.histogram.cpu().double() - plain.histogram).abs().max() <= 1e-6
+        assert (a.grad.cpu().double() - b.grad).abs().max() <= 2e-6 * max(float(b.grad.abs().max()), 1e-30)
+        if vis_sign < 0:
+            assert float(a.grad.abs().max()) == 0.0 and abs(float(la) - 0.6931471805599453) < 1e-6
+
+
+def test_dense_aux_losses_with_an_empty_mask_and_one_pixel_maps():
+    """Edge cases of the dense auxiliary losses (losses.py:281-316): an all-false foreground mask (loss_noc = mean |0 - tgt|, zero
+    coordinate gradient) and 1x1 maps (one pixel per sample: the vectorised path must fall back to scalars)."""
+    import torch.nn.functional as F
+
+    from lc_amd.dense_aux import dense_aux_losses
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    for B, H, W, empty in ((4, 16, 16, True), (5, 1, 1, False), (2, 3, 5, True)):
+        xyz, tgt = torch.randn(B, 3, H, W, generator=g), torch.randn(B, 3, H, W, generator=g)
+        msk = torch.zeros(B, H, W, dtype=torch.bool) if empty else torch.ones(B, H, W, dtype=torch.bool)
+        seg, wl = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 2, H, W, generator=g)
+        vis = (torch.rand(B, H, W, generator=g) > 0.5).float()
+        x64, s64, w64 = (t.double().requires_grad_(True) for t in (xyz, seg, wl))
+        want = [F.l1_loss(x64 * msk[:, None], tgt.double()), F.binary_cross_entropy_with_logits(s64, vis[:, None].double()),
+                F.binary_cross_entropy_with_logits(w64, vis[:, None].double().expand_as(w64))]
+        sum(want).backward()
+        xg, sg, wg = (t.to(dev).requires_grad_(True) for t in (xyz, seg, wl))
+        got = dense_aux_losses(xg, msk.to(dev), tgt.to(dev), sg, vis.to(dev), wg, "bce")
+        sum(got).backward()
+        for a, b in zip(got, want):
+            assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, abs(float(b))), (B, H, W, float(a), float(b))
+        for a, b in ((xg, x64), (sg, s64), (wg, w64)):
+            assert (a.grad.cpu().double() - b.grad).abs().max() <= 2e-6 * max(float(b.grad.abs().max()), 1e-30)
+        if empty:
+            assert float(xg.grad.abs().max()) == 0.0
