@@ -23,11 +23,11 @@ __global__ __launch_bounds__(64, 3) void lc_pnp_lm_big_kernel(const PnpParams p)
 #endif
 
 // four wavefronts per pose for N > 64 (dense heads, ragged inference batches)
-// PPT: correspondences per thread kept in registers (0: block-stride loop over memory, any N)
-template <bool REG, bool OPTS = false, int PPT = 0>
+// PPT: correspondences per thread kept in registers (0: block-stride loop over memory, any N); TAIL: rows may be wider than 256 PPT
+template <bool REG, bool OPTS = false, int PPT = 0, bool TAIL = false>
 __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
-    pnp::solve_pose<REG, 4, false, OPTS, PPT, (PPT >= 8)>(p, blockIdx.x, threadIdx.x, bc);  // PPT 8 serves every Nmax > 1024
+    pnp::solve_pose<REG, 4, false, OPTS, PPT, TAIL>(p, blockIdx.x, threadIdx.x, bc);
 }
 
 // Two dependent solves in one launch (lc_pnp_lm_chain_f32): workgroup b runs pose b % a.B of the first job, then pose b of the second,
@@ -91,8 +91,10 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<true, true>), dim3(p.B), dim3(256), 0, stream, p);
         } else if (p.Nmax <= 1024) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 4>), dim3(p.B), dim3(256), 0, stream, p);
-        } else {  // rows wider than 2048: the first 2048 correspondences of a pose in registers, the rest (if its count gets there) from memory
+        } else if (p.Nmax <= 2048) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 8>), dim3(p.B), dim3(256), 0, stream, p);
+        } else {  // rows wider than 2048: the first 2048 correspondences of a pose in registers, the rest (if its count gets there) from memory
+            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 8, true>), dim3(p.B), dim3(256), 0, stream, p);
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
@@ -107,8 +109,10 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(lc_pnp_lm_wide_kernel<true>, dim3(p.B), dim3(256), 0, stream, p);
     } else if (p.Nmax <= 1024) {
         hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 4>), dim3(p.B), dim3(256), 0, stream, p);
-    } else {
+    } else if (p.Nmax <= 2048) {
         hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 8>), dim3(p.B), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 8, true>), dim3(p.B), dim3(256), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

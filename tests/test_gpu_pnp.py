@@ -29,7 +29,7 @@ def make(B, N, seed, **kw):
     return b, torch.diag_embed(b["inv_std"])
 
 
-@pytest.mark.parametrize("B,N,seed", [(256, 64, 0), (16, 16, 1), (8, 4, 2), (5, 100, 3), (3, 1024, 4)])
+@pytest.mark.parametrize("B,N,seed", [(256, 64, 0), (16, 16, 1), (8, 4, 2), (5, 100, 3), (3, 1024, 4), (3, 1849, 5), (2, 2500, 6), (2, 4096, 7)])
 def test_pnp_device_route_vs_oracle(B, N, seed):
     from lc_amd.pnp import pnp_ceres
 
