@@ -68,13 +68,28 @@ def static_counters(kernel: str, B: int, N: int):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if d.get(kernel):
+            key = kernel
+            if not d.get(key) and kernel.endswith(">"):  # a template whose argument list has grown since: the one recorded instantiation that extends the key
+                hits = [k for k in d if k.startswith(kernel[:-1] + ",")]
+                key = hits[0] if len(hits) == 1 else kernel
+            if d.get(key):
                 meta = d.get("_meta", {})
-                return d[kernel], {"file": os.path.relpath(f, ROOT), "git_sha": meta.get("git_sha", "unrecorded (round 1)"),
+                return d[key], {"file": os.path.relpath(f, ROOT), "git_sha": meta.get("git_sha", "unrecorded (round 1)"),
                                    "command": meta.get("command")}
         except Exception:
             pass
     return None, None
+
+
+def dense_counter_keys(B: int, N: int, tiled: bool):
+    """The keys under which profiles/<round>/pmc_traffic.json (scripts/summarize_prof.py) files the two kernels of a dense block: the
+    tiled loss by its workgroup count (the slicing rule of lc_loss.hip: the smallest of 4 / 8 / 16 tiles per workgroup that leaves >= 3
+    slices and <= 256 workgroups), the wide solve by its points-per-thread template argument.  None where no pass is keyed that way."""
+    T = (N + 63) // 64
+    groups = next((B * ((T + ts - 1) // ts) for ts in (4, 8, 16) if (T + ts - 1) // ts >= 3 and B * ((T + ts - 1) // ts) <= 256), None)
+    loss_key = f"lc_cov_loss_tiled_kernel[{groups} workgroups]" if (tiled and groups) else None
+    pnp_key = f"lc_pnp_lm_wide_kernel<false,false,{4 if N <= 1024 else 8}>" if 256 < N <= 2048 else None
+    return loss_key, pnp_key
 
 
 def rccl_version():
@@ -548,10 +563,7 @@ def main():
                     out["waiting_share_of_wave_cycles"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
                 out["counters_from"] = src
             return out
-        T_ = (Nd + 63) // 64
-        groups = next((Bd * ((T_ + ts - 1) // ts) for ts in (4, 8, 16) if (T_ + ts - 1) // ts >= 3 and Bd * ((T_ + ts - 1) // ts) <= 256), None)
-        loss_key = f"lc_cov_loss_tiled_kernel[{groups} workgroups]" if (u.ws is not None and groups) else None
-        pnp_key = f"lc_pnp_lm_wide_kernel<false,false,{4 if Nd <= 1024 else 8}>" if 256 < Nd <= 2048 else None
+        loss_key, pnp_key = dense_counter_keys(Bd, Nd, u.ws is not None)
         two = {"value": Bd / wall, "unit": "poses/s", "ms_per_step": wall * 1e3,
                "launch": "graph_region (20 steps per replay)" if graphed else "stream order",
                "step_us_events": {"graph": None if t_step is None else t_step * 1e3, "stream_order": t_step_so * 1e3},

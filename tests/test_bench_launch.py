@@ -42,3 +42,17 @@ def test_self_launch_relays_the_ranks_return_code():
     else:
         assert out.returncode != 0 and "needs an MI355X" in out.stderr, out.stderr[-2000:]
         assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_committed_counter_passes_cover_the_bench_shapes():
+    """`roofline.traffic` and the dense blocks' `traffic` come from the newest committed profiles/<round>/pmc_traffic.json: every kernel
+    the line looks up must be found there under the key bench.py forms (a renamed template instantiation once dropped the dense blocks'
+    counters from the line without any CPU test noticing)."""
+    import bench
+
+    c, src = bench.static_counters("lc_pose_unit_kernel", 256, 64)
+    assert c and c["bytes_per_launch"] > 0 and c["sq"]["SQ_ACTIVE_INST_VALU"] > 0 and src["file"].startswith("profiles/")
+    for B, N in ((32, 1024), (32, 1849)):
+        for key in bench.dense_counter_keys(B, N, True):
+            c, src = bench.static_counters(key, B, N)
+            assert c and c["bytes_per_launch"] > 0 and c["sq"]["SQ_WAVE_CYCLES"] > 0 and src["git_sha"], key
