@@ -376,10 +376,12 @@ int lc_dense_frontend_select_f32(const float *xyz, const float *wlogits, const f
  *        losses[2] loss_weight_seg = mean seg(wlogits, msk_vis broadcast over 2 channels)  (warm-up blend, losses.py:303-306)
  *      seg_type 0 = F.binary_cross_entropy_with_logits, 1 = Loss_seg_L1 (|sigmoid(x) - t|, losses.py:219-236).
  *      xyz (B,3,HW)|NULL with noc_tgt and the object mask as bool bytes (msk_noc_u8) or floats (msk_noc_f32), both (B,HW);
- *      seg_logits, msk_vis (B,HW); wlogits (B,2,HW)|NULL.  Forward: partials = 3 * 1024 doubles of workspace, ticket = one unsigned,
- *      zero before the first call (the kernel leaves it zero); sums in double precision, block partials added in block order.
+ *      seg_logits, msk_vis (B,HW); wlogits (B,2,HW)|NULL.  Forward: partials = 3 * 1024 doubles of workspace, ticket = LC_ARRIVAL_WORDS
+ *      unsigned (the workgroups' arrival counters, sharded over 128-byte lines), zero before the first call (the kernel leaves them
+ *      zero); sums in double precision, block partials added in block order.
  *      Backward: g_* = device scalars (the cotangents of the three means, NULL = none), d_* (same shapes as the inputs)|NULL.
  * ------------------------------------------------------------------------------------------------ */
+#define LC_ARRIVAL_WORDS 544 /* (1 + 16 shards) x 32 words: lc_common.h kArrivalWords */
 int lc_dense_aux_fwd_f32(const float *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
                          const float *seg_logits, const float *msk_vis, const float *wlogits, int B, int HW, int seg_type,
                          float *losses, double *partials, unsigned *ticket, void *stream);
@@ -392,7 +394,7 @@ int lc_dense_aux_bwd_f32(const float *xyz, const unsigned char *msk_noc_u8, cons
  * weighted by softmax(3 * min(h, 0.51 - h)) of the EMA histogram h of per-bit Hamming error rates inside that mask.  logits (B,C,HW),
  * gt_bits (B,C,HW) bool bytes, msk_vis_logits (B,HW), C <= 128.  Forward (one pass over the logits): histogram (C) is read and updated in
  * place (h <- h (1 - momentum) + rate momentum), loss (1), bin_weights (C) for the backward pass; partials = C * 32 * 3 doubles, ticket =
- * one unsigned, zero before the first call (left zero).  Backward: d_logits = g_loss (device scalar) * d loss / d logits. */
+ * LC_ARRIVAL_WORDS unsigned, zero before the first call (left zero).  Backward: d_logits = g_loss (device scalar) * d loss / d logits. */
 int lc_xyz_bin_loss_fwd_f32(const float *logits, const unsigned char *gt_bits, const float *msk_vis_logits, int B, int C, int HW,
                             float momentum, float *histogram, float *loss, float *bin_weights, double *partials,
                             unsigned *ticket, void *stream);

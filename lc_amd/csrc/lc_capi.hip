@@ -12,6 +12,8 @@
 #include <cstdint>
 
 #include "lc_host_stage.h"
+
+static_assert(LC_ARRIVAL_WORDS == lc::kArrivalWords, "include/lc_amd.h and lc_common.h disagree on the arrival counters");
 #include "lc_kernels.h"
 
 #ifndef LC_AMD_SRC_HASH

@@ -178,6 +178,23 @@ template <class T>
 __device__ __forceinline__ T xcd_load(const T* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xcd_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// "Which workgroup finishes last" for grids of hundreds of workgroups that all finish together: arrivals on ONE word are served one
+// after the other (11-13 ns each: 512 of them are 6 us behind a 10 us kernel), so the workgroups count themselves in on one of
+// kArrivalShards words, each on a 128-byte line of its own (neighbours in dispatch order -> different words), and only the last of a
+// shard goes on to the top word.  `words`: kArrivalWords zeroed unsigned, left zeroed by arrival_reset() (called by the workgroup
+// that got `true`, after its last use of what the others wrote).  Called by ONE thread, after xcd_stores_done().
+constexpr int kArrivalShards = 16, kArrivalStride = 32;
+constexpr int kArrivalWords = (1 + kArrivalShards) * kArrivalStride;
+__device__ __forceinline__ bool arrive_is_last(unsigned* words, unsigned block, unsigned blocks) {
+    const unsigned shards = blocks < (unsigned)kArrivalShards ? blocks : (unsigned)kArrivalShards;
+    const unsigned g = block % shards, members = (blocks - g + shards - 1) / shards;
+    if (__hip_atomic_fetch_add(words + (1 + g) * kArrivalStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+    return __hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+}
+__device__ __forceinline__ void arrival_reset(unsigned* words, int tid) {
+    if (tid <= kArrivalShards) xcd_store(words + tid * kArrivalStride, 0u);
+}
+
 template <int NW>
 __device__ __forceinline__ void block_sum_sync() {
     if constexpr (NW == 1 && !LC_WAVE_SYNC) wave_sync();

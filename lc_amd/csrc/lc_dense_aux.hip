@@ -20,18 +20,6 @@ namespace {
 constexpr int kThreads = 256;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }  // torch.sigmoid's formula
-// F.binary_cross_entropy_with_logits (ATen Loss.cpp): (1 - t) x - log_sigmoid(x), log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
-__device__ __forceinline__ float seg_loss(float x, float t, int type) {
-    if (type == 0) return (1.f - t) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
-    return fabsf(sigmoidf_(x) - t);
-}
-__device__ __forceinline__ float seg_grad(float x, float t, int type) {
-    const float s = sigmoidf_(x);
-    if (type == 0) return s - t;
-    const float d = s - t;
-    return (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (s * (1.f - s));  // sign(s - t) * sigmoid'(x)
-}
-
 template <int NWAVES = kThreads / 64>
 __device__ __forceinline__ void block_sum3(double (&v)[3], double (*red)[3]) {
     wave_allreduce<3>(v);
@@ -83,35 +71,64 @@ __device__ __forceinline__ Px<V> mask_at(const DenseAuxParams& p, size_t i) {
     return ld<V>(p.msk_noc_f32 + i);
 }
 
-template <int V>
+// Forward terms with the hardware exp / log (see bce_logits below: ~1e-7 absolute on terms of a mean compared at 1e-6)
+template <int SEG>
+__device__ __forceinline__ float seg_term(float x, float t) {
+    if constexpr (SEG == 0) return (1.f - t) * x - (fminf(x, 0.f) - __logf(1.f + __expf(-fabsf(x))));
+    else return fabsf(1.f / (1.f + __expf(-x)) - t);
+}
+
+// SEG: 0 BCE-with-logits, 1 Loss_seg_L1 (a template argument: twelve run-time branches per request kept the scheduler from moving anything)
+template <int V, int SEG>
 __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseAuxParams p) {
     __shared__ double red[4][3];
     __shared__ bool last;
     // 32-bit index arithmetic throughout (the entry points refuse maps of 2^31 elements or more): a 64-bit division per request costs
     // more instructions than the request's arithmetic
     const unsigned HW = (unsigned)p.HW, n = (unsigned)p.B * HW, nv = n / V;
+    const bool has_xyz = p.xyz != nullptr, has_w = p.wlogits != nullptr, mask_bytes = p.msk_noc_u8 != nullptr;
     double acc[3] = {0, 0, 0};
     for (unsigned j = blockIdx.x * kThreads + threadIdx.x; j < nv; j += gridDim.x * kThreads) {
         const unsigned i = j * V, b = i / HW, px = i - b * HW;
-        const Px<V> t = ld<V>(p.msk_vis + i);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;  // the V pixels' terms in fp32, one fp64 add per request and loss
-        if (p.xyz) {
-            const Px<V> m = mask_at<V>(p, (size_t)i);
-            for (int c = 0; c < 3; ++c) {
-                const size_t e = ((size_t)b * 3 + c) * p.HW + px;
-                const Px<V> x = ld<V>(p.xyz + e), g = ld<V>(p.noc_tgt + e);
+        // every request of the iteration first (up to eleven of 16 bytes), the arithmetic after them: as written before -- a map's
+        // loads next to its arithmetic -- an iteration was FOUR dependent round trips (mask, coordinates, mask logits, weight logits)
+        const Px<V> t = ld<V>(p.msk_vis + i), z = ld<V>(p.seg_logits + i);
+        Px<V> x[3], g[3], mf, w0, w1;
+        unsigned mb = 0;
+        if (has_xyz) {
+            if (mask_bytes) {
+                if constexpr (V == 4) mb = *reinterpret_cast<const unsigned*>(p.msk_noc_u8 + i);
+                else mb = p.msk_noc_u8[i];
+            } else {
+                mf = ld<V>(p.msk_noc_f32 + i);
+            }
 #pragma unroll
-                for (int v = 0; v < V; ++v) s0 += fabsf(x.v[v] * m.v[v] - g.v[v]);
+            for (int c = 0; c < 3; ++c) {
+                const unsigned e = (b * 3 + c) * HW + px;
+                x[c] = ld<V>(p.xyz + e);
+                g[c] = ld<V>(p.noc_tgt + e);
             }
         }
-        const Px<V> z = ld<V>(p.seg_logits + i);
+        if (has_w) {
+            const unsigned e = b * 2 * HW + px;
+            w0 = ld<V>(p.wlogits + e);
+            w1 = ld<V>(p.wlogits + e + HW);
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;  // the V pixels' terms in fp32, one fp64 add per request and loss
+        if (has_xyz) {
+            Px<V> m;
 #pragma unroll
-        for (int v = 0; v < V; ++v) s1 += seg_loss(z.v[v], t.v[v], p.seg_type);
-        if (p.wlogits) {
-            const size_t e = (size_t)b * 2 * p.HW + px;
-            const Px<V> w0 = ld<V>(p.wlogits + e), w1 = ld<V>(p.wlogits + e + p.HW);
+            for (int v = 0; v < V; ++v) m.v[v] = mask_bytes ? (((mb >> (8 * v)) & 0xffu) ? 1.f : 0.f) : mf.v[v];
 #pragma unroll
-            for (int v = 0; v < V; ++v) s2 += seg_loss(w0.v[v], t.v[v], p.seg_type) + seg_loss(w1.v[v], t.v[v], p.seg_type);
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int v = 0; v < V; ++v) s0 += fabsf(x[c].v[v] * m.v[v] - g[c].v[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) s1 += seg_term<SEG>(z.v[v], t.v[v]);
+        if (has_w) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) s2 += seg_term<SEG>(w0.v[v], t.v[v]) + seg_term<SEG>(w1.v[v], t.v[v]);
         }
         acc[0] += (double)s0; acc[1] += (double)s1; acc[2] += (double)s2;
     }
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseA
         // reads all of them around the caches: no agent-scope fence (an L2 write-back per block, ~10 us for 512 blocks: lc_common.h)
         for (int k = 0; k < 3; ++k) xcd_store(p.partials + 3 * blockIdx.x + k, acc[k]);
         xcd_stores_done();
-        last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        last = arrive_is_last(p.ticket, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (!last) return;
@@ -133,48 +150,79 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseA
         p.losses[0] = p.xyz ? (float)(s[0] / (3.0 * (double)n)) : 0.f;
         p.losses[1] = (float)(s[1] / (double)n);
         p.losses[2] = p.wlogits ? (float)(s[2] / (2.0 * (double)n)) : 0.f;
-        xcd_store(p.ticket, 0u);  // ready for the next call on this stream
     }
+    arrival_reset(p.ticket, threadIdx.x);  // ready for the next call on this stream
 }
 
-template <int V>
+template <int SEG>
+__device__ __forceinline__ float seg_term_grad(float x, float t) {
+    const float s = 1.f / (1.f + __expf(-x));  // torch.sigmoid's formula on the hardware exp (|error| < 1e-7 on a value in [0, 1])
+    if constexpr (SEG == 0) return s - t;
+    const float d = s - t;
+    return (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (s * (1.f - s));  // sign(s - t) * sigmoid'(x)
+}
+
+// Loads first, arithmetic and stores after them (as in the forward kernel): written map by map, a request was EIGHT dependent round
+// trips -- the compiler cannot move a map's loads above the previous map's stores (the pointers may alias)
+template <int V, int SEG>
 __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseAuxParams p) {
     const unsigned HW = (unsigned)p.HW, n = (unsigned)p.B * HW, nv = n / V;
     const float g0 = (p.g_noc && p.d_xyz) ? *p.g_noc / (3.f * (float)n) : 0.f;
     const float g1 = p.g_seg ? *p.g_seg / (float)n : 0.f;
     const float g2 = (p.g_wseg && p.d_wlogits) ? *p.g_wseg / (2.f * (float)n) : 0.f;
+    const bool do_xyz = p.d_xyz != nullptr, do_seg = p.d_seg != nullptr, do_w = p.d_wlogits != nullptr, mask_bytes = p.msk_noc_u8 != nullptr;
     for (unsigned j = blockIdx.x * kThreads + threadIdx.x; j < nv; j += gridDim.x * kThreads) {
         const unsigned i = j * V, b = i / HW, px = i - b * HW;
+        const unsigned ex = b * 3 * HW + px, ew = b * 2 * HW + px;
         const Px<V> t = ld<V>(p.msk_vis + i);
-        if (p.d_xyz) {
-            const Px<V> m = mask_at<V>(p, (size_t)i);
+        Px<V> x[3], g[3], mf, z, w[2];
+        unsigned mb = 0;
+        if (do_xyz) {
+            if (mask_bytes) {
+                if constexpr (V == 4) mb = *reinterpret_cast<const unsigned*>(p.msk_noc_u8 + i);
+                else mb = p.msk_noc_u8[i];
+            } else {
+                mf = ld<V>(p.msk_noc_f32 + i);
+            }
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const size_t e = ((size_t)b * 3 + c) * p.HW + px;
-                const Px<V> x = ld<V>(p.xyz + e), g = ld<V>(p.noc_tgt + e);
+                x[c] = ld<V>(p.xyz + ex + c * HW);
+                g[c] = ld<V>(p.noc_tgt + ex + c * HW);
+            }
+        }
+        if (do_seg) z = ld<V>(p.seg_logits + i);
+        if (do_w) {
+            w[0] = ld<V>(p.wlogits + ew);
+            w[1] = ld<V>(p.wlogits + ew + HW);
+        }
+        if (do_xyz) {
+            Px<V> m;
+#pragma unroll
+            for (int v = 0; v < V; ++v) m.v[v] = mask_bytes ? (((mb >> (8 * v)) & 0xffu) ? 1.f : 0.f) : mf.v[v];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
                 Px<V> o;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    const float d = x.v[v] * m.v[v] - g.v[v];
+                    const float d = x[c].v[v] * m.v[v] - g[c].v[v];
                     o.v[v] = (d > 0.f ? g0 : (d < 0.f ? -g0 : 0.f)) * m.v[v];  // torch.sign(0) = 0
                 }
-                st<V>(p.d_xyz + e, o);
+                st<V>(p.d_xyz + ex + c * HW, o);
             }
         }
-        if (p.d_seg) {
-            const Px<V> z = ld<V>(p.seg_logits + i);
+        if (do_seg) {
             Px<V> o;
 #pragma unroll
-            for (int v = 0; v < V; ++v) o.v[v] = g1 * seg_grad(z.v[v], t.v[v], p.seg_type);
+            for (int v = 0; v < V; ++v) o.v[v] = g1 * seg_term_grad<SEG>(z.v[v], t.v[v]);
             st<V>(p.d_seg + i, o);
         }
-        if (p.d_wlogits) {
-            const size_t e = (size_t)b * 2 * p.HW + px;
+        if (do_w) {
+#pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const Px<V> w = ld<V>(p.wlogits + e + c * (size_t)p.HW);
                 Px<V> o;
 #pragma unroll
-                for (int v = 0; v < V; ++v) o.v[v] = g2 * seg_grad(w.v[v], t.v[v], p.seg_type);
-                st<V>(p.d_wlogits + e + c * (size_t)p.HW, o);
+                for (int v = 0; v < V; ++v) o.v[v] = g2 * seg_term_grad<SEG>(w[c].v[v], t.v[v]);
+                st<V>(p.d_wlogits + ew + c * HW, o);
             }
         }
     }
@@ -211,6 +259,8 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
     if (p.vec) {  // HW % 4 == 0, 16-byte aligned maps: four pixels per thread and request
         const unsigned n4 = n >> 2, hw4 = (unsigned)p.HW >> 2;
         constexpr int kAhead = 4;  // requests in flight per thread: the loop is a latency chain otherwise (one round trip per iteration)
+        // (prefetching the NEXT four requests while these are evaluated was tried: 94 VGPRs -> one 1024-thread workgroup per compute
+        // unit instead of two, 33 -> 39 us at B=64 128x128)
         const unsigned stride = (unsigned)chunks * kBinThreads;
         for (unsigned i0 = (unsigned)chunk * kBinThreads + threadIdx.x; i0 < n4; i0 += kAhead * stride) {
             float4 x[kAhead], v[kAhead];
@@ -249,7 +299,7 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
     if (threadIdx.x == 0) {
         for (int k = 0; k < 3; ++k) xcd_store(p.partials + 3 * blockIdx.x + k, acc[k]);
         xcd_stores_done();
-        last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        last = arrive_is_last(p.ticket, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (!last) return;
@@ -300,8 +350,8 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
         float loss = 0.f;
         for (int ch = 0; ch < p.C; ++ch) loss += ws[ch];
         *p.loss = loss;
-        xcd_store(p.ticket, 0u);
     }
+    arrival_reset(p.ticket, tid);
 }
 
 __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const BinLossParams p) {
@@ -343,11 +393,17 @@ static bool aux_vec(const DenseAuxParams& p) {
 
 int launch_dense_aux_fwd(const DenseAuxParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
-    // eight pixels per thread up to two blocks per compute unit: every block ends with one counted arrival (~11 ns each)
+    // one request of four pixels per thread up to four blocks per compute unit (the arrivals are counted on sharded words: lc_common.h)
     const long long n = (long long)p.B * p.HW;
-    const int grid = (int)std::min<long long>(512, std::max<long long>(1, (n + 8 * kThreads - 1) / (8 * kThreads)));
-    if (aux_vec(p)) hipLaunchKernelGGL(lc_dense_aux_fwd_kernel<4>, dim3(grid), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL(lc_dense_aux_fwd_kernel<1>, dim3(grid), dim3(kThreads), 0, stream, p);
+    const int grid = (int)std::min<long long>(kDenseAuxMaxBlocks, std::max<long long>(1, (n + 4 * kThreads - 1) / (4 * kThreads)));
+    const bool vec = aux_vec(p);
+    if (p.seg_type == 0) {
+        if (vec) hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<4, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<1, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<4, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<1, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -355,19 +411,25 @@ int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     const bool vec = aux_vec(p);
     const int grid = grid_for(((long long)p.B * p.HW) / (vec ? 4 : 1));
-    if (vec) hipLaunchKernelGGL(lc_dense_aux_bwd_kernel<4>, dim3(grid), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL(lc_dense_aux_bwd_kernel<1>, dim3(grid), dim3(kThreads), 0, stream, p);
+    if (p.seg_type == 0) {
+        if (vec) hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<4, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<1, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<4, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<1, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.C <= 0) return 0;
     if (p.C > kBinMaxChannels) return 3;
-    // every workgroup ends with one counted arrival (~11 ns each on the one counter): 1024-thread workgroups, and no more of them
-    // than keep a thread at about eight requests of four pixels
+    // 1024-thread workgroups, a thread at about four requests of four pixels (all in flight at once), at most kBinChunks workgroups
+    // per code bit (B=64 128x128: 16 -> 32 chunks 38 -> 33 us; B=32 64x64: eight -> four requests 16.4 -> 12.5 us)
     BinLossParams q = p;
     const long long req = ((long long)p.B * p.HW + 3) / 4;
-    q.chunks = (int)std::min<long long>(16, std::max<long long>(1, (req + 8 * kBinThreads - 1) / (8 * kBinThreads)));
+    q.chunks = (int)std::min<long long>(kBinChunks, std::max<long long>(1, (req + 4 * kBinThreads - 1) / (4 * kBinThreads)));
+    q.chunks = std::min(q.chunks, std::max(1, 512 / q.C));  // one round of workgroups: two of 1024 threads fit a compute unit
     hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel, dim3(q.C * q.chunks), dim3(kBinThreads), 0, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

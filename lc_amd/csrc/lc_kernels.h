@@ -212,7 +212,7 @@ struct DenseAuxParams {
     int seg_type;                     // 0: binary_cross_entropy_with_logits, 1: Loss_seg_L1
     float* losses;                    // (3) out: loss_noc, loss_seg, loss_weight_seg (forward)
     double* partials;                 // (kDenseAuxMaxBlocks,3) workspace (forward)
-    unsigned* ticket;                 // zero between launches (forward)
+    unsigned* ticket;                 // kArrivalWords (lc_common.h), zero between launches (forward)
     const float* g_noc;               // upstream cotangents: device scalars or null (backward)
     const float* g_seg;
     const float* g_wseg;
@@ -234,7 +234,7 @@ struct BinLossParams {
     float* loss;                    // (1) out (forward)
     float* bin_weights;             // (C) out (forward), in (backward)
     double* partials;               // (C * 32, 3) workspace (forward)
-    unsigned* ticket;               // zero between launches (forward)
+    unsigned* ticket;               // kArrivalWords (lc_common.h), zero between launches (forward)
     const float* g_loss;            // device scalar (backward)
     float* d_logits;                // (B,C,HW) (backward)
     int B, C, HW;

@@ -10,20 +10,21 @@ from torch import Tensor
 from . import _lib
 
 SEG_TYPES = {"bce": 0, "l1": 1}
+ARRIVAL_WORDS = 544  # include/lc_amd.h LC_ARRIVAL_WORDS: the forward kernels' sharded arrival counters
 _WS = {}  # (device index, stream) -> (partials, ticket): the forward's reduction workspace (launches of one stream are ordered)
 
 
 def _workspace(dev):
     if torch.cuda.is_current_stream_capturing():
-        # a graph owns its workspace; only the arrival counter has to start from zero (its zero-fill is a node of the graph), the
+        # a graph owns its workspace; only the arrival counters have to start from zero (their zero-fill is a node of the graph), the
         # partials are written before they are read
-        return torch.empty(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32)
+        return torch.empty(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(ARRIVAL_WORDS, device=dev, dtype=torch.int32)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         if len(_WS) >= 64:
             _WS.clear()
-        ws = _WS[key] = (torch.zeros(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32))
+        ws = _WS[key] = (torch.zeros(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(ARRIVAL_WORDS, device=dev, dtype=torch.int32))
     return ws
 
 
