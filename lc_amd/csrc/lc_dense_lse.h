@@ -9,6 +9,9 @@
 
 namespace lc {
 
+#ifndef LC_LSE_AHEAD
+#define LC_LSE_AHEAD 4  // requests in flight per thread in block_lse (A/B: scripts/ubench/graph_inference.py with a -DLC_LSE_AHEAD=1 variant build)
+#endif
 constexpr int kDenseLseThreads = 512;  // the NT every caller uses: the front end's workgroup size
 
 // (running max, running sum of exp(x - max)) pairs of the online softmax
@@ -30,12 +33,23 @@ __device__ __forceinline__ float block_lse(const float* __restrict__ lg, int n, 
     float m = -FLT_MAX, s = 0.f;
     if (tid < NT) {
         if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(lg) & 15) == 0) {
+            // four requests in flight per thread, consumed in index order: the same updates in the same order as one request per
+            // iteration (which was one memory round trip per iteration: 4 for a 64x64 map, 16 for 128x128)
             const float4* v4 = reinterpret_cast<const float4*>(lg);
-            for (int i = tid; i < (n >> 2); i += NT) {
-                const float4 v = v4[i];
-                const float mn = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-                s = s * __expf(m - mn) + ((__expf(v.x - mn) + __expf(v.y - mn)) + (__expf(v.z - mn) + __expf(v.w - mn)));
-                m = mn;
+            constexpr int kAhead = LC_LSE_AHEAD;
+            const int n4 = n >> 2;
+            for (int i = tid; i < n4; i += kAhead * NT) {
+                float4 v[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u)
+                    if (i + u * NT < n4) v[u] = v4[i + u * NT];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    if (i + u * NT >= n4) break;
+                    const float mn = fmaxf(fmaxf(m, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+                    s = s * __expf(m - mn) + ((__expf(v[u].x - mn) + __expf(v[u].y - mn)) + (__expf(v[u].z - mn) + __expf(v[u].w - mn)));
+                    m = mn;
+                }
             }
         } else {
             for (int i = tid; i < n; i += NT) ms_push(m, s, lg[i]);

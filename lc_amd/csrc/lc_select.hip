@@ -92,23 +92,31 @@ struct MapSource {
         return y * W + x;
     }
     // the part that does not need the log-sum-exp (requested while it is being formed): logits in s, raw xyz in X
-    __device__ __forceinline__ Entry fetch(int n) const {
+    // Loads ONLY (the visibility logit comes back raw in `v`): nothing in here waits for memory, so the requests of several entries --
+    // each behind its own `if (index < N)` -- are all in flight together (with the sigmoid in here an entry was a round trip of its own)
+    __device__ __forceinline__ Entry fetch(int n, float& v) const {
         int x, y;
         const int px = pixel(n, x, y);
         Entry e;
         e.u = make_float2((float)x, (float)y);
         e.s = make_float2(lg[px], lg[HW + px]);
         for (int d = 0; d < 3; ++d) e.X[d] = xyz[d * HW + px];
-        e.g = vis ? ((1.f / (1.f + expf(-vis[px]))) > vis_thresh ? 1 : 0) : 0;  // torch.sigmoid's own formula
+        v = vis ? vis[px] : 0.f;
+        e.g = 0;
         e.src = n;
         return e;
     }
-    __device__ __forceinline__ Entry finish(Entry e) const {
+    __device__ __forceinline__ Entry finish(Entry e, float v) const {
         e.s = make_float2(__expf(e.s.x - lse) * scale, __expf(e.s.y - lse) * scale);
         for (int d = 0; d < 3; ++d) e.X[d] *= ns[d];
+        e.g = vis ? ((1.f / (1.f + expf(-v))) > vis_thresh ? 1 : 0) : 0;  // torch.sigmoid's own formula
         return e;
     }
-    __device__ __forceinline__ Entry load(int n) const { return finish(fetch(n)); }
+    __device__ __forceinline__ Entry load(int n) const {
+        float v;
+        const Entry e = fetch(n, v);
+        return finish(e, v);
+    }
 };
 
 // The selection of row b by the calling workgroup (kThreads threads).  ec: entries tid + k * 1024 of the row, already in registers -- all
@@ -292,14 +300,15 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
     src.Wn = (d.W - d.left + d.sample - 1) / d.sample;
     src.lse = 0.f;
     Entry ec[kCache] = {};
+    float vraw[kCache] = {};
 #pragma unroll
     for (int k = 0; k < kCache; ++k)
-        if (tid + k * kThreads < p.N) ec[k] = src.fetch(tid + k * kThreads);  // in flight while the log-sum-exp is formed
+        if (tid + k * kThreads < p.N) ec[k] = src.fetch(tid + k * kThreads, vraw[k]);  // in flight while the log-sum-exp is formed
     src.scale = d.wscale[b];
     for (int k = 0; k < 3; ++k) src.ns[k] = d.noc_scale ? d.noc_scale[3 * b + k] : 1.f;
     src.lse = block_lse<kDenseLseThreads>(src.lg, 2 * HW, red);
 #pragma unroll
-    for (int k = 0; k < kCache; ++k) ec[k] = src.finish(ec[k]);
+    for (int k = 0; k < kCache; ++k) ec[k] = src.finish(ec[k], vraw[k]);
     select_row(p, b, p.N, src, ec, srt);
 }
 
