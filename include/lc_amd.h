@@ -136,7 +136,7 @@ int lc_pose_unit_f32(const float *K, const float *pose, const float *pts3d, cons
                      int *pnp_rets, int pnp_max_iter, float pnp_function_tolerance, void *stream);
 
 /* Round 3: the pose unit for the dense shapes as well.  N <= 64: lc_pose_unit_f32 (workspace unused).  256 < N <= 2048 with
- * workspace = lc_cov_loss_workspace_bytes(B, N) > 0 bytes (8-byte aligned, zero-filled once, left zero): the tiled loss's
+ * workspace = lc_cov_loss_workspace_bytes(B, N) > 0 bytes (256-byte aligned like lc_cov_loss3_fwd_bwd_f32's, zero-filled once, left zero): the tiled loss's
  * workgroups and the four-wave solve's share one grid (B = 32, N = 1024: 128 + 32 workgroups at the same time instead of two launches
  * back to back).  Other shapes: return code 3 -- launch lc_cov_loss3_fwd_bwd_f32 and lc_pnp_lm_f32 separately.  pnp_iters (B)|NULL.
  * Results bit for bit those of the two stand-alone launches. */
@@ -238,7 +238,8 @@ int lc_pnp_ransac_init2_f32(const float *K, const float *pts3d, const float *pts
 /* Split form of the same RANSAC for batches that do not fill the chip with one workgroup per pose (64 objects x 150 hypotheses
  * x 1000+ dense correspondences): three launches -- hypotheses (one lane each), scoring (point chunks x hypotheses, spread over
  * all compute units), selection -- over a caller-provided device workspace of lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)
- * bytes (8-byte aligned; contents undefined before and after).  Same hypothesis stream, same per-point arithmetic and the same
+ * bytes (16-byte aligned; contents undefined before and after; B x ceil(Nmax / 64) x hypotheses x 8 bytes of chunk partials: EVERY
+ * point of a pose is sampled from and scored, as cv2.solvePnPRansac does, cv2_solver.py:72-75).  Same hypothesis stream, same per-point arithmetic and the same
  * (count, error, hypothesis index) ordering as the single launch; results do not depend on scheduling (no atomics).
  * workspace == NULL runs the single launch through this entry.  valid_counts (B)|NULL: the pose's point count, 0 when the pose is
  * invalid -- handed as `counts` to a following lc_pnp_lm2_f32 refinement it makes that solve skip the failed poses. */
@@ -359,8 +360,8 @@ int lc_dense_select_f32(const float *pts2d, const float *inv_std, const float *p
                         float *out_pts3d, int *out_index, int *counts, void *stream);
 
 /* Round 3: the dense front end (2d, lc_dense_frontend_fwd2_f32) and the selection above in ONE launch for the test-time pipeline,
- * one workgroup per object, for N = ceil((H-top)/sample) * ceil((W-left)/sample) <= 8192 sampled pixels (128x128 maps at stride 2:
- * 4096; more: an error, use the two launches).  The front end's (B,N,.) rows are never written; every selected value, count and index
+ * one workgroup per object, for N = ceil((H-top)/sample) * ceil((W-left)/sample) <= 16384 sampled pixels (128x128 maps at stride 1,
+ * configs/zlmo.yaml:30-37's test-time shape; more: an error, use the two launches).  The front end's (B,N,.) rows are never written; every selected value, count and index
  * equals what lc_dense_frontend_fwd2_f32 followed by lc_dense_select_f32(mask = the visibility mask) returns, bit for bit
  * (tests/test_gpu_select.py).  xyz (B,3,H,W) required; vis_logits (B,H,W) required by modes 0 and 2. */
 int lc_dense_frontend_select_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale,

@@ -318,9 +318,10 @@ int lc_pose_unit2_f32(const float* K, const float* pose, const float* pts3d, con
     if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss || !d_pts2d || !d_inv_std || !pnp_sqrt_diag ||
         !pnp_start || !pnp_states || !pnp_result_tr || !pnp_rets)
         return fail(1, "null pointer");
-    LC_REQUIRE_ALIGNED(8, pts2d, inv_std, d_pts2d, d_inv_std, pnp_sqrt_diag, workspace);
+    LC_REQUIRE_ALIGNED(8, pts2d, inv_std, d_pts2d, d_inv_std, pnp_sqrt_diag);
+    LC_REQUIRE_ALIGNED(256, workspace);  // one rule for the tiled loss's workspace, here and in lc_cov_loss3_fwd_bwd_f32
     lc::LossParams lp{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, nullptr,
-                      B, N, max_err_len, rel_thresh, w_e_thresh, 0, workspace, workspace_bytes};
+                      B, N, max_err_len, rel_thresh, w_e_thresh, 0, workspace, workspace ? workspace_bytes : 0};
     lc::PnpParams pp{K, pts2d, pts3d, nullptr, pnp_sqrt_diag, nullptr, pnp_start == pnp_states ? nullptr : pnp_start, pnp_states,
                      pnp_result_tr, pnp_rets, pnp_iters, B, N, pnp_max_iter, pnp_function_tolerance};
     const int rc = N <= 64 ? lc::launch_pose_unit(lp, pp, static_cast<hipStream_t>(stream)) : lc::launch_pose_unit_dense(lp, pp, static_cast<hipStream_t>(stream));
@@ -457,7 +458,7 @@ int lc_pnp_ransac_init3_f32(const float* K, const float* pts3d, const float* pts
     if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
-    LC_REQUIRE_ALIGNED(8, workspace);
+    LC_REQUIRE_ALIGNED(16, workspace);  // the selection reads the hypotheses as 16-byte pairs of doubles
     lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
                        (iterations + 63) / 64, reproj_err, seed, best_hyp, valid_counts, workspace, workspace_bytes};
     const int rc = lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream));
@@ -474,7 +475,7 @@ int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts
     if (B == 0) return 0;
     if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
     if (sel_w && (!sel_pts2d || !sel_w_out || !sel_pts3d || !sel_counts)) return fail(1, "null selection output");
-    LC_REQUIRE_ALIGNED(8, workspace);
+    LC_REQUIRE_ALIGNED(16, workspace);  // the selection reads the hypotheses as 16-byte pairs of doubles
     LC_REQUIRE_ALIGNED(8, sel_w);
     LC_REQUIRE_ALIGNED(8, sel_w_out);
     LC_REQUIRE_ALIGNED(8, sel_pts2d);
@@ -630,7 +631,7 @@ int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const f
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     if (mode < 0 || mode > 2 || min_count < 0 || min_count > N) return fail(1, "bad size or mode");
     if (mode != 0 && !(quantile >= 0.0 && quantile <= 1.0)) return fail(1, "quantile outside [0,1]");
-    if (N > 8192) return fail(1, "more than 8192 sampled pixels per object: use lc_dense_frontend_fwd2_f32 + lc_dense_select_f32");
+    if (N > 16384) return fail(1, "more than 16384 sampled pixels per object: use lc_dense_frontend_fwd2_f32 + lc_dense_select_f32");
     if (B == 0) return 0;
     if (!xyz || !wlogits || !wscale || !out_pts2d || !out_weights || !out_pts3d || !counts) return fail(1, "null pointer");
     if (mode != 1 && !vis_logits) return fail(1, "modes 0 (mask) and 2 (quantile_in_mask) need the visibility logits");

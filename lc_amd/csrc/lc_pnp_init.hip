@@ -269,7 +269,11 @@ __device__ void mat_to_quat(const double R[9], float q[4]) {
     q[0] = (float)(w * sg); q[1] = (float)(x * sg); q[2] = (float)(y * sg); q[3] = (float)(z * sg);
 }
 
-constexpr int kMaxLdsPts = 2048;
+// Points of a pose the single-launch form keeps in LDS at a time (40 KB); a pose with more is scored tile after tile.  EVERY point of
+// a pose takes part in the sampling and in the scoring, as in cv2.solvePnPRansac (cv2_solver.py:72-75) -- rounds 1-3 stopped at the
+// first 2048 of a row, which at zlmo's test-time shape (128x128 candidates, selection compacted in raster order) was the upper rows
+// of the object only.
+constexpr int kLdsTilePts = 2048;
 
 // Hypothesis `hyp` of pose b: four distinct sample indices below nl from a counter-based hash stream
 // (oracle/p3p_ransac_oracle.py:sample_indices restates it bit for bit).
@@ -505,8 +509,8 @@ __device__ __forceinline__ void write_too_few(const RansacParams& p, int b, int 
 constexpr int kRansacMaxWaves = 4;  // hypothesis rounds of 64 run on separate wavefronts of the pose's workgroup
 
 __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(const RansacParams p) {
-    __shared__ float sx[kMaxLdsPts * 3];   // 3D points
-    __shared__ float su[kMaxLdsPts * 2];   // normalised image coordinates K^-1 (u,v,1)
+    __shared__ float sx[kLdsTilePts * 3];   // 3D points of the tile
+    __shared__ float su[kLdsTilePts * 2];   // normalised image coordinates K^-1 (u,v,1)
     __shared__ double best_pose[kRansacMaxWaves][12];
     __shared__ int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
     __shared__ float wv_err[kRansacMaxWaves];
@@ -521,12 +525,21 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
         return;
     }
     const CamInv kin(p.K + 9 * (size_t)b);
-    const int nl = min(n, kMaxLdsPts);  // hypotheses are scored on the first kMaxLdsPts points (dense heads: N <= 1849)
-    for (int i = tid; i < nl; i += nthr) {
-        sx[3 * i] = p.pts3d[(base + i) * 3]; sx[3 * i + 1] = p.pts3d[(base + i) * 3 + 1]; sx[3 * i + 2] = p.pts3d[(base + i) * 3 + 2];
-        kin.normalise(p.pts2d[(base + i) * 2], p.pts2d[(base + i) * 2 + 1], su[2 * i], su[2 * i + 1]);
-    }
-    __syncthreads();
+    // points [t0, t0 + kLdsTilePts) of the pose -> LDS (called by the whole workgroup, barriers inside)
+    int tile0 = -1;
+    auto stage_tile = [&](int t0) {
+        if (tile0 == t0) return;  // uniform
+        if (tile0 >= 0) __syncthreads();  // the previous tile's readers
+        const int cnt = min(kLdsTilePts, n - t0);
+        for (int i = tid; i < cnt; i += nthr) {
+            const size_t g = base + t0 + i;
+            sx[3 * i] = p.pts3d[g * 3]; sx[3 * i + 1] = p.pts3d[g * 3 + 1]; sx[3 * i + 2] = p.pts3d[g * 3 + 2];
+            kin.normalise(p.pts2d[g * 2], p.pts2d[g * 2 + 1], su[2 * i], su[2 * i + 1]);
+        }
+        tile0 = t0;
+        __syncthreads();
+    };
+    stage_tile(0);
     // inlier threshold in normalised coordinates: reprojectionError px / focal scale (sqrt|det K2|)
     const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
     const float thr = thr_px * (float)sqrt(fabs(kin.idet));
@@ -535,29 +548,43 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
     int best_cnt = -1, best_hyp = 0;
     float best_err = INFINITY;
     Pose best;
-    for (int round = wave; round < p.rounds; round += nwaves) {  // hypothesis id = round*64 + lane, whatever the wave count
-        int idx[4];
-        sample_indices(p.seed, b, round * kWave + lane, nl, idx);
+    // hypothesis id = round*64 + lane, whatever the wave count; the wavefronts walk the rounds together (the tiles of a pose with
+    // more than kLdsTilePts points are staged by the whole workgroup), a wavefront without a round of its own only keeps the barriers
+    for (int round0 = 0; round0 < p.rounds; round0 += nwaves) {
+        const int round = round0 + wave;
+        const bool active = round < p.rounds;
         Pose cand;
-        const bool have = hypothesis_pose(idx, [&](int i, float (&X)[3], float (&u)[2]) {
-            X[0] = sx[3 * i]; X[1] = sx[3 * i + 1]; X[2] = sx[3 * i + 2];
-            u[0] = su[2 * i]; u[1] = su[2 * i + 1];
-        }, cand);
-        // score on all points (every lane walks the LDS arrays: broadcast reads)
-        int cnt = -1;
-        float err = INFINITY;
-        if (have) {
-            float R[9], t[3];
-            for (int k = 0; k < 9; ++k) R[k] = (float)cand.R[k];
-            for (int k = 0; k < 3; ++k) t[k] = (float)cand.t[k];
-            cnt = 0;
-            err = 0.f;
+        bool have = false;
+        if (active) {
+            int idx[4];
+            sample_indices(p.seed, b, round * kWave + lane, n, idx);
+            have = hypothesis_pose(idx, [&](int i, float (&X)[3], float (&u)[2]) {
+                const int j = i - tile0;
+                if (j >= 0 && j < kLdsTilePts) {  // the same floats either way: the tile holds what the other branch computes
+                    X[0] = sx[3 * j]; X[1] = sx[3 * j + 1]; X[2] = sx[3 * j + 2];
+                    u[0] = su[2 * j]; u[1] = su[2 * j + 1];
+                } else {
+                    X[0] = p.pts3d[(base + i) * 3]; X[1] = p.pts3d[(base + i) * 3 + 1]; X[2] = p.pts3d[(base + i) * 3 + 2];
+                    kin.normalise(p.pts2d[(base + i) * 2], p.pts2d[(base + i) * 2 + 1], u[0], u[1]);
+                }
+            }, cand);
+        }
+        // score on ALL points (every lane walks the LDS arrays: broadcast reads)
+        int cnt = have ? 0 : -1;
+        float err = have ? 0.f : INFINITY;
+        float R[9], t[3];
+        for (int k = 0; k < 9; ++k) R[k] = have ? (float)cand.R[k] : 0.f;
+        for (int k = 0; k < 3; ++k) t[k] = have ? (float)cand.t[k] : 0.f;
+        for (int t0 = 0; t0 < n; t0 += kLdsTilePts) {
+            stage_tile(t0);
+            if (!have) continue;
             // the inlier error is added in the association of the split form (even / odd points of a 64-point chunk in two sums,
             // chunk totals in chunk order), so that both launch forms hand the SAME float to the (count, error, id) tie-break and
             // an object gets the same winner whichever form its batch size selects
-            for (int i0 = 0; i0 < nl; i0 += kWave) {
+            const int nt = min(kLdsTilePts, n - t0);
+            for (int i0 = 0; i0 < nt; i0 += kWave) {
                 float e0 = 0.f, e1 = 0.f;
-                const int i1 = min(nl, i0 + kWave);
+                const int i1 = min(nt, i0 + kWave);
                 for (int i = i0; i < i1; i += 2) {
                     score_point(R, t, sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], su[2 * i], su[2 * i + 1], thr2, cnt, e0);
                     if (i + 1 < i1) score_point(R, t, sx[3 * i + 3], sx[3 * i + 4], sx[3 * i + 5], su[2 * i + 2], su[2 * i + 3], thr2, cnt, e1);
@@ -565,7 +592,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
                 err += e0 + e1;
             }
         }
-        if (cnt > best_cnt || (cnt == best_cnt && err < best_err)) {
+        if (active && (cnt > best_cnt || (cnt == best_cnt && err < best_err))) {
             best_cnt = cnt; best_err = err; best_hyp = round * kWave + lane;
             if (have) best = cand;
         }
@@ -613,7 +640,7 @@ __host__ __device__ inline unsigned long long pack_partial(int cnt, float err) {
 __host__ __device__ inline int partial_cnt(unsigned long long v) { return (int)(unsigned)v; }
 __host__ __device__ inline float partial_err(unsigned long long v) { return __builtin_bit_cast(float, (unsigned)(v >> 32)); }
 
-__host__ __device__ inline size_t ransac_counter_bytes(int B) { return 8 * (((size_t)B + 1) / 2); }  // keeps the doubles behind it aligned
+__host__ __device__ inline size_t ransac_counter_bytes(int B) { return 16 * (((size_t)B + 3) / 4); }  // keeps the double2 loads behind it 16-byte aligned
 
 struct RansacWorkspace {
     unsigned* arrived;  // (B,) chunks of the pose scored so far (ticketed form; zeroed by the hypotheses launch)
@@ -625,8 +652,7 @@ struct RansacWorkspace {
 __host__ __device__ inline RansacWorkspace carve_workspace(void* ws, int B, int Nmax, int rounds) {
     RansacWorkspace w;
     w.H = rounds * kWave;
-    const int nl = Nmax < kMaxLdsPts ? Nmax : kMaxLdsPts;
-    w.C = (nl + kChunkPts - 1) / kChunkPts;
+    w.C = (Nmax + kChunkPts - 1) / kChunkPts;  // every point of a row is scored
     if (w.C < 1) w.C = 1;
     char* q = static_cast<char*>(ws);
     w.arrived = reinterpret_cast<unsigned*>(q); q += ransac_counter_bytes(B);
@@ -646,7 +672,7 @@ __global__ __launch_bounds__(kWave) void lc_ransac_hypotheses_kernel(const Ransa
     const CamInv kin(p.K + 9 * (size_t)b);
     const size_t base = (size_t)b * p.Nmax;
     int idx[4];
-    sample_indices(p.seed, b, hyp, min(n, kMaxLdsPts), idx);
+    sample_indices(p.seed, b, hyp, n, idx);
     LC_P3P_STAMP(1);
     Pose cand;
     const bool have = hypothesis_pose(idx, [&](int i, float (&X)[3], float (&u)[2]) {
@@ -682,7 +708,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
     float *sX = lds[wave][0], *sY = lds[wave][1], *sZ = lds[wave][2], *sU = lds[wave][3], *sV = lds[wave][4];
     // Everything that does not depend on the pose's point count is requested first (the count itself, K, this lane's hypothesis,
     // the chunk's points up to the padded row length): one memory round trip instead of three dependent ones.
-    const int i0 = c * kChunkPts, cap = max(0, min(kChunkPts, min(p.Nmax, kMaxLdsPts) - i0));
+    const int i0 = c * kChunkPts, cap = max(0, min(kChunkPts, p.Nmax - i0));
     const size_t base = (size_t)b * p.Nmax + i0;
     static_assert(kChunkPts == kWave, "one point per lane");
     const bool in_row = lane < cap;
@@ -701,8 +727,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
     const CamInv kin(p.K + 9 * (size_t)b);
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
     if (n < 4) return;
-    const int nl = min(n, kMaxLdsPts);
-    const int cnt_pts = max(0, min(kChunkPts, nl - i0)), cnt4 = (cnt_pts + 3) & ~3;
+    const int cnt_pts = max(0, min(kChunkPts, n - i0)), cnt4 = (cnt_pts + 3) & ~3;
     if (cnt_pts == 0) return;  // the selection step sums the chunks the pose has
     if (lane < cnt_pts) {
         float ux, uy;
@@ -736,6 +761,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
 // Selection of pose b by the calling workgroup: chunk partials of every hypothesis summed in chunk order (the sums do not depend on
 // which workgroup finished first), arg-max of (count, -error, -hypothesis id), outputs.  XCD: the partials were written by other
 // workgroups of THIS launch (read around the caches), else by an earlier launch.
+constexpr int kFirstChunks = 32, kMoreChunks = 16;  // chunk partials a selection thread requests blindly / per further round trip
 struct SelectShared {
     double best_pose[12];
     int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
@@ -755,7 +781,7 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
     // inlier mask below needs them), this thread's own hypothesis in double precision (the winner's is the answer: its thread hands
     // it over through LDS instead of a dependent load), the chunk partials of this thread's first hypothesis.
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
-    const int chunks = n >= 4 ? (min(n, kMaxLdsPts) + kChunkPts - 1) / kChunkPts : 0;
+    const int chunks = n >= 4 ? (n + kChunkPts - 1) / kChunkPts : 0;
     const PointBatch first = load_batch(p, (size_t)b * p.Nmax, 0, n);
     double2 mine[6];
     {
@@ -763,9 +789,9 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
 #pragma unroll
         for (int k = 0; k < 6; ++k) mine[k] = h[k];
     }
-    unsigned long long pc0[kMaxLdsPts / kChunkPts];
+    unsigned long long pc0[kFirstChunks];
 #pragma unroll
-    for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c)
+    for (int c = 0; c < kFirstChunks; ++c)
         pc0[c] = (c < chunks && tid < w.H) ? part_at(((size_t)b * w.C + c) * w.H + tid) : 0ull;
     const CamInv kin(p.K + 9 * (size_t)b);
     unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
@@ -778,9 +804,20 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
         int cnt = 0;
         float err = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxLdsPts / kChunkPts; ++c) {  // chunk order; rows the pose does not have were not requested (zero)
+        for (int c = 0; c < kFirstChunks; ++c) {  // chunk order; rows the pose does not have were not requested (zero)
             cnt += partial_cnt(pc0[c]);
             err += c < chunks ? partial_err(pc0[c]) : 0.f;
+        }
+        // a pose with more than kFirstChunks * 64 points: the further chunks, still in chunk order, kMoreChunks requests in flight
+        for (int c0 = kFirstChunks; c0 < chunks; c0 += kMoreChunks) {
+            unsigned long long pc[kMoreChunks];
+#pragma unroll
+            for (int k = 0; k < kMoreChunks; ++k) pc[k] = c0 + k < chunks ? part_at(((size_t)b * w.C + c0 + k) * w.H + tid) : 0ull;
+#pragma unroll
+            for (int k = 0; k < kMoreChunks; ++k) {
+                cnt += partial_cnt(pc[k]);
+                err += c0 + k < chunks ? partial_err(pc[k]) : 0.f;
+            }
         }
         win_cnt = cnt; win_err = err; win_hyp = tid;
     }
@@ -846,7 +883,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_selec
     const int b = blockIdx.x / w.C, c = blockIdx.x % w.C;
     float *sX = lds[0], *sY = lds[1], *sZ = lds[2], *sU = lds[3], *sV = lds[4];
     // requested before the pose's point count is known, as in the scoring kernel above
-    const int i0 = c * kChunkPts, cap = max(0, min(kChunkPts, min(p.Nmax, kMaxLdsPts) - i0));
+    const int i0 = c * kChunkPts, cap = max(0, min(kChunkPts, p.Nmax - i0));
     const size_t base = (size_t)b * p.Nmax + i0;
     const bool in_row = wave == 0 && lane < cap;
     const float gx = in_row ? p.pts3d[(base + lane) * 3] : 0.f, gy = in_row ? p.pts3d[(base + lane) * 3 + 1] : 0.f,
@@ -870,8 +907,8 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_selec
         }
         return;
     }
-    const int nl = min(n, kMaxLdsPts), chunks = (nl + kChunkPts - 1) / kChunkPts;
-    const int cnt_pts = max(0, min(kChunkPts, nl - i0)), cnt4 = (cnt_pts + 3) & ~3;
+    const int chunks = (n + kChunkPts - 1) / kChunkPts;
+    const int cnt_pts = max(0, min(kChunkPts, n - i0)), cnt4 = (cnt_pts + 3) & ~3;
     if (cnt_pts == 0) return;  // a chunk the pose does not have: not counted
     if (wave == 0) {
         if (lane < cnt_pts) {
@@ -925,8 +962,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_selec
 size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds) {
     if (B <= 0 || rounds <= 0) return 0;
     const int H = rounds * kWave;
-    const int nl = Nmax < kMaxLdsPts ? Nmax : kMaxLdsPts;
-    const int C = nl > 0 ? (nl + kChunkPts - 1) / kChunkPts : 1;
+    const int C = Nmax > 0 ? (Nmax + kChunkPts - 1) / kChunkPts : 1;
     return ransac_counter_bytes(B) + (size_t)B * H * 12 * (sizeof(double) + sizeof(float)) + (size_t)B * C * H * (sizeof(int) + sizeof(float));
 }
 

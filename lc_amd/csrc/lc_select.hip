@@ -28,7 +28,7 @@ namespace lc {
 namespace {
 
 constexpr int kThreads = 1024;
-constexpr int kFusedSelectMaxPoints = 8192;  // lc_dense_frontend_select_f32: keys in 32 KB of LDS; entries beyond the thread's first are re-formed from the maps
+constexpr int kFusedSelectMaxPoints = 16384;  // lc_dense_frontend_select_f32: keys in up to 64 KB of the 160 KB LDS (128x128 maps at stride 1, zlmo's test-time shape); entries beyond the thread's first four are re-formed from the maps
 constexpr int kWaves = kThreads / kWave;
 
 // torch.lerp (aten/src/ATen/native/Lerp.h): the form that is exact at both ends
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
     select_row(p, b, n, src, ec, srt);
 }
 
-// Test time, N <= 8192 sampled pixels per object: the dense front end (joint softmax x scale, strided sub-sampling, visibility mask:
+// Test time, N <= 16384 sampled pixels per object: the dense front end (joint softmax x scale, strided sub-sampling, visibility mask:
 // test.py:85-92) and the point selection (test.py:94-113) in ONE launch, one workgroup per object.  The front end's (B,N,.) arrays
 // are never written: every thread forms the entry of its own sampled pixel in registers (beyond 1024 pixels per object: the further
 // ones again from the maps where the selection needs them) -- the log-sum-exp by the front end's own 512
@@ -333,6 +333,9 @@ int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d, hi
     int P = kThreads;
     while (P < p.N) P <<= 1;
     const size_t lds = p.mode == 0 ? 0 : (size_t)P * sizeof(float);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lc_dense_frontend_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return 2;
     hipLaunchKernelGGL(lc_dense_frontend_select_kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -99,8 +99,8 @@ def p3p_grunert(y, x):
     return sols
 
 
-def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3, max_lds_pts=2048):
-    """One pose.  Returns dict(invalid, best_hyp, n_inliers, inliers (sorted indices), R, t, decided, per_hyp_count)."""
+def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3):
+    """One pose; every one of its `count` points is sampled from and scored, as `cv2.solvePnPRansac` does (`cv2_solver.py:72-75`).  Returns dict(invalid, best_hyp, n_inliers, inliers (sorted indices), R, t, decided, per_hyp_count)."""
     n = int(min(count, len(pts3d)))
     if n < 4:
         return dict(invalid=1, best_hyp=-1, n_inliers=0, inliers=np.zeros(0, np.int64), R=np.eye(3), t=np.zeros(3), decided=True)
@@ -108,10 +108,10 @@ def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3,
     idet = 1.0 / (k[0] * k[4] - k[1] * k[3])
     X = pts3d[:n].astype(np.float64)
     du, dv = pts2d[:n, 0].astype(np.float64) - k[2], pts2d[:n, 1].astype(np.float64) - k[5]
-    # the kernel keeps the normalised image points and the model points as float32 in LDS
+    # the kernel rounds the normalised image points to float32 once (the model points are float32 inputs)
     un = np.stack(((k[4] * du - k[1] * dv) * idet, (-k[3] * du + k[0] * dv) * idet), -1).astype(np.float32).astype(np.float64)
     Xs = X.astype(np.float32).astype(np.float64)
-    nl = min(n, max_lds_pts)
+    nl = n
     thr = float(np.float32(reproj_err) * np.float32(np.sqrt(abs(idet))))
     thr2 = float(np.float32(thr) * np.float32(thr))
     rounds = (iterations + 63) // 64

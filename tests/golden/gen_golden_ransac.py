@@ -23,7 +23,10 @@ CASES = {  # name: (B, N, seed, noise_px, gross outlier fraction, reprojectionEr
     "outliers_B24_N64": (24, 64, 6, 0.5, 0.25, 2.0, 150, 0),
     "dense_B6_N400": (6, 400, 8, 1.0, 0.4, 3.0, 192, 7),
     "ragged_B8_N40": (8, 40, 7, 0.2, 0.1, 2.0, 150, 3),
-    "capped_B6_N2300": (6, 2300, 9, 0.3, 0.3, 2.5, 192, 4),  # more points than the 2048 the hypotheses are scored on (36 chunks of 64)
+    "wide_B6_N2300": (6, 2300, 9, 0.3, 0.3, 2.5, 192, 4),  # more points than one LDS tile of the single launch / 36 chunks of the split form
+    # the first 2500 points of every row are gross outliers: the consensus lives in the tail of the row (a selection compacted in
+    # raster order puts the object's lower rows there), so an implementation that samples or scores a prefix only finds nothing
+    "tail_B4_N5000": (4, 5000, 11, 0.3, 0.2, 2.5, 192, 5),
 }
 
 
@@ -32,6 +35,8 @@ def make_inputs(name):
     b = synth.make_batch(B, N, seed=seed, outlier_frac=0.0, noise_px=noise)
     g = torch.Generator().manual_seed(seed + 1)
     out = torch.rand(B, N, generator=g) < outl
+    if name.startswith("tail"):
+        out[:, :2500] = True
     u = torch.where(out[..., None], torch.rand(B, N, 2, generator=g) * 64, b["pts2d"])
     counts = np.full(B, N, np.int32)
     if name.startswith("ragged"):

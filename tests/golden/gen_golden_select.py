@@ -30,7 +30,8 @@ def main():
     quantile_msk = reference_function("quantile_msk")
     g = torch.Generator().manual_seed(7)
     for name, (B, N, q) in {"q50_B4_N64": (4, 64, 0.5), "q80_B3_N1024": (3, 1024, 0.8), "q05_B2_N37": (2, 37, 0.05),
-                            "q100_B2_N16": (2, 16, 1.0), "q0_B2_N16": (2, 16, 0.0)}.items():
+                            "q100_B2_N16": (2, 16, 1.0), "q0_B2_N16": (2, 16, 0.0),
+                            "q20_B2_N16384": (2, 16384, 0.2)}.items():  # configs/zlmo.yaml:30-37: 128x128 candidates per object, quantile 0.2
         inv_std = torch.rand(B, N, 2, generator=g) * 2 + 0.01
         seg = torch.rand(B, N, generator=g) > 0.4
         out = {"in_inv_std": inv_std.numpy(), "in_seg": seg.numpy(), "q": np.float64(q),

@@ -42,7 +42,7 @@ def test_select_vs_reference_golden(path):
     _check_rows(dense_select(*args, "mask", mask=seg.to(DEV), min_count=0), u, s, x, z["in_seg"], True)
 
 
-@pytest.mark.parametrize("B,N,q", [(5, 1849, 0.7), (2, 4096, 0.9), (3, 300, 0.33), (1, 1, 0.5), (2, 5, 0.5)])
+@pytest.mark.parametrize("B,N,q", [(5, 1849, 0.7), (2, 4096, 0.9), (3, 300, 0.33), (1, 1, 0.5), (2, 5, 0.5), (3, 16384, 0.2), (2, 16384, 0.8), (2, 9000, 0.5)])
 def test_select_vs_oracle_sizes(B, N, q):
     from lc_amd.dense import dense_select
     from oracle import select_oracle as orc
@@ -91,7 +91,8 @@ def test_select_rejects_bad_arguments():
 
 @pytest.mark.parametrize("mode", ["mask", "quantile", "quantile_in_mask"])
 @pytest.mark.parametrize("B,H,W,sample,top_left,min_count", [(64, 64, 64, 2, (0, 0), 4), (5, 32, 32, 1, (0, 0), 4), (3, 37, 45, 2, (1, 0), 4),
-                                                           (4, 64, 64, 3, (2, 1), 6), (2, 16, 16, 4, (0, 0), 12), (3, 86, 86, 2, (0, 0), 4), (2, 128, 128, 2, (0, 0), 4), (2, 96, 80, 1, (0, 0), 4)])
+                                                           (4, 64, 64, 3, (2, 1), 6), (2, 16, 16, 4, (0, 0), 12), (3, 86, 86, 2, (0, 0), 4), (2, 128, 128, 2, (0, 0), 4), (2, 96, 80, 1, (0, 0), 4),
+                                                           (64, 128, 128, 1, (0, 0), 4), (3, 128, 128, 1, (0, 1), 4), (2, 181, 181, 2, (1, 1), 4)])  # zlmo test time: 16384 candidates per object
 def test_front_end_and_selection_in_one_launch(B, H, W, sample, top_left, min_count, mode):
     """lc_dense_frontend_select_f32 against lc_dense_frontend_fwd2_f32 followed by lc_dense_select_f32 on its rows and visibility
     mask: counts, source indices and every selected value bit for bit (same log-sum-exp reduction, same per-pixel arithmetic) --
@@ -121,9 +122,9 @@ def test_front_end_and_selection_in_one_launch(B, H, W, sample, top_left, min_co
         assert torch.equal(got[k][m], want[k][m]), name
 
 
-def test_front_end_select_rejects_more_than_8192_points():
+def test_front_end_select_rejects_more_than_16384_points():
     from lc_amd.dense import dense_front_end_select
 
-    z = torch.zeros(1, 3, 128, 128, device=DEV)
-    with pytest.raises(RuntimeError, match="8192"):
+    z = torch.zeros(1, 3, 130, 128, device=DEV)
+    with pytest.raises(RuntimeError, match="16384"):
         dense_front_end_select(z, z[:, :2], torch.ones(1, device=DEV), None, z[:, :1], "mask", sample=1)

@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_ransac_workspace_contract():
-    """lc_pnp_ransac_workspace_bytes: B arrival counters (padded to 8 bytes), (B, H, 12) doubles + floats for the hypotheses and
+    """lc_pnp_ransac_workspace_bytes: B arrival counters (padded to 16 bytes), (B, H, 12) doubles + floats for the hypotheses and
     (B, chunks of 64 points, H) count/error partials, H = iterations rounded up to 64; a smaller workspace is refused before anything
     is launched (no GPU needed), by both split-form entry points."""
     from lc_amd import _lib
@@ -39,9 +39,9 @@ def test_ransac_workspace_contract():
     assert lib.lc_pnp_ransac_workspace_bytes(0, 10, 150) == 0 and lib.lc_pnp_ransac_workspace_bytes(4, 10, 0) == 0
     B, N, H = 5, 1000, 192
     chunks = (N + 63) // 64
-    ctr = 8 * ((B + 1) // 2)
+    ctr = 16 * ((B + 3) // 4)  # the doubles behind the counters are read as 16-byte pairs
     assert lib.lc_pnp_ransac_workspace_bytes(B, N, 150) == ctr + B * H * 12 * (8 + 4) + B * chunks * H * 8
-    assert lib.lc_pnp_ransac_workspace_bytes(B, 5000, 150) == ctr + B * H * 12 * 12 + B * 32 * H * 8  # scoring stops at 2048 points
+    assert lib.lc_pnp_ransac_workspace_bytes(B, 16384, 150) == ctr + B * H * 12 * 12 + B * 256 * H * 8  # every point of a row is scored
     buf = ctypes.create_string_buffer(64)
     p = ctypes.addressof(buf)
     rc = lib.lc_pnp_ransac_init3_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, p, 64, None)
@@ -287,8 +287,8 @@ def test_chain_and_round3_entry_points_check_their_arguments_before_launching():
     two = _Job(p, p, p, p, p, None, None, None, p, p, p, None, 4, 700, 20, 1e-6, 0, 0)  # two weight forms at once
     assert lib.lc_pnp_lm_chain_f32(ctypes.byref(two), ctypes.byref(empty), None) != 0 and b"exactly one" in lib.lc_amd_last_error()
     # front end + selection: more sampled pixels than the one launch takes; a mask mode without visibility logits
-    rc = lib.lc_dense_frontend_select_f32(p, p, p, None, p, 0.5, 1, 256, 256, 0, 0, 2, 0, 0.5, 1, 4, 0, p, p, p, None, p, None)
-    assert rc != 0 and b"8192" in lib.lc_amd_last_error()
+    rc = lib.lc_dense_frontend_select_f32(p, p, p, None, p, 0.5, 1, 258, 256, 0, 0, 2, 0, 0.5, 1, 4, 0, p, p, p, None, p, None)
+    assert rc != 0 and b"16384" in lib.lc_amd_last_error()
     rc = lib.lc_dense_frontend_select_f32(p, p, p, None, None, 0.5, 1, 64, 64, 0, 0, 2, 2, 0.5, 1, 4, 0, p, p, p, None, p, None)
     assert rc != 0 and b"visibility" in lib.lc_amd_last_error()
     assert lib.lc_dense_frontend_select_f32(p, p, p, None, p, 0.5, 0, 64, 64, 0, 0, 2, 0, 0.5, 1, 4, 0, p, p, p, None, p, None) == 0
