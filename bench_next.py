@@ -186,7 +186,7 @@ def main():
     import time
     from lc_amd.config import AttrDict
     from lc_amd.inference import solve_pnp
-    from tests.golden.gen_golden_lossfn import dense_inputs
+    from lc_amd.synth import dense_inputs
     gt_d, out_d = dense_inputs(B=64, H=64, W=64, seed=3)
     out_d["xyz_weight_logits"] = out_d["xyz_weight_logits"] + 3 * gt_d["msk_vis"][:, None]
     out_d["msk_vis_logits"] = (gt_d["msk_vis"][:, None] * 2 - 1) * 4

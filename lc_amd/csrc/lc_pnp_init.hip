@@ -386,6 +386,15 @@ struct CamInv {
     }
 };
 
+// Inlier threshold of pose b in pixels: the scalar, a per-pose value, or scalar / per-pose value -- test.py:56-57,115-116's
+// `2 / gt_dict['out_pix_scale']` (rel_reproj_err) formed here instead of by two element-wise launches in front of the pipeline
+// (IEEE division: the float torch's `2 / t` produces)
+__device__ __forceinline__ float threshold_px(const RansacParams& p, int b) {
+    if (!p.reproj_err_per_pose) return p.reproj_err;
+    const float v = p.reproj_err_per_pose[b];
+    return p.reproj_err > 0.f ? p.reproj_err / v : v;
+}
+
 __device__ __forceinline__ RowCopy selection_rows(const RansacParams& p) {
     return RowCopy{p.pts2d, p.sel_w, p.pts3d, p.sel_in_index, p.sel_pts2d, p.sel_w_out, p.sel_pts3d, p.sel_index, 0};
 }
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
     };
     stage_tile(0);
     // inlier threshold in normalised coordinates: reprojectionError px / focal scale (sqrt|det K2|)
-    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr_px = threshold_px(p, b);
     const float thr = thr_px * (float)sqrt(fabs(kin.idet));
     const float thr2 = thr * thr;
 
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
         sU[lane] = sV[lane] = -INFINITY;
     }
     __builtin_amdgcn_wave_barrier();  // LDS operations of one wavefront execute in order: no wait beyond the compiler's own
-    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr_px = threshold_px(p, b);
     const float thr = thr_px * (float)sqrt(fabs(kin.idet));
     const float thr2 = thr * thr;
     int cnt = 0;
@@ -854,7 +863,7 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
         }
     }
     __syncthreads();
-    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr_px = threshold_px(p, b);
     const float thr = thr_px * (float)sqrt(fabs(kin.idet));
     LC_SEL_STAMP(3);
     write_result(p, b, n, ok, sh.best_pose, win_hyp, thr * thr, kin, sh.chunk_cnt, first);
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_selec
         }
     }
     __syncthreads();
-    const float thr_px = p.reproj_err_per_pose ? p.reproj_err_per_pose[b] : p.reproj_err;
+    const float thr_px = threshold_px(p, b);
     const float thr = thr_px * (float)sqrt(fabs(kin.idet));
     const float thr2 = thr * thr;
     typedef float v4f_t __attribute__((ext_vector_type(4)));

@@ -41,9 +41,10 @@ def quantile_msk(den_inv_std2d: Tensor, quantile) -> Tensor:
 
 
 def _reprojection_threshold(cfg, gt_dict, default_px):
-    if cfg.get("rel_reproj_err", False):  # test.py:56-57,115-116
-        return 2 / gt_dict["out_pix_scale"]
-    return default_px
+    """-> keyword arguments of `gpu_solver.solve_device`; rel_reproj_err (test.py:56-57,115-116): 2 / out_pix_scale, divided by the kernel."""
+    if cfg.get("rel_reproj_err", False):
+        return dict(reprojectionError=2.0, reproj_divisor=gt_dict["out_pix_scale"])
+    return dict(reprojectionError=default_px)
 
 
 def _weighted(K, pts3d, pts2d, icov, start, counts=None):
@@ -59,7 +60,7 @@ def solve_pnp(cfg, out_dict, gt_dict):
         return solve_pnp_dense(cfg, out_dict, gt_dict)
     K, pts3d = gt_dict["out_K"], gt_dict["pts3d"]
     pts2d, std = out_dict["pts2d"], out_dict["pts2d_std"]
-    start, _inl, _bad = gpu_solver.solve_device(K, pts3d, pts2d, reprojectionError=_reprojection_threshold(cfg, gt_dict, 2))
+    start, _inl, _bad = gpu_solver.solve_device(K, pts3d, pts2d, **_reprojection_threshold(cfg, gt_dict, 2))
     return {"weighted": _weighted(K, pts3d, pts2d, std.pow(-2), start), "ransac": start}
 
 
@@ -116,8 +117,7 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     filtered = None
     if "weighted_filtered" in wanted:
         filtered = dict(weights=icov, index=index, min_count=4, out=half(1) if both else None)
-    start, inliers, _bad, refine = gpu_solver.solve_device(K, x, u, counts, reprojectionError=_reprojection_threshold(cfg, gt_dict, 3),
-                                                           select=filtered, refine="defer")
+    start, inliers, _bad, refine = gpu_solver.solve_device(K, x, u, counts, select=filtered, refine="defer", **_reprojection_threshold(cfg, gt_dict, 3))
     # The RANSAC's inlier refinement and the weighted solve(s) that start from its result: ONE launch (`lc_pnp_lm_chain_f32`), each
     # workgroup refines its object's pose and goes on with its own weighted solve.
     weighted = dict(weights_are_icov=True, nan_to_num=True, start="first")  # `_weighted` above, chained

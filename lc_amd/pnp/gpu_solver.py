@@ -15,9 +15,11 @@ from . import cer_solver, pnp_ceres
 
 
 def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True,
-                 return_hypothesis=False, split=None, ticketed=False, select=None):
+                 return_hypothesis=False, split=None, ticketed=False, select=None, reproj_divisor=None):
     """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool
     [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly].
+    reprojectionError: pixels, a scalar or a (B,) tensor; with reproj_divisor (B,) the threshold of pose b is reprojectionError /
+    reproj_divisor[b], divided inside the launch (test.py:56-57,115-116: `2 / gt_dict['out_pix_scale']`).
 
     refine: True runs the inlier refinement (an unweighted LM solve on the inliers, the role EPnP-on-inliers plays inside
     cv2.solvePnPRansac); 'defer' returns (ransac states, inlier_mask, invalid, job) with `job` the keyword arguments of that solve for
@@ -42,7 +44,11 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
         split = N * ((B + 255) // 256) > 256
     counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
     per_pose = None
-    if isinstance(reprojectionError, torch.Tensor):
+    if reproj_divisor is not None:  # threshold of pose b = reprojectionError / reproj_divisor[b], formed by the kernel (rel_reproj_err)
+        if isinstance(reprojectionError, torch.Tensor) or not reprojectionError > 0:
+            raise ValueError("reproj_divisor goes with a positive scalar reprojectionError")
+        per_pose = reproj_divisor.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
+    elif isinstance(reprojectionError, torch.Tensor):
         per_pose = reprojectionError.to(device=dev, dtype=torch.float32).reshape(B).contiguous()
         reprojectionError = 0.0
     states = torch.empty(B, 7, device=dev, dtype=torch.float32)

@@ -93,3 +93,148 @@ def make_head_logits(B: int, S: int, H: int, W: int, seed: int = 0, dtype=torch.
     ys = torch.arange(H, dtype=torch.float32).view(1, 1, H, 1)
     logits += bump * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * sigma * sigma))
     return logits.to(dtype).contiguous()
+
+
+# ---- synthetic inputs of Loss_fn.forward / solve_pnp (gt_dict, out_dict); tests/golden/gen_golden_lossfn.py feeds the same ones to the
+# reference class, so the committed lossfn_* trajectories are functions of exactly these tensors ----
+
+def sparse_inputs(B=6, N=16, seed=0):
+    b = make_batch(B, N, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    gt = dict(pose_best=b["pose"], out_K=b["K"], pts3d=b["pts3d"], bbox_3d=b["bbox_3d"],
+              msk_noc=torch.ones(B, 4, 4, dtype=torch.bool), msk_vis=torch.ones(B, 4, 4))
+    out = dict(pts2d=b["pts2d"], pts2d_std=torch.rand(B, N, 2, generator=g) * 1.5 + 0.5)
+    return gt, out
+
+
+def dense_inputs(B=3, H=16, W=16, seed=0):
+    """A 16x16 output grid looking at a synthetic surface: xyz head ~ back-projected pixels + noise."""
+    g = torch.Generator().manual_seed(seed)
+    b = make_batch(B, 4, seed=seed + 7, rotate_K=False)
+    K = b["K"].clone()
+    K[:, 0, 0] = 110.0
+    K[:, 1, 1] = 110.0
+    K[:, 0, 2] = W / 2
+    K[:, 1, 2] = H / 2
+    pose = b["pose"].clone()
+    pose[:, 4:6] = 0
+    pose[:, 6] = 500.0
+    from .transforms import quaternion_rep_to_RT, gen_uv
+
+    R, t = quaternion_rep_to_RT(pose)
+    uv = gen_uv((H, W))  # (H,W,2)
+    ones = torch.ones(H, W, 1)
+    rays = torch.cat((uv, ones), -1).reshape(1, -1, 3) @ torch.linalg.inv(K).mT  # (B,HW,3)
+    z = 500.0 + 10 * torch.randn(B, H * W, 1, generator=g)
+    Xc = rays * z
+    Xm = (Xc - t[:, None]) @ R  # R^T (Xc - t)
+    noc_scale = torch.tensor(EXTENT_MM).expand(B, 3).contiguous()
+    noc = (Xm / noc_scale[:, None]).mT.reshape(B, 3, H, W)
+    xyz_noc = noc + 0.02 * torch.randn(B, 3, H, W, generator=g)
+    msk_vis = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    gt = dict(pose_best=pose, out_K=K, bbox_3d=b["bbox_3d"], noc_scale=noc_scale, msk_noc=msk_vis > 0, msk_vis=msk_vis,
+              xyz_noc_tgt=noc * msk_vis[:, None])
+    out = dict(xyz_noc=xyz_noc, xyz_weight_logits=torch.randn(B, 2, H, W, generator=g),
+               xyz_weights_scale=torch.exp(torch.randn(B, 1, 1, 1, generator=g) * 0.2 + 3.0),
+               msk_vis_logits=torch.randn(B, 1, H, W, generator=g))
+    return gt, out
+
+
+def bin_inputs(B=3, H=16, W=16, seed=0, bits=(6, 6, 5)):
+    """ZebraPose structure: binary surface codes instead of the continuous xyz head, with a model transform."""
+    from . import floatbits as fb
+
+    gt, out = dense_inputs(B, H, W, seed)
+    g = torch.Generator().manual_seed(seed + 50)
+    noc = (gt["xyz_noc_tgt"] / 1.0).permute(0, 2, 3, 1).clamp(-0.999, 0.999)  # (B,H,W,3) normalised target coordinates
+    mod_bits, raw_bits = fb.nn_noc2target(noc, list(bits))
+    C = sum(bits)
+    logits = (mod_bits.float() * 2 - 1) * (torch.rand(B, C, H, W, generator=g) * 3 + 0.2)
+    logits = torch.where(torch.rand(B, C, H, W, generator=g) < 0.12, -logits, logits)
+    ang = 0.3
+    T = torch.eye(4).repeat(B, 1, 1)
+    T[:, 0, 0] = T[:, 1, 1] = math.cos(ang)
+    T[:, 0, 1], T[:, 1, 0] = -math.sin(ang), math.sin(ang)
+    T[:, :3, 3] = torch.tensor([1.5, -2.0, 0.5])
+    gt.pop("xyz_noc_tgt")
+    gt.update(xyz_noc_bin_tgt=mod_bits, xyz_noc_bin_raw=raw_bits, bit_cnt=list(bits), model_transform=T)
+    out.pop("xyz_noc")
+    out["xyz_noc_bin"] = logits
+    return gt, out
+
+
+# ---- test-time workloads of the reference's own configs (test.py:67-136; configs/zlmo.yaml:30-37, configs/glmo.yaml:28-32) ----
+
+TEST_TIME_CONFIGS = {
+    # pnp_solver block of the config + the head's output grid and code layout
+    "zlmo": dict(pnp_solver=dict(seg_thresh=0.5, dense_sample=1, rel_reproj_err=True, dense_point_select="quantile_in_mask", quantile=0.2,
+                                 solvers=["weighted_filtered"]), H=128, W=128, bits=(7, 7, 7), model_transform=True),
+    "glmo": dict(pnp_solver=dict(dense_point_select="quantile", quantile=0.3, solvers=["weighted"]), H=64, W=64, bits=None,
+                 model_transform=False),
+}
+
+
+def test_time_inputs(name: str, B: int = 64, seed: int = 0, flip: float = 0.02):
+    """Synthetic network outputs of the dense heads at test time, shaped like the named config's: every object is an ellipsoid with the
+    LM-O extents seen under a random pose, rendered by ray casting (so pixel <-> model point correspondences are exact up to the noise
+    added below and the visible region is a blob of ~20-30 % of the crop); zlmo: 21 code planes (Gray code of the
+    model-transformed, scaled coordinates, `flip` of the bits wrong: gross outliers for the RANSAC), glmo: the continuous xyz head.
+    Weight logits are higher on the object, visibility logits follow the silhouette with a few errors at its rim.
+    -> (cfg dict for AttrDict, gt_dict, out_dict) of CPU tensors; gt_dict['pose_best'] is the pose to recover."""
+    from . import floatbits as fb
+
+    spec = TEST_TIME_CONFIGS[name]
+    H, W, bits = spec["H"], spec["W"], spec["bits"]
+    g = torch.Generator().manual_seed(seed)
+    f64 = torch.float64
+    q = torch.randn(B, 4, generator=g, dtype=f64)
+    q = q / q.norm(dim=-1, keepdim=True)
+    q = torch.where(q[:, :1] < 0, -q, q)
+    z = torch.rand(B, generator=g, dtype=f64) * 400 + 500
+    ext = torch.tensor(EXTENT_MM, dtype=f64)
+    f = (torch.rand(B, generator=g, dtype=f64) * 0.15 + 0.55) * W * z / (2 * ext.max())  # the object spans 55-70 % of the crop's width (zoomed crops, dataset.py:402-423)
+    th = torch.rand(B, generator=g, dtype=f64) * (2 * math.pi)
+    K = torch.zeros(B, 3, 3, dtype=f64)
+    K[:, 0, 0], K[:, 0, 1], K[:, 1, 0], K[:, 1, 1] = f * th.cos(), -f * th.sin(), f * th.sin(), f * th.cos()
+    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = W / 2, H / 2, 1
+    t = torch.stack(((torch.rand(B, generator=g, dtype=f64) - 0.5) * 0.15 * W * z / f, (torch.rand(B, generator=g, dtype=f64) - 0.5) * 0.15 * H * z / f, z), -1)
+    R = _quat_to_R(q)
+    # ray casting in the model frame: o + s d on the ellipsoid |x / ext| = 1, nearest hit
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=f64), torch.arange(W, dtype=f64), indexing="ij")
+    pix = torch.stack((xs, ys, torch.ones_like(xs)), -1).reshape(1, H * W, 3)
+    d = (pix @ torch.linalg.inv(K).mT) @ R            # R^T K^-1 (u, v, 1)
+    o = -(t[:, None, :] @ R)                          # -R^T t
+    dn, on = d / ext, o / ext
+    a, bq, c = (dn * dn).sum(-1), 2 * (dn * on).sum(-1), (on * on).sum(-1) - 1
+    disc = bq * bq - 4 * a * c
+    hit = disc > 0
+    s = (-bq - disc.clamp_min(0).sqrt()) / (2 * a)
+    Xm = torch.where(hit[..., None], o + s[..., None] * d, torch.zeros((), dtype=f64))  # (B,HW,3) model points; background: 0
+    hit = hit.reshape(B, H, W)
+    if spec["model_transform"]:
+        ang = torch.rand(B, generator=g, dtype=f64) * 0.6 - 0.3
+        T = torch.eye(4, dtype=f64).repeat(B, 1, 1)
+        T[:, 0, 0] = T[:, 1, 1] = ang.cos()
+        T[:, 0, 1], T[:, 1, 0] = -ang.sin(), ang.sin()
+        T[:, :3, 3] = torch.randn(B, 3, generator=g, dtype=f64) * 2
+        Xt = Xm @ T[:, :3, :3].mT + T[:, None, :3, 3]
+        noc_scale = (ext * 1.25 + 6).expand(B, 3).contiguous()  # the transformed coordinates stay inside (-1, 1)
+    else:
+        T, Xt, noc_scale = None, Xm, ext.expand(B, 3).contiguous()
+    noc = (Xt / noc_scale[:, None]).reshape(B, H, W, 3)
+    msk_vis = hit.float()
+    wl = torch.randn(B, 2, H, W, generator=g) + 6 * msk_vis[:, None]  # background weights e^-6 of the object's
+    out = dict(xyz_weight_logits=wl, xyz_weights_scale=torch.exp(torch.randn(B, 1, 1, 1, generator=g) * 0.2 + (3.0 if name == "glmo" else 4.5)),
+               msk_vis_logits=(msk_vis[:, None] * 2 - 1) * 4 + torch.randn(B, 1, H, W, generator=g) * 2)
+    gt = dict(pose_best=torch.cat((q, t), -1).float(), out_K=K.float(), noc_scale=noc_scale.float(), msk_vis=msk_vis,
+              bbox_3d=bbox3d_from_scale(ext).expand(B, 8, 3).contiguous().float(),
+              out_pix_scale=(torch.rand(B, generator=g) * 1.5 + 0.5))
+    if bits is None:
+        out["xyz_noc"] = (noc.permute(0, 3, 1, 2) + 0.01 * torch.randn(B, 3, H, W, generator=g, dtype=f64)).float().contiguous()
+    else:
+        mod_bits, _raw = fb.nn_noc2target(noc.float().clamp(-0.999, 0.999), list(bits))
+        C = sum(bits)
+        logits = (mod_bits.float() * 2 - 1) * (torch.rand(B, C, H, W, generator=g) * 3 + 0.2)
+        out["xyz_noc_bin"] = torch.where(torch.rand(B, C, H, W, generator=g) < flip, -logits, logits).contiguous()
+        gt.update(bit_cnt=list(bits), model_transform=T.float())
+    return dict(spec["pnp_solver"]), gt, out

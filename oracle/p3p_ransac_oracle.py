@@ -11,8 +11,9 @@ contract, with integer outputs compared exactly:
     roots by numpy's companion-matrix eigenvalues, rotation by orthogonal Procrustes/SVD) -- the kernel uses a different
     algorithm (pencil of quadrics, cubic, Gauss-Newton polish), so agreement is not shared code;
   * scoring, the (inlier count, inlier error, hypothesis id) arg-max and the winner's inlier index set follow the kernel's
-    definition in float64; `decide()` reports for which poses the float32 kernel MUST agree exactly: no point of any
-    competing hypothesis within `margin` of the inlier threshold and no error-sum tie within `margin`.
+    definition in float64; `decided` reports for which poses the float32 kernel MUST pick the same hypothesis: the winner's count lead
+    exceeds the number of points that it and the rival have within `margin` of the inlier threshold, and no error-sum tie within
+    `margin`; `mask_unsure` lists the points of the winner's inlier mask that float32 may decide either way (the rest is exact).
 """
 from __future__ import annotations
 
@@ -139,26 +140,30 @@ def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3)
         c = Xs[:nl] @ R.T + t
         e = ((c[:, :2] / c[:, 2:3] - un[:nl]) ** 2).sum(1)
         inl = (c[:, 2] > 0) & (e < thr2)
-        unsure = bool((np.abs(e - thr2) < margin * thr2).any()) or bool((np.abs(c[:, 2]) < 1e-6).any())
+        # points the float32 kernel may legitimately put on the other side of the threshold (or of the camera plane): the hypothesis'
+        # count is known up to that many
+        n_unsure = int(((np.abs(e - thr2) < margin * thr2) | (np.abs(c[:, 2]) < 1e-6)).sum())
         ambiguous_pick = pick_gap < margin * max(pick_e, 1e-12)
-        cand.append((int(inl.sum()), float(e[inl].sum()), hyp, R, t, unsure, ambiguous_pick))
+        cand.append((int(inl.sum()), float(e[inl].sum()), hyp, R, t, n_unsure, ambiguous_pick))
     best = max(cand, key=lambda c: (c[0], -c[1], -c[2]))
     ok = best[0] >= 4
     out = dict(invalid=0 if ok else 1, best_hyp=best[2], best_count=best[0], per_hyp_count=np.array([c[0] for c in cand]))
-    # decided: the float32 kernel cannot legitimately pick another hypothesis -- the winner and every hypothesis within reach
-    # of it have no point near the threshold and no ambiguous 4th-point pick, and the winner's (count, err) lead is strict
-    rivals = [c for c in cand if c[2] != best[2] and c[0] >= best[0] - 0 and c[0] >= 0]
-    decided = not best[5] and not best[6]
+    # decided: the float32 kernel cannot legitimately pick another hypothesis.  The winner's own 4th-point pick is unambiguous and its
+    # count, less the points it has near the threshold, still beats every rival's count plus the rival's own near-threshold points
+    # (plus 2 for a rival whose 4th-point pick is ambiguous: it may be another P3P root altogether); rivals that tie in an exactly
+    # known count need a strict lead in the inlier error
+    decided = not best[6] and (best[0] - best[5] >= 4 or not ok)
     for c in cand:
         if c[2] == best[2] or c[0] < 0:
             continue
-        if c[5] or c[6]:  # an uncertain rival could gain / lose points: needs a count lead beyond what could flip -- be strict
-            decided = decided and c[0] + 2 < best[0]
-        elif c[0] == best[0]:
+        if c[0] + c[5] + (2 if c[6] else 0) < best[0] - best[5]:
+            continue
+        if c[5] == 0 and best[5] == 0 and not c[6] and c[0] == best[0]:
             decided = decided and (c[1] - best[1]) > margin * max(best[1], 1e-12)
-    del rivals
+        else:
+            decided = False
     if not ok:
-        out.update(n_inliers=0, inliers=np.zeros(0, np.int64), R=np.eye(3), t=np.zeros(3), decided=decided)
+        out.update(n_inliers=0, inliers=np.zeros(0, np.int64), R=np.eye(3), t=np.zeros(3), decided=decided, mask_unsure=np.zeros(0, np.int64))
         return out
     R, t = best[3], best[4]
     Rf, tf = R.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
@@ -166,8 +171,10 @@ def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3)
     un_all = np.stack(((k[4] * du - k[1] * dv) * idet, (-k[3] * du + k[0] * dv) * idet), -1).astype(np.float32).astype(np.float64)
     e = ((c[:, :2] / c[:, 2:3] - un_all) ** 2).sum(1)
     inl = (c[:, 2] > 0) & (e < thr2)
-    mask_sure = not bool((np.abs(e - thr2) < margin * thr2).any())
-    out.update(n_inliers=int(inl.sum()), inliers=np.nonzero(inl)[0], R=R, t=t, decided=decided, mask_decided=decided and mask_sure)
+    # mask_unsure: the points of the winner's inlier mask float32 may decide either way; everywhere else the mask is exact
+    mask_unsure = np.nonzero((np.abs(e - thr2) < margin * thr2) | (np.abs(c[:, 2]) < 1e-6))[0]
+    out.update(n_inliers=int(inl.sum()), inliers=np.nonzero(inl)[0], R=R, t=t, decided=decided, mask_decided=decided and len(mask_unsure) == 0,
+               mask_unsure=mask_unsure)
     return out
 
 

@@ -9,12 +9,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lc_amd.config import AttrDict  # noqa: E402
 from lc_amd.inference import solve_pnp  # noqa: E402
-from tests.golden.gen_golden_lossfn import dense_inputs  # noqa: E402
+from lc_amd.synth import dense_inputs  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, S = int(os.environ.get("B", 64)), int(os.environ.get("SIZE", 64))
 if os.environ.get("HEAD", "xyz") == "bin":  # ZebraPose structure: binary surface codes + a model transform (zlmo: SIZE=128)
-    from tests.golden.gen_golden_lossfn import bin_inputs
+    from lc_amd.synth import bin_inputs
     gt, out = bin_inputs(B=B, H=S, W=S, seed=3)
 else:
     gt, out = dense_inputs(B=B, H=S, W=S, seed=3)

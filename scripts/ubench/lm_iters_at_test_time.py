@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lc_amd.dense import dense_front_end_select  # noqa: E402
 from lc_amd.pnp import gpu_solver, pnp_ceres  # noqa: E402
-from tests.golden.gen_golden_lossfn import dense_inputs  # noqa: E402
+from lc_amd.synth import dense_inputs  # noqa: E402
 
 dev = torch.device("cuda:0")
 gt, out = dense_inputs(B=64, H=64, W=64, seed=3)

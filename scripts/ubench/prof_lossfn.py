@@ -3,7 +3,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lc_amd.config import AttrDict
 from lc_amd.losses import Loss_fn
-from tests.golden.gen_golden_lossfn import DENSE_CFG, dense_inputs
+from tests.golden.gen_golden_lossfn import DENSE_CFG
+from lc_amd.synth import dense_inputs
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda:0")
 fn = Loss_fn(AttrDict(DENSE_CFG), AttrDict(), 0).to(dev)

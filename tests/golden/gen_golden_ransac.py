@@ -2,7 +2,8 @@
 """Fixtures for the GPU PnP initialiser: inputs + the outputs of oracle/p3p_ransac_oracle.py (an independent float64 P3P over the
 kernel's own hypothesis stream).  OpenCV (cv2.solvePnPRansac, lib/pnp/cv2_solver.py:69-88) is absent from the image and its
 RNG is not reproducible, so these are ORACLE vectors, not reference vectors; they freeze the integer outputs -- best hypothesis
-index, inlier count, inlier index set -- for the poses the oracle marks as decided (no point within 1e-3 of the threshold).
+index, inlier count, inlier index set -- for the poses the oracle marks as decided (the winner's count lead exceeds the points it and
+its rivals have within 1e-3 of the threshold); the inlier mask is exact outside `mask_unsure`.
 
     python tests/golden/gen_golden_ransac.py [case ...]     (build container, CPU, ~1 min)
 """
@@ -51,13 +52,14 @@ def main():
         B, N = c["pts3d"].shape[:2]
         res = [O.ransac(c["K"][i], c["pts3d"][i], c["pts2d"][i], int(c["counts"][i]), float(c["reproj_err"]), int(c["iterations"]),
                         int(c["seed"]), i) for i in range(B)]
-        mask = np.zeros((B, N), np.uint8)
+        mask, unsure = np.zeros((B, N), np.uint8), np.zeros((B, N), np.uint8)
         for i, r in enumerate(res):
             mask[i, r["inliers"]] = 1
+            unsure[i, r.get("mask_unsure", [])] = 1  # points of the winner's mask within 1e-3 of the threshold: float32 may decide either way
         states = np.stack([np.concatenate((O.rot_to_quat(r["R"]), r["t"])) for r in res])
         np.savez_compressed(os.path.join(HERE, f"ransac_{name}.npz"), **{"in_" + k: v for k, v in c.items()},
                             best_hyp=np.array([r["best_hyp"] for r in res], np.int32), invalid=np.array([r["invalid"] for r in res], np.int32),
-                            n_inliers=np.array([r["n_inliers"] for r in res], np.int32), inlier_mask=mask, states=states,
+                            n_inliers=np.array([r["n_inliers"] for r in res], np.int32), inlier_mask=mask, mask_unsure=unsure, states=states,
                             per_hyp_count=np.stack([r.get("per_hyp_count", np.full(((int(c["iterations"]) + 63) // 64) * 64, -1)) for r in res]).astype(np.int16),
                             decided=np.array([r["decided"] for r in res]), mask_decided=np.array([r.get("mask_decided", r["decided"]) for r in res]))
         print(name, "decided", int(sum(r["decided"] for r in res)), "/", B, "invalid", int(sum(r["invalid"] for r in res)))
