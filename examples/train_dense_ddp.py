@@ -122,9 +122,9 @@ def main():
         t0 = time.perf_counter()
         with torch.autocast("cuda", dtype=amp or torch.float16, enabled=amp is not None):
             noc, wlogits, wscale, vis = net(blob["rgb_in"].contiguous(memory_format=torch.channels_last))
-        # the loss runs at the reference's fp32 precision: half-precision maps are up-cast at the boundary (lc_amd/_lib.py)
-        out = {"xyz_noc_bin" if args.bin else "xyz_noc": noc.float(), "xyz_weight_logits": wlogits.float(), "xyz_weights_scale": wscale.float(),
-               "msk_vis_logits": vis.float()}
+        # the heads' maps go to the loss in the autocast type: the kernels read fp16 / bf16 natively, compute in fp32 and write the maps'
+        # gradients in the maps' type (lc_amd/_lib.py: hip_maps) -- no up-cast copy at the boundary
+        out = {"xyz_noc_bin" if args.bin else "xyz_noc": noc, "xyz_weight_logits": wlogits, "xyz_weights_scale": wscale, "msk_vis_logits": vis}
         if args.graphs:
             if graphed is None:
                 from lc_amd.graphs import GraphedLoss

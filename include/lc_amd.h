@@ -404,6 +404,65 @@ int lc_xyz_bin_loss_fwd_f32(const float *logits, const unsigned char *gt_bits, c
 int lc_xyz_bin_loss_bwd_f32(const float *logits, const unsigned char *gt_bits, const float *msk_vis_logits,
                             const float *bin_weights, const float *g_loss, int B, int C, int HW, float *d_logits, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (2i) Round 4: the f1 / f3 entry points above for network outputs in the element type a mixed-precision backbone emits
+ *      (BASELINE.json configs[2] bf16, configs[4] fp16; ptnet.py:68-82 hands the heads' outputs over in the autocast type,
+ *      losses.py:163-184,355-356 and floatbits.py:130-160,194-223 consume them).  map_dtype = LC_F32 | LC_F16 | LC_BF16 is the element
+ *      type of EVERY `const void *` map argument and of every `void *` gradient map; everything else (per-sample scales, targets, masks,
+ *      the (B,N,.) rows, cotangents of the rows, losses) stays fp32 / bytes exactly as in the `_f32` entry point of the same name, which
+ *      is this function with map_dtype = LC_F32.  Arithmetic is fp32 for every type and the element order of every reduction does not
+ *      depend on it: a 16-bit map gives bit for bit the fp32 entry point's result on the up-cast values; a gradient map is that fp32
+ *      gradient rounded to nearest even into the map's type.  No up-cast copy exists anywhere.  Four-element (8-byte) accesses need
+ *      W (HW) % 4 == 0 and 8-byte aligned maps, else one element per access.
+ *      wscale_dtype: the element type of the (B,) weight scale and of its gradient (fp32 under autocast, where exp is an fp32 op; the
+ *      model's 16-bit type in a pure half-precision model).
+ *      xyz_dtype (front end forward, front end + selection): the element type of `xyz` alone -- map_dtype, or LC_F32 next to 16-bit logits
+ *      (test time with binary-code heads: the coordinate planes lc_bits_decode3 writes are fp32 whatever the network's type is).
+ *      *_bstride: elements between consecutive samples of that input map, 0 = a dense batch.  The reference's heads are channel slices
+ *      `out_raw[:, v]` of ONE (B,C_all,H,W) network output (ptnet.py:56): each sample's slice is contiguous, the batch stride is
+ *      C_all*H*W -- passed here, the slice is consumed where it lies instead of being copied into shape first.  Gradient maps are dense.
+ * ------------------------------------------------------------------------------------------------ */
+int lc_dense_frontend_fwd3(const void *xyz, const void *wlogits, const void *wscale, const float *noc_scale,
+                           const void *vis_logits, float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left,
+                           int sample, float *pts2d, float *inv_std, float *pts3d, float *lse, unsigned char *vis_mask,
+                           void *stream);
+int lc_dense_frontend_bwd2(const void *wlogits, const void *wscale, const float *noc_scale, const float *lse,
+                           const float *g_inv_std, const float *g_pts3d, int map_dtype, int wscale_dtype, long long wlogits_bstride, int B, int H, int W, int top, int left,
+                           int sample, void *d_xyz, void *d_wlogits, void *d_wscale, void *stream);
+int lc_dense_frontend_select2(const void *xyz, const void *wlogits, const void *wscale, const float *noc_scale,
+                              const void *vis_logits, float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left,
+                              int sample, int mode, double quantile, int square_weights, int min_count, unsigned seed,
+                              float *out_pts2d, float *out_weights, float *out_pts3d, int *out_index, int *counts,
+                              void *stream);
+int lc_bits_decode_gt_fwd3(const void *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
+                           const float *out_scale, const float *out_xform, int map_dtype, long long logits_bstride, int B, int C, int H, int W, int n0,
+                           int n1, int n2, int black_background, int top, int left, int sample, float *out, void *stream);
+int lc_bits_decode_gt_bwd3(const void *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
+                           const float *out_scale, const float *out_xform, const float *g_out, int map_dtype, long long logits_bstride, int B, int C,
+                           int H, int W, int n0, int n1, int n2, int black_background, int top, int left, int sample,
+                           void *d_logits, void *stream);
+int lc_bits_decode3(const void *logits, const float *out_scale, const float *out_xform, int map_dtype, long long logits_bstride, int B, int C, int H,
+                    int W, int n0, int n1, int n2, int black_background, int planar, float *out, void *stream);
+int lc_dense_aux_fwd2(const void *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
+                      const void *seg_logits, const float *msk_vis, const void *wlogits, int map_dtype, long long xyz_bstride, long long seg_bstride, long long wlogits_bstride, int B, int HW,
+                      int seg_type, float *losses, double *partials, unsigned *ticket, void *stream);
+int lc_dense_aux_bwd2(const void *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
+                      const void *seg_logits, const float *msk_vis, const void *wlogits, int map_dtype, long long xyz_bstride, long long seg_bstride, long long wlogits_bstride, int B, int HW,
+                      int seg_type, const float *g_noc, const float *g_seg, const float *g_wseg, void *d_xyz, void *d_seg,
+                      void *d_wlogits, void *stream);
+int lc_xyz_bin_loss_fwd2(const void *logits, const unsigned char *gt_bits, const void *msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride, int B,
+                         int C, int HW, float momentum, float *histogram, float *loss, float *bin_weights, double *partials,
+                         unsigned *ticket, void *stream);
+/* The NormClipper pair (lc_sqnorm_f32, lc_norm_clip_apply_f32) on a gradient of any map type: the hooks sit on the heads' outputs
+ * (losses.py:343-352), so under mixed precision the gradient they clip is 16-bit; read and written in place of a cast each way. */
+int lc_sqnorm(const void *x, int dtype, long long n, double *partials, unsigned *ticket, float *sq, int accumulate,
+              const float *state, float *state_snapshot, void *stream);
+int lc_norm_clip_apply(const void *grad, int dtype, long long n, const float *sq, const float *state_in, float initial_max_norm,
+                       float scale, double momentum, void *out, float *state_out, float *norm_out, void *stream);
+int lc_xyz_bin_loss_bwd2(const void *logits, const unsigned char *gt_bits, const void *msk_vis_logits,
+                         const float *bin_weights, const float *g_loss, int map_dtype, long long logits_bstride, long long vis_bstride, int B, int C, int HW, void *d_logits,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

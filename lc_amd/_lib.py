@@ -70,6 +70,21 @@ _SIGNATURES = {
     "lc_softargmax2d_bwd_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lc_softargmax2d_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lc_softargmax2d_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lc_sqnorm": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "lc_norm_clip_apply": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_float, c_float, ctypes.c_double,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    # round 4: the f1 / f3 entry points for maps of any element type (map_dtype) lying anywhere a sample is contiguous (batch strides)
+    "lc_dense_frontend_fwd3": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 6 + [c_void_p] * 6),
+    "lc_dense_frontend_bwd2": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_longlong] + [c_int] * 6 + [c_void_p] * 4),
+    "lc_dense_frontend_select2": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint] +
+                                  [c_void_p] * 6),
+    "lc_bits_decode_gt_fwd3": (c_int, [c_void_p] * 5 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),
+    "lc_bits_decode_gt_bwd3": (c_int, [c_void_p] * 6 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),
+    "lc_bits_decode3": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "lc_dense_aux_fwd2": (c_int, [c_void_p] * 7 + [c_int] + [ctypes.c_longlong] * 3 + [c_int] * 3 + [c_void_p] * 4),
+    "lc_dense_aux_bwd2": (c_int, [c_void_p] * 7 + [c_int] + [ctypes.c_longlong] * 3 + [c_int] * 3 + [c_void_p] * 7),
+    "lc_xyz_bin_loss_fwd2": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong, ctypes.c_longlong] + [c_int] * 3 + [c_float] + [c_void_p] * 6),
+    "lc_xyz_bin_loss_bwd2": (c_int, [c_void_p] * 5 + [c_int, ctypes.c_longlong, ctypes.c_longlong] + [c_int] * 3 + [c_void_p] * 2),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -147,6 +162,45 @@ def require_hip_map(name: str, t: torch.Tensor) -> torch.Tensor:
     if t.dtype not in MAP_DTYPES:
         raise TypeError(f"lc_amd: {name} must be float32, float16 or bfloat16, got {t.dtype}")
     return t.contiguous()
+
+
+def hip_maps(**named):
+    """Network-output maps of ONE call (`xyz_noc`, `xyz_weight_logits`, `msk_vis_logits`, code logits ...; None entries pass through):
+    -> (tensors, batch strides in elements, map_dtype code of include/lc_amd.h).
+
+    The kernels read fp32, fp16 and bf16 maps in their own type (no up-cast copy) from wherever every sample is contiguous: a dense
+    batch, or a channel slice `out_raw[:, a:b]` of the network's (B,C_all,H,W) output (what `ptnet.py:56` hands over) -- its batch
+    stride is passed along and the slice is consumed where it lies.  Only two cases copy: a sample that is not contiguous itself
+    (copied into shape), and maps of DIFFERENT element types in one call (the 16-bit ones are up-cast to fp32)."""
+    dtypes = {t.dtype for t in named.values() if t is not None}
+    for name, t in named.items():
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"lc_amd: {name} must be a torch.Tensor, got {type(t)}")
+        if not t.is_cuda:
+            raise RuntimeError(f"lc_amd: {name} is on {t.device}; the HIP path needs tensors on the MI355X "
+                               f"(there is no CPU fallback in the product path)")
+        if t.dtype not in MAP_DTYPES:
+            raise TypeError(f"lc_amd: {name} must be float32, float16 or bfloat16, got {t.dtype}")
+    mixed = len(dtypes) > 1
+    out, strides = [], []
+    for t in named.values():
+        if t is None:
+            out.append(None)
+            strides.append(0)
+            continue
+        if mixed and t.dtype != torch.float32:
+            t = t.float()
+        per_sample = t[0].numel() if t.shape[0] else 0
+        if t.shape[0] > 1 and not (t[0].is_contiguous() and t.stride(0) >= per_sample):
+            t = t.contiguous()
+        elif t.shape[0] <= 1 and not t.is_contiguous():
+            t = t.contiguous()
+        out.append(t)
+        strides.append(int(t.stride(0)) if t.shape[0] > 1 else 0)
+    code = MAP_DTYPES[torch.float32 if (mixed or not dtypes) else next(iter(dtypes))]
+    return out, strides, code
 
 
 class _NoGuard:

@@ -10,6 +10,7 @@
 
 #include "lc_common.h"
 #include "lc_kernels.h"
+#include "lc_map.h"
 
 namespace lc {
 namespace {
@@ -61,16 +62,9 @@ struct AxisState {
     }
 };
 
-// V consecutive pixels of one row per thread: float4 / uchar4 channel reads when V == 4
-template <int V>
-__device__ __forceinline__ void load_px(const float* lg, float (&v)[V]) {
-    if constexpr (V == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(lg);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-        v[0] = lg[0];
-    }
-}
+// V consecutive pixels of one row per thread: one 16-byte (fp32 logits) / 8-byte (fp16, bf16 logits: lc_map.h) / uchar4 channel read when V == 4
+template <int V, typename T>
+__device__ __forceinline__ void load_px(const T* lg, float (&v)[V]) { map_load<V>(lg, v); }
 template <int V>
 __device__ __forceinline__ void load_px(const unsigned char* g, bool (&v)[V]) {
     if constexpr (V == 4) {
@@ -80,14 +74,13 @@ __device__ __forceinline__ void load_px(const unsigned char* g, bool (&v)[V]) {
         v[0] = g[0] != 0;
     }
 }
-template <int V>
-__device__ __forceinline__ void store_px(float* o, const float (&v)[V]) {
-    if constexpr (V == 4) store_stream4(o, v[0], v[1], v[2], v[3]);  // d_logits: written once, read by the next kernel of the backward pass
-    else o[0] = v[0];
+template <int V, typename T>
+__device__ __forceinline__ void store_px(T* o, const float (&v)[V]) {
+    map_store<V>(o, v, V == 4 && LC_NT_GRAD_STORES);  // d_logits: written once, read by the next kernel of the backward pass
 }
 
-template <int V>
-__device__ __forceinline__ void decode_axis_gt(const float* lg, const unsigned char* gt, size_t stride, int n, int black_factor,
+template <int V, typename T>
+__device__ __forceinline__ void decode_axis_gt(const T* lg, const unsigned char* gt, size_t stride, int n, int black_factor,
                                                AxisState (&st)[V]) {
     for (int k = 0; k < n; ++k) {
         float x[V];
@@ -100,8 +93,8 @@ __device__ __forceinline__ void decode_axis_gt(const float* lg, const unsigned c
 }
 
 // floatbits.py:194-223 for one axis of V pixels
-template <int V>
-__device__ __forceinline__ void decode_gray(const float* lg, size_t stride, int n, bool black, float (&out)[V]) {
+template <int V, typename T>
+__device__ __forceinline__ void decode_gray(const T* lg, size_t stride, int n, bool black, float (&out)[V]) {
     unsigned code[V];
     float last[V];
 #pragma unroll
@@ -149,7 +142,7 @@ struct OutMap {
     }
 };
 
-template <int V>
+template <int V, typename T>
 __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_fwd_kernel(const BitsParams p) {
     const int Wn = (p.W - p.left + p.sample - 1) / p.sample;
     const size_t HW = (size_t)p.H * p.W;
@@ -171,9 +164,9 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_fwd_kernel(const B
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
-            const size_t base = ((size_t)b * p.C + c0) * HW + px;
+            const size_t base = ((size_t)b * p.C + c0) * HW + px, lbase = (size_t)b * p.logits_bs + (size_t)c0 * HW + px;
             AxisState st[V];
-            decode_axis_gt<V>(p.logits + base, p.gt_bits + base, HW, nb, p.black_factor, st);
+            decode_axis_gt<V>(static_cast<const T*>(p.logits) + lbase, p.gt_bits + base, HW, nb, p.black_factor, st);
 #pragma unroll
             for (int v = 0; v < V; ++v) res[v][a] = st[v].finish(nb, in_msk[v]).val / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
@@ -193,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_fwd_kernel(const B
 }
 
 // backward: one thread per V pixels of the FULL map: writes every channel (zeros where no gradient arrives)
-template <int V>
+template <int V, typename T>
 __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const BitsParams p) {
     const int Wn = (p.W - p.left + p.sample - 1) / p.sample;
     const size_t HW = (size_t)p.H * p.W;
@@ -229,14 +222,14 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const B
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
-            const size_t base = ((size_t)b * p.C + c0) * HW + px;
+            const size_t base = ((size_t)b * p.C + c0) * HW + px, lbase = (size_t)b * p.logits_bs + (size_t)c0 * HW + px;
             int idx[V];
             float g[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) { idx[v] = -1; g[v] = 0.f; }
             if (any) {
                 AxisState st[V];
-                decode_axis_gt<V>(p.logits + base, p.gt_bits + base, HW, nb, p.black_factor, st);
+                decode_axis_gt<V>(static_cast<const T*>(p.logits) + lbase, p.gt_bits + base, HW, nb, p.black_factor, st);
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     if (live[v]) {
@@ -250,14 +243,14 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const B
                 float o[V];
 #pragma unroll
                 for (int v = 0; v < V; ++v) o[v] = (k == idx[v]) ? g[v] : 0.f;
-                store_px<V>(p.d_logits + base + k * HW, o);
+                store_px<V>(static_cast<T*>(p.d_logits) + base + k * HW, o);
             }
             c0 += nb;
         }
     }
 }
 
-template <int V>
+template <int V, typename T>
 __global__ __launch_bounds__(kThreads) void lc_bits_decode_kernel(const BitsParams p) {
     const size_t HW = (size_t)p.H * p.W;
     const size_t total = (size_t)p.B * HW / V;
@@ -271,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_kernel(const BitsPara
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
             float val[V];
-            decode_gray<V>(p.logits + ((size_t)b * p.C + c0) * HW + px, HW, nb, p.black_factor < 0, val);
+            decode_gray<V>(static_cast<const T*>(p.logits) + (size_t)b * p.logits_bs + (size_t)c0 * HW + px, HW, nb, p.black_factor < 0, val);
 #pragma unroll
             for (int v = 0; v < V; ++v) res[v][a] = val[v] / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
@@ -303,6 +296,11 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_kernel(const BitsPara
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 bool aligned4(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; }
 
+BitsParams with_dense_stride(BitsParams p) {  // a batch stride left at 0 means a dense batch
+    if (!p.logits_bs) p.logits_bs = (long long)p.C * p.H * p.W;
+    return p;
+}
+
 int grid_for(size_t total) {
     size_t g = (total + kThreads - 1) / kThreads;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));  // cap + grid-stride (cdna_hip_programming.md Guideline 11)
@@ -310,25 +308,31 @@ int grid_for(size_t total) {
 
 }  // namespace
 
-int launch_bits_decode_gt_fwd(const BitsParams& p, hipStream_t stream) {
-    if (p.B <= 0 || p.N <= 0) return 0;
-    const bool vec = p.sample == 1 && p.top == 0 && p.left == 0 && p.W % 4 == 0 && aligned16(p.logits) && aligned16(p.out) && aligned4(p.gt_bits) && aligned4(p.gt_msk);
-    if (vec) hipLaunchKernelGGL(lc_bits_decode_gt_fwd_kernel<4>, dim3(grid_for((size_t)p.B * p.N / 4)), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL(lc_bits_decode_gt_fwd_kernel<1>, dim3(grid_for((size_t)p.B * p.N)), dim3(kThreads), 0, stream, p);
+int launch_bits_decode_gt_fwd(const BitsParams& p_in, hipStream_t stream) {
+    if (p_in.B <= 0 || p_in.N <= 0) return 0;
+    const BitsParams p = with_dense_stride(p_in);
+    const bool vec = (p.logits_bs % 4) == 0 && p.sample == 1 && p.top == 0 && p.left == 0 && p.W % 4 == 0 && map_aligned4(p.logits, p.map_dtype) && aligned16(p.out) && aligned4(p.gt_bits) && aligned4(p.gt_msk);
+    LC_MAP_DISPATCH(p.map_dtype,
+                    if (vec) hipLaunchKernelGGL((lc_bits_decode_gt_fwd_kernel<4, T>), dim3(grid_for((size_t)p.B * p.N / 4)), dim3(kThreads), 0, stream, p);
+                    else hipLaunchKernelGGL((lc_bits_decode_gt_fwd_kernel<1, T>), dim3(grid_for((size_t)p.B * p.N)), dim3(kThreads), 0, stream, p));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
-int launch_bits_decode_gt_bwd(const BitsParams& p, hipStream_t stream) {
-    if (p.B <= 0) return 0;
-    const bool vec = p.W % 4 == 0 && aligned16(p.logits) && aligned16(p.d_logits) && aligned4(p.gt_bits) && aligned4(p.gt_msk);
-    if (vec) hipLaunchKernelGGL(lc_bits_decode_gt_bwd_kernel<4>, dim3(grid_for((size_t)p.B * p.H * p.W / 4)), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL(lc_bits_decode_gt_bwd_kernel<1>, dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p);
+int launch_bits_decode_gt_bwd(const BitsParams& p_in, hipStream_t stream) {
+    if (p_in.B <= 0) return 0;
+    const BitsParams p = with_dense_stride(p_in);
+    const bool vec = (p.logits_bs % 4) == 0 && p.W % 4 == 0 && map_aligned4(p.logits, p.map_dtype) && map_aligned4(p.d_logits, p.map_dtype) && aligned4(p.gt_bits) && aligned4(p.gt_msk);
+    LC_MAP_DISPATCH(p.map_dtype,
+                    if (vec) hipLaunchKernelGGL((lc_bits_decode_gt_bwd_kernel<4, T>), dim3(grid_for((size_t)p.B * p.H * p.W / 4)), dim3(kThreads), 0, stream, p);
+                    else hipLaunchKernelGGL((lc_bits_decode_gt_bwd_kernel<1, T>), dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
-int launch_bits_decode(const BitsParams& p, hipStream_t stream) {
-    if (p.B <= 0) return 0;
-    const bool vec = p.W % 4 == 0 && aligned16(p.logits) && aligned16(p.out);
-    if (vec) hipLaunchKernelGGL(lc_bits_decode_kernel<4>, dim3(grid_for((size_t)p.B * p.H * p.W / 4)), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL(lc_bits_decode_kernel<1>, dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p);
+int launch_bits_decode(const BitsParams& p_in, hipStream_t stream) {
+    if (p_in.B <= 0) return 0;
+    const BitsParams p = with_dense_stride(p_in);
+    const bool vec = (p.logits_bs % 4) == 0 && p.W % 4 == 0 && map_aligned4(p.logits, p.map_dtype) && aligned16(p.out);
+    LC_MAP_DISPATCH(p.map_dtype,
+                    if (vec) hipLaunchKernelGGL((lc_bits_decode_kernel<4, T>), dim3(grid_for((size_t)p.B * p.H * p.W / 4)), dim3(kThreads), 0, stream, p);
+                    else hipLaunchKernelGGL((lc_bits_decode_kernel<1, T>), dim3(grid_for((size_t)p.B * p.H * p.W)), dim3(kThreads), 0, stream, p));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

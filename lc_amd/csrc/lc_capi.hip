@@ -399,29 +399,51 @@ int lc_dense_frontend_fwd_f32(const float* xyz, const float* wlogits, const floa
     return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
 }
 
-int lc_dense_frontend_fwd2_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
-                               float vis_thresh, int B, int H, int W, int top, int left, int sample, float* pts2d, float* inv_std,
+int lc_dense_frontend_fwd3(const void* xyz, const void* wlogits, const void* wscale, const float* noc_scale, const void* vis_logits,
+                               float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left, int sample, float* pts2d, float* inv_std,
                                float* pts3d, float* lse, unsigned char* vis_mask, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (wscale_dtype < 0 || wscale_dtype > 2) return fail(1, "wscale_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (xyz_dtype != map_dtype && xyz_dtype != 0) return fail(1, "xyz_dtype must be map_dtype or LC_F32");
+    if (xyz_bstride < 0 || wlogits_bstride < 0 || vis_bstride < 0) return fail(1, "negative batch stride");
+    if ((xyz_bstride && xyz_bstride < 3ll * H * W) || (wlogits_bstride && wlogits_bstride < 2ll * H * W) || (vis_bstride && vis_bstride < 1ll * H * W)) return fail(1, "batch stride smaller than a sample");
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!wlogits || !wscale || !pts2d || !inv_std || !lse || (xyz != nullptr) != (pts3d != nullptr)) return fail(1, "null pointer");
     if ((vis_logits != nullptr) != (vis_mask != nullptr)) return fail(1, "vis_logits and vis_mask go together");
     LC_REQUIRE_ALIGNED(8, pts2d, inv_std);
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
-    lc::DenseParams p{xyz, wlogits, wscale, noc_scale, pts2d, inv_std, pts3d, lse, B, H, W, N, top, left, sample, vis_logits, vis_thresh, vis_mask};
+    lc::DenseParams p{xyz, wlogits, wscale, noc_scale, pts2d, inv_std, pts3d, lse, B, H, W, N, top, left, sample, vis_logits, vis_thresh, vis_mask, map_dtype, wscale_dtype, xyz_dtype,
+                       xyz_bstride ? xyz_bstride : 3ll * H * W, wlogits_bstride ? wlogits_bstride : 2ll * H * W, vis_bstride ? vis_bstride : 1ll * H * W};
     return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
 }
 
-int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const float* noc_scale, const float* lse,
-                              const float* g_inv_std, const float* g_pts3d, int B, int H, int W, int top, int left, int sample,
-                              float* d_xyz, float* d_wlogits, float* d_wscale, void* stream) {
+int lc_dense_frontend_fwd2_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
+                               float vis_thresh, int B, int H, int W, int top, int left, int sample, float* pts2d, float* inv_std,
+                               float* pts3d, float* lse, unsigned char* vis_mask, void* stream) {
+    return lc_dense_frontend_fwd3(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, 0 /* LC_F32 */, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, 0, 0, B, H, W, top, left, sample, pts2d, inv_std, pts3d, lse, vis_mask, stream);
+}
+
+int lc_dense_frontend_bwd2(const void* wlogits, const void* wscale, const float* noc_scale, const float* lse,
+                              const float* g_inv_std, const float* g_pts3d, int map_dtype, int wscale_dtype, long long wlogits_bstride, int B, int H, int W, int top, int left, int sample,
+                              void* d_xyz, void* d_wlogits, void* d_wscale, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (wscale_dtype < 0 || wscale_dtype > 2) return fail(1, "wscale_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (wlogits_bstride < 0) return fail(1, "negative batch stride");
+    if (wlogits_bstride && wlogits_bstride < 2ll * H * W) return fail(1, "batch stride smaller than a sample");
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!wlogits || !wscale || !lse) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, g_inv_std);
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
-    lc::DenseBwdParams p{wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, d_xyz, d_wlogits, d_wscale, B, H, W, N, top, left, sample};
+    lc::DenseBwdParams p{wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, d_xyz, d_wlogits, d_wscale, B, H, W, N, top, left, sample, map_dtype, wscale_dtype, wlogits_bstride ? wlogits_bstride : 2ll * H * W};
     return lc::launch_dense_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end backward launch failed") : 0;
+}
+
+int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const float* noc_scale, const float* lse,
+                              const float* g_inv_std, const float* g_pts3d, int B, int H, int W, int top, int left, int sample,
+                              float* d_xyz, float* d_wlogits, float* d_wscale, void* stream) {
+    return lc_dense_frontend_bwd2(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, B, H, W, top, left, sample, d_xyz, d_wlogits, d_wscale, stream);
 }
 
 int lc_pnp_ransac_init_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
@@ -518,30 +540,48 @@ int lc_bits_decode_gt_bwd_f32(const float* logits, const unsigned char* gt_bits,
     return lc::launch_bits_decode_gt_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode backward launch failed") : 0;
 }
 
-int lc_bits_decode_gt_fwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
-                               const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top,
+int lc_bits_decode_gt_fwd3(const void* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
+                               const float* out_xform, int map_dtype, long long logits_bstride, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top,
                                int left, int sample, float* out, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (logits_bstride < 0) return fail(1, "negative batch stride");
+    if (logits_bstride && logits_bstride < (long long)C * H * W) return fail(1, "batch stride smaller than a sample");
     if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
     if (B == 0) return 0;
     if (!logits || !gt_bits || !out) return fail(1, "null pointer");
     if (out_xform && !out_scale) return fail(1, "the model transform applies to scaled coordinates: out_scale is needed with out_xform");
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     lc::BitsParams p{logits, gt_bits, gt_msk, nullptr, out, nullptr, B, C, H, W, N, top, left, sample, {n0, n1, n2},
-                     black_background ? -1 : 1, out_scale, out_xform};
+                     black_background ? -1 : 1, out_scale, out_xform, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * H * W};
     return lc::launch_bits_decode_gt_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
 }
 
-int lc_bits_decode_gt_bwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
-                               const float* out_xform, const float* g_out, int B, int C, int H, int W, int n0, int n1, int n2,
-                               int black_background, int top, int left, int sample, float* d_logits, void* stream) {
+int lc_bits_decode_gt_fwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
+                               const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top,
+                               int left, int sample, float* out, void* stream) {
+    return lc_bits_decode_gt_fwd3(logits, gt_bits, gt_msk, out_scale, out_xform, 0 /* LC_F32 */, 0, B, C, H, W, n0, n1, n2, black_background, top, left, sample, out, stream);
+}
+
+int lc_bits_decode_gt_bwd3(const void* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
+                               const float* out_xform, const float* g_out, int map_dtype, long long logits_bstride, int B, int C, int H, int W, int n0, int n1, int n2,
+                               int black_background, int top, int left, int sample, void* d_logits, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (logits_bstride < 0) return fail(1, "negative batch stride");
+    if (logits_bstride && logits_bstride < (long long)C * H * W) return fail(1, "batch stride smaller than a sample");
     if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
     if (B == 0) return 0;
     if (!logits || !gt_bits || !g_out || !d_logits) return fail(1, "null pointer");
     if (out_xform && !out_scale) return fail(1, "the model transform applies to scaled coordinates: out_scale is needed with out_xform");
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     lc::BitsParams p{logits, gt_bits, gt_msk, g_out, nullptr, d_logits, B, C, H, W, N, top, left, sample, {n0, n1, n2},
-                     black_background ? -1 : 1, out_scale, out_xform};
+                     black_background ? -1 : 1, out_scale, out_xform, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * H * W};
     return lc::launch_bits_decode_gt_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode backward launch failed") : 0;
+}
+
+int lc_bits_decode_gt_bwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
+                               const float* out_xform, const float* g_out, int B, int C, int H, int W, int n0, int n1, int n2,
+                               int black_background, int top, int left, int sample, float* d_logits, void* stream) {
+    return lc_bits_decode_gt_bwd3(logits, gt_bits, gt_msk, out_scale, out_xform, g_out, 0 /* LC_F32 */, 0, B, C, H, W, n0, n1, n2, black_background, top, left, sample, d_logits, stream);
 }
 
 int lc_bits_decode_f32(const float* logits, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, float* noc,
@@ -553,15 +593,23 @@ int lc_bits_decode_f32(const float* logits, int B, int C, int H, int W, int n0, 
     return lc::launch_bits_decode(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
 }
 
-int lc_bits_decode2_f32(const float* logits, const float* out_scale, const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2,
+int lc_bits_decode3(const void* logits, const float* out_scale, const float* out_xform, int map_dtype, long long logits_bstride, int B, int C, int H, int W, int n0, int n1, int n2,
                         int black_background, int planar, float* out, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (logits_bstride < 0) return fail(1, "negative batch stride");
+    if (logits_bstride && logits_bstride < (long long)C * H * W) return fail(1, "batch stride smaller than a sample");
     if (int rc = bits_check(B, C, H, W, n0, n1, n2, 0, 0, 1)) return rc;
     if (B == 0) return 0;
     if (!logits || !out) return fail(1, "null pointer");
     if (out_xform && !out_scale) return fail(1, "the model transform applies to scaled coordinates: out_scale is needed with out_xform");
     lc::BitsParams p{logits, nullptr, nullptr, nullptr, out, nullptr, B, C, H, W, H * W, 0, 0, 1, {n0, n1, n2}, black_background ? -1 : 1,
-                     out_scale, out_xform, planar ? 1 : 0};
+                     out_scale, out_xform, planar ? 1 : 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * H * W};
     return lc::launch_bits_decode(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
+}
+
+int lc_bits_decode2_f32(const float* logits, const float* out_scale, const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2,
+                        int black_background, int planar, float* out, void* stream) {
+    return lc_bits_decode3(logits, out_scale, out_xform, 0 /* LC_F32 */, 0, B, C, H, W, n0, n1, n2, black_background, planar, out, stream);
 }
 
 int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt, const float* t_gt, const float* pts,
@@ -574,26 +622,38 @@ int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt
     return lc::launch_pose_errors(p, static_cast<hipStream_t>(stream)) ? fail(11, "pose-error kernel launch failed") : 0;
 }
 
-int lc_sqnorm_f32(const float* x, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, const float* state,
-                  float* state_snapshot, void* stream) {
+int lc_sqnorm(const void* x, int dtype, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, const float* state,
+              float* state_snapshot, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(1, "dtype must be LC_F32, LC_F16 or LC_BF16");
     if (n < 0) return fail(1, "bad size");
     if (!partials || !ticket || !sq || (n > 0 && !x)) return fail(1, "null pointer");
     if ((state == nullptr) != (state_snapshot == nullptr)) return fail(1, "state and state_snapshot go together");
     lc::ClipParams p{};
-    p.x = x; p.n = n; p.vec = !misaligned(16, x); p.partials = partials; p.ticket = ticket; p.sq = sq; p.accumulate = accumulate;
-    p.state_in = state; p.state_snapshot = state_snapshot;
+    p.x = x; p.n = n; p.vec = !misaligned(dtype ? 8 : 16, x); p.partials = partials; p.ticket = ticket; p.sq = sq; p.accumulate = accumulate;
+    p.state_in = state; p.state_snapshot = state_snapshot; p.dtype = dtype;
     return lc::launch_sqnorm(p, static_cast<hipStream_t>(stream)) ? fail(11, "sqnorm launch failed") : 0;
+}
+
+int lc_sqnorm_f32(const float* x, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, const float* state,
+                  float* state_snapshot, void* stream) {
+    return lc_sqnorm(x, 0 /* LC_F32 */, n, partials, ticket, sq, accumulate, state, state_snapshot, stream);
+}
+
+int lc_norm_clip_apply(const void* grad, int dtype, long long n, const float* sq, const float* state_in, float initial_max_norm, float scale,
+                       double momentum, void* out, float* state_out, float* norm_out, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(1, "dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (n < 0) return fail(1, "bad size");
+    if (!sq || !state_in || (n > 0 && (!grad || !out))) return fail(1, "null pointer");
+    lc::ClipParams p{};
+    p.x = grad; p.n = n; p.vec = !misaligned(dtype ? 8 : 16, grad, out); p.sq = const_cast<float*>(sq); p.state_in = state_in;
+    p.initial_max_norm = initial_max_norm; p.scale = scale; p.keep = (float)(1.0 - momentum); p.gain = (float)(momentum * (double)scale);
+    p.out = out; p.state_out = state_out; p.norm_out = norm_out; p.dtype = dtype;
+    return lc::launch_clip_apply(p, static_cast<hipStream_t>(stream)) ? fail(11, "clip launch failed") : 0;
 }
 
 int lc_norm_clip_apply_f32(const float* grad, long long n, const float* sq, const float* state_in, float initial_max_norm, float scale,
                            double momentum, float* out, float* state_out, float* norm_out, void* stream) {
-    if (n < 0) return fail(1, "bad size");
-    if (!sq || !state_in || (n > 0 && (!grad || !out))) return fail(1, "null pointer");
-    lc::ClipParams p{};
-    p.x = grad; p.n = n; p.vec = !misaligned(16, grad, out); p.sq = const_cast<float*>(sq); p.state_in = state_in;
-    p.initial_max_norm = initial_max_norm; p.scale = scale; p.keep = (float)(1.0 - momentum); p.gain = (float)(momentum * (double)scale);
-    p.out = out; p.state_out = state_out; p.norm_out = norm_out;
-    return lc::launch_clip_apply(p, static_cast<hipStream_t>(stream)) ? fail(11, "clip launch failed") : 0;
+    return lc_norm_clip_apply(grad, 0 /* LC_F32 */, n, sq, state_in, initial_max_norm, scale, momentum, out, state_out, norm_out, stream);
 }
 
 int lc_kpt_nll_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* pts2d_std, int B,
@@ -623,10 +683,15 @@ int lc_dense_select_f32(const float* pts2d, const float* inv_std, const float* p
     return rc ? fail(11, "dense select launch failed") : 0;
 }
 
-int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
-                                 float vis_thresh, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
+int lc_dense_frontend_select2(const void* xyz, const void* wlogits, const void* wscale, const float* noc_scale, const void* vis_logits,
+                                 float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
                                  int square_weights, int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d,
                                  int* out_index, int* counts, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (wscale_dtype < 0 || wscale_dtype > 2) return fail(1, "wscale_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (xyz_dtype != map_dtype && xyz_dtype != 0) return fail(1, "xyz_dtype must be map_dtype or LC_F32");
+    if (xyz_bstride < 0 || wlogits_bstride < 0 || vis_bstride < 0) return fail(1, "negative batch stride");
+    if ((xyz_bstride && xyz_bstride < 3ll * H * W) || (wlogits_bstride && wlogits_bstride < 2ll * H * W) || (vis_bstride && vis_bstride < 1ll * H * W)) return fail(1, "batch stride smaller than a sample");
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     if (mode < 0 || mode > 2 || min_count < 0 || min_count > N) return fail(1, "bad size or mode");
@@ -638,13 +703,25 @@ int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const f
     LC_REQUIRE_ALIGNED(8, out_pts2d, out_weights);
     lc::SelectParams p{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_pts2d, out_weights, out_pts3d, out_index, counts,
                        B, N, mode, (float)quantile, (float)(1.0 - quantile), square_weights, min_count, seed};
-    lc::DenseParams d{xyz, wlogits, wscale, noc_scale, nullptr, nullptr, nullptr, nullptr, B, H, W, N, top, left, sample, vis_logits, vis_thresh, nullptr};
+    lc::DenseParams d{xyz, wlogits, wscale, noc_scale, nullptr, nullptr, nullptr, nullptr, B, H, W, N, top, left, sample, vis_logits, vis_thresh, nullptr, map_dtype, wscale_dtype, xyz_dtype,
+                       xyz_bstride ? xyz_bstride : 3ll * H * W, wlogits_bstride ? wlogits_bstride : 2ll * H * W, vis_bstride ? vis_bstride : 1ll * H * W};
     return lc::launch_dense_frontend_select(p, d, static_cast<hipStream_t>(stream)) ? fail(11, "front end + select launch failed") : 0;
 }
 
-int lc_dense_aux_fwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
-                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type, float* losses,
+int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
+                                 float vis_thresh, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
+                                 int square_weights, int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d,
+                                 int* out_index, int* counts, void* stream) {
+    return lc_dense_frontend_select2(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, 0 /* LC_F32 */, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, 0, 0, B, H, W, top, left, sample, mode, quantile, square_weights, min_count, seed, out_pts2d, out_weights, out_pts3d, out_index, counts, stream);
+}
+
+int lc_dense_aux_fwd2(const void* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
+                         const void* seg_logits, const float* msk_vis, const void* wlogits, int map_dtype, long long xyz_bstride, long long seg_bstride, long long wlogits_bstride, int B, int HW, int seg_type, float* losses,
                          double* partials, unsigned* ticket, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (xyz_bstride < 0 || seg_bstride < 0 || wlogits_bstride < 0) return fail(1, "negative batch stride");
+    if ((xyz_bstride && xyz_bstride < 3ll * HW) || (seg_bstride && seg_bstride < HW) || (wlogits_bstride && wlogits_bstride < 2ll * HW)) return fail(1, "batch stride smaller than a sample");
+    if (xyz_bstride >= (1ll << 31) / (B > 0 ? B : 1) || seg_bstride >= (1ll << 31) / (B > 0 ? B : 1) || wlogits_bstride >= (1ll << 31) / (B > 0 ? B : 1)) return fail(1, "maps of 2^31 elements or more");
     if (B < 0 || HW <= 0 || seg_type < 0 || seg_type > 1) return fail(1, "bad size or loss type");
     if ((long long)B * HW * 3 >= (1ll << 31)) return fail(1, "maps of 2^31 elements or more");
     if (B == 0) return 0;
@@ -652,47 +729,85 @@ int lc_dense_aux_fwd_f32(const float* xyz, const unsigned char* msk_noc_u8, cons
     if (xyz && (!noc_tgt || (msk_noc_u8 != nullptr) == (msk_noc_f32 != nullptr))) return fail(1, "xyz needs its target and exactly one mask form");
     LC_REQUIRE_ALIGNED(8, partials);
     lc::DenseAuxParams p{xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, seg_type, losses, partials, ticket,
-                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, HW};
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, HW, map_dtype,
+                         xyz_bstride ? xyz_bstride : 3ll * HW, seg_bstride ? seg_bstride : 1ll * HW, wlogits_bstride ? wlogits_bstride : 2ll * HW};
     return lc::launch_dense_aux_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense aux loss launch failed") : 0;
 }
 
-int lc_dense_aux_bwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
-                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type,
-                         const float* g_noc, const float* g_seg, const float* g_wseg, float* d_xyz, float* d_seg, float* d_wlogits,
+int lc_dense_aux_fwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
+                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type, float* losses,
+                         double* partials, unsigned* ticket, void* stream) {
+    return lc_dense_aux_fwd2(xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, 0 /* LC_F32 */, 0, 0, 0, B, HW, seg_type, losses, partials, ticket, stream);
+}
+
+int lc_dense_aux_bwd2(const void* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
+                         const void* seg_logits, const float* msk_vis, const void* wlogits, int map_dtype, long long xyz_bstride, long long seg_bstride, long long wlogits_bstride, int B, int HW, int seg_type,
+                         const float* g_noc, const float* g_seg, const float* g_wseg, void* d_xyz, void* d_seg, void* d_wlogits,
                          void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (xyz_bstride < 0 || seg_bstride < 0 || wlogits_bstride < 0) return fail(1, "negative batch stride");
+    if ((xyz_bstride && xyz_bstride < 3ll * HW) || (seg_bstride && seg_bstride < HW) || (wlogits_bstride && wlogits_bstride < 2ll * HW)) return fail(1, "batch stride smaller than a sample");
+    if (xyz_bstride >= (1ll << 31) / (B > 0 ? B : 1) || seg_bstride >= (1ll << 31) / (B > 0 ? B : 1) || wlogits_bstride >= (1ll << 31) / (B > 0 ? B : 1)) return fail(1, "maps of 2^31 elements or more");
     if (B < 0 || HW <= 0 || seg_type < 0 || seg_type > 1) return fail(1, "bad size or loss type");
     if ((long long)B * HW * 3 >= (1ll << 31)) return fail(1, "maps of 2^31 elements or more");
     if (B == 0) return 0;
     if (!msk_vis || (d_seg && !seg_logits) || (d_wlogits && !wlogits)) return fail(1, "null pointer");
     if (d_xyz && (!xyz || !noc_tgt || (msk_noc_u8 != nullptr) == (msk_noc_f32 != nullptr))) return fail(1, "d_xyz needs xyz, its target and exactly one mask form");
     lc::DenseAuxParams p{xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, seg_type, nullptr, nullptr, nullptr,
-                         g_noc, g_seg, g_wseg, d_xyz, d_seg, d_wlogits, B, HW};
+                         g_noc, g_seg, g_wseg, d_xyz, d_seg, d_wlogits, B, HW, map_dtype,
+                         xyz_bstride ? xyz_bstride : 3ll * HW, seg_bstride ? seg_bstride : 1ll * HW, wlogits_bstride ? wlogits_bstride : 2ll * HW};
     return lc::launch_dense_aux_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense aux loss backward launch failed") : 0;
 }
 
-int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, int B, int C, int HW,
+int lc_dense_aux_bwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
+                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type,
+                         const float* g_noc, const float* g_seg, const float* g_wseg, float* d_xyz, float* d_seg, float* d_wlogits,
+                         void* stream) {
+    return lc_dense_aux_bwd2(xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, 0 /* LC_F32 */, 0, 0, 0, B, HW, seg_type, g_noc, g_seg, g_wseg, d_xyz, d_seg, d_wlogits, stream);
+}
+
+int lc_xyz_bin_loss_fwd2(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride, int B, int C, int HW,
                             float momentum, float* histogram, float* loss, float* bin_weights, double* partials, unsigned* ticket,
                             void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (logits_bstride < 0 || vis_bstride < 0) return fail(1, "negative batch stride");
+    if ((logits_bstride && logits_bstride < (long long)C * HW) || (vis_bstride && vis_bstride < HW)) return fail(1, "batch stride smaller than a sample");
+    if (logits_bstride >= (1ll << 31) / (B > 0 ? B : 1) || vis_bstride >= (1ll << 31) / (B > 0 ? B : 1)) return fail(1, "maps of 2^31 elements or more");
     if (B < 0 || C <= 0 || HW <= 0) return fail(1, "bad size");
     if (C > lc::kBinMaxChannels) return fail(1, "more than 128 code bits");
     if ((long long)B * C * HW >= (1ll << 31)) return fail(1, "logits of 2^31 elements or more");
     if (B == 0) return 0;
     if (!logits || !gt_bits || !msk_vis_logits || !histogram || !loss || !bin_weights || !partials || !ticket) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, partials);
-    const int vec = HW % 4 == 0 && !misaligned(16, logits, msk_vis_logits) && !misaligned(4, gt_bits);
-    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, histogram, momentum, loss, bin_weights, partials, ticket, nullptr, nullptr, B, C, HW, vec, 0};
+    const int vec = HW % 4 == 0 && ((logits_bstride | vis_bstride) & 3) == 0 && !misaligned(map_dtype ? 8 : 16, logits, msk_vis_logits) && !misaligned(4, gt_bits);
+    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, histogram, momentum, loss, bin_weights, partials, ticket, nullptr, nullptr, B, C, HW, vec, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * HW, vis_bstride ? vis_bstride : 1ll * HW};
     return lc::launch_xyz_bin_loss_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss launch failed") : 0;
 }
 
-int lc_xyz_bin_loss_bwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, const float* bin_weights,
-                            const float* g_loss, int B, int C, int HW, float* d_logits, void* stream) {
+int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, int B, int C, int HW,
+                            float momentum, float* histogram, float* loss, float* bin_weights, double* partials, unsigned* ticket,
+                            void* stream) {
+    return lc_xyz_bin_loss_fwd2(logits, gt_bits, msk_vis_logits, 0 /* LC_F32 */, 0, 0, B, C, HW, momentum, histogram, loss, bin_weights, partials, ticket, stream);
+}
+
+int lc_xyz_bin_loss_bwd2(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, const float* bin_weights,
+                            const float* g_loss, int map_dtype, long long logits_bstride, long long vis_bstride, int B, int C, int HW, void* d_logits, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (logits_bstride < 0 || vis_bstride < 0) return fail(1, "negative batch stride");
+    if ((logits_bstride && logits_bstride < (long long)C * HW) || (vis_bstride && vis_bstride < HW)) return fail(1, "batch stride smaller than a sample");
+    if (logits_bstride >= (1ll << 31) / (B > 0 ? B : 1) || vis_bstride >= (1ll << 31) / (B > 0 ? B : 1)) return fail(1, "maps of 2^31 elements or more");
     if (B < 0 || C <= 0 || HW <= 0) return fail(1, "bad size");
     if ((long long)B * C * HW >= (1ll << 31)) return fail(1, "logits of 2^31 elements or more");
     if (B == 0) return 0;
     if (!logits || !gt_bits || !msk_vis_logits || !bin_weights || !g_loss || !d_logits) return fail(1, "null pointer");
-    const int vec = HW % 4 == 0 && !misaligned(16, logits, msk_vis_logits, d_logits) && !misaligned(4, gt_bits);
-    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, nullptr, 0.f, nullptr, const_cast<float*>(bin_weights), nullptr, nullptr, g_loss, d_logits, B, C, HW, vec, 0};
+    const int vec = HW % 4 == 0 && ((logits_bstride | vis_bstride) & 3) == 0 && !misaligned(map_dtype ? 8 : 16, logits, msk_vis_logits, d_logits) && !misaligned(4, gt_bits);
+    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, nullptr, 0.f, nullptr, const_cast<float*>(bin_weights), nullptr, nullptr, g_loss, d_logits, B, C, HW, vec, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * HW, vis_bstride ? vis_bstride : 1ll * HW};
     return lc::launch_xyz_bin_loss_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss backward launch failed") : 0;
+}
+
+int lc_xyz_bin_loss_bwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, const float* bin_weights,
+                            const float* g_loss, int B, int C, int HW, float* d_logits, void* stream) {
+    return lc_xyz_bin_loss_bwd2(logits, gt_bits, msk_vis_logits, bin_weights, g_loss, 0 /* LC_F32 */, 0, 0, B, C, HW, d_logits, stream);
 }
 
 }  // extern "C"

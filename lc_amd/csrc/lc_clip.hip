@@ -9,6 +9,7 @@
 // No host synchronisation: the reference's `self.start and self.max_norm <= 0` test is evaluated on the device.
 #include "lc_common.h"
 #include "lc_kernels.h"
+#include "lc_map.h"
 
 namespace lc {
 namespace {
@@ -24,18 +25,19 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+template <typename T>  // element type of the gradient (lc_map.h)
 __global__ __launch_bounds__(kThreads) void lc_sqnorm_kernel(const ClipParams p) {
     __shared__ double red[4];
     __shared__ bool last;
     const long long tid = (long long)blockIdx.x * kThreads + threadIdx.x, stride = (long long)gridDim.x * kThreads;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const long long n4 = p.vec ? p.n >> 2 : 0;
-    const float4* x4 = reinterpret_cast<const float4*>(p.x);
+    const T* x = static_cast<const T*>(p.x);
     for (long long i = tid; i < n4; i += stride) {
-        const float4 v = x4[i];
+        const float4 v = map_load4(x + 4 * i);
         a0 = fmaf(v.x, v.x, a0); a1 = fmaf(v.y, v.y, a1); a2 = fmaf(v.z, v.z, a2); a3 = fmaf(v.w, v.w, a3);
     }
-    for (long long i = (n4 << 2) + tid; i < p.n; i += stride) a0 = fmaf(p.x[i], p.x[i], a0);
+    for (long long i = (n4 << 2) + tid; i < p.n; i += stride) a0 = fmaf((float)x[i], (float)x[i], a0);
     const double part = block_sum_d(((double)a0 + (double)a1) + ((double)a2 + (double)a3), red);
     if (threadIdx.x == 0) {
         // written through the caches and acknowledged before the block counts itself in, read around them by the last block: no
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(kThreads) void lc_sqnorm_kernel(const ClipParams p)
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(kThreads) void lc_clip_apply_kernel(const ClipParams p) {
     const float norm = sqrtf(*p.sq);
     const float state = *p.state_in;
@@ -64,13 +67,14 @@ __global__ __launch_bounds__(kThreads) void lc_clip_apply_kernel(const ClipParam
     const float coef = fminf(limit / (norm + 1e-6f), 1.f);  // grad.py:76-80
     const long long tid = (long long)blockIdx.x * kThreads + threadIdx.x, stride = (long long)gridDim.x * kThreads;
     const long long n4 = p.vec ? p.n >> 2 : 0;
-    const float4* x4 = reinterpret_cast<const float4*>(p.x);
-    float4* o4 = reinterpret_cast<float4*>(p.out);
+    const T* x = static_cast<const T*>(p.x);
+    T* out = static_cast<T*>(p.out);
     for (long long i = tid; i < n4; i += stride) {
-        const float4 v = x4[i];
-        o4[i] = make_float4(v.x * coef, v.y * coef, v.z * coef, v.w * coef);
+        const float4 v = map_load4(x + 4 * i);
+        const float o[4] = {v.x * coef, v.y * coef, v.z * coef, v.w * coef};
+        map_store<4>(out + 4 * i, o);
     }
-    for (long long i = (n4 << 2) + tid; i < p.n; i += stride) p.out[i] = p.x[i] * coef;
+    for (long long i = (n4 << 2) + tid; i < p.n; i += stride) out[i] = map_round<T>((float)x[i] * coef);
     if (tid == 0 && p.state_out) {
         // grad.py:22 / :26-27 in the reference's fp32 operation order
         *p.state_out = fresh ? norm * p.scale : state * p.keep + p.gain * fminf(norm, state * p.scale);
@@ -86,12 +90,12 @@ int grid_for(long long n) {
 }  // namespace
 
 int launch_sqnorm(const ClipParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(lc_sqnorm_kernel, dim3(grid_for(p.n)), dim3(kThreads), 0, stream, p);
+    LC_MAP_DISPATCH(p.dtype, hipLaunchKernelGGL(lc_sqnorm_kernel<T>, dim3(grid_for(p.n)), dim3(kThreads), 0, stream, p));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 int launch_clip_apply(const ClipParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(lc_clip_apply_kernel, dim3(grid_for(p.n)), dim3(kThreads), 0, stream, p);
+    LC_MAP_DISPATCH(p.dtype, hipLaunchKernelGGL(lc_clip_apply_kernel<T>, dim3(grid_for(p.n)), dim3(kThreads), 0, stream, p));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -13,6 +13,7 @@
 
 #include "lc_common.h"
 #include "lc_kernels.h"
+#include "lc_map.h"
 
 namespace lc {
 namespace {
@@ -40,22 +41,15 @@ template <int V>
 struct Px {
     float v[V];
 };
-template <int V>
-__device__ __forceinline__ Px<V> ld(const float* q) {
+// E: float (targets, masks) or the element type of the network's maps (lc_map.h: fp32 / fp16 / bf16, one 16- or 8-byte access)
+template <int V, typename E>
+__device__ __forceinline__ Px<V> ld(const E* q) {
     Px<V> o;
-    if constexpr (V == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(q);
-        o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
-    } else {
-        o.v[0] = q[0];
-    }
+    map_load<V>(q, o.v);
     return o;
 }
-template <int V>
-__device__ __forceinline__ void st(float* q, const Px<V>& o) {
-    if constexpr (V == 4) *reinterpret_cast<float4*>(q) = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
-    else q[0] = o.v[0];
-}
+template <int V, typename E>
+__device__ __forceinline__ void st(E* q, const Px<V>& o) { map_store<V>(q, o.v); }
 template <int V>
 __device__ __forceinline__ Px<V> mask_at(const DenseAuxParams& p, size_t i) {
     Px<V> o;
@@ -79,10 +73,14 @@ __device__ __forceinline__ float seg_term(float x, float t) {
 }
 
 // SEG: 0 BCE-with-logits, 1 Loss_seg_L1 (a template argument: twelve run-time branches per request kept the scheduler from moving anything)
-template <int V, int SEG>
+template <int V, int SEG, typename T>
 __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseAuxParams p) {
     __shared__ double red[4][3];
     __shared__ bool last;
+    const T* const xyz_map = static_cast<const T*>(p.xyz);
+    const T* const seg_map = static_cast<const T*>(p.seg_logits);
+    const T* const w_map = static_cast<const T*>(p.wlogits);
+    const unsigned xyz_bs = (unsigned)p.xyz_bs, seg_bs = (unsigned)p.seg_bs, wl_bs = (unsigned)p.wl_bs;  // sample strides of the inputs (channel slices in place)
     // 32-bit index arithmetic throughout (the entry points refuse maps of 2^31 elements or more): a 64-bit division per request costs
     // more instructions than the request's arithmetic
     const unsigned HW = (unsigned)p.HW, n = (unsigned)p.B * HW, nv = n / V;
@@ -92,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseA
         const unsigned i = j * V, b = i / HW, px = i - b * HW;
         // every request of the iteration first (up to eleven of 16 bytes), the arithmetic after them: as written before -- a map's
         // loads next to its arithmetic -- an iteration was FOUR dependent round trips (mask, coordinates, mask logits, weight logits)
-        const Px<V> t = ld<V>(p.msk_vis + i), z = ld<V>(p.seg_logits + i);
+        const Px<V> t = ld<V>(p.msk_vis + i), z = ld<V>(seg_map + (b * seg_bs + px));
         Px<V> x[3], g[3], mf, w0, w1;
         unsigned mb = 0;
         if (has_xyz) {
@@ -105,14 +103,14 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_fwd_kernel(const DenseA
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const unsigned e = (b * 3 + c) * HW + px;
-                x[c] = ld<V>(p.xyz + e);
+                x[c] = ld<V>(xyz_map + (b * xyz_bs + c * HW + px));
                 g[c] = ld<V>(p.noc_tgt + e);
             }
         }
         if (has_w) {
-            const unsigned e = b * 2 * HW + px;
-            w0 = ld<V>(p.wlogits + e);
-            w1 = ld<V>(p.wlogits + e + HW);
+            const unsigned e = b * wl_bs + px;
+            w0 = ld<V>(w_map + e);
+            w1 = ld<V>(w_map + e + HW);
         }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;  // the V pixels' terms in fp32, one fp64 add per request and loss
         if (has_xyz) {
@@ -164,9 +162,16 @@ __device__ __forceinline__ float seg_term_grad(float x, float t) {
 
 // Loads first, arithmetic and stores after them (as in the forward kernel): written map by map, a request was EIGHT dependent round
 // trips -- the compiler cannot move a map's loads above the previous map's stores (the pointers may alias)
-template <int V, int SEG>
+template <int V, int SEG, typename T>
 __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseAuxParams p) {
     const unsigned HW = (unsigned)p.HW, n = (unsigned)p.B * HW, nv = n / V;
+    const T* const xyz_map = static_cast<const T*>(p.xyz);
+    const T* const seg_map = static_cast<const T*>(p.seg_logits);
+    const T* const w_map = static_cast<const T*>(p.wlogits);
+    T* const d_xyz = static_cast<T*>(p.d_xyz);  // gradients in the maps' own type
+    T* const d_seg = static_cast<T*>(p.d_seg);
+    T* const d_wl = static_cast<T*>(p.d_wlogits);
+    const unsigned xyz_bs = (unsigned)p.xyz_bs, seg_bs = (unsigned)p.seg_bs, wl_bs = (unsigned)p.wl_bs;  // inputs only: the gradient maps are dense
     const float g0 = (p.g_noc && p.d_xyz) ? *p.g_noc / (3.f * (float)n) : 0.f;
     const float g1 = p.g_seg ? *p.g_seg / (float)n : 0.f;
     const float g2 = (p.g_wseg && p.d_wlogits) ? *p.g_wseg / (2.f * (float)n) : 0.f;
@@ -186,14 +191,14 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                x[c] = ld<V>(p.xyz + ex + c * HW);
+                x[c] = ld<V>(xyz_map + (b * xyz_bs + px + c * HW));
                 g[c] = ld<V>(p.noc_tgt + ex + c * HW);
             }
         }
-        if (do_seg) z = ld<V>(p.seg_logits + i);
+        if (do_seg) z = ld<V>(seg_map + (b * seg_bs + px));
         if (do_w) {
-            w[0] = ld<V>(p.wlogits + ew);
-            w[1] = ld<V>(p.wlogits + ew + HW);
+            w[0] = ld<V>(w_map + (b * wl_bs + px));
+            w[1] = ld<V>(w_map + (b * wl_bs + px + HW));
         }
         if (do_xyz) {
             Px<V> m;
@@ -207,14 +212,14 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
                     const float d = x[c].v[v] * m.v[v] - g[c].v[v];
                     o.v[v] = (d > 0.f ? g0 : (d < 0.f ? -g0 : 0.f)) * m.v[v];  // torch.sign(0) = 0
                 }
-                st<V>(p.d_xyz + ex + c * HW, o);
+                st<V>(d_xyz + ex + c * HW, o);
             }
         }
         if (do_seg) {
             Px<V> o;
 #pragma unroll
             for (int v = 0; v < V; ++v) o.v[v] = g1 * seg_term_grad<SEG>(z.v[v], t.v[v]);
-            st<V>(p.d_seg + i, o);
+            st<V>(d_seg + i, o);
         }
         if (do_w) {
 #pragma unroll
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
                 Px<V> o;
 #pragma unroll
                 for (int v = 0; v < V; ++v) o.v[v] = g2 * seg_term_grad<SEG>(w[c].v[v], t.v[v]);
-                st<V>(p.d_wlogits + ew + c * HW, o);
+                st<V>(d_wl + ew + c * HW, o);
             }
         }
     }
@@ -240,7 +245,11 @@ constexpr int kBinThreads = 1024;  // of 1024 threads each: every workgroup ends
 // to ~1e-7 absolute on log1p(e), e in (0, 1] -- terms of a MEAN of order 0.1-1 that is compared at 1e-6
 __device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - __logf(1.f + __expf(-fabsf(z)))); }
 
+template <typename T>
 __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const BinLossParams p) {
+    const T* const logits = static_cast<const T*>(p.logits);
+    const T* const vis_logits = static_cast<const T*>(p.msk_vis_logits);
+    const size_t lg_bs = (size_t)p.logits_bs, vis_bs = (size_t)p.vis_bs;  // sample strides of the inputs
     __shared__ double red[kBinThreads / 64][3];
     __shared__ bool last;
     __shared__ float zs[kBinMaxChannels], ws[kBinMaxChannels];
@@ -271,9 +280,9 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
                 if (i < n4) {
                     const unsigned b = i / hw4, q = i - b * hw4;
                     const unsigned e = (b * (unsigned)p.C + (unsigned)c) * hw4 + q;
-                    x[u] = reinterpret_cast<const float4*>(p.logits)[e];
+                    x[u] = map_load4(logits + ((size_t)b * lg_bs + 4 * (size_t)((unsigned)c * hw4 + q)));
                     t[u] = reinterpret_cast<const uchar4*>(p.gt_bits)[e];
-                    v[u] = reinterpret_cast<const float4*>(p.msk_vis_logits)[i];
+                    v[u] = map_load4(vis_logits + ((size_t)b * vis_bs + 4 * (size_t)q));
                 }
             }
 #pragma unroll
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
         for (unsigned i = (unsigned)chunk * kBinThreads + threadIdx.x; i < n; i += (unsigned)chunks * kBinThreads) {
             const unsigned b = i / (unsigned)p.HW, px = i - b * (unsigned)p.HW;
             const unsigned e = (b * (unsigned)p.C + (unsigned)c) * (unsigned)p.HW + px;
-            one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[i] > 0.f);
+            one((float)logits[(size_t)b * lg_bs + (size_t)c * (unsigned)p.HW + px], p.gt_bits[e] != 0, (float)vis_logits[(size_t)b * vis_bs + px] > 0.f);
             bce_sum += (double)bce4;
             bce4 = 0.f;
         }
@@ -354,7 +363,12 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
     arrival_reset(p.ticket, tid);
 }
 
+template <typename T>
 __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const BinLossParams p) {
+    const T* const logits = static_cast<const T*>(p.logits);
+    const T* const vis_logits = static_cast<const T*>(p.msk_vis_logits);
+    T* const d_logits = static_cast<T*>(p.d_logits);
+    const size_t lg_bs = (size_t)p.logits_bs, vis_bs = (size_t)p.vis_bs;
     const unsigned n = (unsigned)p.B * (unsigned)p.C * (unsigned)p.HW, C = (unsigned)p.C;
     const float g = *p.g_loss / (float)((unsigned)p.B * (unsigned)p.HW);
     // d/dx BCE(x * m, t) = (sigmoid(x m) - t) m
@@ -364,17 +378,19 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const Bin
         for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < (n >> 2); e += gridDim.x * kThreads) {
             const unsigned bc = e / hw4, q = e - bc * hw4, b = bc / C;
             const float w = p.bin_weights[bc - b * C];
-            const float4 x = reinterpret_cast<const float4*>(p.logits)[e];
+            const float4 x = map_load4(logits + ((size_t)b * lg_bs + 4 * (size_t)((bc - b * C) * hw4 + q)));
             const uchar4 t = reinterpret_cast<const uchar4*>(p.gt_bits)[e];
-            const float4 v = reinterpret_cast<const float4*>(p.msk_vis_logits)[b * hw4 + q];
-            reinterpret_cast<float4*>(p.d_logits)[e] = make_float4(one(x.x, t.x != 0, v.x > 0.f, w), one(x.y, t.y != 0, v.y > 0.f, w),
-                                                                   one(x.z, t.z != 0, v.z > 0.f, w), one(x.w, t.w != 0, v.w > 0.f, w));
+            const float4 v = map_load4(vis_logits + ((size_t)b * vis_bs + 4 * (size_t)q));
+            const float o[4] = {one(x.x, t.x != 0, v.x > 0.f, w), one(x.y, t.y != 0, v.y > 0.f, w), one(x.z, t.z != 0, v.z > 0.f, w),
+                                one(x.w, t.w != 0, v.w > 0.f, w)};
+            map_store<4>(d_logits + 4 * (size_t)e, o);
         }
         return;
     }
     for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < n; e += gridDim.x * kThreads) {
         const unsigned bc = e / (unsigned)p.HW, px = e - bc * (unsigned)p.HW, b = bc / C;
-        p.d_logits[e] = one(p.logits[e], p.gt_bits[e] != 0, p.msk_vis_logits[b * (unsigned)p.HW + px] > 0.f, p.bin_weights[bc - b * C]);
+        d_logits[e] = map_round<T>(one((float)logits[(size_t)b * lg_bs + (size_t)(bc - b * C) * (unsigned)p.HW + px], p.gt_bits[e] != 0,
+                             (float)vis_logits[(size_t)b * vis_bs + px] > 0.f, p.bin_weights[bc - b * C]));
     }
 }
 
@@ -385,39 +401,56 @@ int grid_for(long long n) {
 
 }  // namespace
 
-static bool aux_vec(const DenseAuxParams& p) {
-    const auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-    return p.HW % 4 == 0 && al(p.xyz, 16) && al(p.noc_tgt, 16) && al(p.seg_logits, 16) && al(p.msk_vis, 16) && al(p.wlogits, 16) &&
-           al(p.msk_noc_f32, 16) && al(p.msk_noc_u8, 4) && al(p.d_xyz, 16) && al(p.d_seg, 16) && al(p.d_wlogits, 16);
+static DenseAuxParams aux_with_dense_strides(DenseAuxParams p) {  // batch strides left at 0 mean dense batches
+    if (!p.xyz_bs) p.xyz_bs = 3ll * p.HW;
+    if (!p.seg_bs) p.seg_bs = p.HW;
+    if (!p.wl_bs) p.wl_bs = 2ll * p.HW;
+    return p;
+}
+static BinLossParams bin_with_dense_strides(BinLossParams p) {
+    if (!p.logits_bs) p.logits_bs = (long long)p.C * p.HW;
+    if (!p.vis_bs) p.vis_bs = p.HW;
+    return p;
 }
 
-int launch_dense_aux_fwd(const DenseAuxParams& p, hipStream_t stream) {
-    if (p.B <= 0) return 0;
+static bool aux_vec(const DenseAuxParams& p) {
+    const auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+    const uintptr_t m = 4 * (uintptr_t)map_elem_bytes(p.map_dtype);  // four elements of a network map
+    return p.HW % 4 == 0 && ((p.xyz_bs | p.seg_bs | p.wl_bs) & 3) == 0 && al(p.xyz, m) && al(p.noc_tgt, 16) && al(p.seg_logits, m) && al(p.msk_vis, 16) && al(p.wlogits, m) &&
+           al(p.msk_noc_f32, 16) && al(p.msk_noc_u8, 4) && al(p.d_xyz, m) && al(p.d_seg, m) && al(p.d_wlogits, m);
+}
+
+int launch_dense_aux_fwd(const DenseAuxParams& p_in, hipStream_t stream) {
+    if (p_in.B <= 0) return 0;
+    const DenseAuxParams p = aux_with_dense_strides(p_in);
     // one request of four pixels per thread up to four blocks per compute unit (the arrivals are counted on sharded words: lc_common.h)
     const long long n = (long long)p.B * p.HW;
     const int grid = (int)std::min<long long>(kDenseAuxMaxBlocks, std::max<long long>(1, (n + 4 * kThreads - 1) / (4 * kThreads)));
     const bool vec = aux_vec(p);
-    if (p.seg_type == 0) {
-        if (vec) hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<4, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
-        else hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<1, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<4, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
-        else hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<1, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
-    }
+    LC_MAP_DISPATCH(p.map_dtype,
+                    if (p.seg_type == 0) {
+                        if (vec) hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<4, 0, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                        else hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<1, 0, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                    } else {
+                        if (vec) hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<4, 1, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                        else hipLaunchKernelGGL((lc_dense_aux_fwd_kernel<1, 1, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                    });
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream) {
-    if (p.B <= 0) return 0;
+int launch_dense_aux_bwd(const DenseAuxParams& p_in, hipStream_t stream) {
+    if (p_in.B <= 0) return 0;
+    const DenseAuxParams p = aux_with_dense_strides(p_in);
     const bool vec = aux_vec(p);
     const int grid = grid_for(((long long)p.B * p.HW) / (vec ? 4 : 1));
-    if (p.seg_type == 0) {
-        if (vec) hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<4, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
-        else hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<1, 0>), dim3(grid), dim3(kThreads), 0, stream, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<4, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
-        else hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<1, 1>), dim3(grid), dim3(kThreads), 0, stream, p);
-    }
+    LC_MAP_DISPATCH(p.map_dtype,
+                    if (p.seg_type == 0) {
+                        if (vec) hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<4, 0, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                        else hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<1, 0, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                    } else {
+                        if (vec) hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<4, 1, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                        else hipLaunchKernelGGL((lc_dense_aux_bwd_kernel<1, 1, T>), dim3(grid), dim3(kThreads), 0, stream, p);
+                    });
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -426,19 +459,20 @@ int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream) {
     if (p.C > kBinMaxChannels) return 3;
     // 1024-thread workgroups, a thread at about four requests of four pixels (all in flight at once), at most kBinChunks workgroups
     // per code bit (B=64 128x128: 16 -> 32 chunks 38 -> 33 us; B=32 64x64: eight -> four requests 16.4 -> 12.5 us)
-    BinLossParams q = p;
+    BinLossParams q = bin_with_dense_strides(p);
     const long long req = ((long long)p.B * p.HW + 3) / 4;
     q.chunks = (int)std::min<long long>(kBinChunks, std::max<long long>(1, (req + 4 * kBinThreads - 1) / (4 * kBinThreads)));
     q.chunks = std::min(q.chunks, std::max(1, 512 / q.C));  // one round of workgroups: two of 1024 threads fit a compute unit
-    hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel, dim3(q.C * q.chunks), dim3(kBinThreads), 0, stream, q);
+    LC_MAP_DISPATCH(q.map_dtype, hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel<T>, dim3(q.C * q.chunks), dim3(kBinThreads), 0, stream, q));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int launch_xyz_bin_loss_bwd(const BinLossParams& p, hipStream_t stream) {
-    if (p.B <= 0 || p.C <= 0) return 0;
+int launch_xyz_bin_loss_bwd(const BinLossParams& p_in, hipStream_t stream) {
+    if (p_in.B <= 0 || p_in.C <= 0) return 0;
+    const BinLossParams p = bin_with_dense_strides(p_in);
     const long long n = (long long)p.B * p.C * p.HW;
     const int grid = (int)std::min<long long>(2048, std::max<long long>(1, (n + 4 * kThreads - 1) / (4 * kThreads)));
-    hipLaunchKernelGGL(lc_xyz_bin_loss_bwd_kernel, dim3(grid), dim3(kThreads), 0, stream, p);
+    LC_MAP_DISPATCH(p.map_dtype, hipLaunchKernelGGL(lc_xyz_bin_loss_bwd_kernel<T>, dim3(grid), dim3(kThreads), 0, stream, p));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "lc_common.h"
+#include "lc_map.h"
 
 namespace lc {
 
@@ -26,34 +27,39 @@ __device__ __forceinline__ void ms_merge(float& m, float& s, float om, float os)
     m = mn;
 }
 
-// log-sum-exp of lg[0..n), identical in every thread of every workgroup that calls it with the same arguments; red: NT / 64 rows of LDS
-template <int NT>
-__device__ __forceinline__ float block_lse(const float* __restrict__ lg, int n, float (*red)[2]) {
+// log-sum-exp of lg[0..n), identical in every thread of every workgroup that calls it with the same arguments; red: NT / 64 rows of LDS.
+// T: the map's element type (lc_map.h) -- four elements per request whatever the type, so a 16-bit map is reduced in exactly the order
+// (and to exactly the float) of the fp32 map holding the same values.
+template <int NT, typename T>
+__device__ __forceinline__ float block_lse(const T* __restrict__ lg, int n, float (*red)[2]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float m = -FLT_MAX, s = 0.f;
     if (tid < NT) {
-        if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(lg) & 15) == 0) {
-            // four requests in flight per thread, consumed in index order: the same updates in the same order as one request per
-            // iteration (which was one memory round trip per iteration: 4 for a 64x64 map, 16 for 128x128)
-            const float4* v4 = reinterpret_cast<const float4*>(lg);
-            constexpr int kAhead = LC_LSE_AHEAD;
-            const int n4 = n >> 2;
-            for (int i = tid; i < n4; i += kAhead * NT) {
-                float4 v[kAhead];
+        // Groups of four consecutive logits per request, four requests in flight per thread, consumed in index order: the same updates in
+        // the same order as one request per iteration (which was one memory round trip per iteration: 4 for a 64x64 map, 16 for 128x128).
+        // A map whose sample does not start on a four-element boundary (a channel slice with H*W % 4 == 2) takes four scalar loads per
+        // group instead of one vector load -- the SAME groups in the same order, so the result does not depend on where the map lies.
+        const bool vec = (reinterpret_cast<uintptr_t>(lg) & (4 * sizeof(T) - 1)) == 0;
+        constexpr int kAhead = LC_LSE_AHEAD;
+        const int n4 = n >> 2;
+        for (int i = tid; i < n4; i += kAhead * NT) {
+            float4 v[kAhead];
 #pragma unroll
-                for (int u = 0; u < kAhead; ++u)
-                    if (i + u * NT < n4) v[u] = v4[i + u * NT];
-#pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    if (i + u * NT >= n4) break;
-                    const float mn = fmaxf(fmaxf(m, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
-                    s = s * __expf(m - mn) + ((__expf(v[u].x - mn) + __expf(v[u].y - mn)) + (__expf(v[u].z - mn) + __expf(v[u].w - mn)));
-                    m = mn;
-                }
+            for (int u = 0; u < kAhead; ++u) {
+                if (i + u * NT >= n4) continue;
+                const T* q = lg + 4 * (size_t)(i + u * NT);
+                v[u] = vec ? map_load4(q) : make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
             }
-        } else {
-            for (int i = tid; i < n; i += NT) ms_push(m, s, lg[i]);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                if (i + u * NT >= n4) break;
+                const float mn = fmaxf(fmaxf(m, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+                s = s * __expf(m - mn) + ((__expf(v[u].x - mn) + __expf(v[u].y - mn)) + (__expf(v[u].z - mn) + __expf(v[u].w - mn)));
+                m = mn;
+            }
         }
+        if (tid == 0)  // the up to three logits behind the last full group (H*W odd: two)
+            for (int i = 4 * n4; i < n; ++i) ms_push(m, s, (float)lg[i]);
 #pragma unroll
         for (int k = 32; k >= 1; k >>= 1) ms_merge(m, s, __shfl_xor(m, k, kWave), __shfl_xor(s, k, kWave));
         if (lane == 0) { red[wave][0] = m; red[wave][1] = s; }

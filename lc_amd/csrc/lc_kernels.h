@@ -139,12 +139,12 @@ int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);  // 3: workspa
 size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds);
 
 struct BitsParams {
-    const float* logits;          // (B,C,H,W) code logits, C = bits[0]+bits[1]+bits[2]
+    const void* logits;           // (B,C,H,W) code logits of element type map_dtype (lc_map.h), C = bits[0]+bits[1]+bits[2]
     const unsigned char* gt_bits; // (B,C,H,W) raw ground-truth bits (training decode) or null
     const unsigned char* gt_msk;  // (B,H,W) object mask or null (all inside)
     const float* g_out;           // (B,N,3) cotangent (backward) or null
     float* out;                   // fwd: (B,N,3) normalised coordinates
-    float* d_logits;              // bwd: (B,C,H,W)
+    void* d_logits;               // bwd: (B,C,H,W), element type map_dtype
     int B, C, H, W, N, top, left, sample;
     int bits[3];
     int black_factor;             // -1: black background (default), +1 otherwise
@@ -152,6 +152,9 @@ struct BitsParams {
     const float* out_scale;       // (B,3) noc_scale, or null: out = noc * scale
     const float* out_xform;       // (B,4,4) model transform T, or null: out = (noc * scale - T[:3,3]) @ T[:3,:3]
     int out_planar;               // inference decode only: write (B,3,H,W) planes (what the dense front end reads) instead of (B,H,W,3)
+    int map_dtype;                // kMapF32 / kMapF16 / kMapBF16: element type of logits and d_logits (outputs and cotangents are fp32)
+    long long logits_bs;          // elements between consecutive samples of `logits` (C*H*W for a dense batch; larger for a channel slice of the
+                                  // network's (B,C_all,H,W) output, ptnet.py:56: no copy in front of the kernel); d_logits is dense
 };
 int launch_bits_decode_gt_fwd(const BitsParams& p, hipStream_t stream);
 int launch_bits_decode_gt_bwd(const BitsParams& p, hipStream_t stream);
@@ -171,44 +174,61 @@ struct MetricsParams {
 int launch_pose_errors(const MetricsParams& p, hipStream_t stream);
 
 struct DenseParams {
-    const float* xyz;        // (B,3,H,W) network xyz head
-    const float* wlogits;    // (B,2,H,W) weight logits
-    const float* wscale;     // (B,) per-sample weight scale
+    const void* xyz;         // (B,3,H,W) network xyz head        } element type map_dtype (lc_map.h)
+    const void* wlogits;     // (B,2,H,W) weight logits           }
+    const void* wscale;      // (B,) per-sample weight scale, element type wscale_dtype
     const float* noc_scale;  // (B,3) or null
     float* pts2d;            // (B,N,2)
     float* inv_std;          // (B,N,2)
     float* pts3d;            // (B,N,3)
     float* lse;              // (B,) saved for backward
     int B, H, W, N, top, left, sample;
-    const float* vis_logits; // (B,H,W) visibility logits or null: test-time selection mask of the sampled pixels (test.py:88-90)
+    const void* vis_logits;  // (B,H,W) visibility logits (element type map_dtype) or null: test-time selection mask of the sampled pixels (test.py:88-90)
     float vis_thresh;        //   sigmoid(logit) > vis_thresh
     unsigned char* vis_mask; // (B,N) out (with vis_logits)
+    int map_dtype;           // kMapF32 / kMapF16 / kMapBF16; the (B,N,.) rows are fp32 whatever the maps are
+    int wscale_dtype;        // element type of wscale (fp32 under autocast -- exp is an fp32 op -- or the model's 16-bit type)
+    int xyz_dtype;           // element type of xyz alone: map_dtype, or kMapF32 next to 16-bit logits (test time, binary-code heads: the decoded
+                             // coordinate planes are fp32 whatever the network's type is)
+    long long xyz_bs, wl_bs, vis_bs;  // elements between consecutive samples of xyz / wlogits / vis_logits (3HW, 2HW, HW for dense batches;
+                             // larger for channel slices of the network's (B,C_all,H,W) output, ptnet.py:56: consumed in place)
 };
+// batch strides left at 0 mean a dense batch
+inline DenseParams with_dense_strides(DenseParams p) {
+    const long long HW = (long long)p.H * p.W;
+    if (!p.xyz_bs) p.xyz_bs = 3 * HW;
+    if (!p.wl_bs) p.wl_bs = 2 * HW;
+    if (!p.vis_bs) p.vis_bs = HW;
+    return p;
+}
 int launch_dense_fwd(const DenseParams& p, hipStream_t stream);
 
 struct DenseBwdParams {
-    const float* wlogits;    // (B,2,H,W)
-    const float* wscale;     // (B,)
+    const void* wlogits;     // (B,2,H,W), element type map_dtype
+    const void* wscale;      // (B,), element type wscale_dtype
     const float* noc_scale;  // (B,3) or null
     const float* lse;        // (B,)
     const float* g_inv_std;  // (B,N,2) or null
     const float* g_pts3d;    // (B,N,3) or null
-    float* d_xyz;            // (B,3,H,W) or null
-    float* d_wlogits;        // (B,2,H,W) or null
-    float* d_wscale;         // (B,) or null
+    void* d_xyz;             // (B,3,H,W) or null  } element type map_dtype: the gradient of a map in the map's own type
+    void* d_wlogits;         // (B,2,H,W) or null  }
+    void* d_wscale;          // (B,) or null, element type wscale_dtype
     int B, H, W, N, top, left, sample;
+    int map_dtype;
+    int wscale_dtype;
+    long long wl_bs;         // elements between consecutive samples of wlogits (the gradient maps are dense)
 };
 int launch_dense_bwd(const DenseBwdParams& p, hipStream_t stream);
 
 constexpr int kDenseAuxMaxBlocks = 1024;  // rows of the caller-provided `partials` workspace of lc_dense_aux_fwd_f32 (3 doubles each)
 struct DenseAuxParams {
-    const float* xyz;                 // (B,3,HW) xyz head, or null (binary-code heads have no loss_noc)
+    const void* xyz;                  // (B,3,HW) xyz head (element type map_dtype), or null (binary-code heads have no loss_noc)
     const unsigned char* msk_noc_u8;  // (B,HW) object mask as bool bytes, or
     const float* msk_noc_f32;         // (B,HW) the same as floats (exactly one of the two with xyz)
     const float* noc_tgt;             // (B,3,HW)
-    const float* seg_logits;          // (B,HW) msk_vis_logits
+    const void* seg_logits;           // (B,HW) msk_vis_logits, element type map_dtype
     const float* msk_vis;             // (B,HW) visibility target
-    const float* wlogits;             // (B,2,HW) xyz_weight_logits, or null (no warm-up blend)
+    const void* wlogits;              // (B,2,HW) xyz_weight_logits (element type map_dtype), or null (no warm-up blend)
     int seg_type;                     // 0: binary_cross_entropy_with_logits, 1: Loss_seg_L1
     float* losses;                    // (3) out: loss_noc, loss_seg, loss_weight_seg (forward)
     double* partials;                 // (kDenseAuxMaxBlocks,3) workspace (forward)
@@ -216,19 +236,21 @@ struct DenseAuxParams {
     const float* g_noc;               // upstream cotangents: device scalars or null (backward)
     const float* g_seg;
     const float* g_wseg;
-    float* d_xyz;                     // (B,3,HW) or null (backward)
-    float* d_seg;                     // (B,HW) or null
-    float* d_wlogits;                 // (B,2,HW) or null
+    void* d_xyz;                      // (B,3,HW) or null (backward)   } element type map_dtype
+    void* d_seg;                      // (B,HW) or null                }
+    void* d_wlogits;                  // (B,2,HW) or null              }
     int B, HW;
+    int map_dtype;                    // of the network outputs (xyz, seg_logits, wlogits) and their gradients; targets and masks stay fp32 / bytes
+    long long xyz_bs, seg_bs, wl_bs;  // elements between consecutive samples of xyz / seg_logits / wlogits (channel slices in place); gradients dense
 };
 int launch_dense_aux_fwd(const DenseAuxParams& p, hipStream_t stream);
 int launch_dense_aux_bwd(const DenseAuxParams& p, hipStream_t stream);
 
 constexpr int kBinMaxChannels = 128;  // code bits of Loss_xyz_bin (3 axes x up to 24 bits)
 struct BinLossParams {
-    const float* logits;            // (B,C,HW) code logits
+    const void* logits;             // (B,C,HW) code logits, element type map_dtype
     const unsigned char* gt_bits;   // (B,C,HW) target bits as bool bytes
-    const float* msk_vis_logits;    // (B,HW)
+    const void* msk_vis_logits;     // (B,HW), element type map_dtype
     float* histogram;               // (C) EMA of the per-bit Hamming error rate: read AND updated (forward)
     float momentum;
     float* loss;                    // (1) out (forward)
@@ -236,17 +258,19 @@ struct BinLossParams {
     double* partials;               // (C * 32, 3) workspace (forward)
     unsigned* ticket;               // kArrivalWords (lc_common.h), zero between launches (forward)
     const float* g_loss;            // device scalar (backward)
-    float* d_logits;                // (B,C,HW) (backward)
+    void* d_logits;                 // (B,C,HW) (backward), element type map_dtype
     int B, C, HW;
     int vec;                        // HW % 4 == 0 and all maps 16-byte (bits: 4-byte) aligned: four pixels per request
     int chunks;                     // workgroups per code channel (set by the launcher)
+    int map_dtype;
+    long long logits_bs, vis_bs;    // elements between consecutive samples of logits / msk_vis_logits (channel slices in place); d_logits dense
 };
 int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream);  // 3: more than kBinMaxChannels bits
 int launch_xyz_bin_loss_bwd(const BinLossParams& p, hipStream_t stream);
 
 constexpr int kClipMaxBlocks = 512;  // length of the caller-provided `partials` workspace of lc_sqnorm_f32
 struct ClipParams {
-    const float* x;      // gradient
+    const void* x;       // gradient, element type dtype (lc_map.h: a 16-bit head's gradient is clipped where it lies, fp32 arithmetic)
     long long n;
     int vec;             // x (and out) 16-byte aligned: float4 stream
     // lc_sqnorm
@@ -258,9 +282,10 @@ struct ClipParams {
     // lc_clip_apply
     const float* state_in;   // max_norm before the call (<= 0: not started)
     float initial_max_norm, scale, keep, gain;  // keep = 1 - momentum, gain = momentum * scale
-    float* out;
+    void* out;           // element type dtype
     float* state_out;    // max_norm after the call, or null (do not update)
     float* norm_out;     // total norm, or null
+    int dtype;           // kMapF32 / kMapF16 / kMapBF16
 };
 int launch_sqnorm(const ClipParams& p, hipStream_t stream);
 int launch_clip_apply(const ClipParams& p, hipStream_t stream);

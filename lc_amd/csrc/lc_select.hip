@@ -79,10 +79,11 @@ struct ArraySource {
 
 // Rows that exist only as the network's maps (lc_dense_frontend_select_f32): entry n is sampled pixel n of the dense front end,
 // formed with the front end's own arithmetic (lc_dense.hip: lc_dense_frontend_fwd_kernel)
+template <typename T, typename TX>  // element type of the logit maps / of the xyz map (lc_map.h; TX = T, or float: decoded code planes)
 struct MapSource {
-    const float* lg;   // (2,H,W) weight logits of the sample
-    const float* xyz;  // (3,H,W)
-    const float* vis;  // (H,W) visibility logits or null
+    const T* lg;   // (2,H,W) weight logits of the sample
+    const TX* xyz; // (3,H,W)
+    const T* vis;  // (H,W) visibility logits or null
     float lse, scale, ns[3], vis_thresh;
     int HW, W, Wn, top, left, sample;
     __device__ __forceinline__ int pixel(int n, int& x, int& y) const {
@@ -99,9 +100,9 @@ struct MapSource {
         const int px = pixel(n, x, y);
         Entry e;
         e.u = make_float2((float)x, (float)y);
-        e.s = make_float2(lg[px], lg[HW + px]);
-        for (int d = 0; d < 3; ++d) e.X[d] = xyz[d * HW + px];
-        v = vis ? vis[px] : 0.f;
+        e.s = make_float2((float)lg[px], (float)lg[HW + px]);
+        for (int d = 0; d < 3; ++d) e.X[d] = (float)xyz[d * HW + px];
+        v = vis ? (float)vis[px] : 0.f;
         e.g = 0;
         e.src = n;
         return e;
@@ -287,14 +288,15 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
 // ones again from the maps where the selection needs them) -- the log-sum-exp by the front end's own 512
 // threads in the front end's own order, so every selected value equals what the two launches produce bit for bit -- and hands it to
 // the selection above.
+template <typename T, typename TX>
 __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(const SelectParams p, const DenseParams d) {
     extern __shared__ float srt[];
     __shared__ float red[kDenseLseThreads / kWave][2];
     const int b = blockIdx.x, tid = threadIdx.x, HW = d.H * d.W;
-    MapSource src;
-    src.lg = d.wlogits + (size_t)b * 2 * HW;
-    src.xyz = d.xyz + (size_t)b * 3 * HW;
-    src.vis = d.vis_logits ? d.vis_logits + (size_t)b * HW : nullptr;
+    MapSource<T, TX> src;
+    src.lg = static_cast<const T*>(d.wlogits) + (size_t)b * d.wl_bs;
+    src.xyz = static_cast<const TX*>(d.xyz) + (size_t)b * d.xyz_bs;
+    src.vis = d.vis_logits ? static_cast<const T*>(d.vis_logits) + (size_t)b * d.vis_bs : nullptr;
     src.vis_thresh = d.vis_thresh;
     src.HW = HW; src.W = d.W; src.top = d.top; src.left = d.left; src.sample = d.sample;
     src.Wn = (d.W - d.left + d.sample - 1) / d.sample;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
 #pragma unroll
     for (int k = 0; k < kCache; ++k)
         if (tid + k * kThreads < p.N) ec[k] = src.fetch(tid + k * kThreads, vraw[k]);  // in flight while the log-sum-exp is formed
-    src.scale = d.wscale[b];
+    src.scale = map_scalar_at(d.wscale, d.wscale_dtype, b);
     for (int k = 0; k < 3; ++k) src.ns[k] = d.noc_scale ? d.noc_scale[3 * b + k] : 1.f;
     src.lse = block_lse<kDenseLseThreads>(src.lg, 2 * HW, red);
 #pragma unroll
@@ -327,16 +329,24 @@ int launch_dense_select(const SelectParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d, hipStream_t stream) {
+int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d_in, hipStream_t stream) {
     if (p.B <= 0) return 0;
+    const DenseParams d = with_dense_strides(d_in);
     if (p.N > kFusedSelectMaxPoints) return 3;
     int P = kThreads;
     while (P < p.N) P <<= 1;
     const size_t lds = p.mode == 0 ? 0 : (size_t)P * sizeof(float);
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(lc_dense_frontend_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return 2;
-    hipLaunchKernelGGL(lc_dense_frontend_select_kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
+    if (d.xyz_dtype != d.map_dtype && d.xyz_dtype != kMapF32) return 2;
+    int rc = 0;
+    auto go = [&](auto* kernel) {
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            rc = 2;
+        else hipLaunchKernelGGL(kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
+    };
+    LC_MAP_DISPATCH(d.map_dtype,
+                    if (d.xyz_dtype == d.map_dtype) go(lc_dense_frontend_select_kernel<T, T>);
+                    else go(lc_dense_frontend_select_kernel<T, float>));
+    if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

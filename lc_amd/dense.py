@@ -18,8 +18,29 @@ def _n_points(H, W, top, left, sample):
     return ((H - top + sample - 1) // sample) * ((W - left + sample - 1) // sample)
 
 
+def _head_maps(xyz, wlogits, vis_logits=None):
+    """The heads' maps as the kernels take them (`_lib.hip_maps`): fp32 / fp16 / bf16 in their own type, dense batches or channel slices of
+    the network output in place.  -> ((xyz, wlogits, vis), (batch strides), map_dtype)"""
+    B, _, H, W = wlogits.shape
+    if xyz is not None and xyz.dtype == torch.float32 and wlogits.dtype != torch.float32:
+        # test time, binary-code heads: coordinate planes decoded to fp32 next to logits in the network's 16-bit type -- each in its own type
+        (wl, vis), (ws_, vs), code = _lib.hip_maps(xyz_weight_logits=wlogits, msk_vis_logits=None if vis_logits is None else vis_logits.reshape(B, H, W))
+        (x,), (xs,), xcode = _lib.hip_maps(xyz_noc=xyz)
+        return (x, wl, vis), (xs, ws_, vs), (code, xcode)
+    maps, strides, code = _lib.hip_maps(xyz_noc=xyz, xyz_weight_logits=wlogits, msk_vis_logits=None if vis_logits is None else vis_logits.reshape(B, H, W))
+    return maps, strides, (code, code)
+
+
+def _weight_scale(xyz_weights_scale, B):
+    """(B,1,1,1) | (B,) weight scale -> contiguous (B,) in its own element type (fp32 under autocast, where `exp` is an fp32 op; the model's
+    16-bit type in a pure half-precision model): the kernels read either."""
+    (ws,), _, _ = _lib.hip_maps(xyz_weights_scale=xyz_weights_scale.reshape(B))
+    return ws if ws.is_contiguous() else ws.contiguous()
+
+
 def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample, vis_logits=None, vis_thresh=0.5):
     lib = _lib.load()
+    (xyz, wlogits, vis_logits), (xs, ws_, vs), (code, xcode) = _head_maps(xyz, wlogits, vis_logits)
     B, _, H, W = wlogits.shape
     N = _n_points(H, W, top, left, sample)
     f = dict(device=wlogits.device, dtype=torch.float32)
@@ -27,25 +48,26 @@ def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample, vis_logits=N
     pts3d = torch.empty(B, N, 3, **f) if xyz is not None else None
     vis = torch.empty(B, N, device=wlogits.device, dtype=torch.uint8) if vis_logits is not None else None
     with _lib.on_device(wlogits.device):
-        rc = lib.lc_dense_frontend_fwd2_f32(_lib.ptr(xyz), _lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(vis_logits),
-                                            float(vis_thresh), B, H, W, top, left, sample, _lib.ptr(pts2d), _lib.ptr(inv_std), _lib.ptr(pts3d),
-                                            _lib.ptr(lse), _lib.ptr(vis), _lib.stream_ptr(wlogits.device))
-    _lib.check(rc, "lc_dense_frontend_fwd2_f32")
+        rc = lib.lc_dense_frontend_fwd3(_lib.ptr(xyz), _lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(vis_logits),
+                                        float(vis_thresh), code, xcode, _lib.MAP_DTYPES[wscale.dtype], xs, ws_, vs, B, H, W, top, left, sample, _lib.ptr(pts2d), _lib.ptr(inv_std),
+                                        _lib.ptr(pts3d), _lib.ptr(lse), _lib.ptr(vis), _lib.stream_ptr(wlogits.device))
+    _lib.check(rc, "lc_dense_frontend_fwd3")
     return (pts2d, inv_std, pts3d, lse) if vis_logits is None else (pts2d, inv_std, pts3d, lse, vis)
 
 
 def _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, shape, top, left, sample, need):
     lib = _lib.load()
     B, H, W = shape
-    f = dict(device=wlogits.device, dtype=torch.float32)
-    d_xyz = torch.empty(B, 3, H, W, **f) if need[0] else None
-    d_wl = torch.empty(B, 2, H, W, **f) if need[1] else None
-    d_ws = torch.empty(B, **f) if need[2] else None
+    (wlogits,), (ws_,), code = _lib.hip_maps(xyz_weight_logits=wlogits)
+    m = dict(device=wlogits.device, dtype=wlogits.dtype)  # the gradient of a map in the map's own type (dense)
+    d_xyz = torch.empty(B, 3, H, W, **m) if need[0] else None
+    d_wl = torch.empty(B, 2, H, W, **m) if need[1] else None
+    d_ws = torch.empty(B, device=wlogits.device, dtype=wscale.dtype) if need[2] else None
     with _lib.on_device(wlogits.device):
-        rc = lib.lc_dense_frontend_bwd_f32(_lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(lse), _lib.ptr(g_inv_std),
-                                           _lib.ptr(g_pts3d), B, H, W, top, left, sample, _lib.ptr(d_xyz), _lib.ptr(d_wl), _lib.ptr(d_ws),
-                                           _lib.stream_ptr(wlogits.device))
-    _lib.check(rc, "lc_dense_frontend_bwd_f32")
+        rc = lib.lc_dense_frontend_bwd2(_lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(lse), _lib.ptr(g_inv_std),
+                                        _lib.ptr(g_pts3d), code, _lib.MAP_DTYPES[wscale.dtype], ws_, B, H, W, top, left, sample, _lib.ptr(d_xyz), _lib.ptr(d_wl), _lib.ptr(d_ws),
+                                        _lib.stream_ptr(wlogits.device))
+    _lib.check(rc, "lc_dense_frontend_bwd2")
     return d_xyz, d_wl, d_ws
 
 
@@ -80,9 +102,10 @@ def dense_front_end(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scal
     -> pts2d (B,N,2) pixel grid, inv_std2d (B,N,2), pts3d (B,N,3); differentiable w.r.t. the first three."""
     top, left = np.random.randint(0, sample, size=2) if top_left is None else top_left  # losses.py:152
     B = xyz_weight_logits.shape[0]
-    xyz = None if xyz_noc is None else _lib.require_hip_f32("xyz_noc", xyz_noc)
-    wl = _lib.require_hip_f32("xyz_weight_logits", xyz_weight_logits)
-    ws = _lib.require_hip_f32("xyz_weights_scale", xyz_weights_scale.reshape(B))
+    # the maps in their own element type and layout: no `.float()` / `.contiguous()` copy in front of the launch (`_lib.hip_maps`; here,
+    # outside the autograd function, the two rare copies it can make -- mixed element types, samples not contiguous -- are differentiable)
+    (xyz, wl, _), _, _ = _head_maps(xyz_noc, xyz_weight_logits)
+    ws = _weight_scale(xyz_weights_scale, B)
     ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
     pts2d, inv_std, pts3d = _DenseFrontEndFn.apply(xyz, wl, ws, ns, int(top), int(left), int(sample))
     return pts2d, inv_std, (pts3d if xyz is not None else None)
@@ -96,12 +119,9 @@ def dense_front_end_with_visibility(xyz_noc: Tensor, xyz_weight_logits: Tensor, 
     visible (B,N) bool)."""
     top, left = top_left
     B, _, H, W = xyz_weight_logits.shape
-    xyz = None if xyz_noc is None else _lib.require_hip_f32("xyz_noc", xyz_noc)
-    wl = _lib.require_hip_f32("xyz_weight_logits", xyz_weight_logits)
-    ws = _lib.require_hip_f32("xyz_weights_scale", xyz_weights_scale.reshape(B))
+    ws = _weight_scale(xyz_weights_scale, B)
     ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
-    vl = _lib.require_hip_f32("msk_vis_logits", msk_vis_logits.reshape(B, H, W))
-    pts2d, inv_std, pts3d, _lse, vis = _launch_fwd(xyz, wl, ws, ns, int(top), int(left), int(sample), vl, seg_thresh)
+    pts2d, inv_std, pts3d, _lse, vis = _launch_fwd(xyz_noc, xyz_weight_logits, ws, ns, int(top), int(left), int(sample), msk_vis_logits, seg_thresh)
     return pts2d, inv_std, pts3d, vis.view(torch.bool)
 
 
@@ -134,20 +154,18 @@ def dense_front_end_select(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weigh
     lib = _lib.load()
     top, left = top_left
     B, _, H, W = xyz_weight_logits.shape
-    xyz = _lib.require_hip_f32("xyz_noc", xyz_noc)
-    wl = _lib.require_hip_f32("xyz_weight_logits", xyz_weight_logits)
-    ws = _lib.require_hip_f32("xyz_weights_scale", xyz_weights_scale.reshape(B))
+    (xyz, wl, vl), (xs, wls, vs), (code, xcode) = _head_maps(xyz_noc, xyz_weight_logits, msk_vis_logits)
+    ws = _weight_scale(xyz_weights_scale, B)
     ns = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale)
-    vl = None if msk_vis_logits is None else _lib.require_hip_f32("msk_vis_logits", msk_vis_logits.reshape(B, H, W))
     N = -(-(H - top) // sample) * -(-(W - left) // sample)
     dev = wl.device
     o_u, o_w, o_x, o_c, o_i = _select_buffers(out, B, N, dev, "dense_front_end_select")
     with _lib.on_device(dev):
-        rc = lib.lc_dense_frontend_select_f32(_lib.ptr(xyz), _lib.ptr(wl), _lib.ptr(ws), _lib.ptr(ns), _lib.ptr(vl), float(seg_thresh), B, H, W,
-                                              int(top), int(left), int(sample), SELECT_MODES[mode], float(quantile), int(square_weights),
-                                              int(min_count), int(seed) & 0xFFFFFFFF, _lib.ptr(o_u), _lib.ptr(o_w), _lib.ptr(o_x), _lib.ptr(o_i),
-                                              _lib.ptr(o_c), _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_dense_frontend_select_f32")
+        rc = lib.lc_dense_frontend_select2(_lib.ptr(xyz), _lib.ptr(wl), _lib.ptr(ws), _lib.ptr(ns), _lib.ptr(vl), float(seg_thresh), code, xcode, _lib.MAP_DTYPES[ws.dtype], xs, wls, vs,
+                                           B, H, W, int(top), int(left), int(sample), SELECT_MODES[mode], float(quantile), int(square_weights),
+                                           int(min_count), int(seed) & 0xFFFFFFFF, _lib.ptr(o_u), _lib.ptr(o_w), _lib.ptr(o_x), _lib.ptr(o_i),
+                                           _lib.ptr(o_c), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_dense_frontend_select2")
     return o_u, o_w, o_x, o_c, o_i
 
 

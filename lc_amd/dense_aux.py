@@ -29,22 +29,23 @@ def _workspace(dev):
 
 
 def fused_path_ok(*tensors) -> bool:
-    """fp32 maps on the GPU take the fused launch; half-precision heads keep the torch formulas (same device, no CPU path)."""
-    return all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() > 0) for t in tensors)
+    """Maps on the GPU take the fused launch -- fp32, or the 16-bit types of a mixed-precision backbone, read natively (`_lib.hip_maps`)."""
+    return all(t is None or (t.is_cuda and t.dtype in _lib.MAP_DTYPES and t.numel() > 0) for t in tensors)
 
 
 class _DenseAux(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, msk_noc, noc_tgt, seg_logits, msk_vis, wlogits, seg_type: int):
         lib = _lib.load()
-        seg = _lib.require_hip_f32("msk_vis_logits", seg_logits)
+        # the network's outputs in their own element type and layout (fp32 / fp16 / bf16, dense or channel slices: `_lib.hip_maps`);
+        # targets and masks are labels: fp32 / bytes
+        (x, seg, w), (xs, ss, wls), code = _lib.hip_maps(xyz_noc=xyz, msk_vis_logits=seg_logits, xyz_weight_logits=wlogits)
         B = seg.shape[0]
         HW = seg.numel() // B
         dev = seg.device
         vis = _lib.require_hip_f32("msk_vis", msk_vis.reshape(B, HW))
-        x = tgt = m8 = mf = w = None
+        tgt = m8 = mf = None
         if xyz is not None:
-            x = _lib.require_hip_f32("xyz_noc", xyz)
             tgt = _lib.require_hip_f32("xyz_noc_tgt", noc_tgt)
             m = msk_noc.reshape(B, HW).contiguous()
             if m.dtype == torch.bool:
@@ -53,15 +54,14 @@ class _DenseAux(torch.autograd.Function):
                 m8 = m
             else:
                 mf = _lib.require_hip_f32("msk_noc", m)
-        if wlogits is not None:
-            w = _lib.require_hip_f32("xyz_weight_logits", wlogits)
         losses = torch.empty(3, device=dev, dtype=torch.float32)
         partials, ticket = _workspace(dev)
         P = _lib.ptr
         with _lib.on_device(dev):
-            rc = lib.lc_dense_aux_fwd_f32(P(x), P(m8), P(mf), P(tgt), P(seg), P(vis), P(w), B, HW, int(seg_type), P(losses), P(partials),
-                                          P(ticket), _lib.stream_ptr(dev))
-        _lib.check(rc, "lc_dense_aux_fwd_f32")
+            rc = lib.lc_dense_aux_fwd2(P(x), P(m8), P(mf), P(tgt), P(seg), P(vis), P(w), code, xs, ss, wls, B, HW, int(seg_type), P(losses),
+                                       P(partials), P(ticket), _lib.stream_ptr(dev))
+        _lib.check(rc, "lc_dense_aux_fwd2")
+        ctx.map_args = (code, xs, ss, wls)
         ctx.save_for_backward(*(t for t in (x, m8, mf, tgt, seg, vis, w) if t is not None))
         ctx.have = tuple(t is not None for t in (x, m8, mf, tgt, seg, vis, w))
         ctx.seg_type, ctx.shapes = int(seg_type), (None if xyz is None else xyz.shape, seg_logits.shape, None if wlogits is None else wlogits.shape)
@@ -77,15 +77,17 @@ class _DenseAux(torch.autograd.Function):
         HW = seg.numel() // B
         dev = seg.device
         need_x, _, _, need_seg, _, need_w, _ = ctx.needs_input_grad
-        d_x = torch.empty_like(x) if (need_x and x is not None) else None
-        d_s = torch.empty_like(seg) if need_seg else None
-        d_w = torch.empty_like(w) if (need_w and w is not None) else None
+        dense = lambda t: torch.empty(t.shape, device=dev, dtype=t.dtype)  # noqa: E731  (gradient maps: dense, in the map's own type)
+        d_x = dense(x) if (need_x and x is not None) else None
+        d_s = dense(seg) if need_seg else None
+        d_w = dense(w) if (need_w and w is not None) else None
         gs = [None if g is None else g.to(dtype=torch.float32).contiguous() for g in (g0, g1, g2)]
+        code, xs, ss, wls = ctx.map_args
         P = _lib.ptr
         with _lib.on_device(dev):
-            rc = lib.lc_dense_aux_bwd_f32(P(x), P(m8), P(mf), P(tgt), P(seg), P(vis), P(w), B, HW, ctx.seg_type, P(gs[0]), P(gs[1]), P(gs[2]),
-                                          P(d_x), P(d_s), P(d_w), _lib.stream_ptr(dev))
-        _lib.check(rc, "lc_dense_aux_bwd_f32")
+            rc = lib.lc_dense_aux_bwd2(P(x), P(m8), P(mf), P(tgt), P(seg), P(vis), P(w), code, xs, ss, wls, B, HW, ctx.seg_type, P(gs[0]), P(gs[1]),
+                                       P(gs[2]), P(d_x), P(d_s), P(d_w), _lib.stream_ptr(dev))
+        _lib.check(rc, "lc_dense_aux_bwd2")
         sx, ss, sw = ctx.shapes
         return (None if d_x is None else d_x.view(sx), None, None, None if d_s is None else d_s.view(ss), None,
                 None if d_w is None else d_w.view(sw), None)
@@ -103,13 +105,12 @@ class _XyzBinLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, gt_bits, msk_vis_logits, histogram, momentum: float):
         lib = _lib.load()
-        x = _lib.require_hip_f32("xyz_noc_bin", logits)
-        B, C = x.shape[:2]
-        HW = x.numel() // (B * C)
+        B, C = logits.shape[:2]
+        HW = logits.numel() // (B * C)
+        (x, v), (ls, vs), code = _lib.hip_maps(xyz_noc_bin=logits, msk_vis_logits=msk_vis_logits.reshape(B, HW))  # a (B,1,H,W) channel slice reshapes without a copy
         dev = x.device
         t = gt_bits.contiguous()
         t = t.view(torch.uint8) if t.dtype == torch.bool else (t if t.dtype == torch.uint8 else (t != 0).view(torch.uint8))
-        v = _lib.require_hip_f32("msk_vis_logits", msk_vis_logits.reshape(B, HW))
         if not (histogram.is_cuda and histogram.dtype == torch.float32 and histogram.is_contiguous() and histogram.numel() == C):
             raise ValueError("Loss_xyz_bin: the histogram buffer is a contiguous float32 tensor of one entry per code bit on the GPU")
         loss = torch.empty(1, device=dev, dtype=torch.float32)
@@ -119,9 +120,10 @@ class _XyzBinLoss(torch.autograd.Function):
             raise ValueError("Loss_xyz_bin: more than 128 code bits")
         P = _lib.ptr
         with _lib.on_device(dev):
-            rc = lib.lc_xyz_bin_loss_fwd_f32(P(x), P(t), P(v), B, C, HW, float(momentum), P(histogram), P(loss), P(weights), P(partials),
-                                             P(ticket), _lib.stream_ptr(dev))
-        _lib.check(rc, "lc_xyz_bin_loss_fwd_f32")
+            rc = lib.lc_xyz_bin_loss_fwd2(P(x), P(t), P(v), code, ls, vs, B, C, HW, float(momentum), P(histogram), P(loss), P(weights), P(partials),
+                                          P(ticket), _lib.stream_ptr(dev))
+        _lib.check(rc, "lc_xyz_bin_loss_fwd2")
+        ctx.map_args = (code, ls, vs)
         ctx.save_for_backward(x, t, v, weights)
         ctx.shape = logits.shape
         return loss[0]
@@ -132,12 +134,13 @@ class _XyzBinLoss(torch.autograd.Function):
         x, t, v, weights = ctx.saved_tensors
         B, C = x.shape[:2]
         HW = x.numel() // (B * C)
-        d = torch.empty_like(x)
+        d = torch.empty(x.shape, device=x.device, dtype=x.dtype)  # dense, in the logits' own type
         g = g.to(dtype=torch.float32).contiguous()
+        code, ls, vs = ctx.map_args
         P = _lib.ptr
         with _lib.on_device(x.device):
-            rc = lib.lc_xyz_bin_loss_bwd_f32(P(x), P(t), P(v), P(weights), P(g), B, C, HW, P(d), _lib.stream_ptr(x.device))
-        _lib.check(rc, "lc_xyz_bin_loss_bwd_f32")
+            rc = lib.lc_xyz_bin_loss_bwd2(P(x), P(t), P(v), P(weights), P(g), code, ls, vs, B, C, HW, P(d), _lib.stream_ptr(x.device))
+        _lib.check(rc, "lc_xyz_bin_loss_bwd2")
         return d.view(ctx.shape), None, None, None, None
 
 

@@ -38,31 +38,41 @@ def _as_u8(name, t):
     if not t.is_cuda:
         raise RuntimeError(f"lc_amd: {name} is on {t.device}; the HIP path needs tensors on the MI355X (there is no CPU fallback "
                            f"in the product path)")
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)  # same bytes (0 / 1): no launch
     return (t != 0).to(torch.uint8).contiguous() if t.dtype != torch.uint8 else t.contiguous()
+
+
+def _code_logits(logits):
+    """The code logits as the kernels take them: fp32 / fp16 / bf16, in place wherever every sample is contiguous (`_lib.hip_maps`)."""
+    (lg,), (bs,), code = _lib.hip_maps(logits=logits)
+    return lg, bs, code
 
 
 def _launch_decode_gt(logits, gt_bits, gt_msk, bits, top, left, sample, out_scale=None, out_xform=None):
     lib = _lib.load()
-    B, C, H, W = logits.shape
+    lg, bs, code = _code_logits(logits)
+    B, C, H, W = lg.shape
     N = ((H - top + sample - 1) // sample) * ((W - left + sample - 1) // sample)
-    out = torch.empty(B, N, 3, device=logits.device, dtype=torch.float32)
-    with _lib.on_device(logits.device):
-        rc = lib.lc_bits_decode_gt_fwd2_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(out_scale), _lib.ptr(out_xform),
-                                            B, C, H, W, *bits, int(_black_background), top, left, sample, _lib.ptr(out),
-                                            _lib.stream_ptr(logits.device))
-    _lib.check(rc, "lc_bits_decode_gt_fwd2_f32")
+    out = torch.empty(B, N, 3, device=lg.device, dtype=torch.float32)
+    with _lib.on_device(lg.device):
+        rc = lib.lc_bits_decode_gt_fwd3(_lib.ptr(lg), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(out_scale), _lib.ptr(out_xform), code, bs,
+                                        B, C, H, W, *bits, int(_black_background), top, left, sample, _lib.ptr(out),
+                                        _lib.stream_ptr(lg.device))
+    _lib.check(rc, "lc_bits_decode_gt_fwd3")
     return out
 
 
 def _launch_decode_gt_bwd(logits, gt_bits, gt_msk, g_out, bits, top, left, sample, black, out_scale=None, out_xform=None):
     lib = _lib.load()
-    B, C, H, W = logits.shape
-    d = torch.empty_like(logits)
-    with _lib.on_device(logits.device):
-        rc = lib.lc_bits_decode_gt_bwd2_f32(_lib.ptr(logits), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(out_scale), _lib.ptr(out_xform),
-                                            _lib.ptr(g_out), B, C, H, W, *bits, int(black), top, left, sample, _lib.ptr(d),
-                                            _lib.stream_ptr(logits.device))
-    _lib.check(rc, "lc_bits_decode_gt_bwd2_f32")
+    lg, bs, code = _code_logits(logits)
+    B, C, H, W = lg.shape
+    d = torch.empty(B, C, H, W, device=lg.device, dtype=lg.dtype)  # the gradient of a map in the map's own type, dense
+    with _lib.on_device(lg.device):
+        rc = lib.lc_bits_decode_gt_bwd3(_lib.ptr(lg), _lib.ptr(gt_bits), _lib.ptr(gt_msk), _lib.ptr(out_scale), _lib.ptr(out_xform),
+                                        _lib.ptr(g_out), code, bs, B, C, H, W, *bits, int(black), top, left, sample, _lib.ptr(d),
+                                        _lib.stream_ptr(lg.device))
+    _lib.check(rc, "lc_bits_decode_gt_bwd3")
     return d
 
 
@@ -89,7 +99,7 @@ def decode_with_gt_strided(logits: Tensor, gt_raw_bits: Tensor, bit_cnt, gt_msk:
     sub-sample first, decode second).  out_scale (B,3) / out_xform (B,4,4): the callers' `noc * noc_scale` and
     `(xyz - T[:, :3, 3]) @ T[:, :3, :3]` (losses.py:17-47) applied by the same launch (and undone by the backward launch); neither
     takes a gradient."""
-    lg = _lib.require_hip_f32("logits", logits)
+    lg = _code_logits(logits)[0]  # validated here; consumed in its own element type and layout (no `.float()`, no `.contiguous()`)
     bits = _bits3(bit_cnt, lg.shape[1])
     gb = _as_u8("gt_raw_bits", gt_raw_bits)
     gm = None if gt_msk is None else _as_u8("gt_msk", gt_msk)
@@ -110,13 +120,14 @@ def nn_logits2noc(logits: Tensor, bit_cnt: Union[int, List[int]], nearest_lut: T
     if nearest_lut is not None:
         raise NotImplementedError("lc_amd.floatbits: nearest_lut is not used by any reference call site")
     lib = _lib.load()
-    lg = _lib.require_hip_f32("logits", logits)
+    lg, bs, code = _code_logits(logits)
     B, C, H, W = lg.shape
     bits = _bits3(bit_cnt, C)
     noc = torch.empty(B, H, W, 3, device=lg.device, dtype=torch.float32)
     with _lib.on_device(lg.device):
-        rc = lib.lc_bits_decode_f32(_lib.ptr(lg), B, C, H, W, *bits, int(_black_background), _lib.ptr(noc), _lib.stream_ptr(lg.device))
-    _lib.check(rc, "lc_bits_decode_f32")
+        rc = lib.lc_bits_decode3(_lib.ptr(lg), None, None, code, bs, B, C, H, W, *bits, int(_black_background), 0, _lib.ptr(noc),
+                                 _lib.stream_ptr(lg.device))
+    _lib.check(rc, "lc_bits_decode3")
     return noc
 
 
@@ -126,16 +137,16 @@ def nn_logits2xyz_planes(logits: Tensor, bit_cnt: Union[int, List[int]], noc_sca
     (losses.py:17-47) in one launch: Gray decode, `* noc_scale`, `(. - T[:, :3, 3]) @ T[:, :3, :3]`, channel-first layout (what the
     dense front end reads)."""
     lib = _lib.load()
-    lg = _lib.require_hip_f32("logits", logits)
+    lg, bs, code = _code_logits(logits)
     B, C, H, W = lg.shape
     bits = _bits3(bit_cnt, C)
     sc = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale.reshape(B, 3))
     xf = None if model_transform is None else _lib.require_hip_f32("model_transform", model_transform.reshape(B, 4, 4))
     out = torch.empty(B, 3, H, W, device=lg.device, dtype=torch.float32)
     with _lib.on_device(lg.device):
-        rc = lib.lc_bits_decode2_f32(_lib.ptr(lg), _lib.ptr(sc), _lib.ptr(xf), B, C, H, W, *bits, int(_black_background), 1, _lib.ptr(out),
-                                     _lib.stream_ptr(lg.device))
-    _lib.check(rc, "lc_bits_decode2_f32")
+        rc = lib.lc_bits_decode3(_lib.ptr(lg), _lib.ptr(sc), _lib.ptr(xf), code, bs, B, C, H, W, *bits, int(_black_background), 1, _lib.ptr(out),
+                                 _lib.stream_ptr(lg.device))
+    _lib.check(rc, "lc_bits_decode3")
     return out
 
 

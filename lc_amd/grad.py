@@ -35,9 +35,9 @@ def _launch_sqnorm(grads, workspace, state):
     with _lib.on_device(dev):
         for i, g in enumerate(grads):
             last = i == len(grads) - 1
-            rc = lib.lc_sqnorm_f32(_lib.ptr(g), g.numel(), _lib.ptr(partials), _lib.ptr(ticket), _lib.ptr(sq), int(i > 0),
-                                   _lib.ptr(state) if last else None, _lib.ptr(snap) if last else None, _lib.stream_ptr(dev))
-            _lib.check(rc, "lc_sqnorm_f32")
+            rc = lib.lc_sqnorm(_lib.ptr(g), _lib.MAP_DTYPES[g.dtype], g.numel(), _lib.ptr(partials), _lib.ptr(ticket), _lib.ptr(sq), int(i > 0),
+                               _lib.ptr(state) if last else None, _lib.ptr(snap) if last else None, _lib.stream_ptr(dev))
+            _lib.check(rc, "lc_sqnorm")
     return sq, snap
 
 
@@ -52,10 +52,10 @@ def _launch_apply(grads, sq, state_before, state, initial_max_norm, scale, momen
         for i, g in enumerate(grads):
             o = torch.empty_like(g)
             last = i == len(grads) - 1
-            rc = lib.lc_norm_clip_apply_f32(_lib.ptr(g), g.numel(), _lib.ptr(sq), _lib.ptr(state_before), float(initial_max_norm),
-                                            float(scale), float(momentum), _lib.ptr(o), _lib.ptr(state) if last else None,
-                                            _lib.ptr(norm) if last else None, _lib.stream_ptr(dev))
-            _lib.check(rc, "lc_norm_clip_apply_f32")
+            rc = lib.lc_norm_clip_apply(_lib.ptr(g), _lib.MAP_DTYPES[g.dtype], g.numel(), _lib.ptr(sq), _lib.ptr(state_before), float(initial_max_norm),
+                                        float(scale), float(momentum), _lib.ptr(o), _lib.ptr(state) if last else None,
+                                        _lib.ptr(norm) if last else None, _lib.stream_ptr(dev))
+            _lib.check(rc, "lc_norm_clip_apply")
             outs.append(o)
     return outs, norm
 
@@ -89,8 +89,9 @@ class NormClipper(torch.nn.Module):
         tensors = [grads] if single else list(grads)
         if not tensors:
             return tensors
-        in_dtypes = [g.dtype for g in tensors]  # fp16 / bf16 gradients of a mixed-precision head are clipped in fp32 and handed
-        tensors = [_lib.require_hip_f32("grad", g) for g in tensors]  # back in their own dtype (autograd rejects a hook that changes it)
+        # fp16 / bf16 gradients of a mixed-precision head are read and written in their own type (fp32 arithmetic inside): no cast each way,
+        # and the hook returns the dtype it was given (autograd rejects a hook that changes it)
+        tensors = [_lib.require_hip_map("grad", g) for g in tensors]
         dev = tensors[0].device
         if self.max_norm.device != dev:  # module left on the CPU: the state follows the gradients (once)
             self.max_norm = self.max_norm.to(device=dev)
@@ -102,5 +103,4 @@ class NormClipper(torch.nn.Module):
             if self.shard_loss_scale != 1.0:
                 sq.mul_(self.shard_loss_scale * self.shard_loss_scale)  # the norm of the job's gradient, not of this rank's loss
         clipped, self.last_norm = _launch_apply(tensors, sq, before, self.max_norm, self.initial_max_norm, self.scale, self.momentum)
-        clipped = [o if o.dtype == dt else o.to(dt) for o, dt in zip(clipped, in_dtypes)]  # lib/utils/grad.py:78-82 keeps the dtype
         return clipped[0] if single else clipped

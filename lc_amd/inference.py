@@ -76,8 +76,9 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     if "xyz_noc" in out_dict and gt_dict.get("model_transform", None) is None and gt_dict.get("bit_cnt", None) is None:
         # continuous head: the kernel scales the normalised coordinates itself (losses.py:17-22 is that one multiply)
         xyz_map, noc_scale = out_dict["xyz_noc"], gt_dict["noc_scale"]
-    elif "xyz_noc_bin" in out_dict and out_dict["xyz_noc_bin"].dtype == torch.float32:
-        # binary-code head: Gray decode, noc_scale, model transform and the channel-first layout in one launch
+    elif "xyz_noc_bin" in out_dict:
+        # binary-code head (fp32, fp16 or bf16 logits, read in their own type): Gray decode, noc_scale, model transform and the channel-first
+        # layout in one launch
         xyz_map = floatbits.nn_logits2xyz_planes(out_dict["xyz_noc_bin"], gt_dict["bit_cnt"], gt_dict["noc_scale"],
                                                  gt_dict.get("model_transform", None))
         noc_scale = None

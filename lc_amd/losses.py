@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import dense_aux, floatbits
+from . import _lib, dense_aux, floatbits
 from . import transforms as xforms
 from .cov_mixed import Loss_cov_mixed
 from .dense import dense_front_end
@@ -113,7 +113,7 @@ def dense_pnp_matching_from_noc_bin(noc_bin_out_logits: Tensor, noc_bin_gt_raw: 
 
 def _decode_bin_points(logits, raw_bits, noc_mask, noc_scale, gt_dict, sample, top_left):
     T = gt_dict.get("model_transform", None)
-    if logits.is_cuda and logits.dtype == torch.float32 and noc_scale.dtype == torch.float32 and (T is None or T.dtype == torch.float32):
+    if logits.is_cuda and logits.dtype in _lib.MAP_DTYPES and noc_scale.dtype == torch.float32 and (T is None or T.dtype == torch.float32):  # fp32 / fp16 / bf16 logits, read natively
         # decode, `noc * noc_scale` and the model transform `(xyz - T[:, :3, 3]) @ T[:, :3, :3]` in ONE launch each way
         return floatbits.decode_with_gt_strided(logits, raw_bits, gt_dict["bit_cnt"], noc_mask, sample=sample, top_left=top_left,
                                                 out_scale=noc_scale, out_xform=T)

@@ -81,6 +81,7 @@ def apply(setter):
     setter(losses, "dense_front_end", _dense_front_end)
     setter(losses.floatbits, "decode_with_gt_strided", _decode_with_gt_strided)
     setter(_lib, "require_hip_f32", lambda name, t: t.contiguous())
+    setter(_lib, "require_hip_map", lambda name, t: t.contiguous())
     setter(cov_mixed, "_launch_loss", _launch_loss)
     setter(cov_mixed, "_launch_scale", _launch_scale)
     setter(kpt, "_launch_kpt", _launch_kpt)

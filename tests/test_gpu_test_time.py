@@ -150,7 +150,7 @@ def test_test_time_path_stage_by_stage(name, B):
         key = "weighted"
     w_state, _, w_ret = pnp_ceres.solve_device(gt["out_K"], wx, wu, ww, ref_state, wc, weights_are_icov=True, nan_to_num=True)
     L = np.zeros((B, N, 2, 2), np.float32)
-    L[..., 0, 0], L[..., 1, 1] = np.sqrt(ww.cpu().numpy()[..., 0]), np.sqrt(ww.cpu().numpy()[..., 1])
+    L[..., 0, 0], L[..., 1, 1] = np.sqrt(np.abs(ww.cpu().numpy()[..., 0])), np.sqrt(np.abs(ww.cpu().numpy()[..., 1]))  # (entries behind a row's count are not defined)
     o_w, _, o_ret = pnp_oracle.solve_batched(ref_state.cpu().numpy(), Kc, wu.cpu().numpy(), wx.cpu().numpy(), L, wc.cpu().numpy())
     assert np.array_equal(w_ret.cpu().numpy()[live], o_ret[live])
     dq, dt = pose_err(w_state.cpu().numpy()[live], o_w[live])
