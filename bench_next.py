@@ -120,6 +120,31 @@ def main():
     line("lc_bits_decode_kernel (planes, scale + model transform)", us, B * H * W * (C * 4 + 12), B, "samples", B=B, C=C, H=H, W=W,
          note="replaces decode + broadcast multiply + subtract + batched GEMM + permute-copy")
 
+    # ---- f1 / f3 on the maps a mixed-precision backbone emits (BASELINE.json configs[2] bf16, configs[4] fp16): read in their own type, no
+    # up-cast copy in front (round 3: a 132 MB cast pass each way around a 124 MB kernel at this shape); bytes priced at 2 per map element ----
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        lg16 = lg.to(dt)
+        us = ev(lambda: floatbits.nn_logits2noc(lg16, bits), dev, a.reps)
+        line(f"lc_bits_decode_kernel [{tag} logits]", us, B * H * W * (C * 2 + 12), B, "samples", B=B, C=C, H=H, W=W, map_dtype=tag)
+        us = ev(lambda: floatbits.nn_logits2xyz_planes(lg16, bits, scl, Tm), dev, a.reps)
+        line(f"lc_bits_decode_kernel (planes, scale + model transform) [{tag} logits]", us, B * H * W * (C * 2 + 12), B, "samples", B=B, C=C, H=H, W=W, map_dtype=tag)
+        us = ev(lambda: floatbits._launch_decode_gt(lg16, gb, gm, b3, 0, 0, 1), dev, a.reps)
+        line(f"lc_bits_decode_gt_fwd_kernel [{tag} logits]", us, B * H * W * (C * 2 + C + 1 + 12), B, "samples", B=B, C=C, H=H, W=W, map_dtype=tag)
+        us = ev(lambda: floatbits._launch_decode_gt_bwd(lg16, gb, gm, gn, b3, 0, 0, 1, True), dev, a.reps)
+        line(f"lc_bits_decode_gt_bwd_kernel [{tag} logits, {tag} gradient]", us, B * H * W * (2 * C * 2 + C + 1 + 12), B, "samples", B=B, C=C, H=H, W=W, map_dtype=tag)
+        xyz16, wl16 = xyz.to(dt), wl.to(dt)
+        o16 = dense._launch_fwd(xyz16, wl16, ws, ns, 0, 0, sample)
+        us = ev(lambda: dense._launch_fwd(xyz16, wl16, ws, ns, 0, 0, sample), dev, a.reps)
+        line(f"lc_dense_frontend_fwd_kernel [{tag} maps]", us, B * (2 * H * W * 2 + 3 * N * 2 + 7 * N * 4), B, "samples", B=B, H=H, W=W, sample=sample, map_dtype=tag)
+        us = ev(lambda: dense._launch_bwd(wl16, ws, ns, o16[3], gi, gp, (B, H, W), 0, 0, sample, (True, True, True)), dev, a.reps)
+        line(f"lc_dense_frontend_bwd_kernel [{tag} maps, {tag} gradients]", us, B * (2 * H * W * 2 + 5 * N * 4 + 5 * H * W * 2), B, "samples", B=B, H=H, W=W,
+             sample=sample, map_dtype=tag)
+        vl16 = torch.randn(B, 1, H, W, generator=g).to(dev).to(dt)
+        us = ev(lambda: dense.dense_front_end_select(xyz16, wl16, ws, ns, vl16, "quantile_in_mask", quantile=0.2, sample=1), dev, a.reps)
+        line(f"lc_dense_frontend_select_kernel (quantile_in_mask, 16384 candidates per object) [{tag} maps]", us, B * (6 * H * W * 2 + int(0.4 * H * W) * 32), B, "samples",
+             note="zlmo's test-time shape (configs/zlmo.yaml:30-37): front end + selection of 128x128 candidates per object in one launch; latency-shaped "
+                  "(one workgroup per object, radix select of 16384 keys in LDS), not bandwidth-shaped", B=B, H=H, W=W, sample=1, map_dtype=tag)
+
     # ---- a19, dense heads: the auxiliary losses of Loss_fn (one launch each way) and the code loss (one pass over the logits) ----
     from lc_amd import dense_aux
     xyz_a = torch.randn(B, 3, H, W, generator=g).to(dev)

@@ -79,34 +79,99 @@ __device__ __forceinline__ void store_px(T* o, const float (&v)[V]) {
     map_store<V>(o, v, V == 4 && LC_NT_GRAD_STORES);  // d_logits: written once, read by the next kernel of the backward pass
 }
 
+// The channels of an axis are requested kChanBatch at a time, every request of a batch before the first use: walked one channel at a time
+// (load, use, load, ...) a wavefront had ONE request in flight, and the decode of 16-bit logits -- half the bytes -- was hardly faster than
+// fp32 (17.0 vs 19.3 us at 64 x 21 x 128 x 128: a chain of 21 memory round trips per thread, not bandwidth).  The kernels request the first
+// batch of all three axes up front.
+#ifndef LC_BITS_GT_PIPELINE
+#define LC_BITS_GT_PIPELINE 1
+#endif
+#ifndef LC_BITS_GT_BATCH
+#define LC_BITS_GT_BATCH 1
+#endif
+constexpr int kGrayBatch = 8, kGtBatch = LC_BITS_GT_BATCH;  // channels per batch: inference decode / training decode (which also holds the ground-truth bits and the axis state)
+template <int V, int kChanBatch>
+struct ChanBatch {
+    float x[kChanBatch][V];
+    unsigned t[kChanBatch];  // the V ground-truth bits of the channel as loaded (one byte each): unpacked where they are used -- a compare next
+                             // to the load is a wait for that load
+    __device__ __forceinline__ bool bit(int j, int v) const { return ((t[j] >> (8 * v)) & 0xffu) != 0; }
+};
+template <int V, typename T, int kChanBatch>
+__device__ __forceinline__ void load_channels(const T* lg, const unsigned char* gt, size_t stride, int k0, int n, ChanBatch<V, kChanBatch>& q) {
+    // branch-free: a slot behind the axis' last channel re-requests that channel (a cache hit) instead of being skipped -- with a branch per
+    // slot every request sat in a basic block of its own behind an s_waitcnt vmcnt(0), i.e. one request in flight again
+#pragma unroll
+    for (int j = 0; j < kChanBatch; ++j) {
+        const size_t k = (size_t)min(k0 + j, n - 1);
+        load_px<V>(lg + k * stride, q.x[j]);
+        if (gt) {
+            if constexpr (V == 4) q.t[j] = *reinterpret_cast<const unsigned*>(gt + k * stride);
+            else q.t[j] = gt[k * stride];
+        }
+    }
+}
+
+// first: channels 0 .. kChanBatch-1 of the axis, already requested
 template <int V, typename T>
 __device__ __forceinline__ void decode_axis_gt(const T* lg, const unsigned char* gt, size_t stride, int n, int black_factor,
-                                               AxisState (&st)[V]) {
-    for (int k = 0; k < n; ++k) {
-        float x[V];
-        bool bt[V];
-        load_px<V>(lg + k * stride, x);
-        load_px<V>(gt + k * stride, bt);
+                                               AxisState (&st)[V], const ChanBatch<V, kGtBatch>& first) {
+    constexpr int kChanBatch = kGtBatch;
+    auto walk = [&](const ChanBatch<V, kGtBatch>& q, int k0) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) st[v].push(k, n, x[v], bt[v], black_factor);
+        for (int j = 0; j < kChanBatch; ++j) {
+            if (k0 + j < n) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) st[v].push(k0 + j, n, q.x[j][v], q.bit(j, v), black_factor);
+            }
+        }
+    };
+#if LC_BITS_GT_PIPELINE
+    // one batch ahead: the next batch is requested before the current one is walked (the last request repeats the axis' last channel)
+    ChanBatch<V, kGtBatch> cur = first;
+    for (int k0 = 0; k0 < n; k0 += kChanBatch) {
+        ChanBatch<V, kGtBatch> nxt;
+        load_channels<V>(lg, gt, stride, k0 + kChanBatch, n, nxt);
+        walk(cur, k0);
+        cur = nxt;
     }
+#else
+    walk(first, 0);
+    for (int k0 = kChanBatch; k0 < n; k0 += kChanBatch) {  // more than kChanBatch code bits on the axis
+        ChanBatch<V, kGtBatch> more;
+        load_channels<V>(lg, gt, stride, k0, n, more);
+        walk(more, k0);
+    }
+#endif
 }
 
 // floatbits.py:194-223 for one axis of V pixels
 template <int V, typename T>
-__device__ __forceinline__ void decode_gray(const T* lg, size_t stride, int n, bool black, float (&out)[V]) {
+__device__ __forceinline__ void decode_gray(const T* lg, size_t stride, int n, bool black, float (&out)[V], const ChanBatch<V, kGrayBatch>& first) {
+    constexpr int kChanBatch = kGrayBatch;
     unsigned code[V];
     float last[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) code[v] = 0;
-    for (int k = 0; k < n; ++k) {
-        load_px<V>(lg + k * stride, last);
+    for (int v = 0; v < V; ++v) { code[v] = 0; last[v] = 0.f; }
+    auto walk = [&](const ChanBatch<V, kGrayBatch>& q, int k0) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            bool bit = last[v] > 0.f;
-            if (black && k < 2) bit = !bit;
-            code[v] = (code[v] << 1) | (bit ? 1u : 0u);
+        for (int j = 0; j < kChanBatch; ++j) {
+            if (k0 + j < n) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    last[v] = q.x[j][v];
+                    bool bit = last[v] > 0.f;
+                    if (black && k0 + j < 2) bit = !bit;
+                    code[v] = (code[v] << 1) | (bit ? 1u : 0u);
+                }
+            }
         }
+    };
+    walk(first, 0);
+    for (int k0 = kChanBatch; k0 < n; k0 += kChanBatch) {  // more than kChanBatch code bits on the axis
+        ChanBatch<V, kGrayBatch> more;
+        load_channels<V>(lg, static_cast<const unsigned char*>(nullptr), stride, k0, n, more);
+        walk(more, k0);
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -160,13 +225,21 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_fwd_kernel(const B
             for (int v = 0; v < V; ++v) in_msk[v] = true;
         }
         float res[V][3];
+        ChanBatch<V, kGtBatch> q[3];
         int c0 = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {  // every axis' first batch of channels in flight together
+            load_channels<V>(static_cast<const T*>(p.logits) + (size_t)b * p.logits_bs + (size_t)c0 * HW + px, p.gt_bits + ((size_t)b * p.C + c0) * HW + px,
+                             HW, 0, p.bits[a], q[a]);
+            c0 += p.bits[a];
+        }
+        c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
             const size_t base = ((size_t)b * p.C + c0) * HW + px, lbase = (size_t)b * p.logits_bs + (size_t)c0 * HW + px;
             AxisState st[V];
-            decode_axis_gt<V>(static_cast<const T*>(p.logits) + lbase, p.gt_bits + base, HW, nb, p.black_factor, st);
+            decode_axis_gt<V>(static_cast<const T*>(p.logits) + lbase, p.gt_bits + base, HW, nb, p.black_factor, st, q[a]);
 #pragma unroll
             for (int v = 0; v < V; ++v) res[v][a] = st[v].finish(nb, in_msk[v]).val / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
@@ -218,7 +291,17 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const B
             any = any || live[v];
         }
         const OutMap om(p, b);
+        ChanBatch<V, kGtBatch> q[3];
         int c0 = 0;
+        if (any) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {  // every axis' first batch of channels in flight together
+                load_channels<V>(static_cast<const T*>(p.logits) + (size_t)b * p.logits_bs + (size_t)c0 * HW + px,
+                                 p.gt_bits + ((size_t)b * p.C + c0) * HW + px, HW, 0, p.bits[a], q[a]);
+                c0 += p.bits[a];
+            }
+        }
+        c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
@@ -229,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const B
             for (int v = 0; v < V; ++v) { idx[v] = -1; g[v] = 0.f; }
             if (any) {
                 AxisState st[V];
-                decode_axis_gt<V>(static_cast<const T*>(p.logits) + lbase, p.gt_bits + base, HW, nb, p.black_factor, st);
+                decode_axis_gt<V>(static_cast<const T*>(p.logits) + lbase, p.gt_bits + base, HW, nb, p.black_factor, st, q[a]);
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     if (live[v]) {
@@ -259,12 +342,20 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_kernel(const BitsPara
         const int b = (int)(i0 / HW);
         const size_t px = i0 % HW;
         float res[V][3];
+        ChanBatch<V, kGrayBatch> q[3];
         int c0 = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {  // every axis' first batch of channels in flight together
+            load_channels<V>(static_cast<const T*>(p.logits) + (size_t)b * p.logits_bs + (size_t)c0 * HW + px, static_cast<const unsigned char*>(nullptr), HW,
+                             0, p.bits[a], q[a]);
+            c0 += p.bits[a];
+        }
+        c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int nb = p.bits[a];
             float val[V];
-            decode_gray<V>(static_cast<const T*>(p.logits) + (size_t)b * p.logits_bs + (size_t)c0 * HW + px, HW, nb, p.black_factor < 0, val);
+            decode_gray<V>(static_cast<const T*>(p.logits) + (size_t)b * p.logits_bs + (size_t)c0 * HW + px, HW, nb, p.black_factor < 0, val, q[a]);
 #pragma unroll
             for (int v = 0; v < V; ++v) res[v][a] = val[v] / ((float)((1 << nb) - 1) * 0.5f) - 1.f;
             c0 += nb;
