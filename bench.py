@@ -383,7 +383,7 @@ def main():
 
     step_fused = main_unit.launch_fused
 
-    # --launch streams (NOT the default, reported separately in DESIGN.md): `slots` independent B-sized batches in flight, each
+    # --launch streams (NOT the default, reported separately in profiles/r03/NOTES.md): `slots` independent B-sized batches in flight, each
     # with its own inputs, outputs and stream -- the serving-side picture (independent requests), where a 512-workgroup step
     # leaves most of the chip idle.  A step is still one fused launch over one batch; steps of different slots overlap.
     slot_state = []

@@ -236,7 +236,7 @@ def main():
         K, X, U, Wt, S0 = (bt[k].to(dev) for k in ("K", "pts3d", "pts2d", "inv_std", "start"))
         us = ev(lambda: pnp_ceres.solve_device(K, X, U, Wt, S0), dev, a.reps)
         line("lc_pnp_lm_wide_kernel", us, 256 * (Nw * 28 + 36 + 28 + 36), 256, "poses",
-             note="latency/VALU-bound LM iterations (see DESIGN.md 4.2)", B=256, N=Nw)
+             note="latency/VALU-bound LM iterations (see DESIGN.md 4, lc_pnp_lm_kernel)", B=256, N=Nw)
 
 
 if __name__ == "__main__":

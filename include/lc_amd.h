@@ -262,7 +262,7 @@ int lc_pnp_ransac_init3_f32(const float *K, const float *pts3d, const float *pts
  *  - ticketed != 0 and workspace != NULL: TWO launches (hypotheses; scoring + selection).  One workgroup per (pose, chunk of 64
  *    points) scores, counts itself in, and the workgroup that completes the pose's count selects; nobody waits.  The chunk partials
  *    are still summed in chunk order: every output equals the three launches'.  Same workspace contract as init3 (the arrival
- *    counters in it are zeroed by the hypotheses launch).  Measured slower than the three launches on MI355X: an
+ *    counters in it are zeroed by the hypotheses launch).  Measured slower than the three launches on MI355X (profiles/r03/NOTES.md 8): an
  *    option for the record, not the default of the Python host side. */
 int lc_pnp_ransac_init4_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
                             float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,

@@ -171,7 +171,7 @@ __device__ __forceinline__ void wave_sync() {
 // Values handed from one workgroup to another INSIDE a launch (the workgroups may sit on different XCDs, whose L2s are not
 // coherent with each other): written through and read around the caches as agent-scope relaxed atomics (sc1 accesses).  The
 // writer orders them before its arrival count with xcd_stores_done() + a workgroup barrier; no cache-wide fence anywhere
-// (DESIGN.md 4.1 "Tiled form" has the measurements behind this choice).
+// (profiles/r03/NOTES.md 4.1 "Tiled form" has the measurements behind this choice).
 template <class T>
 __device__ __forceinline__ void xcd_store(T* q, T v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T>

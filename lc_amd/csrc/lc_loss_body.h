@@ -12,7 +12,7 @@
 //   H = sum w (J J^T + r Hess r);  S = H^-1 (or I if H is not SPD);  Mc = sum w^2 c J J^T;  v = sum w e J
 //   G = d(bbox corners)/d(pose);  P = mean_k sqrt(tr_k(G S G^T)); C = mean_k sqrt(tr_k(G S Mc S G^T)); L = mean_k |G_k S v|
 //   loss = log P + (C + L) / (2 P)
-// and its hand-derived reverse mode (see DESIGN.md "LC-loss backward").
+// and its hand-derived reverse mode (see profiles/r03/NOTES.md "LC-loss backward").
 #pragma once
 #include <type_traits>
 #include "lc_common.h"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the reference ABI `pnp_ceres_f32_omp` (host pointer arrays in, GPU body): DESIGN.md section 5."""
+"""PCIe-inclusive rate of the reference ABI `pnp_ceres_f32_omp` (host pointer arrays in, GPU body): profiles/r03/NOTES.md section 5."""
 import ctypes
 import sys
 import time
