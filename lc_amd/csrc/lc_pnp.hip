@@ -94,7 +94,7 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
         } else if (p.Nmax <= 2048) {
             hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 8>), dim3(p.B), dim3(256), 0, stream, p);
         } else {  // rows wider than 2048: the first 2048 correspondences of a pose in registers, the rest (if its count gets there) from memory
-            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 8, true>), dim3(p.B), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, true, 16, true>), dim3(p.B), dim3(256), 0, stream, p);
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
@@ -112,7 +112,7 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     } else if (p.Nmax <= 2048) {
         hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 8>), dim3(p.B), dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 8, true>), dim3(p.B), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((lc_pnp_lm_wide_kernel<false, false, 16, true>), dim3(p.B), dim3(256), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -424,6 +424,20 @@ __device__ __forceinline__ PointBatch load_batch(const RansacParams& p, size_t b
     return q;
 }
 
+// mask[from, to) := 0 by the calling workgroup: 16-byte stores between the aligned ends (rows of 16 384 candidates: one byte per thread and
+// iteration was 64 iterations of the selection kernel -- most of its 27 us at zlmo's test-time shape)
+__device__ __forceinline__ void zero_bytes(unsigned char* m, int from, int to) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (to <= from) return;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(m);
+    int lo = from + (int)((16 - ((a + from) & 15)) & 15);  // first 16-byte boundary at or after `from`
+    if (lo > to) lo = to;
+    const int hi = lo + ((to - lo) & ~15);
+    for (int i = from + tid; i < lo; i += nthr) m[i] = 0;
+    for (int i = lo + 16 * tid; i < hi; i += 16 * nthr) *reinterpret_cast<uint4*>(m + i) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = hi + tid; i < to; i += nthr) m[i] = 0;
+}
+
 // Winner of pose b -> outputs: inlier mask over ALL n points, their count, the pose as quaternion + translation, flags and (when
 // asked for) the inliers compacted to the front of the selection rows.  Called by every thread of the workgroup; cc: LDS scratch, one
 // int per (chunk of the batch, wavefront); first: load_batch(p, base, 0, cap >= n), which the caller may have requested long before
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
     const size_t base = (size_t)b * p.Nmax;
     unsigned char* mask = p.inlier_mask + base;
-    for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
+    zero_bytes(mask, 0, p.Nmax);
     if (n < 4) {
         write_too_few(p, b, max(n, 0));
         return;
@@ -767,6 +781,75 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
     w.part[o] = pack_partial(cnt, err2.x + err2.y);
 }
 
+// Rows wider than 4096 candidates (zlmo's test-time shape: 16 384 per object, of which a pose's count keeps a fifth): one wavefront per
+// (pose, GROUP of kWideGroup consecutive chunks, round of 64 hypotheses).  The pose's count is read FIRST -- most groups of such a row lie
+// behind it and leave at once (the one-chunk kernel above requests its points before it knows: 49 k wavefronts, four fifths of them for
+// nothing, 42 us) -- the hypothesis is loaded once per group, and the next chunk's points are in flight while this one is scored.  Same
+// per-point arithmetic, one partial per 64-point chunk as before: the selection step sees the same numbers.
+constexpr int kWideGroup = 4;
+__global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_wide_kernel(const RansacParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kRansacMaxWaves][5][kChunkPts];
+    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long unit = (long long)blockIdx.x * kRansacMaxWaves + wave;
+    const int groups = (w.C + kWideGroup - 1) / kWideGroup, per_pose = groups * p.rounds;
+    if (unit >= (long long)p.B * per_pose) return;
+    const int b = (int)(unit / per_pose), rem = (int)(unit % per_pose), c0 = (rem / p.rounds) * kWideGroup, round = rem % p.rounds;
+    const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
+    if (n < 4 || c0 * kChunkPts >= n) return;
+    const int c1 = min(min(c0 + kWideGroup, w.C), (n + kChunkPts - 1) / kChunkPts);  // chunks [c0, c1) of this pose exist
+    float *sX = lds[wave][0], *sY = lds[wave][1], *sZ = lds[wave][2], *sU = lds[wave][3], *sV = lds[wave][4];
+    const size_t row = (size_t)b * p.Nmax;
+    struct Pt { float x, y, z, u, v; };
+    auto fetch = [&](int c) {  // lane's point of chunk c (rows are padded to Nmax: every index below Nmax may be read)
+        const size_t i = row + min(c * kChunkPts + lane, p.Nmax - 1);
+        return Pt{p.pts3d[i * 3], p.pts3d[i * 3 + 1], p.pts3d[i * 3 + 2], p.pts2d[i * 2], p.pts2d[i * 2 + 1]};
+    };
+    Pt cur = fetch(c0);
+    const int hyp = round * kWave + lane;
+    float R[9], t[3];
+    {
+        const float* h32 = w.hyp32 + 12 * ((size_t)b * w.H + hyp);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = h32[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = h32[9 + k];
+    }
+    const CamInv kin(p.K + 9 * (size_t)b);
+    const float thr_px = threshold_px(p, b);
+    const float thr = thr_px * (float)sqrt(fabs(kin.idet));
+    const float thr2 = thr * thr;
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    auto rd = [](const float* a, int i) { return *reinterpret_cast<const v4f_t*>(a + i); };
+    for (int c = c0; c < c1; ++c) {
+        const Pt nxt = fetch(c + 1 < c1 ? c + 1 : c);  // branch-free: the last iteration re-requests its own chunk (a cache hit)
+        const int i0 = c * kChunkPts, cnt_pts = min(kChunkPts, n - i0), cnt4 = (cnt_pts + 3) & ~3;
+        if (lane < cnt_pts) {
+            float ux, uy;
+            kin.normalise(cur.u, cur.v, ux, uy);
+            sU[lane] = -ux; sV[lane] = -uy;
+            sX[lane] = cur.x; sY[lane] = cur.y; sZ[lane] = cur.z;
+        } else if (lane < cnt4) {
+            sX[lane] = sY[lane] = sZ[lane] = 0.f;
+            sU[lane] = sV[lane] = -INFINITY;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int cnt = 0;
+        v2f_t err2 = {0.f, 0.f};
+        v4f_t X = rd(sX, 0), Y = rd(sY, 0), Z = rd(sZ, 0), U = rd(sU, 0), V = rd(sV, 0);
+        for (int i = 0; i < cnt4; i += 4) {
+            const int nx = i + 4 < cnt4 ? i + 4 : i;
+            const v4f_t Xn = rd(sX, nx), Yn = rd(sY, nx), Zn = rd(sZ, nx), Un = rd(sU, nx), Vn = rd(sV, nx);
+            score_pair(R, t, X.xy, Y.xy, Z.xy, U.xy, V.xy, thr2, cnt, err2);
+            score_pair(R, t, X.zw, Y.zw, Z.zw, U.zw, V.zw, thr2, cnt, err2);
+            X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
+        }
+        w.part[((size_t)b * w.C + c) * w.H + hyp] = pack_partial(cnt, err2.x + err2.y);
+        __builtin_amdgcn_wave_barrier();  // the chunk's LDS reads precede the next chunk's writes (one wavefront: program order)
+        cur = nxt;
+    }
+}
+
 // Selection of pose b by the calling workgroup: chunk partials of every hypothesis summed in chunk order (the sums do not depend on
 // which workgroup finished first), arg-max of (count, -error, -hypothesis id), outputs.  XCD: the partials were written by other
 // workgroups of THIS launch (read around the caches), else by an earlier launch.
@@ -804,7 +887,7 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
         pc0[c] = (c < chunks && tid < w.H) ? part_at(((size_t)b * w.C + c) * w.H + tid) : 0ull;
     const CamInv kin(p.K + 9 * (size_t)b);
     unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
-    for (int i = tid; i < p.Nmax; i += nthr) mask[i] = 0;
+    zero_bytes(mask, 0, p.Nmax);
     if (n < 4) {
         write_too_few(p, b, max(n, 0));
         return;
@@ -911,7 +994,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_selec
     if (n < 4) {  // nothing was scored: chunk 0's workgroup flags the pose
         if (c == 0) {
             unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
-            for (int i = tid; i < p.Nmax; i += (int)blockDim.x) mask[i] = 0;
+            zero_bytes(mask, 0, p.Nmax);
             write_too_few(p, b, max(n, 0));
         }
         return;
@@ -990,7 +1073,12 @@ int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(lc_ransac_score_select_kernel, dim3((unsigned)p.B * w.C), dim3(kWave * waves), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-    hipLaunchKernelGGL(lc_ransac_score_kernel, dim3((unsigned)((units + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
+    if (w.C > 64) {  // more than 4096 candidates per row: chunk groups, the count first
+        const long long wide = (long long)p.B * ((w.C + kWideGroup - 1) / kWideGroup) * p.rounds;
+        hipLaunchKernelGGL(lc_ransac_score_wide_kernel, dim3((unsigned)((wide + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(lc_ransac_score_kernel, dim3((unsigned)((units + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
+    }
     hipLaunchKernelGGL(lc_ransac_select_kernel, dim3(p.B), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

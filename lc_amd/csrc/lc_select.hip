@@ -120,128 +120,111 @@ struct MapSource {
     }
 };
 
-// The selection of row b by the calling workgroup (kThreads threads).  ec: entries tid + k * 1024 of the row, already in registers -- all
-// this thread handles when N <= 4096: their weights feed the threshold search, and their coordinates are there by the time the
-// compaction knows where they go.  srt: n floats of LDS (modes 1, 2).
-constexpr int kCache = 4;  // entries tid, tid + 1024, ... a thread keeps in registers (rows of up to 4096 candidates never re-read one)
-
-template <class Source>
-__device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, const Source& src, const Entry (&ec)[kCache], float* srt) {
-    __shared__ int wave_cnt[kWaves];    // compaction: survivors per wavefront
+// torch.quantile's threshold of the row whose n order-preserving integer keys the calling workgroup (kThreads threads) has just written to
+// `keys` (LDS; no barrier yet); segc: this thread's count of visible entries (mode 2).  Same value in every thread.
+// torch.quantile needs only the two order statistics around q (n - 1): a most-significant-digit RADIX SELECT over the order-preserving
+// integer image of the weights (4 passes of 8 bits) finds the lower one in O(n), one counting pass the upper one -- the bitonic sort it
+// replaces took 78 barrier-separated stages for n = 4096.  The threshold is formed from the same two floats, so the selected index sets
+// are unchanged bit for bit.  Barriers are what this costs (16 wavefronts each): every pass has ONE -- the histogram of pass k is scanned
+// by every wavefront for itself (no broadcast), the histogram of pass k+1 was zeroed while pass k was counting, and with three of them in
+// rotation the one zeroed during pass k+2 is the one whose scan ended before pass k+1's barrier.
+__device__ __forceinline__ unsigned weight_key(float w) {
+    const unsigned u = __float_as_uint(w);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending unsigned order == ascending float order
+}
+__device__ __forceinline__ float quantile_threshold(const SelectParams& p, int n, const unsigned* keys, int segc) {
     __shared__ int wave_seg[kWaves];    // mode 2: visible entries per wavefront
     __shared__ int wave_le[kWaves];     // upper order statistic: keys <= the lower one / smallest key above it, per wavefront
     __shared__ unsigned wave_above[kWaves];
-    __shared__ int hist[3][256];        // radix passes rotate through three histograms: ONE barrier per pass (see below)
+    __shared__ int hist[3][256];        // radix passes rotate through three histograms: ONE barrier per pass
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t base = (size_t)b * p.N;
-    auto weight_of = [&](const Entry& e) { return (p.mode == 2 && !e.g) ? 0.f : e.s.x + e.s.y; };  // mode 2: (inv_std * seg).sum(-1)
-    float thr = -FLT_MAX;
-    if (p.mode != 0 && n > 0) {
-        // torch.quantile needs only the two order statistics around q (n - 1): a most-significant-digit RADIX SELECT over the
-        // order-preserving integer image of the weights (4 passes of 8 bits) finds the lower one in O(n), one counting pass the upper
-        // one -- the bitonic sort it replaces took 78 barrier-separated stages for n = 4096.  The threshold is formed from the same
-        // two floats, so the selected index sets are unchanged bit for bit.
-        // Barriers are what this section costs (16 wavefronts each): every pass has ONE -- the histogram of pass k is scanned by
-        // every wavefront for itself (no broadcast), the histogram of pass k+1 was zeroed while pass k was counting, and with three
-        // of them in rotation the one zeroed during pass k+2 is the one whose scan ended before pass k+1's barrier.
-        unsigned* keys = reinterpret_cast<unsigned*>(srt);
-        int segc = 0;
-        if (tid < 256) hist[0][tid] = 0;
-        auto stage = [&](const Entry& e, int i) {
-            const unsigned u = __float_as_uint(weight_of(e));
-            keys[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending unsigned order == ascending float order
-            if (p.mode == 2 && e.g) ++segc;
-        };
+    if (tid < 256) hist[0][tid] = 0;
+    if (p.mode == 2) {
 #pragma unroll
-        for (int k = 0; k < kCache; ++k)
-            if (tid + k * kThreads < n) stage(ec[k], tid + k * kThreads);
-        for (int i = tid + kCache * kThreads; i < n; i += kThreads) stage(src.load(i), i);
-        if (p.mode == 2) {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) segc += __shfl_xor(segc, m, kWave);
-            if (lane == 0) wave_seg[wave] = segc;
-        }
-        __syncthreads();
-        float q = p.quantile;
-        if (p.mode == 2) {
-            int seg_total = 0;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) seg_total += wave_seg[w];
-            q = 1.f - p.one_minus_q * ((float)seg_total / (float)n);  // test.py:102-103, fp32 like the tensor op
-        }
-        q = fminf(fmaxf(q, 0.f), 1.f);
-        const float rank = q * (float)(n - 1);
-        const float lo = floorf(rank), hi = ceilf(rank);
-        const int klo = (int)lo, khi = min((int)hi, n - 1);
-        // rank klo by the radix select; rank khi = klo + 1 is then either the same key (a duplicate: more than klo + 1 keys are <= it)
-        // or the smallest key above it -- one counting / min pass instead of four more histogram passes
-        unsigned found[2] = {0u, 0u};
-        {
-            unsigned prefix = 0u, mask = 0u;
-            int k = klo;  // 0-based rank among the elements that still match the prefix
-            for (int pass = 3; pass >= 0; --pass) {
-                const int shift = 8 * pass, cur = (3 - pass) % 3, nxt = (cur + 1) % 3;
-                if (tid < 256) hist[nxt][tid] = 0;
-                for (int i0 = 0; i0 < n; i0 += kThreads) {
-                    const int i = i0 + tid;
-                    const unsigned key = i < n ? keys[i] : 0u;
-                    hist_add(hist[cur], (key >> shift) & 255u, i < n && (key & mask) == prefix, lane);
-                }
-                __syncthreads();
-                // every wavefront: lane l owns bins 4l .. 4l+3, exclusive prefix over the lanes, then the bin holding rank k
-                const int c0 = hist[cur][4 * lane], c1 = hist[cur][4 * lane + 1], c2 = hist[cur][4 * lane + 2], c3 = hist[cur][4 * lane + 3];
-                const int mine = c0 + c1 + c2 + c3;
-                int incl = mine;
-#pragma unroll
-                for (int d = 1; d < kWave; d <<= 1) {
-                    const int up = __shfl_up(incl, d, kWave);
-                    if (lane >= d) incl += up;
-                }
-                const int excl = incl - mine;
-                const bool hit = k >= excl && k < incl;  // exactly one lane
-                int r = k - excl, bin = 4 * lane;
-                if (r >= c0) { r -= c0; ++bin; if (r >= c1) { r -= c1; ++bin; if (r >= c2) { r -= c2; ++bin; } } }
-                const int owner = __ffsll((long long)__ballot(hit)) - 1;
-                prefix |= (unsigned)__shfl(bin, owner, kWave) << shift;
-                mask |= 255u << shift;
-                k = __shfl(r, owner, kWave);
-            }
-            found[0] = found[1] = prefix;
-        }
-        if (khi != klo) {  // uniform
-            int le = 0;
-            unsigned above = 0xFFFFFFFFu;
-            for (int i = tid; i < n; i += kThreads) {
-                const unsigned key = keys[i];
-                if (key <= found[0]) ++le;
-                else above = min(above, key);
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                le += __shfl_xor(le, m, kWave);
-                above = min(above, (unsigned)__shfl_xor((int)above, m, kWave));
-            }
-            if (lane == 0) { wave_le[wave] = le; wave_above[wave] = above; }
-            __syncthreads();
-            int le_total = 0;
-            unsigned above_min = 0xFFFFFFFFu;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) { le_total += wave_le[w]; above_min = min(above_min, wave_above[w]); }
-            if (le_total <= khi) found[1] = above_min;  // no duplicate reaches rank khi: the next distinct key
-        }
-        auto unkey = [](unsigned kk) { return __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk); };
-        const float vlo = unkey(found[0]), vhi = khi != klo ? unkey(found[1]) : vlo;
-        thr = torch_lerp(vlo, vhi, rank - lo);  // every thread forms it from the same two floats
+        for (int m = 32; m >= 1; m >>= 1) segc += __shfl_xor(segc, m, kWave);
+        if (lane == 0) wave_seg[wave] = segc;
     }
-    const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
-    auto put = [&](const Entry& e, int o) { rows.entry_from(base, o, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src); };
-    int running = 0;  // survivors in the chunks before this one (same value in every thread)
-    auto chunk = [&](int i0, const Entry& e, bool mine) {  // mine: this thread has an entry in the chunk (e)
-        bool keep = false;
-        if (mine) {
-            if (p.mode == 0) keep = e.g != 0;
-            else keep = weight_of(e) >= thr && (p.mode == 1 || e.g != 0);
+    __syncthreads();
+    float q = p.quantile;
+    if (p.mode == 2) {
+        int seg_total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) seg_total += wave_seg[w];
+        q = 1.f - p.one_minus_q * ((float)seg_total / (float)n);  // test.py:102-103, fp32 like the tensor op
+    }
+    q = fminf(fmaxf(q, 0.f), 1.f);
+    const float rank = q * (float)(n - 1);
+    const float lo = floorf(rank), hi = ceilf(rank);
+    const int klo = (int)lo, khi = min((int)hi, n - 1);
+    // rank klo by the radix select; rank khi = klo + 1 is then either the same key (a duplicate: more than klo + 1 keys are <= it)
+    // or the smallest key above it -- one counting / min pass instead of four more histogram passes
+    unsigned found[2] = {0u, 0u};
+    {
+        unsigned prefix = 0u, mask = 0u;
+        int k = klo;  // 0-based rank among the elements that still match the prefix
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = 8 * pass, cur = (3 - pass) % 3, nxt = (cur + 1) % 3;
+            if (tid < 256) hist[nxt][tid] = 0;
+            for (int i0 = 0; i0 < n; i0 += kThreads) {
+                const int i = i0 + tid;
+                const unsigned key = i < n ? keys[i] : 0u;
+                hist_add(hist[cur], (key >> shift) & 255u, i < n && (key & mask) == prefix, lane);
+            }
+            __syncthreads();
+            // every wavefront: lane l owns bins 4l .. 4l+3, exclusive prefix over the lanes, then the bin holding rank k
+            const int c0 = hist[cur][4 * lane], c1 = hist[cur][4 * lane + 1], c2 = hist[cur][4 * lane + 2], c3 = hist[cur][4 * lane + 3];
+            const int mine = c0 + c1 + c2 + c3;
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int up = __shfl_up(incl, d, kWave);
+                if (lane >= d) incl += up;
+            }
+            const int excl = incl - mine;
+            const bool hit = k >= excl && k < incl;  // exactly one lane
+            int r = k - excl, bin = 4 * lane;
+            if (r >= c0) { r -= c0; ++bin; if (r >= c1) { r -= c1; ++bin; if (r >= c2) { r -= c2; ++bin; } } }
+            const int owner = __ffsll((long long)__ballot(hit)) - 1;
+            prefix |= (unsigned)__shfl(bin, owner, kWave) << shift;
+            mask |= 255u << shift;
+            k = __shfl(r, owner, kWave);
         }
+        found[0] = found[1] = prefix;
+    }
+    if (khi != klo) {  // uniform
+        int le = 0;
+        unsigned above = 0xFFFFFFFFu;
+        for (int i = tid; i < n; i += kThreads) {
+            const unsigned key = keys[i];
+            if (key <= found[0]) ++le;
+            else above = min(above, key);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            le += __shfl_xor(le, m, kWave);
+            above = min(above, (unsigned)__shfl_xor((int)above, m, kWave));
+        }
+        if (lane == 0) { wave_le[wave] = le; wave_above[wave] = above; }
+        __syncthreads();
+        int le_total = 0;
+        unsigned above_min = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { le_total += wave_le[w]; above_min = min(above_min, wave_above[w]); }
+        if (le_total <= khi) found[1] = above_min;  // no duplicate reaches rank khi: the next distinct key
+    }
+    auto unkey = [](unsigned kk) { return __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk); };
+    const float vlo = unkey(found[0]), vhi = khi != klo ? unkey(found[1]) : vlo;
+    return torch_lerp(vlo, vhi, rank - lo);  // every thread forms it from the same two floats
+}
+
+// Order-preserving compaction of a row, 1024 candidates (one per thread) at a time: slot(keep, more) returns where this thread's entry
+// goes (wave ballots + prefix over the wavefronts); `running` = survivors so far, the same value in every thread.  more: another call
+// follows (its barrier keeps the per-wave counts of this one alive until everybody has read them).
+struct Compactor {
+    int running = 0;
+    __device__ __forceinline__ int slot(bool keep, bool more) {
+        __shared__ int wave_cnt[kWaves];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const unsigned long long bal = __ballot(keep);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wave_cnt[wave] = __popcll(bal);
@@ -252,9 +235,47 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
             if (w < wave) off += wave_cnt[w];
             tot += wave_cnt[w];
         }
-        if (keep) put(e, off + before);
         running = tot;
-        if (i0 + kThreads < n) __syncthreads();  // wave_cnt is rewritten by the next chunk
+        if (more) __syncthreads();  // wave_cnt is rewritten by the next call
+        return off + before;
+    }
+};
+
+// The selection of row b by the calling workgroup (kThreads threads).  ec: entries tid + k * 1024 of the row, already in registers -- all
+// this thread handles when N <= 4096: their weights feed the threshold search, and their coordinates are there by the time the
+// compaction knows where they go.  srt: n floats of LDS (modes 1, 2).
+constexpr int kCache = 4;  // entries tid, tid + 1024, ... a thread keeps in registers (rows of up to 4096 candidates never re-read one)
+
+template <class Source>
+__device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, const Source& src, const Entry (&ec)[kCache], float* srt) {
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)b * p.N;
+    auto weight_of = [&](const Entry& e) { return (p.mode == 2 && !e.g) ? 0.f : e.s.x + e.s.y; };  // mode 2: (inv_std * seg).sum(-1)
+    float thr = -FLT_MAX;
+    if (p.mode != 0 && n > 0) {
+        unsigned* keys = reinterpret_cast<unsigned*>(srt);
+        int segc = 0;
+        auto stage = [&](const Entry& e, int i) {
+            keys[i] = weight_key(weight_of(e));
+            if (p.mode == 2 && e.g) ++segc;
+        };
+#pragma unroll
+        for (int k = 0; k < kCache; ++k)
+            if (tid + k * kThreads < n) stage(ec[k], tid + k * kThreads);
+        for (int i = tid + kCache * kThreads; i < n; i += kThreads) stage(src.load(i), i);
+        thr = quantile_threshold(p, n, keys, segc);
+    }
+    const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
+    auto put = [&](const Entry& e, int o) { rows.entry_from(base, o, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src); };
+    Compactor cmp;
+    auto chunk = [&](int i0, const Entry& e, bool mine) {  // mine: this thread has an entry in the chunk (e)
+        bool keep = false;
+        if (mine) {
+            if (p.mode == 0) keep = e.g != 0;
+            else keep = weight_of(e) >= thr && (p.mode == 1 || e.g != 0);
+        }
+        const int o = cmp.slot(keep, i0 + kThreads < n);
+        if (keep) put(e, o);
     };
 #pragma unroll
     for (int k = 0; k < kCache; ++k) {
@@ -265,7 +286,7 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
         const bool mine = i0 + tid < n;
         chunk(i0, mine ? src.load(i0 + tid) : ec[0], mine);
     }
-    const int total = pad_rows(b, n, running, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
+    const int total = pad_rows(b, n, cmp.running, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
     if (tid == 0) p.counts[b] = total;
 }
 
@@ -288,7 +309,86 @@ __global__ __launch_bounds__(kThreads) void lc_dense_select_kernel(const SelectP
 // ones again from the maps where the selection needs them) -- the log-sum-exp by the front end's own 512
 // threads in the front end's own order, so every selected value equals what the two launches produce bit for bit -- and hands it to
 // the selection above.
+// Rows of more than kCache * 1024 candidates per object (zlmo's test-time shape: 128x128 at stride 1 = 16 per thread).  Walking the entries
+// beyond the cached four one at a time -- form an entry from the maps, use it, form the next -- was a dependent memory round trip per entry
+// and phase: 12 in the staging loop, 12 in the compaction, 55 us per 64 objects.  Here a thread requests what a phase needs of ALL its entries
+// at once, branch-free (an index behind the row re-requests the row's last entry, a cache hit): the two weight logits and the visibility
+// logit of its 16 pixels before the log-sum-exp, and -- once the threshold is known -- the xyz of eight entries at a time.  Weights and
+// visibility bits stay in registers in between (32 + 1); every value is formed exactly as MapSource forms it: same results bit for bit.
+constexpr int kWideCache = 16, kWideBatch = 8;
 template <typename T, typename TX>
+__device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, MapSource<T, TX>& src, const int two_hw, float (*red)[2], float* srt) {
+    const int tid = threadIdx.x, n = p.N;
+    const size_t base = (size_t)b * p.N;
+    float2 w[kWideCache];   // raw logits, then the weights
+    float vraw[kWideCache];
+    unsigned gbits = 0u;
+#pragma unroll
+    for (int k = 0; k < kWideCache; ++k) {
+        int x, y;
+        const int px = src.pixel(min(tid + k * kThreads, n - 1), x, y);
+        w[k] = make_float2((float)src.lg[px], (float)src.lg[src.HW + px]);
+        vraw[k] = src.vis ? (float)src.vis[px] : 0.f;
+    }
+    src.lse = block_lse<kDenseLseThreads>(src.lg, two_hw, red);
+#pragma unroll
+    for (int k = 0; k < kWideCache; ++k) {
+        w[k] = make_float2(__expf(w[k].x - src.lse) * src.scale, __expf(w[k].y - src.lse) * src.scale);
+        if (src.vis && (1.f / (1.f + expf(-vraw[k]))) > src.vis_thresh) gbits |= 1u << k;  // torch.sigmoid's own formula
+    }
+    auto weight_of = [&](int k) { return (p.mode == 2 && !((gbits >> k) & 1u)) ? 0.f : w[k].x + w[k].y; };
+    float thr = -FLT_MAX;
+    if (p.mode != 0) {
+        unsigned* keys = reinterpret_cast<unsigned*>(srt);
+        int segc = 0;
+#pragma unroll
+        for (int k = 0; k < kWideCache; ++k) {
+            const int i = tid + k * kThreads;
+            if (i < n) {
+                keys[i] = weight_key(weight_of(k));
+                if (p.mode == 2 && ((gbits >> k) & 1u)) ++segc;
+            }
+        }
+        thr = quantile_threshold(p, n, keys, segc);
+    }
+    const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
+    Compactor cmp;
+#pragma unroll
+    for (int h = 0; h < kWideCache; h += kWideBatch) {
+        if (h * kThreads >= n) break;  // uniform
+        float X[kWideBatch][3];
+#pragma unroll
+        for (int j = 0; j < kWideBatch; ++j) {
+            int x, y;
+            const int px = src.pixel(min(tid + (h + j) * kThreads, n - 1), x, y);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) X[j][d] = (float)src.xyz[d * src.HW + px];
+        }
+#pragma unroll
+        for (int j = 0; j < kWideBatch; ++j) {
+            const int k = h + j, i0 = k * kThreads, i = i0 + tid;
+            if (i0 >= n) break;  // uniform
+            bool keep = false;
+            if (i < n) {
+                const bool g = (gbits >> k) & 1u;
+                keep = p.mode == 0 ? g : (weight_of(k) >= thr && (p.mode == 1 || g));
+            }
+            const int o = cmp.slot(keep, i0 + kThreads < n);
+            if (keep) {
+                int x, y;
+                src.pixel(i, x, y);  // (recomputed for the survivors rather than held for everybody: registers)
+                rows.entry_from(base, o, (float)x, (float)y, w[k], X[j][0] * src.ns[0], X[j][1] * src.ns[1], X[j][2] * src.ns[2], i);
+            }
+        }
+    }
+    const int total = pad_rows(b, n, cmp.running, p.min_count, p.seed, [&](int i, int k) {
+        const Entry e = src.load(i);
+        rows.entry_from(base, k, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src);
+    });  // test.py:108-113
+    if (tid == 0) p.counts[b] = total;
+}
+
+template <typename T, typename TX, bool WIDE>
 __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(const SelectParams p, const DenseParams d) {
     extern __shared__ float srt[];
     __shared__ float red[kDenseLseThreads / kWave][2];
@@ -301,17 +401,21 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
     src.HW = HW; src.W = d.W; src.top = d.top; src.left = d.left; src.sample = d.sample;
     src.Wn = (d.W - d.left + d.sample - 1) / d.sample;
     src.lse = 0.f;
-    Entry ec[kCache] = {};
-    float vraw[kCache] = {};
-#pragma unroll
-    for (int k = 0; k < kCache; ++k)
-        if (tid + k * kThreads < p.N) ec[k] = src.fetch(tid + k * kThreads, vraw[k]);  // in flight while the log-sum-exp is formed
     src.scale = map_scalar_at(d.wscale, d.wscale_dtype, b);
     for (int k = 0; k < 3; ++k) src.ns[k] = d.noc_scale ? d.noc_scale[3 * b + k] : 1.f;
-    src.lse = block_lse<kDenseLseThreads>(src.lg, 2 * HW, red);
+    if constexpr (WIDE) {
+        select_row_wide(p, b, src, 2 * HW, red, srt);
+    } else {
+        Entry ec[kCache] = {};
+        float vraw[kCache] = {};
 #pragma unroll
-    for (int k = 0; k < kCache; ++k) ec[k] = src.finish(ec[k], vraw[k]);
-    select_row(p, b, p.N, src, ec, srt);
+        for (int k = 0; k < kCache; ++k)
+            if (tid + k * kThreads < p.N) ec[k] = src.fetch(tid + k * kThreads, vraw[k]);  // in flight while the log-sum-exp is formed
+        src.lse = block_lse<kDenseLseThreads>(src.lg, 2 * HW, red);
+#pragma unroll
+        for (int k = 0; k < kCache; ++k) ec[k] = src.finish(ec[k], vraw[k]);
+        select_row(p, b, p.N, src, ec, srt);
+    }
 }
 
 }  // namespace
@@ -343,9 +447,10 @@ int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d_in,
             rc = 2;
         else hipLaunchKernelGGL(kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
     };
+    const bool wide = p.N > kCache * kThreads;  // more candidates per thread than the register cache of the one-entry-at-a-time walk holds
     LC_MAP_DISPATCH(d.map_dtype,
-                    if (d.xyz_dtype == d.map_dtype) go(lc_dense_frontend_select_kernel<T, T>);
-                    else go(lc_dense_frontend_select_kernel<T, float>));
+                    if (d.xyz_dtype == d.map_dtype) { if (wide) go(lc_dense_frontend_select_kernel<T, T, true>); else go(lc_dense_frontend_select_kernel<T, T, false>); }
+                    else { if (wide) go(lc_dense_frontend_select_kernel<T, float, true>); else go(lc_dense_frontend_select_kernel<T, float, false>); });
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
