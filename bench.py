@@ -716,6 +716,7 @@ def main():
             "rccl_version": rccl_version() if (coll and coll["backend"] == "nccl") else None,
             "per_rank_ms_per_step": agg["per_rank_ms_per_step"],
             "roofline": roof,
+            "library": {"embedded_source_hash": lib.lc_amd_source_hash().decode(), "source_hash_on_disk": __import__("lc_amd.build", fromlist=["x"]).source_hash()},
         }
         if coll and coll["rccl_error"]:
             out["rccl_error"] = coll["rccl_error"]

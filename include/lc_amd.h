@@ -159,8 +159,9 @@ int lc_cov_loss2_fwd_bwd_f32(const float *K, const float *pose, const float *pts
  * workgroups (4, 8 or 16 tiles each) that exchange the partial sums of the normal equations once through the workspace.
  * Results are bit-identical to the workspace-less call (all forms add the per-sample sums in the same tile order).
  *   lc_cov_loss_workspace_bytes(B, N): bytes needed, 0 when the shape would not use it (N <= 256, or a batch that fills the
- *   chip anyway).  The caller zero-fills the workspace ONCE per (B, N); every launch leaves it zeroed (re-zero it after a launch
- *   that returned NaN losses: its hand-off timed out).  One workspace serves the launches of ONE stream (or of graphs replayed
+ *   chip anyway).  The caller zero-fills the workspace ONCE per (B, N); every launch leaves it zeroed except word 2 of its header,
+ *   which counts hand-offs that timed out (none can, by construction); a sample any of whose workgroups timed out returns loss = NaN
+ *   (its gradients are then undefined): re-zero the workspace after that.  One workspace serves the launches of ONE stream (or of graphs replayed
  *   one at a time); concurrent launches need one each.  workspace == NULL is (2b'). */
 size_t lc_cov_loss_workspace_bytes(int B, int N);
 int lc_cov_loss3_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,

@@ -103,11 +103,15 @@ def load(build_if_missing: bool = True):
         # missing, or built from other .hip/.h contents than the ones on disk (the library carries the hash of its sources):
         # rebuild (hipcc cross-compiles without a GPU); never silently run a library that ignores edited sources
         if os.path.exists(path) and not _build.hipcc_available():
-            # a deployed copy on a box without the compiler: it cannot be rebuilt, so say what it is and use it
+            # a deployed copy on a box without the compiler: it cannot be rebuilt.  A library whose struct or argument layouts may differ
+            # from the sources next to it is refused unless the caller says so explicitly (a warning is lost wherever stderr is discarded)
+            if os.environ.get("LC_AMD_ALLOW_STALE") != "1":
+                raise RuntimeError(f"lc_amd: {path} was built from other sources than the ones next to it (embedded hash "
+                                   f"{_build.embedded_hash(path)}, sources {_build.source_hash()}) and hipcc is not available to rebuild it; "
+                                   f"set LC_AMD_ALLOW_STALE=1 to load it as it is")
             import warnings
 
-            warnings.warn(f"lc_amd: {path} was built from other sources than the ones next to it (embedded hash "
-                          f"{_build.embedded_hash(path)}) and hipcc is not available to rebuild it; loading it as it is")
+            warnings.warn(f"lc_amd: loading {path} although it was built from other sources than the ones next to it (LC_AMD_ALLOW_STALE=1)")
         elif not build_if_missing:
             raise RuntimeError(f"lc_amd: {path} is missing or stale; run `python __graft_entry__.py build`")
         else:

@@ -39,9 +39,14 @@ __device__ __forceinline__ void tiled_workgroup(const LossParams& p, int T, int 
     // retire: relaxed device-scope atomics only (no cache maintenance) -- a workgroup counts itself finished after the hand-off,
     // the counters it may then zero are touched by nobody else any more
     if (threadIdx.x == 0) {
-        if (g.timed_out && g.slice == 0) p.loss[b] = __builtin_nanf("");  // never silently wrong
-        const unsigned d = __hip_atomic_fetch_add(g.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == (unsigned)S - 1u) {  // every workgroup of the sample is past the hand-off
+        // A hand-off that timed out (it cannot: tickets) poisons the sample whichever slice it happened in: the slice counts itself out
+        // with a flag in the counter's upper half, and the LAST workgroup of the sample to retire -- every slice, slice 0 and its finite
+        // loss included, is past its stores by then -- overwrites loss[b] with NaN (written through, like the counters).  The slice's own
+        // gradient rows were formed from incomplete sums; the NaN loss is what tells the caller (never silently wrong).  head[2] counts the
+        // time-outs of the workspace's lifetime and is NOT reset: a caller that sees it non-zero (or a NaN loss) re-zeroes the workspace.
+        const unsigned d = __hip_atomic_fetch_add(g.ctr + 1, g.timed_out ? 0x10001u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((d & 0xFFFFu) == (unsigned)S - 1u) {  // every workgroup of the sample is past the hand-off
+            if ((d >> 16) || g.timed_out) __hip_atomic_store(p.loss + b, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned s = __hip_atomic_fetch_add(head + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -30,16 +30,17 @@ __global__ __launch_bounds__(256) void lc_pnp_lm_wide_kernel(const PnpParams p) 
     pnp::solve_pose<REG, 4, false, OPTS, PPT, TAIL>(p, blockIdx.x, threadIdx.x, bc);
 }
 
-// Two dependent solves in one launch (lc_pnp_lm_chain_f32): workgroup b runs pose b % a.B of the first job, then pose b of the second,
-// whose start may be the first's result.  Between the two: the first solve's outputs were written by this workgroup's own threads
-// (and, identically, by the other workgroups that solve the same first-stage pose); a workgroup-scope fence + barrier orders them
-// before the second solve's loads.
-__global__ __launch_bounds__(256) void lc_pnp_lm_chain_kernel(const PnpParams a, const PnpParams b) {
+// Two dependent solves in one launch (lc_pnp_lm_chain_f32): workgroup w runs pose w % a.B of the first job, then pose w of the second,
+// whose start may be the first's result.  The first job's outputs are written by ONE workgroup per pose (w < a.B); a workgroup that
+// repeats the solve for a further selection of the same object (w >= a.B: the solve is bit-deterministic) keeps the result to itself.
+// Either way the refined state reaches the second solve through 7 floats of LDS, not through a.states in global memory -- no two
+// workgroups write the same rows, nobody reads a row another workgroup is writing.
+__global__ __launch_bounds__(256) void lc_pnp_lm_chain_kernel(const PnpParams a, const PnpParams b, const int second_starts_from_first) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<4>];
-    pnp::solve_pose<false, 4, false, true, 4>(a, (int)(blockIdx.x % (unsigned)a.B), threadIdx.x, bc);
-    __threadfence_block();
+    __shared__ float refined[8];
+    pnp::solve_pose<false, 4, false, true, 4>(a, (int)(blockIdx.x % (unsigned)a.B), threadIdx.x, bc, blockIdx.x < (unsigned)a.B, refined);
     __syncthreads();
-    pnp::solve_pose<false, 4, false, true, 4>(b, blockIdx.x, threadIdx.x, bc);
+    pnp::solve_pose<false, 4, false, true, 4>(b, blockIdx.x, threadIdx.x, bc, true, nullptr, second_starts_from_first ? refined : nullptr);
 }
 
 // diagnostic twins that also record the per-iteration trace (tests/test_gpu_pnp_trace.py)
@@ -69,7 +70,7 @@ int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stre
     // them read a start the other has already overwritten: one launch only when every first-stage pose has one solver, or a separate start
     const bool first_is_safe = a.start != nullptr || b.B == a.B;
     if (a.B > 0 && b.B > 0 && wide4(a) && wide4(b) && b.B % a.B == 0 && rows_match && first_is_safe) {
-        hipLaunchKernelGGL(lc_pnp_lm_chain_kernel, dim3(b.B), dim3(256), 0, stream, a, b);
+        hipLaunchKernelGGL(lc_pnp_lm_chain_kernel, dim3(b.B), dim3(256), 0, stream, a, b, b_start == a.states ? 1 : 0);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     if (int rc = launch_pnp_lm(a, stream)) return rc;

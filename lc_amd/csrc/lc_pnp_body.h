@@ -262,8 +262,12 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 // each) across the whole solve; the block-stride loop otherwise re-reads them from L2 in every evaluation, ~1 us of exposed latency
 // each time.  TAIL: correspondences behind the cached prefix (n > 64 NW PPT) are read from memory; instantiations whose rows always fit
 // the prefix leave it out (the never-taken loop cost the test-time chain 1 us).  Same accumulation order, same results.
+// store / handoff / start_override (the chained launch, lc_pnp.hip): store = false keeps the job's outputs in registers (a workgroup that
+// repeats a solve another workgroup owns must not write the owner's rows a second time); handoff (7 floats of LDS) receives the state the
+// solve would leave in p.states[b]; start_override replaces the start pose (7 floats, e.g. a previous solve's handoff).
 template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0, bool TAIL = false>
-__device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc) {
+__device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc, bool store = true, float* handoff = nullptr,
+                                           const float* start_override = nullptr) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
 #ifdef LC_TRACE_CLOCK
     const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
@@ -274,16 +278,20 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     // pose_mod (OPTS launches): K and start hold pose_mod rows shared by the poses b, b + pose_mod, ... (several solves of the same
     // objects -- different correspondence selections -- batched into one launch)
     const int bk = (OPTS && p.pose_mod > 0) ? b % p.pose_mod : b;
-    const float* st_in = (p.start ? p.start + 7 * (size_t)bk : p.states + 7 * (size_t)b);
+    const float* st_in = start_override ? start_override : (p.start ? p.start + 7 * (size_t)bk : p.states + 7 * (size_t)b);
     const bool filter = OPTS && (p.options & kPnpNanToNum);
     auto fin = [&](float f) { return filter ? nan_to_num(f) : f; };
     if (n < 3) {  // ceres.cpp:84-91
-        if (lane == 0) {
+        if (lane == 0 && store) {
             p.rets[b] = 1;
             p.result_tr[b] = 1.f;
             if (p.iters) p.iters[b] = 0;
         }
-        if ((p.start || filter) && lane < 7) p.states[7 * (size_t)b + lane] = fin(st_in[lane]);
+        if (lane < 7) {
+            const float v = fin(st_in[lane]);
+            if (store && (p.start || start_override || filter)) p.states[7 * (size_t)b + lane] = v;
+            if (handoff) handoff[lane] = v;
+        }
         return;
     }
     const size_t base = (size_t)b * p.Nmax;
@@ -512,15 +520,22 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     }
 #endif
     const bool invalid = failed || !converged;
-    if (invalid && (p.start || filter) && lane < 7) p.states[7 * (size_t)b + lane] = fin(st_in[lane]);
+    if (invalid && lane < 7) {
+        const float v = fin(st_in[lane]);
+        if (store && (p.start || start_override || filter)) p.states[7 * (size_t)b + lane] = v;
+        if (handoff) handoff[lane] = v;
+    }
     if (lane == 0) {
-        p.rets[b] = invalid ? 1 : 0;
-        p.result_tr[b] = (float)radius;
+        if (store) {
+            p.rets[b] = invalid ? 1 : 0;
+            p.result_tr[b] = (float)radius;
 #ifndef LC_STAMPS
-        if (p.iters) p.iters[b] = iter;
+            if (p.iters) p.iters[b] = iter;
 #endif
+        }
         if (!invalid) {  // ceres.cpp:131-144: AngleAxisToQuaternion, write back in place
-            float* st = p.states + 7 * (size_t)b;
+            float stq[7];
+            float* st = stq;
             const double t2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
             double q0 = 1.0, kk = 0.5;
             if (t2 > 0.0) {
@@ -532,6 +547,11 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             }
             st[0] = (float)q0; st[1] = (float)(x[0] * kk); st[2] = (float)(x[1] * kk); st[3] = (float)(x[2] * kk);
             st[4] = (float)x[3]; st[5] = (float)x[4]; st[6] = (float)x[5];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if (store) p.states[7 * (size_t)b + k] = stq[k];
+                if (handoff) handoff[k] = stq[k];
+            }
         }
     }
 }
