@@ -442,7 +442,8 @@ __device__ __forceinline__ void zero_bytes(unsigned char* m, int from, int to) {
 // asked for) the inliers compacted to the front of the selection rows.  Called by every thread of the workgroup; cc: LDS scratch, one
 // int per (chunk of the batch, wavefront); first: load_batch(p, base, 0, cap >= n), which the caller may have requested long before
 // the winner was known.
-typedef int ChunkCounts[kBatch][4];
+constexpr int kSelMaxWaves = 16;  // wavefronts of the workgroup that writes a pose's result (4; 16 for rows of more than 4096 candidates)
+typedef int ChunkCounts[kBatch][kSelMaxWaves];
 __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n, bool ok, const double* bp, int win_hyp, float thr2,
                                              const CamInv& kin, ChunkCounts& cc, const PointBatch& first) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
@@ -853,14 +854,14 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_wide_
 // Selection of pose b by the calling workgroup: chunk partials of every hypothesis summed in chunk order (the sums do not depend on
 // which workgroup finished first), arg-max of (count, -error, -hypothesis id), outputs.  XCD: the partials were written by other
 // workgroups of THIS launch (read around the caches), else by an earlier launch.
-constexpr int kFirstChunks = 32, kMoreChunks = 16;  // chunk partials a selection thread requests blindly / per further round trip
+constexpr int kMoreChunks = 16;  // chunk partials a selection thread requests per round trip behind the first kFirstChunks (template argument)
 struct SelectShared {
     double best_pose[12];
-    int wv_cnt[kRansacMaxWaves], wv_hyp[kRansacMaxWaves];
-    float wv_err[kRansacMaxWaves];
+    int wv_cnt[kSelMaxWaves], wv_hyp[kSelMaxWaves];
+    float wv_err[kSelMaxWaves];
     ChunkCounts chunk_cnt;
 };
-template <bool XCD>
+template <bool XCD, int kFirstChunks = 32>
 __device__ __forceinline__ void select_winner(const RansacParams& p, const RansacWorkspace& w, int b, SelectShared& sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     auto part_at = [&](size_t o) { return XCD ? xcd_load(w.part + o) : w.part[o]; };
@@ -956,6 +957,12 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
 __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_select_kernel(const RansacParams p) {
     __shared__ SelectShared sh;
     select_winner<false>(p, carve_workspace(p.workspace, p.B, p.Nmax, p.rounds), blockIdx.x, sh);
+}
+// rows of more than 4096 candidates: 16 wavefronts write the inlier mask and the re-selection (4096 points per pass and barrier pair instead
+// of 1024); fewer chunk partials are requested blindly (128 VGPRs per thread at this workgroup size)
+__global__ __launch_bounds__(kWave * kSelMaxWaves) void lc_ransac_select_wide_kernel(const RansacParams p) {
+    __shared__ SelectShared sh;
+    select_winner<false, 8>(p, carve_workspace(p.workspace, p.B, p.Nmax, p.rounds), blockIdx.x, sh);
 }
 
 // Ticketed form (lc_pnp_ransac_init4_f32 with `ticketed`): scoring AND selection in one launch.  One workgroup per (pose, chunk of 64 points), its
@@ -1079,7 +1086,8 @@ int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL(lc_ransac_score_kernel, dim3((unsigned)((units + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     }
-    hipLaunchKernelGGL(lc_ransac_select_kernel, dim3(p.B), dim3(kWave * kRansacMaxWaves), 0, stream, p);
+    if (w.C > 64) hipLaunchKernelGGL(lc_ransac_select_wide_kernel, dim3(p.B), dim3(kWave * kSelMaxWaves), 0, stream, p);
+    else hipLaunchKernelGGL(lc_ransac_select_kernel, dim3(p.B), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

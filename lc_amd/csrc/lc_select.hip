@@ -24,6 +24,13 @@
 #include "lc_kernels.h"
 #include "lc_select_rows.h"
 
+#ifdef LC_SELECT_STAMPS  // diagnostic build (scripts/ubench/select_stamps.py): s_memtime stamps of the wide front end + selection's phases
+namespace lc { namespace select_diag { __device__ unsigned long long g_stamp[10]; } }
+#define LC_FS_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) ::lc::select_diag::g_stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define LC_FS_STAMP(i)
+#endif
+
 namespace lc {
 namespace {
 
@@ -40,16 +47,22 @@ __device__ __forceinline__ float torch_lerp(float a, float b, float w) {
 // it, and the top byte of positive floats of similar size is the same -- so a plain atomicAdd per lane sends hundreds of adds to ONE
 // address, which the LDS serialises.  Two rounds of leader aggregation (the lanes that share the first active lane's bin are counted
 // by one add of their ballot's population) take the crowd off; whoever is left adds for itself.
-__device__ __forceinline__ void hist_add(int* hist, unsigned bin, bool active, int lane) {
+// aggregate: the leader rounds pay on the TOP digit only (sign + high exponent bits: nearly every key in a handful of bins); on the lower
+// digits the keys that are still in play spread over the bins and the two rounds were pure latency.  The leader's bin is fetched with
+// v_readlane (its lane index is wave-uniform), not through the LDS crossbar: at 16 384 candidates per object the selection was bound by
+// the number of LDS instructions it issued (key read + two permutes + atomics per key and pass).
+__device__ __forceinline__ void hist_add(int* hist, unsigned bin, bool active, int lane, bool aggregate) {
+    if (aggregate) {
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        const unsigned long long act = __ballot(active);
-        if (act == 0ull) return;  // wave-uniform
-        const int leader = __ffsll((long long)act) - 1;
-        const unsigned lb = (unsigned)__shfl((int)bin, leader, kWave);
-        const unsigned long long same = __ballot(active && bin == lb);
-        if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
-        active = active && bin != lb;
+        for (int round = 0; round < 2; ++round) {
+            const unsigned long long act = __ballot(active);
+            if (act == 0ull) return;  // wave-uniform
+            const int leader = __ffsll((long long)act) - 1;
+            const unsigned lb = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+            const unsigned long long same = __ballot(active && bin == lb);
+            if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+            active = active && bin != lb;
+        }
     }
     if (active) atomicAdd(&hist[bin], 1);
 }
@@ -132,7 +145,10 @@ __device__ __forceinline__ unsigned weight_key(float w) {
     const unsigned u = __float_as_uint(w);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending unsigned order == ascending float order
 }
-__device__ __forceinline__ float quantile_threshold(const SelectParams& p, int n, const unsigned* keys, int segc) {
+// key_at(j, i): key of entry i = tid + j * kThreads (from LDS, or from the caller's registers: then ITERS = the number of entries a thread
+// holds, and the walks over them are unrolled so that j is a compile-time register index)
+template <int ITERS = 0, class KeyAt>
+__device__ __forceinline__ float quantile_threshold(const SelectParams& p, int n, KeyAt&& key_at, int segc) {
     __shared__ int wave_seg[kWaves];    // mode 2: visible entries per wavefront
     __shared__ int wave_le[kWaves];     // upper order statistic: keys <= the lower one / smallest key above it, per wavefront
     __shared__ unsigned wave_above[kWaves];
@@ -165,10 +181,20 @@ __device__ __forceinline__ float quantile_threshold(const SelectParams& p, int n
         for (int pass = 3; pass >= 0; --pass) {
             const int shift = 8 * pass, cur = (3 - pass) % 3, nxt = (cur + 1) % 3;
             if (tid < 256) hist[nxt][tid] = 0;
-            for (int i0 = 0; i0 < n; i0 += kThreads) {
-                const int i = i0 + tid;
-                const unsigned key = i < n ? keys[i] : 0u;
-                hist_add(hist[cur], (key >> shift) & 255u, i < n && (key & mask) == prefix, lane);
+            if constexpr (ITERS > 0) {
+#pragma unroll
+                for (int j = 0; j < ITERS; ++j) {
+                    const int i = j * kThreads + tid;
+                    if (j * kThreads >= n) break;  // uniform
+                    const unsigned key = i < n ? key_at(j, i) : 0u;
+                    hist_add(hist[cur], (key >> shift) & 255u, i < n && (key & mask) == prefix, lane, pass == 3);
+                }
+            } else {
+                for (int i0 = 0, j = 0; i0 < n; i0 += kThreads, ++j) {
+                    const int i = i0 + tid;
+                    const unsigned key = i < n ? key_at(j, i) : 0u;
+                    hist_add(hist[cur], (key >> shift) & 255u, i < n && (key & mask) == prefix, lane, pass == 3);
+                }
             }
             __syncthreads();
             // every wavefront: lane l owns bins 4l .. 4l+3, exclusive prefix over the lanes, then the bin holding rank k
@@ -194,10 +220,17 @@ __device__ __forceinline__ float quantile_threshold(const SelectParams& p, int n
     if (khi != klo) {  // uniform
         int le = 0;
         unsigned above = 0xFFFFFFFFu;
-        for (int i = tid; i < n; i += kThreads) {
-            const unsigned key = keys[i];
+        auto count = [&](int j, int i) {
+            const unsigned key = key_at(j, i);
             if (key <= found[0]) ++le;
             else above = min(above, key);
+        };
+        if constexpr (ITERS > 0) {
+#pragma unroll
+            for (int j = 0; j < ITERS; ++j)
+                if (j * kThreads + tid < n) count(j, j * kThreads + tid);
+        } else {
+            for (int i = tid, j = 0; i < n; i += kThreads, ++j) count(j, i);
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -263,7 +296,7 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
         for (int k = 0; k < kCache; ++k)
             if (tid + k * kThreads < n) stage(ec[k], tid + k * kThreads);
         for (int i = tid + kCache * kThreads; i < n; i += kThreads) stage(src.load(i), i);
-        thr = quantile_threshold(p, n, keys, segc);
+        thr = quantile_threshold(p, n, [&](int, int i) { return keys[i]; }, segc);
     }
     const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
     auto put = [&](const Entry& e, int o) { rows.entry_from(base, o, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src); };
@@ -320,6 +353,7 @@ template <typename T, typename TX>
 __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, MapSource<T, TX>& src, const int two_hw, float (*red)[2], float* srt) {
     const int tid = threadIdx.x, n = p.N;
     const size_t base = (size_t)b * p.N;
+    LC_FS_STAMP(0);
     float2 w[kWideCache];   // raw logits, then the weights
     float vraw[kWideCache];
     unsigned gbits = 0u;
@@ -331,6 +365,7 @@ __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, Ma
         vraw[k] = src.vis ? (float)src.vis[px] : 0.f;
     }
     src.lse = block_lse<kDenseLseThreads>(src.lg, two_hw, red);
+    LC_FS_STAMP(1);
 #pragma unroll
     for (int k = 0; k < kWideCache; ++k) {
         w[k] = make_float2(__expf(w[k].x - src.lse) * src.scale, __expf(w[k].y - src.lse) * src.scale);
@@ -339,20 +374,57 @@ __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, Ma
     auto weight_of = [&](int k) { return (p.mode == 2 && !((gbits >> k) & 1u)) ? 0.f : w[k].x + w[k].y; };
     float thr = -FLT_MAX;
     if (p.mode != 0) {
-        unsigned* keys = reinterpret_cast<unsigned*>(srt);
-        int segc = 0;
-#pragma unroll
-        for (int k = 0; k < kWideCache; ++k) {
-            const int i = tid + k * kThreads;
-            if (i < n) {
-                keys[i] = weight_key(weight_of(k));
-                if (p.mode == 2 && ((gbits >> k) & 1u)) ++segc;
-            }
-        }
-        thr = quantile_threshold(p, n, keys, segc);
+        // the keys never leave the registers: a thread's entry j of every pass is its own w[j] (the generic path stages them in LDS)
+        const int mine = min(kWideCache, max(0, (n - tid + kThreads - 1) / kThreads));  // entries tid, tid + 1024, ... below n
+        const int segc = p.mode == 2 ? __popc(gbits & ((1u << mine) - 1u)) : 0;        // (a slot behind the row repeats the row's last entry)
+        LC_FS_STAMP(2);
+        thr = quantile_threshold<kWideCache>(p, n, [&](int j, int) { return weight_key(weight_of(j)); }, segc);  // j: a compile-time index there
     }
+    LC_FS_STAMP(3);
     const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
-    Compactor cmp;
+    // Order-preserving compaction of all 16 chunks of 1024 candidates with THREE barriers (one barrier pair per chunk was 32 of them,
+    // 16 wavefronts each): the keep flags of a thread's 16 entries are known at once, so every wavefront posts its 16 per-chunk counts,
+    // the first 256 threads scan the 16 x 16 table in (chunk, wavefront) order, and a thread's entry k goes to
+    // offs[k][wave] + (kept entries of chunk k in lower lanes of its wavefront).
+    __shared__ int cnt[kWideCache][kWaves], offs[kWideCache][kWaves], wtot[4];
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned keepbits = 0u;
+    unsigned before[kWideCache / 4] = {};  // 8 bits per chunk
+#pragma unroll
+    for (int k = 0; k < kWideCache; ++k) {
+        const int i = tid + k * kThreads;
+        bool keep = false;
+        if (i < n) {
+            const bool g = (gbits >> k) & 1u;
+            keep = p.mode == 0 ? g : (weight_of(k) >= thr && (p.mode == 1 || g));
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (keep) keepbits |= 1u << k;
+        before[k >> 2] |= (unsigned)__popcll(bal & ((1ull << lane) - 1ull)) << (8 * (k & 3));
+        if (lane == 0) cnt[k][wave] = __popcll(bal);
+    }
+    __syncthreads();
+    int v = 0, incl = 0;
+    if (tid < kWideCache * kWaves) {
+        v = cnt[tid / kWaves][tid % kWaves];
+        incl = v;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int up = __shfl_up(incl, d, kWave);
+            if (lane >= d) incl += up;
+        }
+        if (lane == kWave - 1) wtot[wave] = incl;
+    }
+    __syncthreads();
+    static_assert(kWideCache * kWaves == 4 * kWave, "the table is scanned by four wavefronts");
+    if (tid < kWideCache * kWaves) {
+        int pre = 0;
+        for (int w = 0; w < wave; ++w) pre += wtot[w];
+        offs[tid / kWaves][tid % kWaves] = pre + incl - v;
+    }
+    const int kept = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+    LC_FS_STAMP(4);
 #pragma unroll
     for (int h = 0; h < kWideCache; h += kWideBatch) {
         if (h * kThreads >= n) break;  // uniform
@@ -366,26 +438,21 @@ __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, Ma
         }
 #pragma unroll
         for (int j = 0; j < kWideBatch; ++j) {
-            const int k = h + j, i0 = k * kThreads, i = i0 + tid;
-            if (i0 >= n) break;  // uniform
-            bool keep = false;
-            if (i < n) {
-                const bool g = (gbits >> k) & 1u;
-                keep = p.mode == 0 ? g : (weight_of(k) >= thr && (p.mode == 1 || g));
-            }
-            const int o = cmp.slot(keep, i0 + kThreads < n);
-            if (keep) {
+            const int k = h + j, i = k * kThreads + tid;
+            if ((keepbits >> k) & 1u) {
                 int x, y;
                 src.pixel(i, x, y);  // (recomputed for the survivors rather than held for everybody: registers)
+                const int o = offs[k][wave] + (int)((before[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 rows.entry_from(base, o, (float)x, (float)y, w[k], X[j][0] * src.ns[0], X[j][1] * src.ns[1], X[j][2] * src.ns[2], i);
             }
         }
     }
-    const int total = pad_rows(b, n, cmp.running, p.min_count, p.seed, [&](int i, int k) {
+    const int total = pad_rows(b, n, kept, p.min_count, p.seed, [&](int i, int k) {
         const Entry e = src.load(i);
         rows.entry_from(base, k, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src);
     });  // test.py:108-113
     if (tid == 0) p.counts[b] = total;
+    LC_FS_STAMP(5);
 }
 
 template <typename T, typename TX, bool WIDE>
@@ -456,3 +523,9 @@ int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d_in,
 }
 
 }  // namespace lc
+
+#ifdef LC_SELECT_STAMPS
+extern "C" __attribute__((visibility("default"))) int lc_debug_select_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::select_diag::g_stamp), sizeof(unsigned long long) * 10) == hipSuccess ? 0 : 1;
+}
+#endif
