@@ -271,6 +271,15 @@ int lc_pnp_ransac_init4_f32(const float *K, const float *pts3d, const float *pts
                             int *valid_counts, void *workspace, size_t workspace_bytes, int ticketed, const float *sel_w,
                             const int *sel_in_index, int sel_min_count, unsigned sel_seed, float *sel_pts2d, float *sel_w_out,
                             float *sel_pts3d, int *sel_index, int *sel_counts, void *stream);
+/* init4 for a batch that is a slice [pose_index_offset, pose_index_offset + B) of a larger one: the hypothesis stream and the padding draw of
+ * pose b are those of pose pose_index_offset + b, so sub-batches solved concurrently on several streams (lc_amd/inference.py) return what the
+ * one call over the whole batch returns.  lc_dense_frontend_select2 takes the same offset for its padding draw. */
+int lc_pnp_ransac_init5_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
+                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
+                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
+                            int *valid_counts, void *workspace, size_t workspace_bytes, int ticketed, const float *sel_w,
+                            const int *sel_in_index, int sel_min_count, unsigned sel_seed, float *sel_pts2d, float *sel_w_out,
+                            float *sel_pts3d, int *sel_index, int *sel_counts, int pose_index_offset, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2f) ZebraPose binary surface codes -- floatbits.py.  logits (B,C,H,W), C = n0+n1+n2 code bits
@@ -432,7 +441,7 @@ int lc_dense_frontend_bwd2(const void *wlogits, const void *wscale, const float 
                            int sample, void *d_xyz, void *d_wlogits, void *d_wscale, void *stream);
 int lc_dense_frontend_select2(const void *xyz, const void *wlogits, const void *wscale, const float *noc_scale,
                               const void *vis_logits, float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left,
-                              int sample, int mode, double quantile, int square_weights, int min_count, unsigned seed,
+                              int sample, int mode, double quantile, int square_weights, int min_count, unsigned seed, int pose_index_offset,
                               float *out_pts2d, float *out_weights, float *out_pts3d, int *out_index, int *counts,
                               void *stream);
 int lc_bits_decode_gt_fwd3(const void *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,

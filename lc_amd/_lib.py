@@ -47,6 +47,8 @@ _SIGNATURES = {
                                 [ctypes.c_size_t, c_void_p]),
     "lc_pnp_ransac_init4_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +
                                 [ctypes.c_size_t, c_int, c_void_p, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6),
+    "lc_pnp_ransac_init5_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +
+                                [ctypes.c_size_t, c_int, c_void_p, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 5 + [c_int, c_void_p]),
     "lc_pnp_ransac_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "lc_bits_decode_gt_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_gt_bwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
@@ -76,7 +78,7 @@ _SIGNATURES = {
     # round 4: the f1 / f3 entry points for maps of any element type (map_dtype) lying anywhere a sample is contiguous (batch strides)
     "lc_dense_frontend_fwd3": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 6 + [c_void_p] * 6),
     "lc_dense_frontend_bwd2": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_longlong] + [c_int] * 6 + [c_void_p] * 4),
-    "lc_dense_frontend_select2": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint] +
+    "lc_dense_frontend_select2": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint, c_int] +
                                   [c_void_p] * 6),
     "lc_bits_decode_gt_fwd3": (c_int, [c_void_p] * 5 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_gt_bwd3": (c_int, [c_void_p] * 6 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),

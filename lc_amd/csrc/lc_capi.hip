@@ -488,11 +488,11 @@ int lc_pnp_ransac_init3_f32(const float* K, const float* pts3d, const float* pts
     return rc ? fail(11, "ransac kernel launch failed") : 0;
 }
 
-int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+int lc_pnp_ransac_init5_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
                             float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
                             unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
                             size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
-                            float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, void* stream) {
+                            float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, int pose_index_offset, void* stream) {
     if (B < 0 || Nmax < 0 || iterations <= 0 || sel_min_count < 0) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
@@ -504,10 +504,18 @@ int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts
     LC_REQUIRE_ALIGNED(8, pts2d);
     lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
                        (iterations + 63) / 64, reproj_err, seed, best_hyp, valid_counts, workspace, workspace_bytes,
-                       sel_w, sel_in_index, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, sel_min_count, sel_seed, (workspace && ticketed) ? 1 : 0};
+                       sel_w, sel_in_index, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, sel_min_count, sel_seed, (workspace && ticketed) ? 1 : 0, pose_index_offset};
     const int rc = lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream));
     if (rc == 3) return fail(1, "workspace smaller than lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)");
     return rc ? fail(11, "ransac kernel launch failed") : 0;
+}
+
+int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
+                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
+                            size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
+                            float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, void* stream) {
+    return lc_pnp_ransac_init5_f32(K, pts3d, pts2d, counts, B, Nmax, reproj_err, reproj_err_per_pose, iterations, seed, states, inlier_mask, n_inliers, invalid, best_hyp, valid_counts, workspace, workspace_bytes, ticketed, sel_w, sel_in_index, sel_min_count, sel_seed, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, 0, stream);
 }
 
 static int bits_check(int B, int C, int H, int W, int n0, int n1, int n2, int top, int left, int sample) {
@@ -685,7 +693,7 @@ int lc_dense_select_f32(const float* pts2d, const float* inv_std, const float* p
 
 int lc_dense_frontend_select2(const void* xyz, const void* wlogits, const void* wscale, const float* noc_scale, const void* vis_logits,
                                  float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
-                                 int square_weights, int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d,
+                                 int square_weights, int min_count, unsigned seed, int pose_index_offset, float* out_pts2d, float* out_weights, float* out_pts3d,
                                  int* out_index, int* counts, void* stream) {
     if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
     if (wscale_dtype < 0 || wscale_dtype > 2) return fail(1, "wscale_dtype must be LC_F32, LC_F16 or LC_BF16");
@@ -702,7 +710,7 @@ int lc_dense_frontend_select2(const void* xyz, const void* wlogits, const void* 
     if (mode != 1 && !vis_logits) return fail(1, "modes 0 (mask) and 2 (quantile_in_mask) need the visibility logits");
     LC_REQUIRE_ALIGNED(8, out_pts2d, out_weights);
     lc::SelectParams p{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_pts2d, out_weights, out_pts3d, out_index, counts,
-                       B, N, mode, (float)quantile, (float)(1.0 - quantile), square_weights, min_count, seed};
+                       B, N, mode, (float)quantile, (float)(1.0 - quantile), square_weights, min_count, seed, pose_index_offset};
     lc::DenseParams d{xyz, wlogits, wscale, noc_scale, nullptr, nullptr, nullptr, nullptr, B, H, W, N, top, left, sample, vis_logits, vis_thresh, nullptr, map_dtype, wscale_dtype, xyz_dtype,
                        xyz_bstride ? xyz_bstride : 3ll * H * W, wlogits_bstride ? wlogits_bstride : 2ll * H * W, vis_bstride ? vis_bstride : 1ll * H * W};
     return lc::launch_dense_frontend_select(p, d, static_cast<hipStream_t>(stream)) ? fail(11, "front end + select launch failed") : 0;
@@ -712,7 +720,7 @@ int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const f
                                  float vis_thresh, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
                                  int square_weights, int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d,
                                  int* out_index, int* counts, void* stream) {
-    return lc_dense_frontend_select2(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, 0 /* LC_F32 */, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, 0, 0, B, H, W, top, left, sample, mode, quantile, square_weights, min_count, seed, out_pts2d, out_weights, out_pts3d, out_index, counts, stream);
+    return lc_dense_frontend_select2(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, 0 /* LC_F32 */, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, 0, 0, B, H, W, top, left, sample, mode, quantile, square_weights, min_count, seed, 0, out_pts2d, out_weights, out_pts3d, out_index, counts, stream);
 }
 
 int lc_dense_aux_fwd2(const void* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,

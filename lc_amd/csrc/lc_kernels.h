@@ -134,6 +134,9 @@ struct RansacParams {
     int sel_min_count;
     unsigned sel_seed;
     int ticketed;              // split form only: scoring and selection in ONE launch, the last workgroup of a pose to finish selects
+    int pose0;                 // index of the batch's first pose in the caller's numbering: the hypothesis stream and the padding draw of pose b are
+                               // those of pose pose0 + b, so a batch solved in several sub-batches (concurrently, on several streams) gives the
+                               // results of the one call
 };
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);  // 3: workspace too small
 size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds);
@@ -320,6 +323,7 @@ struct SelectParams {
     float quantile, one_minus_q;
     int square, min_count;
     unsigned seed;
+    int pose0;                  // as RansacParams::pose0: the padding draw of row b is that of row pose0 + b
 };
 int launch_dense_select(const SelectParams& p, hipStream_t stream);
 // front end + selection in one launch (test time, N <= 1024): the input arrays of `p` are unused (null), `d` names the maps

@@ -509,7 +509,7 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
     }
     LC_SEL_STAMP(5);
     if (sel) {
-        const int cnt = rows.pad(base, b, n, kept, p.sel_min_count, p.sel_seed);
+        const int cnt = rows.pad(base, p.pose0 + b, n, kept, p.sel_min_count, p.sel_seed);
         if (tid == 0) p.sel_counts[b] = cnt;
     }
 }
@@ -518,7 +518,7 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
 // (cv2_solver.py:74-80).  Called by every thread of the workgroup (the inlier mask is all zero: the selection keeps nothing and pads).
 __device__ __forceinline__ void write_too_few(const RansacParams& p, int b, int n) {
     if (p.sel_w) {
-        const int cnt = selection_rows(p).pad((size_t)b * p.Nmax, b, n, 0, p.sel_min_count, p.sel_seed);
+        const int cnt = selection_rows(p).pad((size_t)b * p.Nmax, p.pose0 + b, n, 0, p.sel_min_count, p.sel_seed);
         if (threadIdx.x == 0) p.sel_counts[b] = cnt;
     }
     if (threadIdx.x != 0) return;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
         bool have = false;
         if (active) {
             int idx[4];
-            sample_indices(p.seed, b, round * kWave + lane, n, idx);
+            sample_indices(p.seed, p.pose0 + b, round * kWave + lane, n, idx);
             have = hypothesis_pose(idx, [&](int i, float (&X)[3], float (&u)[2]) {
                 const int j = i - tile0;
                 if (j >= 0 && j < kLdsTilePts) {  // the same floats either way: the tile holds what the other branch computes
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kWave) void lc_ransac_hypotheses_kernel(const Ransa
     const CamInv kin(p.K + 9 * (size_t)b);
     const size_t base = (size_t)b * p.Nmax;
     int idx[4];
-    sample_indices(p.seed, b, hyp, n, idx);
+    sample_indices(p.seed, p.pose0 + b, hyp, n, idx);
     LC_P3P_STAMP(1);
     Pose cand;
     const bool have = hypothesis_pose(idx, [&](int i, float (&X)[3], float (&u)[2]) {

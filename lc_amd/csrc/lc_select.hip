@@ -319,7 +319,7 @@ __device__ __forceinline__ void select_row(const SelectParams& p, int b, int n, 
         const bool mine = i0 + tid < n;
         chunk(i0, mine ? src.load(i0 + tid) : ec[0], mine);
     }
-    const int total = pad_rows(b, n, cmp.running, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
+    const int total = pad_rows(p.pose0 + b, n, cmp.running, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
     if (tid == 0) p.counts[b] = total;
 }
 
@@ -447,7 +447,7 @@ __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, Ma
             }
         }
     }
-    const int total = pad_rows(b, n, kept, p.min_count, p.seed, [&](int i, int k) {
+    const int total = pad_rows(p.pose0 + b, n, kept, p.min_count, p.seed, [&](int i, int k) {
         const Entry e = src.load(i);
         rows.entry_from(base, k, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src);
     });  // test.py:108-113

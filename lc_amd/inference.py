@@ -64,9 +64,54 @@ def solve_pnp(cfg, out_dict, gt_dict):
     return {"weighted": _weighted(K, pts3d, pts2d, std.pow(-2), start), "ransac": start}
 
 
+_SIDE_STREAMS = {}  # device index -> streams the sub-batches of a wide test-time batch run on
+
+
+def _sub_batch_count(B: int, N: int) -> int:
+    """How many sub-batches `solve_pnp_dense` cuts a batch into: 1 unless LC_AMD_TEST_TIME_STREAMS says otherwise.
+    At zlmo's test-time shape (16 384 candidates per object) five of the chain's seven launches are one workgroup per object -- 64 objects keep a
+    quarter of the chip busy -- and the other two (code decode, RANSAC scoring) fill it.  Cut into sub-batches on side streams the narrow
+    launches of one sub-batch COULD run beside the wide ones of another; results do not change (every object is independent, and the RANSAC's
+    hypothesis streams / padding draws are keyed by the object's index in the WHOLE batch: `pose_index_offset`,
+    tests/test_gpu_test_time.py::test_sub_batches_on_streams_return_the_one_batch_result).  MEASURED (round 4, one MI355X, 64 objects, four
+    sub-batches): the replayed graph takes 254 us against 225 us for the one batch -- the runtime does not overlap the graph's parallel
+    branches enough to pay for 4 x 7 smaller launches -- and the eager call is host-bound (894 us).  Hence off by default; the switch stays for
+    callers whose batches are larger than one round of the chip."""
+    import os
+
+    forced = os.environ.get("LC_AMD_TEST_TIME_STREAMS")
+    return max(1, min(int(forced), B)) if forced else 1
+
+
 @torch.no_grad()
 def solve_pnp_dense(cfg, out_dict, gt_dict):
     """Dense heads (`test.py:67-136`)."""
+    B, _, H, W = out_dict["xyz_weight_logits"].shape
+    stride = cfg.get("dense_sample", 2)
+    parts = _sub_batch_count(B, -(-H // stride) * -(-W // stride))
+    if parts <= 1:
+        return _solve_pnp_dense(cfg, out_dict, gt_dict, 0)
+    dev = out_dict["xyz_weight_logits"].device
+    cur = torch.cuda.current_stream(dev)
+    pool = _SIDE_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+    while len(pool) < parts:
+        pool.append(torch.cuda.Stream(dev))
+    cut = lambda d, b0, b1: {k: (v[b0:b1] if isinstance(v, Tensor) and v.dim() > 0 and v.shape[0] == B else v) for k, v in d.items()}  # noqa: E731
+    bounds = [(B * k // parts, B * (k + 1) // parts) for k in range(parts)]
+    results = []
+    for (b0, b1), side in zip(bounds, pool):
+        side.wait_stream(cur)  # the network's outputs are ready on the caller's stream
+        with torch.cuda.stream(side):
+            results.append(_solve_pnp_dense(cfg, cut(out_dict, b0, b1), cut(gt_dict, b0, b1), b0))
+    for side in pool[:parts]:
+        cur.wait_stream(side)
+    for res in results:  # allocated on the side streams, read from here on by the caller's
+        for t in res.values():
+            t.record_stream(cur)
+    return {k: torch.cat([res[k] for res in results]) for k in results[0]}
+
+
+def _solve_pnp_dense(cfg, out_dict, gt_dict, pose0):
     K = gt_dict["out_K"]
     stride = cfg.get("dense_sample", 2)
     thr = cfg.get("seg_thresh", 0.5)
@@ -108,7 +153,8 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
         # joint softmax x scale, the (0,0)-phase stride sub-sampling (test.py:85-92), the visibility mask of the sampled pixels
         # (test.py:88-90) AND the point selection (test.py:94-113) in one launch
         u, icov, x, counts, index = dense_front_end_select(xyz_map, out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"], noc_scale,
-                                                           out_dict["msk_vis_logits"], mode, seg_thresh=thr, sample=stride, **select_args)
+                                                           out_dict["msk_vis_logits"], mode, seg_thresh=thr, sample=stride, pose_index_offset=pose0,
+                                                           **select_args)
     else:
         pts2d, inv_std, pts3d, visible = dense_front_end_with_visibility(xyz_map, out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"],
                                                                          noc_scale, out_dict["msk_vis_logits"], thr, sample=stride)
@@ -118,7 +164,8 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     filtered = None
     if "weighted_filtered" in wanted:
         filtered = dict(weights=icov, index=index, min_count=4, out=half(1) if both else None)
-    start, inliers, _bad, refine = gpu_solver.solve_device(K, x, u, counts, select=filtered, refine="defer", **_reprojection_threshold(cfg, gt_dict, 3))
+    start, inliers, _bad, refine = gpu_solver.solve_device(K, x, u, counts, select=filtered, refine="defer", pose_index_offset=pose0,
+                                                           **_reprojection_threshold(cfg, gt_dict, 3))
     # The RANSAC's inlier refinement and the weighted solve(s) that start from its result: ONE launch (`lc_pnp_lm_chain_f32`), each
     # workgroup refines its object's pose and goes on with its own weighted solve.
     weighted = dict(weights_are_icov=True, nan_to_num=True, start="first")  # `_weighted` above, chained

@@ -15,9 +15,11 @@ from . import cer_solver, pnp_ceres
 
 
 def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True,
-                 return_hypothesis=False, split=None, ticketed=False, select=None, reproj_divisor=None):
+                 return_hypothesis=False, split=None, ticketed=False, select=None, reproj_divisor=None, pose_index_offset=0):
     """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool
     [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly].
+    pose_index_offset: this batch is the slice [offset, offset + B) of a larger one -- hypothesis streams and padding draws are those of the
+    larger batch's poses, so sub-batches solved on several streams return what one call over the whole batch returns.
     reprojectionError: pixels, a scalar or a (B,) tensor; with reproj_divisor (B,) the threshold of pose b is reprojectionError /
     reproj_divisor[b], divided inside the launch (test.py:56-57,115-116: `2 / gt_dict['out_pix_scale']`).
 
@@ -82,11 +84,11 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
         head = (_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError), _lib.ptr(per_pose),
                 int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask), _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp),
                 _lib.ptr(rows), _lib.ptr(ws), nbytes)
-        if ticketed or select is not None:
-            name = "lc_pnp_ransac_init4_f32"
-            rc = lib.lc_pnp_ransac_init4_f32(*head, int(bool(ticketed)), _lib.ptr(sel_w), _lib.ptr(sel_idx), int(select.get("min_count", 4)) if select else 0,
+        if ticketed or select is not None or pose_index_offset:
+            name = "lc_pnp_ransac_init5_f32"
+            rc = lib.lc_pnp_ransac_init5_f32(*head, int(bool(ticketed)), _lib.ptr(sel_w), _lib.ptr(sel_idx), int(select.get("min_count", 4)) if select else 0,
                                              (int(select.get("seed", 0)) if select else 0) & 0xFFFFFFFF, *(_lib.ptr(sel_out[k]) for k in (0, 1, 2, 4, 3)),  # C order: rows, index, counts
-                                             _lib.stream_ptr(dev))
+                                             int(pose_index_offset), _lib.stream_ptr(dev))
         else:
             name = "lc_pnp_ransac_init3_f32"
             rc = lib.lc_pnp_ransac_init3_f32(*head, _lib.stream_ptr(dev))

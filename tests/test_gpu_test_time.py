@@ -184,3 +184,24 @@ def test_test_time_path_batch_of_64_and_graph_replay(name):
     gt2, out2 = _to(gt2, DEV), _to(out2, DEV)
     assert torch.equal(solver(out2, gt2)[key], solve_pnp(cfg, out2, gt2)[key])
     assert torch.equal(solver(out, gt)[key], ref[key])
+
+
+@pytest.mark.parametrize("parts", [2, 4, 5])
+def test_sub_batches_on_streams_return_the_one_batch_result(parts, monkeypatch):
+    """zlmo's chain cut into sub-batches that run on side streams (what `solve_pnp_dense` does at 16 384 candidates per object): every pose
+    bit for bit the pose of the one call over the whole batch -- the hypothesis streams and padding draws are keyed by the object's index in
+    the whole batch -- incl. an object nothing of which is visible (padded entries) and a split that does not divide the batch."""
+    from lc_amd import synth
+    from lc_amd.config import AttrDict
+    from lc_amd.inference import solve_pnp
+
+    cfg, gt_c, out_c = synth.test_time_inputs("zlmo", B=37, seed=8)
+    out_c["msk_vis_logits"][20] = -9.0
+    cfg = AttrDict(cfg)
+    gt, out = _to(gt_c, DEV), _to(out_c, DEV)
+    monkeypatch.setenv("LC_AMD_TEST_TIME_STREAMS", "1")
+    one = solve_pnp(cfg, out, gt)
+    monkeypatch.setenv("LC_AMD_TEST_TIME_STREAMS", str(parts))
+    cut = solve_pnp(cfg, out, gt)
+    torch.cuda.synchronize()
+    assert list(one) == list(cut) and all(torch.equal(one[k], cut[k]) for k in one)
