@@ -21,8 +21,15 @@ done
 TT=gpurun_out/test_time_$TAG
 if [ -d "$TT" ]; then  # scripts/profile_test_time.sh
   mkdir -p "$DST/test_time"
-  for f in graph_inference kernel_avgs ransac_forms select_modes p3p_stamps sel_stamps; do
+  for f in zlmo glmo kernel_avgs_zlmo kernel_avgs_glmo graph_inference_hybrid select_stamps graph_inference kernel_avgs ransac_forms select_modes p3p_stamps sel_stamps; do
     [ -s "$TT/$f.txt" ] && { echo "# scripts/profile_test_time.sh on one MI355X, commit $SHA"; cat "$TT/$f.txt"; } > "$DST/test_time/$f.txt"
   done
+fi
+NX=gpurun_out/prof_next_$TAG
+if [ -d "$NX" ]; then  # scripts/profile_next.sh
+  mkdir -p "$DST/next"
+  cp "$NX/NEXT_SUMMARY.md" "$DST/next/" 2>/dev/null || true
+  cp "$NX"/trace/*kernel_stats.csv "$DST/next/next_kernel_stats.csv" 2>/dev/null || true
+  [ -s "$NX/bench_next.jsonl" ] && grep '^{' "$NX/bench_next.jsonl" > "$DST/next/bench_next.jsonl"
 fi
 ls -la "$DST"
