@@ -20,7 +20,7 @@ rows = list(csv.DictReader(open(f)))
 with open(out + "/NEXT_SUMMARY.md", "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats of bench_next.py\n\n| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|\n")
     for r in rows:
-        if r["Name"].startswith("lc_") or "lc::" in r["Name"]:
+        if r["Name"].startswith("lc_") or "lc::" in r["Name"] or "_ZN2lc" in r["Name"]:
             o.write("| %s | %s | %s | %s | %s |\n" % (r["Name"][:80], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
     from collections import defaultdict
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
