@@ -178,7 +178,6 @@ def hip_maps(**named):
     batch, or a channel slice `out_raw[:, a:b]` of the network's (B,C_all,H,W) output (what `ptnet.py:56` hands over) -- its batch
     stride is passed along and the slice is consumed where it lies.  Only two cases copy: a sample that is not contiguous itself
     (copied into shape), and maps of DIFFERENT element types in one call (the 16-bit ones are up-cast to fp32)."""
-    dtypes = {t.dtype for t in named.values() if t is not None}
     for name, t in named.items():
         if t is None:
             continue
@@ -189,6 +188,7 @@ def hip_maps(**named):
                                f"(there is no CPU fallback in the product path)")
         if t.dtype not in MAP_DTYPES:
             raise TypeError(f"lc_amd: {name} must be float32, float16 or bfloat16, got {t.dtype}")
+    dtypes = {t.dtype for t in named.values() if t is not None}
     mixed = len(dtypes) > 1
     out, strides = [], []
     for t in named.values():

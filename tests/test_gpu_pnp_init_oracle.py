@@ -169,3 +169,39 @@ def test_ticketed_form_under_concurrency_and_replay():
         torch.cuda.synchronize()
         for x, y in zip(outs, want[0]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("split", [True, False], ids=["split", "single_launch"])
+@pytest.mark.parametrize("B,N,cut", [(24, 64, 8), (10, 700, 3), (5, 5000, 2)])
+def test_pose_index_offset_makes_sub_batches_equal_the_one_batch(B, N, cut, split):
+    """lc_pnp_ransac_init5_f32: a slice [cut, B) of a batch solved with pose_index_offset = cut draws the hypothesis streams (and the padding of
+    the inlier re-selection) of poses cut .. B-1 of the whole batch: states, masks, winners, re-selected rows bit for bit."""
+    from lc_amd import synth
+    from lc_amd.pnp import gpu_solver
+
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=B * N, outlier_frac=0.35, noise_px=0.6).items()}
+    g = torch.Generator().manual_seed(N)
+    counts = torch.randint(max(4, N // 2), N + 1, (B,), generator=g).to(torch.int32).to(dev)
+    b["pts3d"][cut + 1] = 0  # a degenerate object in the slice: RANSAC gives up, the re-selection pads with pseudo-random entries keyed by the pose index
+    w = (torch.rand(B, N, 2, generator=g) + 0.1).to(dev)
+
+    def run(lo, hi, off):
+        sel = dict(weights=w[lo:hi], min_count=4, seed=9)
+        out = gpu_solver.solve_device(b["K"][lo:hi], b["pts3d"][lo:hi], b["pts2d"][lo:hi], counts[lo:hi], reprojectionError=2.0, seed=5, refine=False,
+                                      return_hypothesis=True, split=split, select=sel, pose_index_offset=off)
+        return out, sel["result"]
+
+    (st, inl, bad, hyp, n_in), rows = run(0, B, 0)
+    (st2, inl2, bad2, hyp2, n2), rows2 = run(cut, B, cut)
+    assert bool(bad[cut + 1]) and torch.equal(bad[cut:], bad2)
+    assert torch.equal(st[cut:], st2) and torch.equal(inl[cut:], inl2) and torch.equal(hyp[cut:], hyp2) and torch.equal(n_in[cut:], n2)
+    cnt = rows[3][cut:]
+    assert torch.equal(cnt, rows2[3])
+    live = torch.arange(N, device=dev)[None, :] < cnt[:, None]
+    for k in (0, 1, 2, 4):
+        m = live if rows[k].dim() == 2 else live[..., None].expand_as(rows2[k])
+        assert torch.equal(rows[k][cut:][m], rows2[k][m]), k
+    # without the offset the slice is a batch of its own: other hypothesis streams (the winners differ somewhere)
+    (_, _, _, hyp3, _), _ = run(cut, B, 0)
+    assert not torch.equal(hyp3, hyp2)
