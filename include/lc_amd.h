@@ -453,6 +453,13 @@ int lc_bits_decode_gt_bwd3(const void *logits, const unsigned char *gt_bits, con
                            void *d_logits, void *stream);
 int lc_bits_decode3(const void *logits, const float *out_scale, const float *out_xform, int map_dtype, long long logits_bstride, int B, int C, int H,
                     int W, int n0, int n1, int n2, int black_background, int planar, float *out, void *stream);
+/* Inference decode of the SELECTED pixels only (test time, test.py:67-136 with binary-code heads): entry k < rows_counts[b] of row b is sampled
+ * pixel rows_index[b][k] of the (top, left, sample) grid -- what lc_dense_frontend_select2 (called with xyz = out_pts3d = NULL: the selection alone)
+ * leaves in out_index / counts -- and its object coordinates `(noc * out_scale - T[:3,3]) @ T[:3,:3]` go to out_pts3d[b][k] (B,rows_N,3).  The floats
+ * of lc_bits_decode3 at those pixels; a fifth of its work at zlmo's test-time shape. */
+int lc_bits_decode_rows(const void *logits, const float *out_scale, const float *out_xform, int map_dtype, long long logits_bstride,
+                        int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top, int left, int sample,
+                        const int *rows_index, const int *rows_counts, int rows_N, float *out_pts3d, void *stream);
 int lc_dense_aux_fwd2(const void *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
                       const void *seg_logits, const float *msk_vis, const void *wlogits, int map_dtype, long long xyz_bstride, long long seg_bstride, long long wlogits_bstride, int B, int HW,
                       int seg_type, float *losses, double *partials, unsigned *ticket, void *stream);

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "lc_bits_decode_gt_fwd3": (c_int, [c_void_p] * 5 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_gt_bwd3": (c_int, [c_void_p] * 6 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode3": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "lc_bits_decode_rows": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "lc_dense_aux_fwd2": (c_int, [c_void_p] * 7 + [c_int] + [ctypes.c_longlong] * 3 + [c_int] * 3 + [c_void_p] * 4),
     "lc_dense_aux_bwd2": (c_int, [c_void_p] * 7 + [c_int] + [ctypes.c_longlong] * 3 + [c_int] * 3 + [c_void_p] * 7),
     "lc_xyz_bin_loss_fwd2": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong, ctypes.c_longlong] + [c_int] * 3 + [c_float] + [c_void_p] * 6),

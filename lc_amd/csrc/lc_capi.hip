@@ -615,6 +615,22 @@ int lc_bits_decode3(const void* logits, const float* out_scale, const float* out
     return lc::launch_bits_decode(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
 }
 
+int lc_bits_decode_rows(const void* logits, const float* out_scale, const float* out_xform, int map_dtype, long long logits_bstride, int B, int C, int H,
+                        int W, int n0, int n1, int n2, int black_background, int top, int left, int sample, const int* rows_index,
+                        const int* rows_counts, int rows_N, float* out_pts3d, void* stream) {
+    if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
+    if (logits_bstride < 0 || (logits_bstride && logits_bstride < (long long)C * H * W)) return fail(1, "batch stride smaller than a sample");
+    if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
+    if (rows_N < 0) return fail(1, "bad size");
+    if (B == 0 || rows_N == 0) return 0;
+    if (B > 65535) return fail(1, "more than 65535 rows");
+    if (!logits || !rows_index || !rows_counts || !out_pts3d) return fail(1, "null pointer");
+    if (out_xform && !out_scale) return fail(1, "the model transform applies to scaled coordinates: out_scale is needed with out_xform");
+    lc::BitsParams p{logits, nullptr, nullptr, nullptr, out_pts3d, nullptr, B, C, H, W, H * W, top, left, sample, {n0, n1, n2}, black_background ? -1 : 1,
+                     out_scale, out_xform, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * H * W, rows_index, rows_counts, rows_N};
+    return lc::launch_bits_decode_rows(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode (rows) launch failed") : 0;
+}
+
 int lc_bits_decode2_f32(const float* logits, const float* out_scale, const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2,
                         int black_background, int planar, float* out, void* stream) {
     return lc_bits_decode3(logits, out_scale, out_xform, 0 /* LC_F32 */, 0, B, C, H, W, n0, n1, n2, black_background, planar, out, stream);
@@ -706,7 +722,8 @@ int lc_dense_frontend_select2(const void* xyz, const void* wlogits, const void* 
     if (mode != 0 && !(quantile >= 0.0 && quantile <= 1.0)) return fail(1, "quantile outside [0,1]");
     if (N > 16384) return fail(1, "more than 16384 sampled pixels per object: use lc_dense_frontend_fwd2_f32 + lc_dense_select_f32");
     if (B == 0) return 0;
-    if (!xyz || !wlogits || !wscale || !out_pts2d || !out_weights || !out_pts3d || !counts) return fail(1, "null pointer");
+    if (!wlogits || !wscale || !out_pts2d || !out_weights || !counts) return fail(1, "null pointer");
+    if ((xyz == nullptr) != (out_pts3d == nullptr)) return fail(1, "xyz and out_pts3d go together (both NULL: the selection alone, lc_bits_decode_rows fills the points)");
     if (mode != 1 && !vis_logits) return fail(1, "modes 0 (mask) and 2 (quantile_in_mask) need the visibility logits");
     LC_REQUIRE_ALIGNED(8, out_pts2d, out_weights);
     lc::SelectParams p{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_pts2d, out_weights, out_pts3d, out_index, counts,

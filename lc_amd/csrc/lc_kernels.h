@@ -158,10 +158,16 @@ struct BitsParams {
     int map_dtype;                // kMapF32 / kMapF16 / kMapBF16: element type of logits and d_logits (outputs and cotangents are fp32)
     long long logits_bs;          // elements between consecutive samples of `logits` (C*H*W for a dense batch; larger for a channel slice of the
                                   // network's (B,C_all,H,W) output, ptnet.py:56: no copy in front of the kernel); d_logits is dense
+    // inference decode of SELECTED pixels only (launch_bits_decode_rows): entry k < rows_counts[b] of row b is sampled pixel rows_index[b][k] of the
+    // (top, left, sample) grid; its object coordinates go to out[(b * rows_N + k) * 3 ..]
+    const int* rows_index;        // (B, rows_N)
+    const int* rows_counts;       // (B,)
+    int rows_N;
 };
 int launch_bits_decode_gt_fwd(const BitsParams& p, hipStream_t stream);
 int launch_bits_decode_gt_bwd(const BitsParams& p, hipStream_t stream);
 int launch_bits_decode(const BitsParams& p, hipStream_t stream);
+int launch_bits_decode_rows(const BitsParams& p, hipStream_t stream);
 
 struct MetricsParams {
     const float* R_est;  // (B,3,3)

@@ -114,7 +114,7 @@ struct MapSource {
         Entry e;
         e.u = make_float2((float)x, (float)y);
         e.s = make_float2((float)lg[px], (float)lg[HW + px]);
-        for (int d = 0; d < 3; ++d) e.X[d] = (float)xyz[d * HW + px];
+        for (int d = 0; d < 3; ++d) e.X[d] = xyz ? (float)xyz[d * HW + px] : 0.f;  // null: the selection alone (the points are decoded for the selected rows afterwards)
         v = vis ? (float)vis[px] : 0.f;
         e.g = 0;
         e.src = n;
@@ -434,7 +434,7 @@ __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, Ma
             int x, y;
             const int px = src.pixel(min(tid + (h + j) * kThreads, n - 1), x, y);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) X[j][d] = (float)src.xyz[d * src.HW + px];
+            for (int d = 0; d < 3; ++d) X[j][d] = src.xyz ? (float)src.xyz[d * src.HW + px] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < kWideBatch; ++j) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
     const int b = blockIdx.x, tid = threadIdx.x, HW = d.H * d.W;
     MapSource<T, TX> src;
     src.lg = static_cast<const T*>(d.wlogits) + (size_t)b * d.wl_bs;
-    src.xyz = static_cast<const TX*>(d.xyz) + (size_t)b * d.xyz_bs;
+    src.xyz = d.xyz ? static_cast<const TX*>(d.xyz) + (size_t)b * d.xyz_bs : nullptr;
     src.vis = d.vis_logits ? static_cast<const T*>(d.vis_logits) + (size_t)b * d.vis_bs : nullptr;
     src.vis_thresh = d.vis_thresh;
     src.HW = HW; src.W = d.W; src.top = d.top; src.left = d.left; src.sample = d.sample;

@@ -48,8 +48,10 @@ struct RowCopy {
     __device__ __forceinline__ void entry_from(size_t base, int o, float u, float v, float2 s, float X, float Y, float Z, int src) const {
         *reinterpret_cast<float2*>(o_pts2d + (base + o) * 2) = make_float2(u, v);
         *reinterpret_cast<float2*>(o_w + (base + o) * 2) = square ? make_float2(s.x * s.x, s.y * s.y) : s;
-        float* oX = o_pts3d + (base + o) * 3;
-        oX[0] = X; oX[1] = Y; oX[2] = Z;
+        if (o_pts3d) {  // null: the caller fills the model points of the selected rows afterwards (lc_bits_decode_rows: code heads)
+            float* oX = o_pts3d + (base + o) * 3;
+            oX[0] = X; oX[1] = Y; oX[2] = Z;
+        }
         if (o_index) o_index[base + o] = src;
     }
 

@@ -151,7 +151,8 @@ def dense_front_end_select(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weigh
                            pose_index_offset: int = 0):
     """`dense_front_end_with_visibility` followed by `dense_select(..., mask=visible)` as ONE launch (test time, at most
     FUSED_SELECT_MAX_POINTS sampled pixels per object): the (B,N,.) rows in between are never written.  Returns what `dense_select`
-    returns -- (pts2d, weights, pts3d, counts, index), bit for bit."""
+    returns -- (pts2d, weights, pts3d, counts, index), bit for bit.  xyz_noc = None: the selection alone -- pts3d comes back unwritten, for the
+    caller to fill from `index` / `counts` (binary-code heads: `floatbits.decode_selected_rows`, which decodes the selected pixels only)."""
     lib = _lib.load()
     top, left = top_left
     B, _, H, W = xyz_weight_logits.shape
@@ -164,8 +165,8 @@ def dense_front_end_select(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weigh
     with _lib.on_device(dev):
         rc = lib.lc_dense_frontend_select2(_lib.ptr(xyz), _lib.ptr(wl), _lib.ptr(ws), _lib.ptr(ns), _lib.ptr(vl), float(seg_thresh), code, xcode, _lib.MAP_DTYPES[ws.dtype], xs, wls, vs,
                                            B, H, W, int(top), int(left), int(sample), SELECT_MODES[mode], float(quantile), int(square_weights),
-                                           int(min_count), int(seed) & 0xFFFFFFFF, int(pose_index_offset), _lib.ptr(o_u), _lib.ptr(o_w), _lib.ptr(o_x),
-                                           _lib.ptr(o_i), _lib.ptr(o_c), _lib.stream_ptr(dev))
+                                           int(min_count), int(seed) & 0xFFFFFFFF, int(pose_index_offset), _lib.ptr(o_u), _lib.ptr(o_w),
+                                           _lib.ptr(o_x) if xyz is not None else None, _lib.ptr(o_i), _lib.ptr(o_c), _lib.stream_ptr(dev))
     _lib.check(rc, "lc_dense_frontend_select2")
     return o_u, o_w, o_x, o_c, o_i
 

@@ -151,6 +151,30 @@ def nn_logits2xyz_planes(logits: Tensor, bit_cnt: Union[int, List[int]], noc_sca
 
 
 @torch.no_grad()
+def decode_selected_rows(logits: Tensor, bit_cnt: Union[int, List[int]], index: Tensor, counts: Tensor, out_pts3d: Tensor, *, noc_scale: Tensor = None,
+                         model_transform: Tensor = None, sample: int = 1, top_left=(0, 0)) -> Tensor:
+    """Inference decode of the SELECTED pixels only: fills out_pts3d[b, :counts[b]] (B,N,3) with the object coordinates of the sampled pixels
+    index[b, :counts[b]] (the `index` / `counts` a point selection returns) -- `nn_logits2xyz_planes(...)` gathered at those pixels, without
+    decoding (writing, re-reading) the other four fifths of the map."""
+    lib = _lib.load()
+    lg, bs, code = _code_logits(logits)
+    B, C, H, W = lg.shape
+    bits = _bits3(bit_cnt, C)
+    sc = None if noc_scale is None else _lib.require_hip_f32("noc_scale", noc_scale.reshape(B, 3))
+    xf = None if model_transform is None else _lib.require_hip_f32("model_transform", model_transform.reshape(B, 4, 4))
+    N = index.shape[1]
+    if not (index.dtype == counts.dtype == torch.int32 and index.is_contiguous() and counts.is_contiguous() and index.shape == (B, N)
+            and out_pts3d.shape == (B, N, 3) and out_pts3d.dtype == torch.float32 and out_pts3d.is_contiguous()
+            and index.device == counts.device == out_pts3d.device == lg.device):
+        raise ValueError("decode_selected_rows: index (B,N) / counts (B,) int32 and out_pts3d (B,N,3) float32, contiguous, on the logits' device")
+    with _lib.on_device(lg.device):
+        rc = lib.lc_bits_decode_rows(_lib.ptr(lg), _lib.ptr(sc), _lib.ptr(xf), code, bs, B, C, H, W, *bits, int(_black_background), int(top_left[0]),
+                                     int(top_left[1]), int(sample), _lib.ptr(index), _lib.ptr(counts), N, _lib.ptr(out_pts3d), _lib.stream_ptr(lg.device))
+    _lib.check(rc, "lc_bits_decode_rows")
+    return out_pts3d
+
+
+@torch.no_grad()
 def mod_noc2bits_bb(numbers: Tensor, N: int, black_background=True):
     """floatbits.py:77-97 (label prep): normalised coordinate (-1,1) -> Gray-coded bits + raw bits, (*,N) bool."""
     max_num = 2 ** N - 1

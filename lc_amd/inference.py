@@ -122,10 +122,16 @@ def _solve_pnp_dense(cfg, out_dict, gt_dict, pose0):
         # continuous head: the kernel scales the normalised coordinates itself (losses.py:17-22 is that one multiply)
         xyz_map, noc_scale = out_dict["xyz_noc"], gt_dict["noc_scale"]
     elif "xyz_noc_bin" in out_dict:
-        # binary-code head (fp32, fp16 or bf16 logits, read in their own type): Gray decode, noc_scale, model transform and the channel-first
-        # layout in one launch
-        xyz_map = floatbits.nn_logits2xyz_planes(out_dict["xyz_noc_bin"], gt_dict["bit_cnt"], gt_dict["noc_scale"],
-                                                 gt_dict.get("model_transform", None))
+        # binary-code head (fp32, fp16 or bf16 logits, read in their own type).  Up to FUSED_SELECT_MAX_POINTS candidates per object the
+        # selection runs WITHOUT model points and the codes of the selected pixels only are decoded afterwards (Gray decode, noc_scale, model
+        # transform: `decode_selected_rows` -- a fifth of the whole-map decode's work at zlmo's shape); beyond that, the whole map is decoded
+        # into the (B,3,H,W) planes the two-launch front end reads.
+        _, _, H_, W_ = out_dict["xyz_weight_logits"].shape
+        if -(-H_ // stride) * -(-W_ // stride) <= FUSED_SELECT_MAX_POINTS:
+            xyz_map = None
+        else:
+            xyz_map = floatbits.nn_logits2xyz_planes(out_dict["xyz_noc_bin"], gt_dict["bit_cnt"], gt_dict["noc_scale"],
+                                                     gt_dict.get("model_transform", None))
         noc_scale = None
     else:
         head = out_dict["xyz_noc"] if "xyz_noc" in out_dict else out_dict["xyz_noc_bin"]
@@ -155,6 +161,9 @@ def _solve_pnp_dense(cfg, out_dict, gt_dict, pose0):
         u, icov, x, counts, index = dense_front_end_select(xyz_map, out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"], noc_scale,
                                                            out_dict["msk_vis_logits"], mode, seg_thresh=thr, sample=stride, pose_index_offset=pose0,
                                                            **select_args)
+        if xyz_map is None:  # code heads: the model points of the selected pixels (padding entries included: they carry source indices too)
+            floatbits.decode_selected_rows(out_dict["xyz_noc_bin"], gt_dict["bit_cnt"], index, counts, x, noc_scale=gt_dict["noc_scale"],
+                                           model_transform=gt_dict.get("model_transform", None), sample=stride)
     else:
         pts2d, inv_std, pts3d, visible = dense_front_end_with_visibility(xyz_map, out_dict["xyz_weight_logits"], out_dict["xyz_weights_scale"],
                                                                          noc_scale, out_dict["msk_vis_logits"], thr, sample=stride)

@@ -205,3 +205,38 @@ def test_sub_batches_on_streams_return_the_one_batch_result(parts, monkeypatch):
     cut = solve_pnp(cfg, out, gt)
     torch.cuda.synchronize()
     assert list(one) == list(cut) and all(torch.equal(one[k], cut[k]) for k in one)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,bits,stride", [(5, 128, 128, (7, 7, 7), 1), (3, 37, 45, (5, 7, 3), 2), (2, 64, 64, (6, 6, 5), 1)])
+def test_decode_of_the_selected_rows_equals_the_whole_map_decode(B, H, W, bits, stride, dtype):
+    """Binary-code heads at test time: the selection without model points followed by `decode_selected_rows` (codes of the selected pixels only) leaves
+    the rows that the whole-map decode + selection leaves, bit for bit -- padding entries of an invisible object included."""
+    from lc_amd import floatbits
+    from lc_amd.dense import dense_front_end_select
+
+    g = torch.Generator().manual_seed(H + W)
+    C = sum(bits)
+    logits = (torch.randn(B, C, H, W, generator=g) * 2).to(DEV).to(dtype)
+    wl = (torch.randn(B, 2, H, W, generator=g) * 2).to(DEV).to(dtype)
+    vl = (torch.randn(B, 1, H, W, generator=g) * 3).to(DEV).to(dtype)
+    vl[0] = -9.0
+    ws = (torch.rand(B, generator=g) * 30 + 5).to(DEV)
+    ns = (torch.rand(B, 3, generator=g) * 50 + 20).to(DEV)
+    T = torch.eye(4).repeat(B, 1, 1)
+    T[:, :3, :3] = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+    T[:, :3, 3] = torch.randn(B, 3, generator=g)
+    T = T.to(DEV)
+    kw = dict(seg_thresh=0.5, sample=stride, quantile=0.2, min_count=4, seed=3)
+    planes = floatbits.nn_logits2xyz_planes(logits, list(bits), ns, T)
+    want = dense_front_end_select(planes, wl, ws, None, vl, "quantile_in_mask", **kw)
+    got = dense_front_end_select(None, wl, ws, None, vl, "quantile_in_mask", **kw)
+    got[2].fill_(float("nan"))  # the selection alone does not touch the model points
+    floatbits.decode_selected_rows(logits, list(bits), got[4], got[3], got[2], noc_scale=ns, model_transform=T, sample=stride)
+    cnt = want[3]
+    assert torch.equal(got[3], cnt) and int(cnt[0]) == 4
+    live = torch.arange(got[0].shape[1], device=DEV)[None, :] < cnt[:, None]
+    for k in (0, 1, 2, 4):
+        m = live if got[k].dim() == 2 else live[..., None].expand_as(got[k])
+        assert torch.equal(got[k][m], want[k][m]), k
+    assert torch.isnan(got[2][~live]).all()  # nothing behind a row's count is written
