@@ -79,6 +79,23 @@ int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const
                    int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod,
                    void *stream);
 
+/* lc_pnp_lm2_f32 for batches of FEW poses with THOUSANDS of correspondences each (the test-time solves behind the dense heads,
+ * test.py:120-133 with 64 objects x ~3000 selected pixels): given a workspace, such a batch is solved by several workgroups per pose
+ * -- each sums its share of the correspondences, the partial normal equations meet in the workspace, and all of them take the same
+ * LM steps -- instead of one workgroup per pose on a quarter of the chip.
+ *   lc_pnp_lm_workspace_bytes(B, Nmax): bytes that shape needs; 0 when it is solved by one workgroup per pose anyway (Nmax <= 2048,
+ *       or B > 128: the grid would not fit the chip at one workgroup per CU).
+ *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller; after that it belongs to these calls (each leaves it ready for
+ *       the next of any shape on the same stream; calls that may run concurrently need a workspace each).  NULL: lc_pnp_lm2_f32.
+ * Results: those of lc_pnp_lm2_f32 up to the order of the fp64 sums over the correspondences (tests/test_gpu_pnp_split.py).
+ * The workgroups of a pose wait for each other; the wait is bounded (about a second), after which the pose is reported invalid (rets = 1)
+ * -- which can only happen when more than two such launches run concurrently on one device. */
+size_t lc_pnp_lm_workspace_bytes(int B, int Nmax);
+int lc_pnp_lm3_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
+                   const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,
+                   int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
 /* Two solves, the second starting where the first ends -- the RANSAC inlier refinement followed by the weighted solve(s) of
  * test.py:120,133 -- as ONE call.  A job is the argument list of lc_pnp_lm2_f32; the call is defined as
  *     lc_pnp_lm2_f32(first ...);  lc_pnp_lm2_f32(second ...);      on `stream`
@@ -100,6 +117,8 @@ typedef struct lc_pnp_lm_job {
     int options, pose_mod;
 } lc_pnp_lm_job;
 int lc_pnp_lm_chain_f32(const lc_pnp_lm_job *first, const lc_pnp_lm_job *second, void *stream);
+/* the same with a workspace for jobs that take the split form: max over the two jobs of lc_pnp_lm_workspace_bytes(B, Nmax) bytes */
+int lc_pnp_lm_chain2_f32(const lc_pnp_lm_job *first, const lc_pnp_lm_job *second, void *workspace, size_t workspace_bytes, void *stream);
 
 /* (2a') Parity diagnostics of (2a): the same solve (same template body, so the same arithmetic) that also records the
  *      trust-region schedule -- what `Solver::Summary::iterations` holds after ceres::Solve (ceres.cpp:126-130) --

@@ -26,6 +26,9 @@ _SIGNATURES = {
     "pnp_ceres_f32_omp": (None, [_FP, _FP, _FP, _FP, _FP, _I, c_int, c_float, c_int, _F, _I, c_int, c_int]),
     "lc_pnp_lm_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p]),
     "lc_pnp_lm2_f32": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "lc_pnp_lm3_f32": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p]),
+    "lc_pnp_lm_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "lc_pnp_lm_chain2_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "lc_pnp_lm_trace_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "lc_cov_loss_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 6),
     "lc_cov_loss2_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float, c_int] + [c_void_p] * 6),

@@ -221,7 +221,39 @@ int lc_pnp_lm2_f32(const float* K, const float* pts3d, const float* pts2d, const
     return 0;
 }
 
+// hands a job the caller's workspace when its shape takes the split form (lc_kernels.h: pnp_split_parts); 0 / 1
+static int pnp_attach_workspace(lc::PnpParams& p, void* workspace, size_t workspace_bytes) {
+    if (!workspace || p.B <= 0) return 0;
+    const size_t need = lc::pnp_split_workspace_bytes(p.B, p.Nmax);
+    if (need == 0) return 0;
+    if (workspace_bytes < need) return fail(1, "pnp workspace smaller than lc_pnp_lm_workspace_bytes(B, Nmax)");
+    if (reinterpret_cast<uintptr_t>(workspace) & 127u) return fail(1, "pnp workspace must be 128-byte aligned");
+    p.split_ws = workspace;
+    p.split_parts = lc::pnp_split_parts(p.B, p.Nmax);
+    return 0;
+}
+
+size_t lc_pnp_lm_workspace_bytes(int B, int Nmax) { return lc::pnp_split_workspace_bytes(B, Nmax); }
+
+int lc_pnp_lm3_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
+                   const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
+                   int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    lc::PnpParams p;
+    if (int rc = pnp_params(K, pts3d, pts2d, sqrtL, weights_diag, weight_mask, counts, start, states, result_tr, rets, iters, B, Nmax, max_iter,
+                            function_tolerance, options, pose_mod, p))
+        return rc;
+    if (B == 0) return 0;
+    if (int rc = pnp_attach_workspace(p, workspace, workspace_bytes)) return rc;
+    if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
+    return 0;
+}
+
 int lc_pnp_lm_chain_f32(const lc_pnp_lm_job* first, const lc_pnp_lm_job* second, void* stream) {
+    return lc_pnp_lm_chain2_f32(first, second, nullptr, 0, stream);
+}
+
+int lc_pnp_lm_chain2_f32(const lc_pnp_lm_job* first, const lc_pnp_lm_job* second, void* workspace, size_t workspace_bytes, void* stream) {
     if (!first || !second) return fail(1, "null job");
     lc::PnpParams a, b;
     const lc_pnp_lm_job* jobs[2] = {first, second};
@@ -231,6 +263,7 @@ int lc_pnp_lm_chain_f32(const lc_pnp_lm_job* first, const lc_pnp_lm_job* second,
         if (int rc = pnp_params(j.K, j.pts3d, j.pts2d, j.sqrtL, j.weights_diag, j.weight_mask, j.counts, j.start, j.states, j.result_tr, j.rets,
                                 j.iters, j.B, j.Nmax, j.max_iter, j.function_tolerance, j.options, j.pose_mod, *ps[k]))
             return rc;
+        if (int rc = pnp_attach_workspace(*ps[k], workspace, workspace_bytes)) return rc;  // the two launches are ordered: one workspace serves both
     }
     if (lc::launch_pnp_lm_chain(a, b, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
     return 0;

@@ -294,6 +294,97 @@ __device__ __forceinline__ void block_sum_waves4(double (&v)[K], double* lds, in
     for (int k = 0; k < K; ++k) v[k] = tot[k];
 }
 
+// The same sum across the G workgroups that share ONE pose (lc_pnp.hip: lc_pnp_lm_split_kernel -- a batch of few poses with thousands of
+// correspondences each leaves three quarters of the chip idle at one workgroup per pose).  Every workgroup reduces its own share as above
+// and hands its 32 partial totals to the others through the pose's exchange rows in global memory; each then adds the G rows IN PART ORDER,
+// so all of them continue with the same bits and take the same branches of the solve.
+// The hand-off is one write and one (polled) read, no counter and no fence: a total travels as two 8-byte words {32 bits of the double,
+// 32-bit ticket}, each stored and loaded as ONE agent-scope atomic, and a reader takes a word when it carries the ticket of the sum it is
+// waiting for.  Tickets count the sums of a pose over the life of the workspace: `epoch` (a word of the pose's region) holds the ticket of
+// the last sum of the previous launch; every part reads it on entry, part 0 writes the new value when it leaves (no part can still be
+// waiting to read the old one: part 0 only gets through its first sum after every part has contributed, i.e. has read it).  A slot is
+// rewritten every second sum (two rows, by sum parity: a workgroup can be one sum ahead of the slowest, not two -- it cannot finish sum s+1
+// before every part has written its s+1 words, i.e. finished reading the rows of sum s), so what a reader finds there is older than the
+// ticket it waits for, or it.  Zeroed workspace = ticket 0 everywhere, first sum = ticket 1.
+// The wait is bounded (~1 s): workgroups of one launch that are not all resident at the same time (more spinning launches in flight than the
+// chip holds -- pnp_split_parts() sizes grids to at most one workgroup per CU) end as a failed solve, not as a hung device.
+constexpr int kSplitMaxParts = 8, kSplitMaxPolls = 1 << 20;
+constexpr int kSplitRowWords = 64;                                                             // 32 totals x 2 words
+constexpr size_t kSplitPoseBytes = 2 * kSplitMaxParts * kSplitRowWords * sizeof(unsigned long long) + 128;  // two rows per part + the epoch's line
+constexpr int kSplitLdsDoubles = 128 + 64 + 2;
+struct SplitSum {
+    unsigned long long* exch;  // this pose's [2][kSplitMaxParts][64] words
+    unsigned* epoch;           // this pose's epoch word
+    int G, part;
+    unsigned base;             // *epoch on entry
+    unsigned seq;              // sums finished in this launch
+    bool timed_out;
+};
+__device__ __forceinline__ SplitSum split_sum_enter(void* pose_region, int G, int part) {
+    char* q = static_cast<char*>(pose_region);
+    unsigned* epoch = reinterpret_cast<unsigned*>(q + kSplitPoseBytes - 128);
+    return SplitSum{reinterpret_cast<unsigned long long*>(q), epoch, G, part, xcd_load(epoch), 0u, false};
+}
+// one thread of part 0, after its last sum.  A launch that timed out leaves tickets of unknown height behind: jump well past them
+__device__ __forceinline__ void split_sum_leave(const SplitSum& sx) {
+    if (sx.part == 0 && sx.seq > 0) xcd_store(sx.epoch, sx.base + sx.seq + (sx.timed_out ? 4096u : 0u));
+}
+
+template <int K>
+__device__ __forceinline__ void block_sum_split(double (&v)[K], double* lds, int tid, int& phase, SplitSum& sx) {
+    static_assert(K <= 32, "one reduce-scatter of 32");
+    const int lane = tid & 63, wave = tid >> 6;
+    double w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = k < K ? v[k] : 0.0;
+    wave_reduce_scatter16<32>(w, lane);
+    double* part = lds;                      // [4][32]
+    double* tot = lds + 128 + 32 * phase;    // [2][32]
+    int* arrived_ok = reinterpret_cast<int*>(lds + 192);
+    phase ^= 1;
+    if ((lane & 3) == 0) *reinterpret_cast<double2*>(part + 32 * wave + scatter16_base(lane, 2)) = make_double2(w[0], w[1]);
+    __syncthreads();
+    if (tid < 32) {
+        const unsigned long long ticket = (unsigned long long)(sx.base + sx.seq + 1u) << 32;
+        unsigned long long* rows = sx.exch + (size_t)(sx.seq & 1u) * (kSplitMaxParts * kSplitRowWords) + 2 * tid;
+        {
+            const unsigned long long bits = __builtin_bit_cast(unsigned long long, ((part[tid] + part[32 + tid]) + part[64 + tid]) + part[96 + tid]);
+            unsigned long long* mine = rows + sx.part * kSplitRowWords;
+            xcd_store(mine, ticket | (bits & 0xFFFFFFFFull));
+            xcd_store(mine + 1, ticket | (bits >> 32));
+        }
+        // all G rows requested at once, again until every word carries the ticket (a row that is already there costs one read)
+        unsigned long long lo[kSplitMaxParts], hi[kSplitMaxParts];
+        bool ok = true;
+        for (int polls = 0;; ++polls) {
+#pragma unroll
+            for (int g = 0; g < kSplitMaxParts; ++g)
+                if (g < sx.G) {
+                    lo[g] = xcd_load(rows + g * kSplitRowWords);
+                    hi[g] = xcd_load(rows + g * kSplitRowWords + 1);
+                }
+            unsigned long long late = 0;
+#pragma unroll
+            for (int g = 0; g < kSplitMaxParts; ++g)
+                if (g < sx.G) late |= ((lo[g] ^ ticket) | (hi[g] ^ ticket)) >> 32;
+            if (late == 0) break;
+            if (polls >= kSplitMaxPolls) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < kSplitMaxParts; ++g)  // in part order
+            if (g < sx.G) s += __builtin_bit_cast(double, (hi[g] << 32) | (lo[g] & 0xFFFFFFFFull));
+        tot[tid] = s;
+        if (!ok) *arrived_ok = 0;  // (set to 1 by the workgroup before its first sum)
+    }
+    __syncthreads();
+    if (!*arrived_ok) sx.timed_out = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = tot[k];
+    ++sx.seq;
+}
+
 #ifndef LC_HORNER_ASM
 #define LC_HORNER_ASM 1  // A/B switch (scripts/ubench/pnp_ab.py)
 #endif

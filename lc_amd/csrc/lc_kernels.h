@@ -62,7 +62,12 @@ struct PnpParams {
     int options;          // kPnp* bits (launch_pnp_lm only): what the callers otherwise do with element-wise launches in front
     const unsigned char* weight_mask;  // (B,Nmax) or null: unit information where non-zero, none elsewhere (instead of sqrtL / sqrt_diag)
     int pose_mod;         // > 0: K and start have pose_mod rows, pose b reads row b % pose_mod (start must be given)
+    void* split_ws;       // launch_pnp_lm only, or null: pnp_split_workspace_bytes(B, Nmax) bytes, zeroed once -> split_parts workgroups per pose
+    int split_parts;      // pnp_split_parts(B, Nmax) when split_ws is given
 };
+constexpr int kSplitMinPoints = 2048;  // rows up to here: one workgroup per pose (the exchange between the parts would cost more than it saves)
+int pnp_split_parts(int B, int Nmax);  // workgroups per pose of the split form: 1 (not worth it / grid would not be resident at once), 2, 4, 8
+size_t pnp_split_workspace_bytes(int B, int Nmax);
 enum PnpOptions { kPnpWeightsAreIcov = 1,  // sqrt_diag holds inverse VARIANCES: take the square root at the load (cer_solver.py:33-36)
                   kPnpNanToNum = 2 };      // torch.nan_to_num on K, points, weights and start at the load (cer_solver.py:29-31)
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream);

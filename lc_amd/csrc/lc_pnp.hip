@@ -43,6 +43,21 @@ __global__ __launch_bounds__(256) void lc_pnp_lm_chain_kernel(const PnpParams a,
     pnp::solve_pose<false, 4, false, true, 4>(b, blockIdx.x, threadIdx.x, bc, true, nullptr, second_starts_from_first ? refined : nullptr);
 }
 
+// Few poses, thousands of correspondences each (the test-time solves of the dense heads: 64 objects x ~3000 selected pixels): p.split_parts
+// workgroups per pose, each with its share of the correspondences (lc_pnp_body.h: SPLIT, lc_common.h: block_sum_split).  The parts of a pose
+// are dispatched to the same XCD (workgroups go round the 8 XCDs in launch order), so their exchange rows stay in one L2.
+template <bool OPTS>
+__global__ __launch_bounds__(256) void lc_pnp_lm_split_kernel(const PnpParams p) {
+    __shared__ __attribute__((aligned(16))) double bc[kSplitLdsDoubles];
+    const int xcd = (int)(blockIdx.x % 8u), j = (int)(blockIdx.x / 8u);
+    const int part = j % p.split_parts, b = (j / p.split_parts) * 8 + xcd;
+    if (b >= p.B) return;
+    SplitSum sx = split_sum_enter(static_cast<char*>(p.split_ws) + (size_t)b * kSplitPoseBytes, p.split_parts, part);
+    if (threadIdx.x == 0) *reinterpret_cast<int*>(bc + 192) = 1;  // block_sum_split's "all parts arrived" (its first barrier orders this)
+    pnp::solve_pose<false, 4, false, OPTS, 8, true, true>(p, b, threadIdx.x, bc, part == 0, nullptr, nullptr, &sx);
+    if (threadIdx.x == 0) split_sum_leave(sx);
+}
+
 // diagnostic twins that also record the per-iteration trace (tests/test_gpu_pnp_trace.py)
 __global__ __launch_bounds__(64, 1) void lc_pnp_lm_trace_kernel(const PnpParams p) {
     __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<1>];
@@ -77,8 +92,20 @@ int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stre
     return launch_pnp_lm(b, stream);
 }
 
+int pnp_split_parts(int B, int Nmax) {
+    if (Nmax <= kSplitMinPoints || B <= 0 || B > 128) return 1;
+    return B <= 32 ? 8 : (B <= 64 ? 4 : 2);  // at most one workgroup per CU (256): all of them resident together
+}
+size_t pnp_split_workspace_bytes(int B, int Nmax) { return pnp_split_parts(B, Nmax) > 1 ? (size_t)B * kSplitPoseBytes : 0; }
+
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
+    if (p.split_ws && p.split_parts > 1) {
+        const dim3 grid((unsigned)((p.B + 7) / 8 * 8 * p.split_parts));
+        if (p.options || p.weight_mask || p.pose_mod > 0) hipLaunchKernelGGL(lc_pnp_lm_split_kernel<true>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(lc_pnp_lm_split_kernel<false>, grid, dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     const bool big = p.B > kLatencyGridMax;
     if (p.options || p.weight_mask || p.pose_mod > 0) {  // input filtering / weight forms folded into the load
         if (p.Nmax <= 64) {

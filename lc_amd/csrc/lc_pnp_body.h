@@ -265,10 +265,15 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 // store / handoff / start_override (the chained launch, lc_pnp.hip): store = false keeps the job's outputs in registers (a workgroup that
 // repeats a solve another workgroup owns must not write the owner's rows a second time); handoff (7 floats of LDS) receives the state the
 // solve would leave in p.states[b]; start_override replaces the start pose (7 floats, e.g. a previous solve's handoff).
-template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0, bool TAIL = false>
+// SPLIT (NW = 4, PPT > 0): workgroup sx->part of the sx->G that share pose b -- it owns the correspondences part * 64 NW + lane + k * 64 NW G,
+// the block sum runs across the G workgroups (lc_common.h: block_sum_split), everything else is replicated; part 0 stores.
+template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0, bool TAIL = false, bool SPLIT = false>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc, bool store = true, float* handoff = nullptr,
-                                           const float* start_override = nullptr) {
+                                           const float* start_override = nullptr, [[maybe_unused]] SplitSum* sx = nullptr) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
+    static_assert(!SPLIT || (NW == 4 && !REG && PPT > 0 && !TRACE), "the split form is the four-wave cached-prefix solve");
+    const int slot = SPLIT ? lane + kThreads * sx->part : lane;  // first correspondence of this thread, and the distance to its next
+    const int stride = SPLIT ? kThreads * sx->G : kThreads;
 #ifdef LC_TRACE_CLOCK
     const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -302,7 +307,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     if constexpr (!REG && PPT > 0) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if (lane + k * kThreads < n) rawc[k] = load_raw_point<OPTS>(p, base, lane + k * kThreads);
+            if (slot + k * stride < n) rawc[k] = load_raw_point<OPTS>(p, base, slot + k * stride);
     }
     double cam[6];
     {
@@ -363,16 +368,17 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             if constexpr (PPT > 0) {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k)
-                    if (lane + k * kThreads < n) accumulate_point<false>(to_point(rawc[k], cam), rt, t, cam, sc, acc);
+                    if (slot + k * stride < n) accumulate_point<false>(to_point(rawc[k], cam), rt, t, cam, sc, acc);
                 // rows wider than the cached prefix (Nmax > 64 NW PPT): the correspondences behind it from memory, in the same per-thread
                 // order as the plain loop below -- same sums bit for bit; empty when the pose's count fits the prefix
                 if constexpr (TAIL)
-                    for (int i = lane + PPT * kThreads; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
+                    for (int i = slot + PPT * stride; i < n; i += stride) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
             } else {
                 for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
             }
             LC_PSTAMP(3);
-            if constexpr (NW == 4 && LC_WIDE_SUM_REGS) block_sum_waves4<28>(acc, bc, lane, sum_phase);
+            if constexpr (SPLIT) block_sum_split<28>(acc, bc, lane, sum_phase, *sx);
+            else if constexpr (NW == 4 && LC_WIDE_SUM_REGS) block_sum_waves4<28>(acc, bc, lane, sum_phase);
             else block_sum_bcast_lds<28, NW>(acc, bc, lane);
         }
         LC_PSTAMP(4);
@@ -386,6 +392,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
 #pragma unroll
         for (int i = 0; i < 6; ++i) chk += H[tri6(i, i)];
         LC_PSTAMP(5);
+        if constexpr (SPLIT) {
+            if (sx->timed_out) return false;  // a workgroup of this pose never arrived: the solve fails (lc_common.h: SplitSum)
+        }
         return chk <= DBL_MAX;
     };
 

@@ -101,7 +101,7 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     results = []
     for (b0, b1), side in zip(bounds, pool):
         side.wait_stream(cur)  # the network's outputs are ready on the caller's stream
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), pnp_ceres.owned_split_workspace(None):  # concurrent solves: a workspace per stream, not a shared one
             results.append(_solve_pnp_dense(cfg, cut(out_dict, b0, b1), cut(gt_dict, b0, b1), b0))
     for side in pool[:parts]:
         cur.wait_stream(side)
@@ -240,7 +240,10 @@ class GraphedSolvePnP:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with quiet_capture(), torch.cuda.graph(self.graph):
+        # the split solves' workspace (few objects x thousands of points): zeroed once here, kept consistent by the launches themselves -- no fill node in the graph
+        self._split_ws = torch.zeros(pnp_ceres.SPLIT_WORKSPACE_MAX_BYTES, device=dev, dtype=torch.uint8)
+        torch.cuda.synchronize(dev)
+        with quiet_capture(), torch.cuda.graph(self.graph), pnp_ceres.owned_split_workspace(self._split_ws):
             self._res = solve_pnp(cfg, self._out, self._gt)
 
     @torch.no_grad()

@@ -8,7 +8,9 @@ Returns `(state, result_tr, invalid_flags)` like the reference (`:61`): float32 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -25,8 +27,51 @@ def _to_np(val):
 LC_PNP_WEIGHTS_ARE_ICOV, LC_PNP_NAN_TO_NUM = 1, 2  # include/lc_amd.h
 
 
+_SPLIT_WS = {}  # (device index, stream) -> workspace of the split form (zeroed once, consistent from launch to launch; launches of one stream are ordered)
+
+
+_OWNED_WS = None
+SPLIT_WORKSPACE_MAX_BYTES = 128 * (2 * 8 * 64 * 8 + 128)  # lc_pnp_lm_workspace_bytes at its largest batch (include/lc_amd.h)
+
+
+@contextlib.contextmanager
+def owned_split_workspace(ws):
+    """Solves inside the block use `ws` (zeroed uint8 tensor, allocated by the caller BEFORE a stream capture: the launches keep it
+    consistent from one to the next, so a replayed graph needs no fill node) instead of the per-stream one.  The caller orders the launches that share it."""
+    global _OWNED_WS
+    prev, _OWNED_WS = _OWNED_WS, ws
+    try:
+        yield ws
+    finally:
+        _OWNED_WS = prev
+
+
+def split_workspace(dev, *shapes, split=None):
+    """Workspace for solves of few poses x thousands of correspondences (`lc_pnp_lm_workspace_bytes`: several workgroups per pose), sized for
+    the largest of `shapes` = (B, N) pairs; None when none of them takes that form, or with split=False / LC_AMD_PNP_SPLIT=0."""
+    if split is None:
+        split = os.environ.get("LC_AMD_PNP_SPLIT", "1") != "0"
+    if not split:
+        return None
+    lib = _lib.load()
+    need = max(int(lib.lc_pnp_lm_workspace_bytes(int(B), int(N))) for B, N in shapes)
+    if need == 0:
+        return None
+    if _OWNED_WS is not None and _OWNED_WS.device == dev and _OWNED_WS.numel() >= need:
+        return _OWNED_WS
+    if torch.cuda.is_current_stream_capturing():  # a graph owns its workspace; without `owned_split_workspace` its zero-fill is a node of the graph
+        return torch.zeros(need, device=dev, dtype=torch.uint8)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _SPLIT_WS.get(key)
+    if ws is None or ws.numel() < need:
+        if len(_SPLIT_WS) >= 64:
+            _SPLIT_WS.clear()
+        ws = _SPLIT_WS[key] = torch.zeros(need, device=dev, dtype=torch.uint8)
+    return ws
+
+
 def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6,
-                 return_iters=False, trace_rows=0, weights_are_icov=False, nan_to_num=False, weight_mask=None, shared_poses=0):
+                 return_iters=False, trace_rows=0, weights_are_icov=False, nan_to_num=False, weight_mask=None, shared_poses=0, split=None):
     """Device route. cam_mat (B,3,3) pts3d (B,N,3) pts2d (B,N,2) start (B,7); sqrtL (B,N,2,2) lower factor or
     (B,N,2) diagonal; n_points (B,) int or None.  trace_rows > 0 runs the diagnostic twin of the kernel and appends the
     (B,trace_rows,8) float64 per-iteration schedule (`lc_pnp_lm_trace_f32`, include/lc_amd.h) to the returned tuple.
@@ -34,7 +79,9 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     Folded into the kernel's loads instead of separate element-wise launches (`lc_pnp_lm2_f32`): weights_are_icov (the diagonal
     tensor holds inverse variances), nan_to_num (torch.nan_to_num on every input; an invalid job returns the filtered start),
     weight_mask (B,N) uint8/bool in place of sqrtL: unit information where set; shared_poses = P > 0: cam_mat and start have P rows
-    and pose b of the B = k P correspondence sets reads row b % P (several selections of the same objects in one launch)."""
+    and pose b of the B = k P correspondence sets reads row b % P (several selections of the same objects in one launch).
+    split (default: on, LC_AMD_PNP_SPLIT=0 turns it off): batches of at most 128 poses with rows wider than 2048 are solved by several
+    workgroups per pose (`lc_pnp_lm3_f32`) -- the same solve up to the order of the fp64 sums."""
     lib = _lib.load()
     K = _lib.require_hip_f32("cam_mat", cam_mat)
     X = _lib.require_hip_f32("pts3d", pts3d)
@@ -70,12 +117,14 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
                                          _lib.ptr(trace), int(trace_rows), _lib.stream_ptr(dev))
         _lib.check(rc, "lc_pnp_lm_trace_f32")
         return (state, tr, ret, iters, trace) if return_iters else (state, tr, ret, trace)
-    with _lib.on_device(dev):  # options = 0 without a mask is lc_pnp_lm_f32 (same kernel instantiation)
-        rc = lib.lc_pnp_lm2_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
+    with _lib.on_device(dev):  # options = 0 without a mask and without a workspace is lc_pnp_lm_f32 (same kernel instantiation)
+        ws = split_workspace(dev, (B, N), split=split)
+        rc = lib.lc_pnp_lm3_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
                                 _lib.ptr(L) if (L is not None and not full) else None, _lib.ptr(M), _lib.ptr(counts), _lib.ptr(start),
                                 _lib.ptr(state), _lib.ptr(tr), _lib.ptr(ret), _lib.ptr(iters), B, N, int(max_iter_count),
-                                float(function_tolerance), opts, int(shared_poses), _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_pnp_lm2_f32")
+                                float(function_tolerance), opts, int(shared_poses), _lib.ptr(ws), 0 if ws is None else ws.numel(),
+                                _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_lm3_f32")
     return (state, tr, ret, iters) if return_iters else (state, tr, ret)
 
 
@@ -117,7 +166,7 @@ def _job(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=5
     return job, (state, tr, ret), (K, X, U, L, M, counts, start), dev
 
 
-def solve_chain_device(first: dict, second: dict):
+def solve_chain_device(first: dict, second: dict, split=None):
     """Two solves as one call (`lc_pnp_lm_chain_f32`): `first` and `second` are keyword arguments of `solve_device`; second['start'] may be
     the string 'first' -- the states the first solve returns (with shared_poses = the first job's batch when the second holds several
     selections of the same objects).  One launch where the shapes allow (both 256 < N <= 1024), else the two launches; the same
@@ -132,8 +181,9 @@ def solve_chain_device(first: dict, second: dict):
     if dev2 != dev:
         raise ValueError("solve_chain_device: both jobs on one device")
     with _lib.on_device(dev):
-        rc = lib.lc_pnp_lm_chain_f32(ctypes.byref(j1), ctypes.byref(j2), _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_pnp_lm_chain_f32")
+        ws = split_workspace(dev, (j1.B, j1.Nmax), (j2.B, j2.Nmax), split=split)
+        rc = lib.lc_pnp_lm_chain2_f32(ctypes.byref(j1), ctypes.byref(j2), _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_lm_chain2_f32")
     del keep1, keep2
     return out1, out2
 

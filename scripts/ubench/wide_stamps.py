@@ -23,15 +23,16 @@ from lc_amd import _lib, synth  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.load()
 P = _lib.ptr
-B, N = 64, 1024
-for used in (200, 350, 700, 1024):
+B, N = 64, int(os.environ.get("LC_WIDE_N", "1024"))
+for used in ((200, 350, 700, 1024) if N == 1024 else tuple(int(v) for v in os.environ.get("LC_WIDE_USED", str(N)).split(","))):
     b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=1, outlier_frac=0.0, noise_px=0.7).items()}
     counts = torch.full((B,), used, dtype=torch.int32, device=dev)
     states = torch.empty_like(b["start"]); tr = torch.empty(B, device=dev); ret = torch.empty(B, device=dev, dtype=torch.int32)
     stamps = torch.zeros(B, 16, device=dev, dtype=torch.int32)
     for rep in range(3):
-        rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), P(counts), P(b["start"]), P(states), P(tr), P(ret),
-                               P(stamps), B, N, 50, 1e-6, None)
+        ws = torch.zeros(int(lib.lc_pnp_lm_workspace_bytes(B, N)) or 1, device=dev, dtype=torch.uint8) if os.environ.get("LC_WIDE_SPLIT") == "1" else None
+        rc = lib.lc_pnp_lm3_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), None, P(counts), P(b["start"]), P(states), P(tr), P(ret),
+                                P(stamps), B, N, 50, 1e-6, 0, 0, P(ws), 0 if ws is None else ws.numel(), None)
         assert rc == 0
         torch.cuda.synchronize()
     ps = stamps.cpu().numpy().view(np.uint64).reshape(B, 8).astype(np.int64)
