@@ -378,7 +378,11 @@ __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, Ma
         const int mine = min(kWideCache, max(0, (n - tid + kThreads - 1) / kThreads));  // entries tid, tid + 1024, ... below n
         const int segc = p.mode == 2 ? __popc(gbits & ((1u << mine) - 1u)) : 0;        // (a slot behind the row repeats the row's last entry)
         LC_FS_STAMP(2);
+#ifdef LC_SELECT_SKIP_SEARCH  // timing experiment only (wrong results; scripts/ubench/select_skip_ab.py): the kernel without the threshold search
+        thr = 1e-4f * (float)segc * 0.f + 3e-5f;
+#else
         thr = quantile_threshold<kWideCache>(p, n, [&](int j, int) { return weight_key(weight_of(j)); }, segc);  // j: a compile-time index there
+#endif
     }
     LC_FS_STAMP(3);
     const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};

@@ -27,12 +27,13 @@ lib = _lib.load()
 fn = lib.lc_debug_sel_stamps
 fn.argtypes = [ctypes.c_void_p]
 rows = []
-B, N = 64, 1024
+B, N = 64, int(os.environ.get("LC_SEL_N", "1024"))
+LOW, HIGH = (300, 560) if N == 1024 else (int(os.environ.get("LC_SEL_LOW", N // 6)), int(os.environ.get("LC_SEL_HIGH", N // 4)))
 g = torch.Generator().manual_seed(0)
 w = (torch.rand(B, N, 2, generator=g) + 0.1).to(dev)
-for seed in range(24):
+for seed in range(24 if N == 1024 else 8):
     bt = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=seed, outlier_frac=0.3, noise_px=0.7).items()}
-    counts = torch.randint(300, 560, (B,), generator=g).to(torch.int32).to(dev)
+    counts = torch.randint(LOW, HIGH, (B,), generator=g).to(torch.int32).to(dev)
     for _ in range(2):
         gpu_solver.solve_device(bt["K"], bt["pts3d"], bt["pts2d"], counts, reprojectionError=3.0, refine=False, split=True, select=dict(weights=w))
     torch.cuda.synchronize()
@@ -40,7 +41,7 @@ for seed in range(24):
     assert fn(out) == 0
     rows.append(np.diff(np.array(list(out)[:7], dtype=np.float64)))
 d = np.median(np.array(rows), axis=0)
-print("# scripts/ubench/sel_stamps.py: lc_ransac_select_kernel, workgroup 0, median over 24 batches of 64 x 1024 (300-560 used), s_memtime counts")
+print(f"# scripts/ubench/sel_stamps.py: lc_ransac_select_kernel, workgroup 0, median over 24 batches of {B} x {N} ({LOW}-{HIGH} used), s_memtime counts")
 for n_, v in zip(NAMES, d):
     print(f"  {n_:40s} {v:9.0f}  {100 * v / d.sum():5.1f} %")
 print(f"  {'total':40s} {d.sum():9.0f}")

@@ -1,5 +1,5 @@
 """Phase clock of lc_dense_frontend_select_kernel's wide path (16 384 candidates per object; workgroup 0, thread 0): diagnostic build
--DLC_SELECT_STAMPS, shader cycles (s_memtime, 100 MHz ticks on gfx950 -> reported in us)."""
+-DLC_SELECT_STAMPS, s_memtime ticks and each phase's share (the tick is not a documented unit here: quote shares, and kernel times from rocprofv3)."""
 import ctypes
 import os
 import sys
@@ -39,7 +39,8 @@ for it in range(24):
     assert fn(o) == 0
     rows.append(np.diff(np.array(list(o)[:6], dtype=np.float64)))
 d = np.median(np.array(rows), axis=0)
-print("# scripts/ubench/select_stamps.py: lc_dense_frontend_select_kernel<.., true>, workgroup 0, median of 24 launches of 64 x 128x128, s_memtime ticks (10 ns)")
+print("# scripts/ubench/select_stamps.py: lc_dense_frontend_select_kernel<.., true>, workgroup 0, median of 24 launches of 64 x 128x128, s_memtime ticks")
+print("# (ONE wavefront's clock: its waits at the barriers are the other wavefronts' work -- scripts/ubench/select_skip_ab.py has the search's cost in kernel time)")
 for n_, v in zip(NAMES, d):
-    print(f"  {n_:60s} {v:9.0f} ticks = {v / 100:6.2f} us  {100 * v / d.sum():5.1f} %")
-print(f"  {'total':60s} {d.sum():9.0f} ticks = {d.sum() / 100:6.2f} us")
+    print(f"  {n_:60s} {v:9.0f} ticks  {100 * v / d.sum():5.1f} %")
+print(f"  {'total':60s} {d.sum():9.0f} ticks")
