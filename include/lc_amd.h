@@ -88,8 +88,10 @@ int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const
  *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller; after that it belongs to these calls (each leaves it ready for
  *       the next of any shape on the same stream; calls that may run concurrently need a workspace each).  NULL: lc_pnp_lm2_f32.
  * Results: those of lc_pnp_lm2_f32 up to the order of the fp64 sums over the correspondences (tests/test_gpu_pnp_split.py).
- * The workgroups of a pose wait for each other; the wait is bounded (about a second), after which the pose is reported invalid (rets = 1)
- * -- which can only happen when more than two such launches run concurrently on one device. */
+ * The workgroups of a pose wait for each other, and such a launch is sized to fill the chip by itself (one workgroup per compute unit): run
+ * these calls one at a time per device.  Two of them admitted side by side (different streams) can each hold compute units the other's
+ * missing workgroups need; the wait is bounded (about a second), after which the poses concerned are reported invalid (rets = 1) -- a failed
+ * solve, not a hung device.  Callers that overlap solves on several streams pass workspace = NULL. */
 size_t lc_pnp_lm_workspace_bytes(int B, int Nmax);
 int lc_pnp_lm3_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
                    const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,

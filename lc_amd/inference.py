@@ -101,7 +101,7 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     results = []
     for (b0, b1), side in zip(bounds, pool):
         side.wait_stream(cur)  # the network's outputs are ready on the caller's stream
-        with torch.cuda.stream(side), pnp_ceres.owned_split_workspace(None):  # concurrent solves: a workspace per stream, not a shared one
+        with torch.cuda.stream(side), pnp_ceres.no_split():  # concurrent launches: no forms whose workgroups wait for each other
             results.append(_solve_pnp_dense(cfg, cut(out_dict, b0, b1), cut(gt_dict, b0, b1), b0))
     for side in pool[:parts]:
         cur.wait_stream(side)

@@ -46,12 +46,29 @@ def owned_split_workspace(ws):
         _OWNED_WS = prev
 
 
+_SPLIT_OFF = 0
+
+
+@contextlib.contextmanager
+def no_split():
+    """Solves inside the block take one workgroup per pose whatever their shape.  For callers that run several solves CONCURRENTLY on one
+    device (side streams): the workgroups of a split solve wait for each other, a split launch fills the chip by itself (its workgroups take a
+    compute unit each), and two of them admitted half and half would wait for workgroups that cannot start -- until the wait's bound (about a
+    second) fails the poses."""
+    global _SPLIT_OFF
+    _SPLIT_OFF += 1
+    try:
+        yield
+    finally:
+        _SPLIT_OFF -= 1
+
+
 def split_workspace(dev, *shapes, split=None):
     """Workspace for solves of few poses x thousands of correspondences (`lc_pnp_lm_workspace_bytes`: several workgroups per pose), sized for
     the largest of `shapes` = (B, N) pairs; None when none of them takes that form, or with split=False / LC_AMD_PNP_SPLIT=0."""
     if split is None:
         split = os.environ.get("LC_AMD_PNP_SPLIT", "1") != "0"
-    if not split:
+    if not split or _SPLIT_OFF:
         return None
     lib = _lib.load()
     need = max(int(lib.lc_pnp_lm_workspace_bytes(int(B), int(N))) for B, N in shapes)
