@@ -20,6 +20,8 @@ import torch  # noqa: E402
 from lc_amd import _lib, synth  # noqa: E402
 from lc_amd.pnp import gpu_solver  # noqa: E402
 
+NAMES = ["count, points and partials requested .. column sums", "the parts' bests meet (barrier)", "inlier flags of the part's points (barrier)",
+               "the parts' counts meet (barrier)", "rows written", "scalars, padding"]
 NAMES = ["count, then all requests .. partial sums", "arg-max over lanes and waves (barrier)", "winner's pose through LDS (barrier)",
          "inlier mask + compaction + state outputs", "inlier count", "padding + selection count"]
 dev = torch.device("cuda:0")
