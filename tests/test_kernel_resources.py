@@ -51,6 +51,14 @@ def test_dense_kernels_do_not_spill(res):
             assert d["vgpr_count"] <= 512 and d.get("group_segment_fixed_size", 0) <= 64 * 1024, d["name"]
 
 
+def test_split_solve_fits_one_workgroup_per_compute_unit(res):
+    # lc_pnp_lm_split_kernel: its workgroups wait for each other, so every one of a launch must be resident -- pnp_split_parts() sizes the grid to
+    # at most 256 workgroups, one per compute unit: 256 threads, registers of one wave per SIMD (VGPRs + AGPRs <= 512), a few KB of LDS, no scratch
+    for d in _find(res, "lc_pnp_lm_split_kernel"):
+        assert d.get("private_segment_fixed_size", 0) == 0, (d["name"], "scratch")
+        assert d["vgpr_count"] <= 512 and d.get("group_segment_fixed_size", 0) <= 8 * 1024, d["name"]
+
+
 def test_head_kernels_keep_their_occupancy(res):
     # HBM-bound streams: the backward needs many waves in flight; the one-wave-per-map forward holds 64 values per lane and is
     # faster under the max-ILP schedule at three waves per SIMD than under the default one at four (bench_head.py: 42.9 -> 41.8 us)
