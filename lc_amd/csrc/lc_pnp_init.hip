@@ -787,7 +787,11 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
 // behind it and leave at once (the one-chunk kernel above requests its points before it knows: 49 k wavefronts, four fifths of them for
 // nothing, 42 us) -- the hypothesis is loaded once per group, and the next chunk's points are in flight while this one is scored.  Same
 // per-point arithmetic, one partial per 64-point chunk as before: the selection step sees the same numbers.
-constexpr int kWideGroup = 4;
+#ifndef LC_WIDE_GROUP
+#define LC_WIDE_GROUP 1  // (-D: A/B of the group size.  zlmo, 64 x ~3300 of 16 384 points, 3 rounds: 8 -> 62.4, 4 -> 42.2, 2 -> 40.3, 1 -> 37.7 us: the
+                         // kernel wants MORE wavefronts per SIMD to hide its chains behind, not fewer hypothesis loads; profiles/r04/NOTES.md)
+#endif
+constexpr int kWideGroup = LC_WIDE_GROUP;
 __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_wide_kernel(const RansacParams p) {
     __shared__ __attribute__((aligned(16))) float lds[kRansacMaxWaves][5][kChunkPts];
     const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
