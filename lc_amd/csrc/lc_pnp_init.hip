@@ -770,13 +770,19 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
     v2f_t err2 = {0.f, 0.f};
     typedef float v4f_t __attribute__((ext_vector_type(4)));
     auto rd = [](const float* a, int i) { return *reinterpret_cast<const v4f_t*>(a + i); };
+    // two groups of four points per iteration, in two register sets: the LDS reads of one are in flight while the other is scored
+    const int last = __builtin_amdgcn_readfirstlane(cnt4) - 4;
     v4f_t X = rd(sX, 0), Y = rd(sY, 0), Z = rd(sZ, 0), U = rd(sU, 0), V = rd(sV, 0);
-    for (int i = 0; i < cnt4; i += 4) {
-        const int nx = i + 4 < cnt4 ? i + 4 : i;  // the next group is in flight while this one is scored
-        const v4f_t Xn = rd(sX, nx), Yn = rd(sY, nx), Zn = rd(sZ, nx), Un = rd(sU, nx), Vn = rd(sV, nx);
+    for (int i = 0; i <= last; i += 8) {
+        const int i1 = min(i + 4, last), i2 = min(i + 8, last);
+        const v4f_t X1 = rd(sX, i1), Y1 = rd(sY, i1), Z1 = rd(sZ, i1), U1 = rd(sU, i1), V1 = rd(sV, i1);
         score_pair(R, t, X.xy, Y.xy, Z.xy, U.xy, V.xy, thr2, cnt, err2);
         score_pair(R, t, X.zw, Y.zw, Z.zw, U.zw, V.zw, thr2, cnt, err2);
-        X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
+        X = rd(sX, i2); Y = rd(sY, i2); Z = rd(sZ, i2); U = rd(sU, i2); V = rd(sV, i2);
+        if (i + 4 <= last) {  // uniform
+            score_pair(R, t, X1.xy, Y1.xy, Z1.xy, U1.xy, V1.xy, thr2, cnt, err2);
+            score_pair(R, t, X1.zw, Y1.zw, Z1.zw, U1.zw, V1.zw, thr2, cnt, err2);
+        }
     }
     const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
     w.part[o] = pack_partial(cnt, err2.x + err2.y);
@@ -841,13 +847,20 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_wide_
         __builtin_amdgcn_wave_barrier();
         int cnt = 0;
         v2f_t err2 = {0.f, 0.f};
+        // two groups of four points per iteration, in two register sets: the LDS reads of one are in flight while the other is scored (with one
+        // set the compiler rotates the loop and every iteration waits out its own reads).  cnt4 is wave-uniform: a scalar loop.
+        const int last = __builtin_amdgcn_readfirstlane(cnt4) - 4;
         v4f_t X = rd(sX, 0), Y = rd(sY, 0), Z = rd(sZ, 0), U = rd(sU, 0), V = rd(sV, 0);
-        for (int i = 0; i < cnt4; i += 4) {
-            const int nx = i + 4 < cnt4 ? i + 4 : i;
-            const v4f_t Xn = rd(sX, nx), Yn = rd(sY, nx), Zn = rd(sZ, nx), Un = rd(sU, nx), Vn = rd(sV, nx);
+        for (int i = 0; i <= last; i += 8) {
+            const int i1 = min(i + 4, last), i2 = min(i + 8, last);
+            const v4f_t X1 = rd(sX, i1), Y1 = rd(sY, i1), Z1 = rd(sZ, i1), U1 = rd(sU, i1), V1 = rd(sV, i1);
             score_pair(R, t, X.xy, Y.xy, Z.xy, U.xy, V.xy, thr2, cnt, err2);
             score_pair(R, t, X.zw, Y.zw, Z.zw, U.zw, V.zw, thr2, cnt, err2);
-            X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
+            X = rd(sX, i2); Y = rd(sY, i2); Z = rd(sZ, i2); U = rd(sU, i2); V = rd(sV, i2);
+            if (i + 4 <= last) {  // uniform
+                score_pair(R, t, X1.xy, Y1.xy, Z1.xy, U1.xy, V1.xy, thr2, cnt, err2);
+                score_pair(R, t, X1.zw, Y1.zw, Z1.zw, U1.zw, V1.zw, thr2, cnt, err2);
+            }
         }
         w.part[((size_t)b * w.C + c) * w.H + hyp] = pack_partial(cnt, err2.x + err2.y);
         __builtin_amdgcn_wave_barrier();  // the chunk's LDS reads precede the next chunk's writes (one wavefront: program order)
