@@ -588,7 +588,7 @@ def main():
 
     def test_time_block(name, objects=64):
         """SURVEY.md 8f rows f1 + f2 + f3 + a24 chained -- the reference's test.py:67-136 for one batch of detections AT THE REFERENCE'S OWN KNOBS
-        (lc_amd.synth.TEST_TIME_CONFIGS): zlmo = configs/zlmo.yaml:30-37 (128x128 maps, dense_sample 1 -> 16 384 candidates per object,
+        (lc_amd.synth.TEST_TIME_CONFIGS; gsplmo = the sparse head's path, test.py:47-64 at configs/gsplmo.yaml's 16 keypoints): zlmo = configs/zlmo.yaml:30-37 (128x128 maps, dense_sample 1 -> 16 384 candidates per object,
         quantile_in_mask 0.2, rel_reproj_err, solvers [weighted_filtered], 21 code planes + model_transform), glmo = configs/glmo.yaml:28-32
         (64x64 maps, stride 2, quantile 0.3, solvers [weighted]).  [code decode,] dense front end + point selection (one launch), P3P RANSAC
         over ALL selected points (three launches, the inlier re-selection inside the last), inlier refinement + weighted solve; no host
@@ -600,7 +600,13 @@ def main():
         from lc_amd.inference import GraphedSolvePnP, solve_pnp
         from lc_amd.transforms import quaternion_rep_to_RT
 
-        if name == "hybrid_r03":  # rounds 2-3's block (neither config): kept as history only
+        if name == "gsplmo":  # the sparse head's test-time path (test.py:47-64; configs/gsplmo.yaml: sparse_cnt 16, solvers [ransac, weighted], reprojection error 2 px)
+            b = synth.make_batch(objects, 16, seed=3, noise_px=0.3, outlier_frac=0.0)  # (the weighted solve takes every keypoint: a network marks its bad ones by a large predicted deviation)
+            gt = dict(out_K=b["K"], pts3d=b["pts3d"], pose_best=b["pose"])
+            net = dict(pts2d=b["pts2d"], pts2d_std=1 / b["inv_std"])
+            cfg = dict(rel_reproj_err=False, solvers=["ransac", "weighted"])
+            key, what = "weighted", "16 keypoints with predicted standard deviations (sparse head), reprojection error 2 px, solvers ransac + weighted"
+        elif name == "hybrid_r03":  # rounds 2-3's block (neither config): kept as history only
             gt, net = synth.dense_inputs(B=objects, H=64, W=64, seed=3)
             net["xyz_weight_logits"] = net["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
             net["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
@@ -737,7 +743,7 @@ def main():
             out["dense"] = {k: dense_block(k, *v) for k, v in DENSE_WORKLOADS.items() if args.workload in ("all", k)}
         if world == 1 and args.workload == "all":
             out["test_time"] = {}
-            for tt in ("zlmo", "glmo", "hybrid_r03"):
+            for tt in ("zlmo", "glmo", "gsplmo", "hybrid_r03"):
                 try:  # auxiliary blocks: whatever happens in one, the headline above is printed
                     out["test_time"][tt] = test_time_block(tt)
                 except Exception as e:  # noqa: BLE001

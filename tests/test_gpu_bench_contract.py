@@ -61,13 +61,15 @@ def test_single_gpu_line_has_the_contract_keys():
             assert blk[k]["traffic"] > 0 and blk[k]["counters_from"]["file"].startswith("profiles/") and 0 < blk[k]["valu_active_share_of_wave_cycles"] < 1
     # the test-time chain (8f rows f1 + f2 + a24), replayed as one graph
     # ... at the reference's own knobs: configs/zlmo.yaml:30-37 (16 384 candidates per object, weighted_filtered) and configs/glmo.yaml:28-32
-    assert set(d["test_time"]) == {"zlmo", "glmo", "hybrid_r03"}
+    assert set(d["test_time"]) == {"zlmo", "glmo", "gsplmo", "hybrid_r03"}
+    assert "16 keypoints" in d["test_time"]["gsplmo"]["workload"] and d["test_time"]["gsplmo"]["solver"] == "weighted"
     assert "16384 candidates" in d["test_time"]["zlmo"]["workload"] and "quantile_in_mask 0.2" in d["test_time"]["zlmo"]["workload"]
     assert "1024 candidates" in d["test_time"]["glmo"]["workload"] and "quantile 0.3" in d["test_time"]["glmo"]["workload"]
     assert d["test_time"]["zlmo"]["solver"] == "weighted-filtered" and d["test_time"]["glmo"]["solver"] == "weighted"
     for tt in d["test_time"].values():
         assert tt["replay_equals_eager"] and 0 < tt["us_per_call_replayed_200"] <= tt["us_per_call_replayed"] * 1.05 and 0 < tt["us_per_call_replayed"] <= tt["us_per_call_eager"] * 1.05 < 4000  # zlmo is GPU-bound: eager == replayed
-        assert tt["median_translation_error_mm"] < 5.0 and tt["max_translation_error_mm"] < 25.0 and tt["max_rotation_error"] < 0.1
+        sparse = "keypoints" in tt["workload"]  # 16 points at 0.3 px of noise: depth is known to a few mm at best
+        assert tt["median_translation_error_mm"] < (12.0 if sparse else 5.0) and tt["max_translation_error_mm"] < (100.0 if sparse else 25.0) and tt["max_rotation_error"] < 0.1
     assert d["steady_state"]["B"] == 4096 and d["steady_state"]["poses_per_s"] > d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
