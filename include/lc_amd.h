@@ -465,6 +465,20 @@ int lc_dense_frontend_select2(const void *xyz, const void *wlogits, const void *
                               int sample, int mode, double quantile, int square_weights, int min_count, unsigned seed, int pose_index_offset,
                               float *out_pts2d, float *out_weights, float *out_pts3d, int *out_index, int *counts,
                               void *stream);
+/* lc_dense_frontend_select2 for FEW objects with THOUSANDS of candidates each (zlmo's test-time shape: 64 objects x 16 384): given a workspace,
+ * rows of more than 4096 candidates of at most 128 objects are selected by several workgroups per object -- each forms its share of the
+ * log-sum-exp, of the radix select's histograms and of the compaction, the shares meet through ticketed words in the workspace -- instead of
+ * one workgroup pulling the object's maps through one compute unit.  Every output bit for bit that of lc_dense_frontend_select2.
+ *   lc_dense_frontend_select_workspace_bytes: bytes that shape needs (0: one workgroup per object anyway).
+ *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller, then owned by these calls (each leaves it ready for the next on the
+ *       same stream).  NULL: lc_dense_frontend_select2.  As for lc_pnp_lm3_f32: the workgroups of an object wait for each other (bounded; an
+ *       object whose parts never all arrive gets count 0) and the launch fills the chip -- one such call at a time per device. */
+size_t lc_dense_frontend_select_workspace_bytes(int B, int H, int W, int top, int left, int sample);
+int lc_dense_frontend_select3(const void *xyz, const void *wlogits, const void *wscale, const float *noc_scale,
+                              const void *vis_logits, float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left,
+                              int sample, int mode, double quantile, int square_weights, int min_count, unsigned seed, int pose_index_offset,
+                              float *out_pts2d, float *out_weights, float *out_pts3d, int *out_index, int *counts,
+                              void *workspace, size_t workspace_bytes, void *stream);
 int lc_bits_decode_gt_fwd3(const void *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
                            const float *out_scale, const float *out_xform, int map_dtype, long long logits_bstride, int B, int C, int H, int W, int n0,
                            int n1, int n2, int black_background, int top, int left, int sample, float *out, void *stream);

@@ -83,6 +83,9 @@ _SIGNATURES = {
     "lc_dense_frontend_bwd2": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_longlong] + [c_int] * 6 + [c_void_p] * 4),
     "lc_dense_frontend_select2": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint, c_int] +
                                   [c_void_p] * 6),
+    "lc_dense_frontend_select3": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint, c_int] +
+                                  [c_void_p] * 5 + [c_void_p, ctypes.c_size_t, c_void_p]),
+    "lc_dense_frontend_select_workspace_bytes": (ctypes.c_size_t, [c_int] * 6),
     "lc_bits_decode_gt_fwd3": (c_int, [c_void_p] * 5 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode_gt_bwd3": (c_int, [c_void_p] * 6 + [c_int, ctypes.c_longlong] + [c_int] * 11 + [c_void_p, c_void_p]),
     "lc_bits_decode3": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong] + [c_int] * 9 + [c_void_p, c_void_p]),

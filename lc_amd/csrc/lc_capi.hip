@@ -744,6 +744,19 @@ int lc_dense_frontend_select2(const void* xyz, const void* wlogits, const void* 
                                  float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
                                  int square_weights, int min_count, unsigned seed, int pose_index_offset, float* out_pts2d, float* out_weights, float* out_pts3d,
                                  int* out_index, int* counts, void* stream) {
+    return lc_dense_frontend_select3(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, map_dtype, xyz_dtype, wscale_dtype, xyz_bstride, wlogits_bstride, vis_bstride, B, H, W, top, left, sample, mode, quantile,
+                                     square_weights, min_count, seed, pose_index_offset, out_pts2d, out_weights, out_pts3d, out_index, counts, nullptr, 0, stream);
+}
+
+size_t lc_dense_frontend_select_workspace_bytes(int B, int H, int W, int top, int left, int sample) {
+    if (B <= 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return 0;
+    return lc::dense_select_split_workspace_bytes(B, ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample));
+}
+
+int lc_dense_frontend_select3(const void* xyz, const void* wlogits, const void* wscale, const float* noc_scale, const void* vis_logits,
+                                 float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
+                                 int square_weights, int min_count, unsigned seed, int pose_index_offset, float* out_pts2d, float* out_weights, float* out_pts3d,
+                                 int* out_index, int* counts, void* workspace, size_t workspace_bytes, void* stream) {
     if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
     if (wscale_dtype < 0 || wscale_dtype > 2) return fail(1, "wscale_dtype must be LC_F32, LC_F16 or LC_BF16");
     if (xyz_dtype != map_dtype && xyz_dtype != 0) return fail(1, "xyz_dtype must be map_dtype or LC_F32");
@@ -761,6 +774,14 @@ int lc_dense_frontend_select2(const void* xyz, const void* wlogits, const void* 
     LC_REQUIRE_ALIGNED(8, out_pts2d, out_weights);
     lc::SelectParams p{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_pts2d, out_weights, out_pts3d, out_index, counts,
                        B, N, mode, (float)quantile, (float)(1.0 - quantile), square_weights, min_count, seed, pose_index_offset};
+    if (workspace) {  // several workgroups per object where the shape takes them (lc_kernels.h: dense_select_split_parts)
+        const size_t need = lc::dense_select_split_workspace_bytes(B, N);
+        if (need) {
+            if (workspace_bytes < need) return fail(1, "workspace smaller than lc_dense_frontend_select_workspace_bytes(B, H, W, top, left, sample)");
+            if (reinterpret_cast<uintptr_t>(workspace) & 127u) return fail(1, "workspace must be 128-byte aligned");
+            p.split_ws = workspace;
+        }
+    }
     lc::DenseParams d{xyz, wlogits, wscale, noc_scale, nullptr, nullptr, nullptr, nullptr, B, H, W, N, top, left, sample, vis_logits, vis_thresh, nullptr, map_dtype, wscale_dtype, xyz_dtype,
                        xyz_bstride ? xyz_bstride : 3ll * H * W, wlogits_bstride ? wlogits_bstride : 2ll * H * W, vis_bstride ? vis_bstride : 1ll * H * W};
     return lc::launch_dense_frontend_select(p, d, static_cast<hipStream_t>(stream)) ? fail(11, "front end + select launch failed") : 0;

@@ -27,6 +27,41 @@ __device__ __forceinline__ void ms_merge(float& m, float& s, float om, float os)
     m = mn;
 }
 
+// One thread's share of the reduction below: thread `ft` of NT takes the groups of four logits ft, ft + NT, ..., AHEAD requests in flight, consumed in
+// index order (the updates and their order do not depend on AHEAD); thread 0 also takes the up to three logits behind the last full group.
+template <int NT, int AHEAD, typename T>
+__device__ __forceinline__ void lse_thread_share(const T* __restrict__ lg, int n, int ft, float& m, float& s) {
+    // Groups of four consecutive logits per request, consumed in index order: the same updates in the same order as one request per
+    // iteration (which was one memory round trip per iteration: 4 for a 64x64 map, 16 for 128x128).
+    // A map whose sample does not start on a four-element boundary (a channel slice with H*W % 4 == 2) takes four scalar loads per
+    // group instead of one vector load -- the SAME groups in the same order, so the result does not depend on where the map lies.
+    const bool vec = (reinterpret_cast<uintptr_t>(lg) & (4 * sizeof(T) - 1)) == 0;
+    const int n4 = n >> 2;
+    for (int i = ft; i < n4; i += AHEAD * NT) {
+        float4 v[AHEAD];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            if (i + u * NT >= n4) continue;
+            const T* q = lg + 4 * (size_t)(i + u * NT);
+            v[u] = vec ? map_load4(q) : make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            if (i + u * NT >= n4) break;
+            const float mn = fmaxf(fmaxf(m, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+            s = s * __expf(m - mn) + ((__expf(v[u].x - mn) + __expf(v[u].y - mn)) + (__expf(v[u].z - mn) + __expf(v[u].w - mn)));
+            m = mn;
+        }
+    }
+    if (ft == 0)  // the up to three logits behind the last full group (H*W odd: two)
+        for (int i = 4 * n4; i < n; ++i) ms_push(m, s, (float)lg[i]);
+}
+// ... and a wavefront's: the 64 shares merged (every lane ends with the wavefront's pair)
+__device__ __forceinline__ void lse_wave_merge(float& m, float& s) {
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) ms_merge(m, s, __shfl_xor(m, k, kWave), __shfl_xor(s, k, kWave));
+}
+
 // log-sum-exp of lg[0..n), identical in every thread of every workgroup that calls it with the same arguments; red: NT / 64 rows of LDS.
 // T: the map's element type (lc_map.h) -- four elements per request whatever the type, so a 16-bit map is reduced in exactly the order
 // (and to exactly the float) of the fp32 map holding the same values.
@@ -35,33 +70,8 @@ __device__ __forceinline__ float block_lse(const T* __restrict__ lg, int n, floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float m = -FLT_MAX, s = 0.f;
     if (tid < NT) {
-        // Groups of four consecutive logits per request, four requests in flight per thread, consumed in index order: the same updates in
-        // the same order as one request per iteration (which was one memory round trip per iteration: 4 for a 64x64 map, 16 for 128x128).
-        // A map whose sample does not start on a four-element boundary (a channel slice with H*W % 4 == 2) takes four scalar loads per
-        // group instead of one vector load -- the SAME groups in the same order, so the result does not depend on where the map lies.
-        const bool vec = (reinterpret_cast<uintptr_t>(lg) & (4 * sizeof(T) - 1)) == 0;
-        constexpr int kAhead = LC_LSE_AHEAD;
-        const int n4 = n >> 2;
-        for (int i = tid; i < n4; i += kAhead * NT) {
-            float4 v[kAhead];
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) {
-                if (i + u * NT >= n4) continue;
-                const T* q = lg + 4 * (size_t)(i + u * NT);
-                v[u] = vec ? map_load4(q) : make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
-            }
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) {
-                if (i + u * NT >= n4) break;
-                const float mn = fmaxf(fmaxf(m, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
-                s = s * __expf(m - mn) + ((__expf(v[u].x - mn) + __expf(v[u].y - mn)) + (__expf(v[u].z - mn) + __expf(v[u].w - mn)));
-                m = mn;
-            }
-        }
-        if (tid == 0)  // the up to three logits behind the last full group (H*W odd: two)
-            for (int i = 4 * n4; i < n; ++i) ms_push(m, s, (float)lg[i]);
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) ms_merge(m, s, __shfl_xor(m, k, kWave), __shfl_xor(s, k, kWave));
+        lse_thread_share<NT, LC_LSE_AHEAD>(lg, n, tid, m, s);
+        lse_wave_merge(m, s);
         if (lane == 0) { red[wave][0] = m; red[wave][1] = s; }
     }
     __syncthreads();

@@ -335,7 +335,11 @@ struct SelectParams {
     int square, min_count;
     unsigned seed;
     int pose0;                  // as RansacParams::pose0: the padding draw of row b is that of row pose0 + b
+    void* split_ws;             // launch_dense_frontend_select only, or null: dense_select_split_workspace_bytes(B, N) bytes, zeroed once
+    int split_parts;            // set by the launch: workgroups per object (dense_select_split_parts), 1 = one workgroup per object
 };
+int dense_select_split_parts(int B, int N);  // 1 (rows of up to 4096 candidates / more than 128 objects: the grid would not be resident at once), 2, 4, 8
+size_t dense_select_split_workspace_bytes(int B, int N);
 int launch_dense_select(const SelectParams& p, hipStream_t stream);
 // front end + selection in one launch (test time, N <= 1024): the input arrays of `p` are unused (null), `d` names the maps
 int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d, hipStream_t stream);  // 3: N > 1024

@@ -145,6 +145,7 @@ __device__ __forceinline__ unsigned weight_key(float w) {
     const unsigned u = __float_as_uint(w);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending unsigned order == ascending float order
 }
+__device__ __forceinline__ float key_weight(unsigned key) { return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key); }  // its inverse
 // key_at(j, i): key of entry i = tid + j * kThreads (from LDS, or from the caller's registers: then ITERS = the number of entries a thread
 // holds, and the walks over them are unrolled so that j is a compile-time register index)
 template <int ITERS = 0, class KeyAt>
@@ -245,8 +246,7 @@ __device__ __forceinline__ float quantile_threshold(const SelectParams& p, int n
         for (int w = 0; w < kWaves; ++w) { le_total += wave_le[w]; above_min = min(above_min, wave_above[w]); }
         if (le_total <= khi) found[1] = above_min;  // no duplicate reaches rank khi: the next distinct key
     }
-    auto unkey = [](unsigned kk) { return __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk); };
-    const float vlo = unkey(found[0]), vhi = khi != klo ? unkey(found[1]) : vlo;
+    const float vlo = key_weight(found[0]), vhi = khi != klo ? key_weight(found[1]) : vlo;
     return torch_lerp(vlo, vhi, rank - lo);  // every thread forms it from the same two floats
 }
 
@@ -489,7 +489,281 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
     }
 }
 
+// ---- Front end + selection of ONE object by several workgroups (rows of more than 4096 candidates, at most 128 objects) -----------------------
+// One workgroup per object pulls the object's maps (128x128: 196 KB of logits) through ONE compute unit and walks 16 candidates per thread
+// through every phase: 36.7 us at zlmo's test-time shape, 24 of them without the threshold search, on a quarter of the chip.  Here part g of
+// P = 2 / 4 / 8 owns the candidates [4096 g, 4096 (g + 1)) -- four per thread, in registers, the shape the narrow kernel above was built for --
+// and the parts meet five to seven times through ticketed words in the workspace (lc_common.h: SplitSum; rows of 256 words here):
+//   1. log-sum-exp: part g plays threads [512 g / P, 512 (g + 1) / P) of the front end's 512-thread reduction (lse_thread_share: same groups,
+//      same order), the 8 wavefront pairs meet and are merged in wavefront order -- the SAME float as block_lse; the visible counts ride along;
+//   2. radix select: every pass counts its own keys, the 256 bins meet (one word per thread), every part scans the merged histogram;
+//      the upper order statistic is read off the last pass' merged bins (exact keys) -- or, the rank closing its prefix, one more meeting;
+//   3. compaction: the parts' survivor counts meet, part g writes behind the parts before it.
+// Every value is formed by the expressions of the one-workgroup kernels and every decision is taken on the same integers: outputs bit for bit
+// those of lc_dense_frontend_select_kernel (tests/test_gpu_select.py).  The parts wait for each other (bounded; an object whose parts never
+// all arrive gets count 0) and the grid is sized to one workgroup per compute unit: one such launch at a time per device.
+constexpr int kSelRowWords = 256;
+constexpr size_t kSelSplitPoseBytes = 2 * kSplitMaxParts * kSelRowWords * sizeof(unsigned long long) + 128;
+
+// The parts of an object meet: threads tid < nw publish word tid of this part (`mine`); the nw x G words of all parts are then fetched by the
+// workgroup's threads one word each (thread t: word t % nw of part t / nw -- one or two registers per thread, not G) and handed to
+// consume(g, l, word).  With every thread of a few polling G words each the kernel took 28.3 us, spread like this 25.6.
+// false: a part never arrived (bounded wait, lc_common.h).
+template <class F>
+__device__ __forceinline__ bool parts_meet(SplitSum& sx, int tid, int nw, unsigned mine, F&& consume) {
+    const unsigned long long ticket = (unsigned long long)(sx.base + sx.seq + 1u) << 32;
+    unsigned long long* rows = sx.exch + (size_t)(sx.seq & 1u) * (kSplitMaxParts * kSelRowWords);
+    ++sx.seq;
+    if (tid < nw) xcd_store(rows + sx.part * kSelRowWords + tid, ticket | mine);
+    bool ok = true;
+    for (int idx = tid; idx < nw * sx.G; idx += kThreads) {
+        const int g = idx / nw, l = idx - g * nw;
+        const unsigned long long* at = rows + g * kSelRowWords + l;
+        unsigned long long word = 0;
+        for (int polls = 0;; ++polls) {  // (several reads in flight per word, a sleep apart, were measured slower: 25.6 us with one, 26.1 / 27.1 / 27.8 with 2 / 3 / 5)
+            word = xcd_load(at);
+            if (((word ^ ticket) >> 32) == 0) break;
+            if (polls >= kSplitMaxPolls) { ok = false; break; }
+        }
+        if (ok) consume(g, l, (unsigned)word);
+    }
+    return ok;
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_split_kernel(const SelectParams p, const DenseParams d) {
+    constexpr int kLseWaves = kDenseLseThreads / kWave;
+    __shared__ float red[kLseWaves][2];
+    __shared__ int wave_seg[kWaves], seg_parts[kSplitMaxParts], kept_parts[kSplitMaxParts], never_arrived;
+    __shared__ unsigned wave_above[kWaves], above_parts[kSplitMaxParts];
+    __shared__ int hist[3][256], merged[3][256];
+    __shared__ int cnt[kCache][kWaves];
+    const int P = p.split_parts, b = blockIdx.x / P, part = blockIdx.x % P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, HW = d.H * d.W, n = p.N;
+    const size_t base = (size_t)b * p.N;
+    MapSource<T, TX> src;
+    src.lg = static_cast<const T*>(d.wlogits) + (size_t)b * d.wl_bs;
+    src.xyz = d.xyz ? static_cast<const TX*>(d.xyz) + (size_t)b * d.xyz_bs : nullptr;
+    src.vis = d.vis_logits ? static_cast<const T*>(d.vis_logits) + (size_t)b * d.vis_bs : nullptr;
+    src.vis_thresh = d.vis_thresh;
+    src.HW = HW; src.W = d.W; src.top = d.top; src.left = d.left; src.sample = d.sample;
+    src.Wn = (d.W - d.left + d.sample - 1) / d.sample;
+    src.lse = 0.f;
+    src.scale = map_scalar_at(d.wscale, d.wscale_dtype, b);
+    for (int k = 0; k < 3; ++k) src.ns[k] = d.noc_scale ? d.noc_scale[3 * b + k] : 1.f;
+    char* region = static_cast<char*>(p.split_ws) + (size_t)b * kSelSplitPoseBytes;
+    unsigned* epoch = reinterpret_cast<unsigned*>(region + kSelSplitPoseBytes - 128);
+    SplitSum sx{reinterpret_cast<unsigned long long*>(region), epoch, P, part, xcd_load(epoch), 0u, false};
+    LC_FS_STAMP(0);
+    if (tid == 0) never_arrived = 0;
+    if (tid < 256) { hist[0][tid] = 0; merged[0][tid] = 0; }  // the first pass' pair (the later ones are zeroed a pass ahead)
+    // this part's candidates: entries i0 + tid + 1024 k, requested while the log-sum-exp is formed
+    const int i0 = part * kCache * kThreads;
+    Entry ec[kCache] = {};
+    float vraw[kCache] = {};
+    bool have[kCache];
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) {
+        have[k] = i0 + tid + k * kThreads < n;
+        if (have[k]) ec[k] = src.fetch(i0 + tid + k * kThreads, vraw[k]);
+    }
+    // 1. this part's threads of the front end's reduction
+    const int per = kDenseLseThreads / P, wpp = per / kWave;  // threads / wavefronts of that reduction this part plays
+    if (tid < per) {
+        float m = -FLT_MAX, s = 0.f;
+        lse_thread_share<kDenseLseThreads, 8>(src.lg, 2 * HW, part * per + tid, m, s);
+        lse_wave_merge(m, s);
+        if (lane == 0) { red[wave][0] = m; red[wave][1] = s; }
+    }
+    int segc = 0;
+    if (p.mode == 2) {
+#pragma unroll
+        for (int k = 0; k < kCache; ++k)
+            if (have[k] && src.vis && (1.f / (1.f + expf(-vraw[k]))) > src.vis_thresh) ++segc;  // MapSource::finish's own test
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) segc += __shfl_xor(segc, m, kWave);
+        if (lane == 0) wave_seg[wave] = segc;
+    }
+    __syncthreads();
+    auto meet = [&](int nw, unsigned mine, auto&& consume) {  // + the barrier that makes what `consume` wrote to LDS visible; false: give up
+        if (!parts_meet(sx, tid, nw, mine, consume)) never_arrived = 1;
+        __syncthreads();
+        return never_arrived == 0;
+    };
+    auto give_up = [&]() {  // (uniform) an object whose parts did not all arrive: no points -- the RANSAC behind flags it invalid
+        if (part == 0 && tid == 0) {
+            p.counts[b] = 0;
+            xcd_store(sx.epoch, sx.base + sx.seq + 4096u);
+        }
+    };
+    {
+        unsigned mine = 0u;
+        if (tid < 2 * wpp) mine = __float_as_uint(red[tid >> 1][tid & 1]);
+        else if (tid == 2 * wpp) {
+            int mine_seg = 0;
+            if (p.mode == 2)
+                for (int w = 0; w < kWaves; ++w) mine_seg += wave_seg[w];
+            mine = (unsigned)mine_seg;
+        }
+        __syncthreads();  // red[] is rewritten with all eight pairs
+        LC_FS_STAMP(1);
+        if (!meet(2 * wpp + 1, mine, [&](int g, int l, unsigned word) {
+                if (l < 2 * wpp) red[g * wpp + (l >> 1)][l & 1] = __uint_as_float(word);
+                else seg_parts[g] = (int)word;
+            })) {
+            give_up();
+            return;
+        }
+    }
+    {
+        float m = red[0][0], s = red[0][1];
+#pragma unroll
+        for (int w = 1; w < kLseWaves; ++w) ms_merge(m, s, red[w][0], red[w][1]);
+        src.lse = m + __logf(s);  // block_lse's own last lines
+    }
+    LC_FS_STAMP(2);
+    int seg_total = 0;
+    for (int g = 0; g < P; ++g) seg_total += seg_parts[g];
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) ec[k] = src.finish(ec[k], vraw[k]);
+    auto weight_of = [&](const Entry& e) { return (p.mode == 2 && !e.g) ? 0.f : e.s.x + e.s.y; };
+    // 2. the threshold (quantile_threshold above, the bins of every pass merged over the parts)
+    float thr = -FLT_MAX;
+    if (p.mode != 0) {
+        unsigned key[kCache];
+#pragma unroll
+        for (int k = 0; k < kCache; ++k) key[k] = have[k] ? weight_key(weight_of(ec[k])) : 0u;
+        float q = p.quantile;
+        if (p.mode == 2) q = 1.f - p.one_minus_q * ((float)seg_total / (float)n);
+        q = fminf(fmaxf(q, 0.f), 1.f);
+        const float rank = q * (float)(n - 1);
+        const float lo = floorf(rank), hi = ceilf(rank);
+        const int klo = (int)lo, khi = min((int)hi, n - 1);
+        LC_FS_STAMP(3);
+        unsigned prefix = 0u, mask = 0u, found[2];
+        int k = klo, in_bin = 0, next_bin = 256;
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = 8 * pass, cur = (3 - pass) % 3, nxt = (cur + 1) % 3;
+            const int* all = merged[cur];  // the parts' bins added up (three in rotation, zeroed a pass ahead, like the histograms)
+            if (tid < 256) { hist[nxt][tid] = 0; merged[nxt][tid] = 0; }
+#pragma unroll
+            for (int j = 0; j < kCache; ++j) hist_add(hist[cur], (key[j] >> shift) & 255u, have[j] && (key[j] & mask) == prefix, lane, pass == 3);
+            __syncthreads();
+            if (!meet(256, tid < 256 ? (unsigned)hist[cur][tid] : 0u, [&](int, int l, unsigned word) { if (word) atomicAdd(&merged[cur][l], (int)word); })) {
+                give_up();
+                return;
+            }
+            // every wavefront: lane l owns bins 4l .. 4l+3, exclusive prefix over the lanes, then the bin holding rank k
+            const int c0 = all[4 * lane], c1 = all[4 * lane + 1], c2 = all[4 * lane + 2], c3 = all[4 * lane + 3];
+            const int mine4 = c0 + c1 + c2 + c3;
+            int incl = mine4;
+#pragma unroll
+            for (int dd = 1; dd < kWave; dd <<= 1) {
+                const int up = __shfl_up(incl, dd, kWave);
+                if (lane >= dd) incl += up;
+            }
+            const int excl = incl - mine4;
+            const bool hit = k >= excl && k < incl;  // exactly one lane
+            int r = k - excl, bin = 4 * lane, cb = c0;
+            if (r >= c0) { r -= c0; ++bin; cb = c1; if (r >= c1) { r -= c1; ++bin; cb = c2; if (r >= c2) { r -= c2; ++bin; cb = c3; } } }
+            const int owner = __ffsll((long long)__ballot(hit)) - 1;
+            bin = __shfl(bin, owner, kWave);
+            prefix |= (unsigned)bin << shift;
+            mask |= 255u << shift;
+            k = __shfl(r, owner, kWave);
+            if (pass == 0) {  // the bins are exact keys: how many copies of the found key, and the next key present under the same 24-bit prefix
+                in_bin = __shfl(cb, owner, kWave);
+                int nb = 256;
+                if (4 * lane + 3 > bin) {
+                    if (c3 > 0 && 4 * lane + 3 > bin) nb = 4 * lane + 3;
+                    if (c2 > 0 && 4 * lane + 2 > bin) nb = 4 * lane + 2;
+                    if (c1 > 0 && 4 * lane + 1 > bin) nb = 4 * lane + 1;
+                    if (c0 > 0 && 4 * lane > bin) nb = 4 * lane;
+                }
+#pragma unroll
+                for (int mm = 32; mm >= 1; mm >>= 1) nb = min(nb, __shfl_xor(nb, mm, kWave));
+                next_bin = nb;
+            }
+        }
+        found[0] = found[1] = prefix;
+        if (khi != klo && k + 1 >= in_bin) {  // (uniform) rank khi = klo + 1 is the next distinct key
+            if (next_bin < 256) {
+                found[1] = (prefix & ~255u) | (unsigned)next_bin;
+            } else {  // none under this prefix: the smallest key above, over all parts
+                unsigned above = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < kCache; ++j)
+                    if (have[j] && key[j] > found[0]) above = min(above, key[j]);
+#pragma unroll
+                for (int mm = 32; mm >= 1; mm >>= 1) above = min(above, (unsigned)__shfl_xor((int)above, mm, kWave));
+                if (lane == 0) wave_above[wave] = above;
+                __syncthreads();
+                unsigned mine = 0xFFFFFFFFu;
+                for (int w = 0; w < kWaves; ++w) mine = min(mine, wave_above[w]);
+                if (!meet(1, mine, [&](int g, int, unsigned word) { above_parts[g] = word; })) {
+                    give_up();
+                    return;
+                }
+                unsigned above_min = 0xFFFFFFFFu;
+                for (int g = 0; g < P; ++g) above_min = min(above_min, above_parts[g]);
+                found[1] = above_min;
+            }
+        }
+        const float vlo = key_weight(found[0]), vhi = khi != klo ? key_weight(found[1]) : vlo;
+        thr = torch_lerp(vlo, vhi, rank - lo);
+    }
+    LC_FS_STAMP(4);
+    // 3. compaction: this part's survivors behind those of the parts before it
+    bool keep[kCache];
+    unsigned long long bal[kCache];
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) {
+        keep[k] = have[k] && (p.mode == 0 ? ec[k].g != 0 : (weight_of(ec[k]) >= thr && (p.mode == 1 || ec[k].g != 0)));
+        bal[k] = __ballot(keep[k]);
+        if (lane == 0) cnt[k][wave] = __popcll(bal[k]);
+    }
+    __syncthreads();
+    int off[kCache], mine_total = 0;
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) {
+        off[k] = mine_total;
+        for (int w = 0; w < kWaves; ++w) {
+            if (w < wave) off[k] += cnt[k][w];
+            mine_total += cnt[k][w];
+        }
+    }
+    if (!meet(1, (unsigned)mine_total, [&](int g, int, unsigned word) { kept_parts[g] = (int)word; })) {
+        give_up();
+        return;
+    }
+    LC_FS_STAMP(5);
+    int before = 0, kept = 0;
+    for (int g = 0; g < P; ++g) {
+        if (g < part) before += kept_parts[g];
+        kept += kept_parts[g];
+    }
+    const RowCopy rows{nullptr, nullptr, nullptr, nullptr, p.o_pts2d, p.o_w, p.o_pts3d, p.o_index, p.square};
+    auto put = [&](const Entry& e, int o) { rows.entry_from(base, o, e.u.x, e.u.y, e.s, e.X[0], e.X[1], e.X[2], e.src); };
+#pragma unroll
+    for (int k = 0; k < kCache; ++k)
+        if (keep[k]) put(ec[k], before + off[k] + __popcll(bal[k] & ((1ull << lane) - 1ull)));
+    if (part != 0) return;
+    const int total = pad_rows(p.pose0 + b, n, kept, p.min_count, p.seed, [&](int i, int k) { put(src.load(i), k); });  // test.py:108-113
+    LC_FS_STAMP(6);
+    if (tid == 0) {
+        p.counts[b] = total;
+        xcd_store(sx.epoch, sx.base + sx.seq);  // the tickets of this object's next launch count on from here
+    }
+}
+
 }  // namespace
+
+int dense_select_split_parts(int B, int N) {
+    if (N <= kCache * kThreads || N > kFusedSelectMaxPoints || B <= 0 || B > 128) return 1;
+    const int P = B <= 32 ? 8 : (B <= 64 ? 4 : 2);  // at most one workgroup per compute unit (256): all resident together
+    return N <= P * kCache * kThreads ? P : 1;     // a part's candidates are the four per thread its registers hold
+}
+size_t dense_select_split_workspace_bytes(int B, int N) { return dense_select_split_parts(B, N) > 1 ? (size_t)B * kSelSplitPoseBytes : 0; }
 
 int launch_dense_select(const SelectParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
@@ -518,6 +792,17 @@ int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d_in,
             rc = 2;
         else hipLaunchKernelGGL(kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
     };
+    if (p.split_ws) {
+        const int parts = dense_select_split_parts(p.B, p.N);
+        if (parts > 1) {  // several workgroups per object, four candidates per thread (keys in registers: no dynamic LDS)
+            SelectParams ps = p;
+            ps.split_parts = parts;
+            auto split = [&](auto* kernel) { hipLaunchKernelGGL(kernel, dim3((unsigned)p.B * parts), dim3(kThreads), 0, stream, ps, d); };
+            LC_MAP_DISPATCH(d.map_dtype, if (d.xyz_dtype == d.map_dtype) split(lc_dense_frontend_select_split_kernel<T, T>);
+                                         else split(lc_dense_frontend_select_split_kernel<T, float>));
+            return hipGetLastError() == hipSuccess ? 0 : 2;
+        }
+    }
     const bool wide = p.N > kCache * kThreads;  // more candidates per thread than the register cache of the one-entry-at-a-time walk holds
     LC_MAP_DISPATCH(d.map_dtype,
                     if (d.xyz_dtype == d.map_dtype) { if (wide) go(lc_dense_frontend_select_kernel<T, T, true>); else go(lc_dense_frontend_select_kernel<T, T, false>); }

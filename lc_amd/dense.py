@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from . import _lib
+from . import _lib, splitws
 
 
 def _n_points(H, W, top, left, sample):
@@ -148,11 +148,13 @@ def _select_buffers(out, B, N, dev, what):
 def dense_front_end_select(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weights_scale: Tensor, noc_scale: Tensor,
                            msk_vis_logits: Tensor, mode: str, *, seg_thresh: float = 0.5, sample: int = 2, top_left=(0, 0),
                            quantile: float = 0.0, square_weights: bool = True, min_count: int = 4, seed: int = 0, out=None,
-                           pose_index_offset: int = 0):
+                           pose_index_offset: int = 0, split=None):
     """`dense_front_end_with_visibility` followed by `dense_select(..., mask=visible)` as ONE launch (test time, at most
     FUSED_SELECT_MAX_POINTS sampled pixels per object): the (B,N,.) rows in between are never written.  Returns what `dense_select`
     returns -- (pts2d, weights, pts3d, counts, index), bit for bit.  xyz_noc = None: the selection alone -- pts3d comes back unwritten, for the
-    caller to fill from `index` / `counts` (binary-code heads: `floatbits.decode_selected_rows`, which decodes the selected pixels only)."""
+    caller to fill from `index` / `counts` (binary-code heads: `floatbits.decode_selected_rows`, which decodes the selected pixels only).
+    split (default: on unless `splitws.no_split()` / LC_AMD_PNP_SPLIT=0): rows of more than 4096 candidates of at most 128 objects are selected by
+    several workgroups per object (`lc_dense_frontend_select3` + workspace) -- the same outputs bit for bit."""
     lib = _lib.load()
     top, left = top_left
     B, _, H, W = xyz_weight_logits.shape
@@ -163,11 +165,13 @@ def dense_front_end_select(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weigh
     dev = wl.device
     o_u, o_w, o_x, o_c, o_i = _select_buffers(out, B, N, dev, "dense_front_end_select")
     with _lib.on_device(dev):
-        rc = lib.lc_dense_frontend_select2(_lib.ptr(xyz), _lib.ptr(wl), _lib.ptr(ws), _lib.ptr(ns), _lib.ptr(vl), float(seg_thresh), code, xcode, _lib.MAP_DTYPES[ws.dtype], xs, wls, vs,
+        work = splitws.get("select", dev, int(lib.lc_dense_frontend_select_workspace_bytes(B, H, W, int(top), int(left), int(sample))), split)
+        rc = lib.lc_dense_frontend_select3(_lib.ptr(xyz), _lib.ptr(wl), _lib.ptr(ws), _lib.ptr(ns), _lib.ptr(vl), float(seg_thresh), code, xcode, _lib.MAP_DTYPES[ws.dtype], xs, wls, vs,
                                            B, H, W, int(top), int(left), int(sample), SELECT_MODES[mode], float(quantile), int(square_weights),
                                            int(min_count), int(seed) & 0xFFFFFFFF, int(pose_index_offset), _lib.ptr(o_u), _lib.ptr(o_w),
-                                           _lib.ptr(o_x) if xyz is not None else None, _lib.ptr(o_i), _lib.ptr(o_c), _lib.stream_ptr(dev))
-    _lib.check(rc, "lc_dense_frontend_select2")
+                                           _lib.ptr(o_x) if xyz is not None else None, _lib.ptr(o_i), _lib.ptr(o_c), _lib.ptr(work),
+                                           0 if work is None else work.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_dense_frontend_select3")
     return o_u, o_w, o_x, o_c, o_i
 
 

@@ -20,7 +20,7 @@ import gc
 import torch
 from torch import Tensor
 
-from . import floatbits
+from . import floatbits, splitws
 from .dense import FUSED_SELECT_MAX_POINTS, dense_front_end_select, dense_front_end_with_visibility, dense_select
 from .losses import nn_out_to_xyz
 from .pnp import gpu_solver, pnp_ceres
@@ -101,7 +101,7 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     results = []
     for (b0, b1), side in zip(bounds, pool):
         side.wait_stream(cur)  # the network's outputs are ready on the caller's stream
-        with torch.cuda.stream(side), pnp_ceres.no_split():  # concurrent launches: no forms whose workgroups wait for each other
+        with torch.cuda.stream(side), splitws.no_split():  # concurrent launches: no forms whose workgroups wait for each other
             results.append(_solve_pnp_dense(cfg, cut(out_dict, b0, b1), cut(gt_dict, b0, b1), b0))
     for side in pool[:parts]:
         cur.wait_stream(side)
@@ -240,10 +240,10 @@ class GraphedSolvePnP:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        # the split solves' workspace (few objects x thousands of points): zeroed once here, kept consistent by the launches themselves -- no fill node in the graph
-        self._split_ws = torch.zeros(pnp_ceres.SPLIT_WORKSPACE_MAX_BYTES, device=dev, dtype=torch.uint8)
+        # the workspaces of the split launches (few objects x thousands of points: selection, solves): zeroed once here, kept consistent by the launches themselves -- no fill node in the graph
+        self._split_ws = (torch.zeros(splitws.PNP_MAX_BYTES, device=dev, dtype=torch.uint8), torch.zeros(splitws.SELECT_MAX_BYTES, device=dev, dtype=torch.uint8))
         torch.cuda.synchronize(dev)
-        with quiet_capture(), torch.cuda.graph(self.graph), pnp_ceres.owned_split_workspace(self._split_ws):
+        with quiet_capture(), torch.cuda.graph(self.graph), splitws.owned(pnp=self._split_ws[0], select=self._split_ws[1]):
             self._res = solve_pnp(cfg, self._out, self._gt)
 
     @torch.no_grad()

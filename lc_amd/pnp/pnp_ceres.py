@@ -8,14 +8,12 @@ Returns `(state, result_tr, invalid_flags)` like the reference (`:61`): float32 
 """
 from __future__ import annotations
 
-import contextlib
 import ctypes
-import os
 
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, splitws
 
 
 def _to_np(val):
@@ -27,64 +25,21 @@ def _to_np(val):
 LC_PNP_WEIGHTS_ARE_ICOV, LC_PNP_NAN_TO_NUM = 1, 2  # include/lc_amd.h
 
 
-_SPLIT_WS = {}  # (device index, stream) -> workspace of the split form (zeroed once, consistent from launch to launch; launches of one stream are ordered)
+SPLIT_WORKSPACE_MAX_BYTES = splitws.PNP_MAX_BYTES
+no_split = splitws.no_split
+split_is_off = splitws.is_off
 
 
-_OWNED_WS = None
-SPLIT_WORKSPACE_MAX_BYTES = 128 * (2 * 8 * 64 * 8 + 128)  # lc_pnp_lm_workspace_bytes at its largest batch (include/lc_amd.h)
-
-
-@contextlib.contextmanager
 def owned_split_workspace(ws):
-    """Solves inside the block use `ws` (zeroed uint8 tensor, allocated by the caller BEFORE a stream capture: the launches keep it
-    consistent from one to the next, so a replayed graph needs no fill node) instead of the per-stream one.  The caller orders the launches that share it."""
-    global _OWNED_WS
-    prev, _OWNED_WS = _OWNED_WS, ws
-    try:
-        yield ws
-    finally:
-        _OWNED_WS = prev
-
-
-_SPLIT_OFF = 0
-
-
-@contextlib.contextmanager
-def no_split():
-    """Solves inside the block take one workgroup per pose whatever their shape.  For callers that run several solves CONCURRENTLY on one
-    device (side streams): the workgroups of a split solve wait for each other, a split launch fills the chip by itself (its workgroups take a
-    compute unit each), and two of them admitted half and half would wait for workgroups that cannot start -- until the wait's bound (about a
-    second) fails the poses."""
-    global _SPLIT_OFF
-    _SPLIT_OFF += 1
-    try:
-        yield
-    finally:
-        _SPLIT_OFF -= 1
+    """`splitws.owned(pnp=ws)`: solves inside the block use `ws` (zeroed uint8 tensor allocated before a stream capture) as their workspace."""
+    return splitws.owned(pnp=ws)
 
 
 def split_workspace(dev, *shapes, split=None):
     """Workspace for solves of few poses x thousands of correspondences (`lc_pnp_lm_workspace_bytes`: several workgroups per pose), sized for
-    the largest of `shapes` = (B, N) pairs; None when none of them takes that form, or with split=False / LC_AMD_PNP_SPLIT=0."""
-    if split is None:
-        split = os.environ.get("LC_AMD_PNP_SPLIT", "1") != "0"
-    if not split or _SPLIT_OFF:
-        return None
+    the largest of `shapes` = (B, N) pairs; None when none of them takes that form, or with split=False / LC_AMD_PNP_SPLIT=0 / `no_split()`."""
     lib = _lib.load()
-    need = max(int(lib.lc_pnp_lm_workspace_bytes(int(B), int(N))) for B, N in shapes)
-    if need == 0:
-        return None
-    if _OWNED_WS is not None and _OWNED_WS.device == dev and _OWNED_WS.numel() >= need:
-        return _OWNED_WS
-    if torch.cuda.is_current_stream_capturing():  # a graph owns its workspace; without `owned_split_workspace` its zero-fill is a node of the graph
-        return torch.zeros(need, device=dev, dtype=torch.uint8)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
-    ws = _SPLIT_WS.get(key)
-    if ws is None or ws.numel() < need:
-        if len(_SPLIT_WS) >= 64:
-            _SPLIT_WS.clear()
-        ws = _SPLIT_WS[key] = torch.zeros(need, device=dev, dtype=torch.uint8)
-    return ws
+    return splitws.get("pnp", dev, max(int(lib.lc_pnp_lm_workspace_bytes(int(B), int(N))) for B, N in shapes), split)
 
 
 def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6,

@@ -21,6 +21,8 @@ import torch  # noqa: E402
 from lc_amd import _lib, synth  # noqa: E402
 from lc_amd.dense import dense_front_end_select  # noqa: E402
 
+SPLIT_NAMES = ["own entries and the log-sum-exp share requested, wavefront pairs formed", "the pairs and visible counts meet", "weights, keys",
+               "radix select: four passes, the bins meet in each", "keep flags, local offsets; the counts meet", "rows written, padding"]
 NAMES = ["48 requests + log-sum-exp over 32768 logits", "weights, visibility bits, keys to LDS", "quantile threshold (radix select)",
          "keep flags, 16 x 16 count table, scan (3 barriers)", "xyz of the entries, survivors written, padding"]
 dev = torch.device("cuda:0")
@@ -30,17 +32,18 @@ fn.argtypes = [ctypes.c_void_p]
 cfg, gt, out = synth.test_time_inputs("zlmo", B=64, seed=3)
 xyz = torch.randn(64, 3, 128, 128).to(dev)
 wl, ws, vl = out["xyz_weight_logits"].to(dev), out["xyz_weights_scale"].to(dev), out["msk_vis_logits"].to(dev)
+SPLIT = os.environ.get("LC_SELECT_SPLIT") == "1"  # four workgroups per object (part 0 of object 0 holds the clock)
 rows = []
 for it in range(24):
     for _ in range(2):
-        dense_front_end_select(xyz, wl, ws, None, vl, "quantile_in_mask", quantile=0.2, sample=1)
+        dense_front_end_select(xyz, wl, ws, None, vl, "quantile_in_mask", quantile=0.2, sample=1, split=SPLIT)
     torch.cuda.synchronize()
     o = (ctypes.c_ulonglong * 10)()
     assert fn(o) == 0
-    rows.append(np.diff(np.array(list(o)[:6], dtype=np.float64)))
+    rows.append(np.diff(np.array(list(o)[:7 if SPLIT else 6], dtype=np.float64)))
 d = np.median(np.array(rows), axis=0)
 print("# scripts/ubench/select_stamps.py: lc_dense_frontend_select_kernel<.., true>, workgroup 0, median of 24 launches of 64 x 128x128, s_memtime ticks")
 print("# (ONE wavefront's clock: its waits at the barriers are the other wavefronts' work -- scripts/ubench/select_skip_ab.py has the search's cost in kernel time)")
-for n_, v in zip(NAMES, d):
+for n_, v in zip(SPLIT_NAMES if SPLIT else NAMES, d):
     print(f"  {n_:60s} {v:9.0f} ticks  {100 * v / d.sum():5.1f} %")
 print(f"  {'total':60s} {d.sum():9.0f} ticks")

@@ -128,3 +128,47 @@ def test_front_end_select_rejects_more_than_16384_points():
     z = torch.zeros(1, 3, 130, 128, device=DEV)
     with pytest.raises(RuntimeError, match="16384"):
         dense_front_end_select(z, z[:, :2], torch.ones(1, device=DEV), None, z[:, :1], "mask", sample=1)
+
+
+@pytest.mark.parametrize("B,H,W,sample,top_left", [(64, 128, 128, 1, (0, 0)), (24, 128, 128, 1, (0, 0)), (100, 90, 90, 1, (0, 0)), (5, 200, 160, 2, (1, 0)),
+                                                   (64, 96, 100, 1, (0, 0)), (3, 65, 64, 1, (0, 0))])
+@pytest.mark.parametrize("mode,q", [("quantile_in_mask", 0.2), ("quantile", 0.3), ("mask", 0.0), ("quantile_in_mask", 0.999), ("quantile", 0.0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_several_workgroups_per_object_select_what_one_workgroup_selects(B, H, W, sample, top_left, mode, q, dtype):
+    """`lc_dense_frontend_select3` with a workspace (rows of more than 4096 candidates: 2 / 4 / 8 workgroups per object, the shares of the
+    log-sum-exp, of the radix select's histograms and of the compaction meeting through the workspace) against the one-workgroup launch: rows,
+    weights, points, indices and counts bit for bit -- incl. rows that do not fill the last part, an object with nothing visible (padded), all
+    weights equal (every key in one bin), repeated launches on the same workspace, maps in 16 bits."""
+    from lc_amd.dense import dense_front_end_select
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * H + W)
+    xyz = torch.randn(B, 3, H, W, generator=g).to(dev, dtype)
+    wl = (torch.randn(B, 2, H, W, generator=g) * 1.5)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    blob = (((yy - H / 2) / (0.3 * H)) ** 2 + ((xx - W / 2) / (0.25 * W)) ** 2 < 1).float()
+    wl = wl + 4 * blob
+    vl = (blob * 2 - 1) * 3 + torch.randn(B, 1, H, W, generator=g)
+    vl[1] = -5.0      # nothing visible: modes with the mask keep nothing, the row is padded
+    wl[2] = 0.25      # all weights equal
+    wl, vl = wl.to(dev, dtype), vl.to(dev, dtype)
+    ws = (torch.rand(B, generator=g) + 0.5).to(dev)
+    ns = (torch.rand(B, 3, generator=g) + 0.5).to(dev)
+    kw = dict(seg_thresh=0.5, sample=sample, top_left=top_left, quantile=q, min_count=6, seed=3)
+    one = dense_front_end_select(xyz, wl, ws, ns, vl, mode, split=False, **kw)
+    N = one[0].shape[1]
+    for rep in range(3):
+        many = dense_front_end_select(xyz, wl, ws, ns, vl, mode, split=True, **kw)
+        cnt = one[3]
+        assert torch.equal(many[3], cnt), (many[3] - cnt).nonzero().flatten().tolist()
+        live = torch.arange(N, device=dev)[None, :] < cnt[:, None]
+        for name, x, y in zip(("pts2d", "weights", "pts3d", "", "index"), many, one):
+            if name:
+                m = live if x.dim() == 2 else live[..., None].expand_as(x)
+                assert torch.equal(x[m], y[m]), name
+    # the selection alone (binary-code heads: the points are decoded afterwards)
+    one = dense_front_end_select(None, wl, ws, None, vl, mode, split=False, **kw)
+    many = dense_front_end_select(None, wl, ws, None, vl, mode, split=True, **kw)
+    assert torch.equal(many[3], one[3])
+    live = torch.arange(N, device=dev)[None, :] < one[3][:, None]
+    assert torch.equal(many[4][live], one[4][live]) and torch.equal(many[1][live[..., None].expand_as(many[1])], one[1][live[..., None].expand_as(one[1])])
