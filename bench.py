@@ -595,7 +595,7 @@ def main():
         synchronisation, replayed as ONE hipGraph.  Timed like the headline in small: 11 regions of 20 replays, synchronize around each, median
         (`us_per_call_replayed_200`: regions of 200 replays, where the one synchronisation per region no longer shows); the eager call (launches
         issued from Python) beside it."""
-        from lc_amd import synth
+        from lc_amd import splitws, synth
         from lc_amd.config import AttrDict
         from lc_amd.inference import GraphedSolvePnP, solve_pnp
         from lc_amd.transforms import quaternion_rep_to_RT
@@ -646,6 +646,7 @@ def main():
         return {"workload": f"{objects} objects x {what}, 150 hypotheses",
                 "us_per_call_replayed": t_replay * 1e6, "us_per_call_replayed_200": t_long * 1e6, "us_per_call_eager": t_eager * 1e6,
                 "objects_per_s_replayed": objects / t_long, "replay_equals_eager": bool(same), "solver": key,
+                "split_forms": not splitws.is_off(),  # several workgroups per object where the shapes take them (lc_amd/splitws.py; LC_AMD_PNP_SPLIT=0 turns them off)
                 "median_translation_error_mm": float((te - tg).norm(dim=-1).median()), "max_translation_error_mm": float((te - tg).norm(dim=-1).max()),
                 "max_rotation_error": float((Re - Rg).abs().max())}
 

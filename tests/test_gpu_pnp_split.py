@@ -113,3 +113,37 @@ def test_chain_call_with_a_workspace_equals_the_two_split_solves():
     e1 = pnp_ceres.solve_device(**first, split=True)
     e2 = pnp_ceres.solve_device(**dict(second, start=e1[0]), split=True)
     assert torch.equal(s1, e1[0]) and torch.equal(r1, e1[2]) and torch.equal(s2, e2[0]) and torch.equal(r2, e2[2])
+
+
+@pytest.mark.timeout(180)
+def test_split_launches_side_by_side_end_instead_of_hanging():
+    """What include/lc_amd.h warns about, exercised: split solves launched on TWO streams at once (each with a workspace of its own).  A split launch is
+    sized to one workgroup per compute unit, so two of them can hold units the other's missing workgroups need; the wait for a part is bounded, and
+    a pose whose parts never all arrived is reported invalid with its start pose returned.  The contract checked here: the calls END, every pose that
+    is reported valid carries the one-launch-at-a-time result, and the workspaces are usable afterwards."""
+    B, N = 64, 4096
+    b = _batch(B, N, seed=41)
+    counts = torch.full((B,), 3000, dtype=torch.int32, device="cuda:0")
+    args = (b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"], counts)
+    want = pnp_ceres.solve_device(*args, split=True)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(6):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[k].append(pnp_ceres.solve_device(*args, split=True))
+    torch.cuda.synchronize()
+    failed = 0
+    for per_stream in outs:
+        for state, _tr, ret in per_stream:
+            ok = ret == 0
+            failed += int((~ok).sum())
+            assert torch.equal(state[ok], want[0][ok]), "a pose reported valid is the pose of the undisturbed solve"
+            assert torch.equal(state[~ok], b["start"][~ok]), "a failed pose returns its start"
+    print(f"poses failed by the bounded wait under two overlapping split launches: {failed} of {2 * 6 * B}")
+    for st in streams:  # the workspaces survive: an undisturbed solve on either stream is exact again
+        with torch.cuda.stream(st):
+            again = pnp_ceres.solve_device(*args, split=True)
+        st.synchronize()
+        assert torch.equal(again[0], want[0]) and int(again[2].sum()) == 0
