@@ -21,6 +21,7 @@
 // from one distance constraint; the candidate that reprojects a fourth correspondence best is Gauss-Newton polished and R,t follow
 // from the three point pairs.  ONE root is decomposed and its up-to-four candidates are formed without branches (P3P::solve).  (Divisions and square roots are the Newton-refined v_rcp_f64 / v_rsq_f64 forms of lc_common.h,
 // 2-4e-15 relative: the result is polished and compared at 1e-4.)
+#include <algorithm>
 #include <cfloat>
 
 #include "lc_common.h"
@@ -868,6 +869,87 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_wide_
     }
 }
 
+// The same for at most 128 poses (the test-time batches of the dense heads), without the wavefronts that leave at once: at zlmo's shape four fifths of
+// the grid above -- 39 k of 49 k wavefronts, 9.8 k of 12.3 k workgroups -- read a count and exit, and the kernel's 37 us are what DISPATCHING 12 k
+// workgroups takes (the SQ counters of profiles/r04/test_time/pmc_zlmo.md: 1.7 wavefronts resident per SIMD on average, VALU-active 29 % of the wave
+// cycles).  Here a fixed grid of five wavefronts per SIMD walks the LIVE (pose, chunk, round) units: every wavefront forms the prefix of the poses'
+// unit counts (lane l: poses l and l + 64) and takes units w, w + W, ...; the unit's pose falls out of two ballots.  Same arithmetic per unit, same
+// partials.
+#ifndef LC_LIVE_WORKGROUPS
+#define LC_LIVE_WORKGROUPS 2048  // (768: 24.2, 1024: 23.2, 1280: 23.1, 2048: 22.5, 2560: 22.7 us at zlmo's shape)
+#endif
+constexpr int kLiveMaxPoses = 2 * kWave, kLiveWorkgroups = LC_LIVE_WORKGROUPS;
+__global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_live_kernel(const RansacParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kRansacMaxWaves][5][kChunkPts];
+    const RansacWorkspace w = carve_workspace(p.workspace, p.B, p.Nmax, p.rounds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = (int)blockIdx.x * kRansacMaxWaves + wave, stride = (int)gridDim.x * kRansacMaxWaves;
+    auto count_of = [&](int b) { return b < p.B ? min(p.counts ? p.counts[b] : p.Nmax, p.Nmax) : 0; };
+    const int n_lo = count_of(lane), n_hi = count_of(lane + kWave);
+    auto units_of = [&](int n) { return n >= 4 ? ((n + kChunkPts - 1) / kChunkPts) * p.rounds : 0; };
+    int incl_lo = units_of(n_lo), incl_hi = units_of(n_hi);  // -> inclusive prefixes in pose order (poses 0..63, then 64..127)
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int a = __shfl_up(incl_lo, d, kWave), c = __shfl_up(incl_hi, d, kWave);
+        if (lane >= d) { incl_lo += a; incl_hi += c; }
+    }
+    incl_hi += __shfl(incl_lo, kWave - 1, kWave);
+    const int live = __shfl(incl_hi, kWave - 1, kWave);
+    float *sX = lds[wave][0], *sY = lds[wave][1], *sZ = lds[wave][2], *sU = lds[wave][3], *sV = lds[wave][4];
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    auto rd = [](const float* a, int i) { return *reinterpret_cast<const v4f_t*>(a + i); };
+    for (int u = first; u < live; u += stride) {  // wave-uniform
+        // the pose whose units hold u: the first whose inclusive prefix exceeds it (poses without units share their predecessor's prefix)
+        const int b = __builtin_amdgcn_readfirstlane(__popcll(__ballot(incl_lo <= u)) + __popcll(__ballot(incl_hi <= u)));
+        const int before = b == 0 ? 0 : (b <= kWave ? __shfl(incl_lo, b - 1, kWave) : __shfl(incl_hi, b - 1 - kWave, kWave));
+        const int n = b < kWave ? __shfl(n_lo, b, kWave) : __shfl(n_hi, b - kWave, kWave);
+        const int rem = __builtin_amdgcn_readfirstlane(u - before), c = rem / p.rounds, round = rem - c * p.rounds;  // neighbours share a chunk
+        const size_t i = (size_t)b * p.Nmax + min(c * kChunkPts + lane, p.Nmax - 1);
+        const float gx = p.pts3d[i * 3], gy = p.pts3d[i * 3 + 1], gz = p.pts3d[i * 3 + 2], gu = p.pts2d[i * 2], gv = p.pts2d[i * 2 + 1];
+        const int hyp = round * kWave + lane;
+        float R[9], t[3];
+        {
+            const float* h32 = w.hyp32 + 12 * ((size_t)b * w.H + hyp);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = h32[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t[k] = h32[9 + k];
+        }
+        const CamInv kin(p.K + 9 * (size_t)b);
+        const float thr_px = threshold_px(p, b);
+        const float thr = thr_px * (float)sqrt(fabs(kin.idet));
+        const float thr2 = thr * thr;
+        const int i0 = c * kChunkPts, cnt_pts = min(kChunkPts, n - i0), cnt4 = (cnt_pts + 3) & ~3;
+        if (lane < cnt_pts) {
+            float ux, uy;
+            kin.normalise(gu, gv, ux, uy);
+            sU[lane] = -ux; sV[lane] = -uy;
+            sX[lane] = gx; sY[lane] = gy; sZ[lane] = gz;
+        } else if (lane < cnt4) {
+            sX[lane] = sY[lane] = sZ[lane] = 0.f;
+            sU[lane] = sV[lane] = -INFINITY;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int cnt = 0;
+        v2f_t err2 = {0.f, 0.f};
+        const int last = __builtin_amdgcn_readfirstlane(cnt4) - 4;
+        v4f_t X = rd(sX, 0), Y = rd(sY, 0), Z = rd(sZ, 0), U = rd(sU, 0), V = rd(sV, 0);
+        for (int j = 0; j <= last; j += 8) {
+            const int j1 = min(j + 4, last), j2 = min(j + 8, last);
+            const v4f_t X1 = rd(sX, j1), Y1 = rd(sY, j1), Z1 = rd(sZ, j1), U1 = rd(sU, j1), V1 = rd(sV, j1);
+            score_pair(R, t, X.xy, Y.xy, Z.xy, U.xy, V.xy, thr2, cnt, err2);
+            score_pair(R, t, X.zw, Y.zw, Z.zw, U.zw, V.zw, thr2, cnt, err2);
+            X = rd(sX, j2); Y = rd(sY, j2); Z = rd(sZ, j2); U = rd(sU, j2); V = rd(sV, j2);
+            if (j + 4 <= last) {  // uniform
+                score_pair(R, t, X1.xy, Y1.xy, Z1.xy, U1.xy, V1.xy, thr2, cnt, err2);
+                score_pair(R, t, X1.zw, Y1.zw, Z1.zw, U1.zw, V1.zw, thr2, cnt, err2);
+            }
+        }
+        w.part[((size_t)b * w.C + c) * w.H + hyp] = pack_partial(cnt, err2.x + err2.y);
+        __builtin_amdgcn_wave_barrier();  // the unit's LDS reads precede the next unit's writes (one wavefront: program order)
+    }
+}
+
 // Selection of pose b by the calling workgroup: chunk partials of every hypothesis summed in chunk order (the sums do not depend on
 // which workgroup finished first), arg-max of (count, -error, -hypothesis id), outputs.  XCD: the partials were written by other
 // workgroups of THIS launch (read around the caches), else by an earlier launch.
@@ -1097,9 +1179,16 @@ int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(lc_ransac_score_select_kernel, dim3((unsigned)p.B * w.C), dim3(kWave * waves), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-    if (w.C > 64) {  // more than 4096 candidates per row: chunk groups, the count first
+#ifndef LC_LIVE_MIN_CHUNKS
+#define LC_LIVE_MIN_CHUNKS 64  // (-D: A/B of the live-unit kernel on narrower rows)
+#endif
+    if (w.C > LC_LIVE_MIN_CHUNKS) {  // more than 4096 candidates per row: chunk groups, the count first
         const long long wide = (long long)p.B * ((w.C + kWideGroup - 1) / kWideGroup) * p.rounds;
-        hipLaunchKernelGGL(lc_ransac_score_wide_kernel, dim3((unsigned)((wide + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
+        if (p.B <= kLiveMaxPoses)
+            hipLaunchKernelGGL(lc_ransac_score_live_kernel, dim3((unsigned)std::min<long long>(kLiveWorkgroups, (wide + kRansacMaxWaves - 1) / kRansacMaxWaves)),
+                               dim3(kWave * kRansacMaxWaves), 0, stream, p);
+        else
+            hipLaunchKernelGGL(lc_ransac_score_wide_kernel, dim3((unsigned)((wide + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     } else {
         hipLaunchKernelGGL(lc_ransac_score_kernel, dim3((unsigned)((units + kRansacMaxWaves - 1) / kRansacMaxWaves)), dim3(kWave * kRansacMaxWaves), 0, stream, p);
     }

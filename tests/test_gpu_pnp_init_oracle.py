@@ -64,7 +64,8 @@ def test_ransac_kernel_vs_oracle_fixture(path, split):
 
 @pytest.mark.parametrize("noise", [0.7, 0.0], ids=["noisy", "noise-free"])
 @pytest.mark.parametrize("B,N,iters", [(64, 1024, 150), (5, 300, 64), (3, 2500, 200), (40, 64, 150), (7, 129, 150), (6, 700, 300),
-                                       (4, 9000, 150), (2, 16384, 150), (3, 4097, 300)])  # several LDS tiles / more than 32 chunks per pose
+                                       (4, 9000, 150), (2, 16384, 150), (3, 4097, 300),  # several LDS tiles / more than 32 chunks per pose
+                                       (130, 4100, 64), (100, 5000, 200)])  # wide rows: more / fewer than 128 poses (the two scoring kernels of wide rows)
 def test_split_form_equals_single_launch(B, N, iters, noise):
     """lc_pnp_ransac_init3_f32 (three launches, point chunks spread over the chip) against the one-workgroup-per-pose launch: same
     hypothesis stream, same per-point arithmetic, the same integers in the inlier counts AND the same float in the inlier error
