@@ -25,10 +25,12 @@ print("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
 for k in sorted(acc):
     m = {c: v[0] / v[1] for c, v in acc[k].items()}
     print(f"| {k} | " + " | ".join(f"{m[c]:.4g}" if c in m else "n/a" for c in cols) + " |")
-print("\n| kernel | wavefronts | VALU instructions per wavefront | VALU-active / wave cycles | waiting for an instruction / wave cycles | LDS-active / wave cycles |\n|---|---|---|---|---|---|")
+print("\n| kernel | wavefronts | VALU instructions per wavefront | VALU-active / wave cycles | waiting for an instruction / wave cycles | waiting for anything / wave cycles | "
+      "LDS-active / wave cycles | wave cycles x 4 / GRBM_GUI_ACTIVE (wavefronts resident on average, in the counters' scope) |\n|---|---|---|---|---|---|---|---|")
 for k in sorted(acc):
     m = {c: v[0] / v[1] for c, v in acc[k].items()}
     f = lambda a, b, s=1.0: f"{s * m[a] / m[b]:.3g}" if (a in m and b in m and m[b]) else "n/a"  # noqa: E731
-    print(f"| {k} | {m.get('SQ_WAVES', float('nan')):.0f} | {f('SQ_INSTS_VALU', 'SQ_WAVES')} | {f('SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 4.0)} | {f('SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', 4.0)} | "
-          f"{f('SQ_ACTIVE_INST_LDS', 'SQ_WAVE_CYCLES', 4.0)} |")
-print("\n(SQ_ACTIVE_INST_* and SQ_WAIT_* count in quad-cycles on gfx950 -- the x4 of MI355X_MICROARCH.md -- so the ratios above are shares of the wave cycles.)")
+    print(f"| {k} | {m.get('SQ_WAVES', float('nan')):.0f} | {f('SQ_INSTS_VALU', 'SQ_WAVES')} | {f('SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES')} | {f('SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES')} | "
+          f"{f('SQ_WAIT_ANY', 'SQ_WAVE_CYCLES')} | {f('SQ_ACTIVE_INST_LDS', 'SQ_WAVE_CYCLES')} | {f('SQ_WAVE_CYCLES', 'GRBM_GUI_ACTIVE', 4.0)} |")
+print("\n(SQ_WAVE_CYCLES, SQ_ACTIVE_INST_* and SQ_WAIT_* all count quad-cycles on gfx950 (MI355X_MICROARCH.md): their ratios are shares of the wave cycles as they stand; "
+      "GRBM_GUI_ACTIVE counts cycles.)")
