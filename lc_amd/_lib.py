@@ -240,5 +240,16 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the current stream's handle without building a Stream object (~0.3 us against ~2)
+
+
+def raw_stream(device=None) -> int:
+    """Handle of torch's current stream on `device` as an integer."""
+    if _raw_stream is not None:
+        idx = None if device is None else getattr(device, "index", device)
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def stream_ptr(device=None):
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return c_void_p(raw_stream(device))

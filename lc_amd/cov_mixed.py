@@ -27,7 +27,7 @@ def tiled_workspace(device, B: int, N: int):
         return None
     if torch.cuda.is_current_stream_capturing():
         return torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, B, N)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _lib.raw_stream(device), B, N)
     ws = _TILED_WS.get(key)
     if ws is None:
         if len(_TILED_WS) >= 64:

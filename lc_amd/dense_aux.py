@@ -19,7 +19,7 @@ def _workspace(dev):
         # a graph owns its workspace; only the arrival counters have to start from zero (their zero-fill is a node of the graph), the
         # partials are written before they are read
         return torch.empty(3 * 4096, device=dev, dtype=torch.float64), torch.zeros(ARRIVAL_WORDS, device=dev, dtype=torch.int32)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.raw_stream(dev))
     ws = _WS.get(key)
     if ws is None:
         if len(_WS) >= 64:

@@ -10,6 +10,8 @@ import os
 
 import torch
 
+from . import _lib
+
 _CACHE = {}   # (kind, device index, stream) -> zeroed-once uint8 tensor
 _OWNED = {}   # kind -> tensor handed over by `owned`
 _OFF = 0
@@ -59,7 +61,7 @@ def get(kind: str, dev, need: int, split=None):
         return ws
     if torch.cuda.is_current_stream_capturing():  # a graph owns its workspace; without `owned` its zero-fill is a node of the graph
         return torch.zeros(need, device=dev, dtype=torch.uint8)
-    key = (kind, dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    key = (kind, dev.index if dev.index is not None else torch.cuda.current_device(), _lib.raw_stream(dev))
     ws = _CACHE.get(key)
     if ws is None or ws.numel() < need:
         if len(_CACHE) >= 64:

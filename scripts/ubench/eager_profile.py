@@ -14,12 +14,18 @@ from lc_amd.inference import solve_pnp  # noqa: E402
 from lc_amd.synth import dense_inputs  # noqa: E402
 
 dev = torch.device("cuda:0")
-gt, out = dense_inputs(B=64, H=64, W=64, seed=3)
-out["xyz_weight_logits"] = out["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
-out["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
+if os.environ.get("CFG"):  # a reference config's knobs (lc_amd.synth.TEST_TIME_CONFIGS)
+    from lc_amd import synth
+
+    cfg, gt, out = synth.test_time_inputs(os.environ["CFG"], B=64, seed=3)
+    cfg = AttrDict(cfg)
+else:
+    gt, out = dense_inputs(B=64, H=64, W=64, seed=3)
+    out["xyz_weight_logits"] = out["xyz_weight_logits"] + 3 * gt["msk_vis"][:, None]
+    out["msk_vis_logits"] = (gt["msk_vis"][:, None] * 2 - 1) * 4
+    cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
 gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
 out = {k: v.to(dev).contiguous() for k, v in out.items()}
-cfg = AttrDict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
 for _ in range(20):
     solve_pnp(cfg, out, gt)
 torch.cuda.synchronize()
