@@ -84,7 +84,7 @@ int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const
  * -- each sums its share of the correspondences, the partial normal equations meet in the workspace, and all of them take the same
  * LM steps -- instead of one workgroup per pose on a quarter of the chip.
  *   lc_pnp_lm_workspace_bytes(B, Nmax): bytes that shape needs; 0 when it is solved by one workgroup per pose anyway (Nmax <= 2048,
- *       or B > 128: the grid would not fit the chip at one workgroup per CU).
+ *       or more poses than half the device's compute units -- B > 128 on an MI355X: the grid would not fit the chip at one workgroup per CU).
  *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller; after that it belongs to these calls (each leaves it ready for
  *       the next of any shape on the same stream; calls that may run concurrently need a workspace each).  NULL: lc_pnp_lm2_f32.
  * Results: those of lc_pnp_lm2_f32 up to the order of the fp64 sums over the correspondences (tests/test_gpu_pnp_split.py).

@@ -65,7 +65,9 @@ struct PnpParams {
     void* split_ws;       // launch_pnp_lm only, or null: pnp_split_workspace_bytes(B, Nmax) bytes, zeroed once -> split_parts workgroups per pose
     int split_parts;      // pnp_split_parts(B, Nmax) when split_ws is given
 };
-constexpr int kSplitMinPoints = 2048;  // rows up to here: one workgroup per pose (the exchange between the parts would cost more than it saves)
+constexpr int kSplitMinPoints = 2048;
+int device_compute_units();          // of the current device, cached
+int split_parts_for(int units);      // 8 / 4 / 2 workgroups per unit of work while units x parts fits the device's compute units, else 1  // rows up to here: one workgroup per pose (the exchange between the parts would cost more than it saves)
 int pnp_split_parts(int B, int Nmax);  // workgroups per pose of the split form: 1 (not worth it / grid would not be resident at once), 2, 4, 8
 size_t pnp_split_workspace_bytes(int B, int Nmax);
 enum PnpOptions { kPnpWeightsAreIcov = 1,  // sqrt_diag holds inverse VARIANCES: take the square root at the load (cer_solver.py:33-36)

@@ -92,9 +92,28 @@ int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stre
     return launch_pnp_lm(b, stream);
 }
 
+// Compute units of the current device (256 on an MI355X in SPX mode; a partitioned device reports its share), cached per device.
+int device_compute_units() {
+    static int cached[64] = {};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && cached[dev]) return cached[dev];
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) cached[dev] = n;
+    return n;
+}
+// workgroups per unit of work for the launches whose workgroups wait for each other: the largest of 8 / 4 / 2 that keeps the grid (`units` slots,
+// each workgroup a compute unit to itself) within the device -- every workgroup resident at once -- else 1
+int split_parts_for(int units) {
+    const int cus = device_compute_units();
+    for (int parts = 8; parts >= 2; parts >>= 1)
+        if ((long long)units * parts <= cus) return parts;
+    return 1;
+}
+
 int pnp_split_parts(int B, int Nmax) {
-    if (Nmax <= kSplitMinPoints || B <= 0 || B > 128) return 1;
-    return B <= 32 ? 8 : (B <= 64 ? 4 : 2);  // at most one workgroup per CU (256): all of them resident together
+    if (Nmax <= kSplitMinPoints || B <= 0) return 1;
+    return split_parts_for((B + 7) / 8 * 8);  // (the grid pads the poses to a multiple of 8: lc_pnp_lm_split_kernel)
 }
 size_t pnp_split_workspace_bytes(int B, int Nmax) { return pnp_split_parts(B, Nmax) > 1 ? (size_t)B * kSplitPoseBytes : 0; }
 

@@ -759,9 +759,9 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_split_kerne
 }  // namespace
 
 int dense_select_split_parts(int B, int N) {
-    if (N <= kCache * kThreads || N > kFusedSelectMaxPoints || B <= 0 || B > 128) return 1;
-    const int P = B <= 32 ? 8 : (B <= 64 ? 4 : 2);  // at most one workgroup per compute unit (256): all resident together
-    return N <= P * kCache * kThreads ? P : 1;     // a part's candidates are the four per thread its registers hold
+    if (N <= kCache * kThreads || N > kFusedSelectMaxPoints || B <= 0) return 1;
+    const int P = split_parts_for(B);           // at most one workgroup per compute unit: all resident together
+    return N <= P * kCache * kThreads ? P : 1;  // a part's candidates are the four per thread its registers hold
 }
 size_t dense_select_split_workspace_bytes(int B, int N) { return dense_select_split_parts(B, N) > 1 ? (size_t)B * kSelSplitPoseBytes : 0; }
 
