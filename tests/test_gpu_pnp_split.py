@@ -147,3 +147,29 @@ def test_split_launches_side_by_side_end_instead_of_hanging():
             again = pnp_ceres.solve_device(*args, split=True)
         st.synchronize()
         assert torch.equal(again[0], want[0]) and int(again[2].sum()) == 0
+
+
+def test_split_solve_soak_over_random_shapes():
+    """Forty random batches (poses, row length, ragged counts incl. poses below three points, weight forms): the split solve keeps the LM schedule of the
+    one-workgroup solve pose for pose -- same validity flags, same iteration counts -- and the poses within 2e-6."""
+    g = torch.Generator().manual_seed(123)
+    tried = 0
+    for case in range(40):
+        B = int(torch.randint(1, 129, (1,), generator=g))
+        N = int(torch.randint(2049, 9000, (1,), generator=g))
+        if _lib.load().lc_pnp_lm_workspace_bytes(B, N) == 0:
+            continue
+        tried += 1
+        b = _batch(B, N, seed=1000 + case, noise_px=float(torch.rand(1, generator=g)) * 1.5, outlier_frac=0.1 * float(torch.rand(1, generator=g)))
+        counts = torch.randint(0, N + 1, (B,), generator=g, dtype=torch.int32).cuda()
+        kw = {}
+        if case % 3 == 1:
+            kw = dict(weight_mask=(torch.rand(B, N, generator=g) < 0.7).cuda(), max_iter_count=20)
+        elif case % 3 == 2:
+            kw = dict(weights_are_icov=True, nan_to_num=True)
+        w = None if "weight_mask" in kw else (b["inv_std"] ** 2 if kw else b["inv_std"])
+        one = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], w, b["start"], counts, return_iters=True, split=False, **kw)
+        many = pnp_ceres.solve_device(b["K"], b["pts3d"], b["pts2d"], w, b["start"], counts, return_iters=True, split=True, **kw)
+        assert torch.equal(one[2], many[2]) and torch.equal(one[3], many[3]), (case, B, N)
+        np.testing.assert_allclose(many[0].cpu().numpy(), one[0].cpu().numpy(), rtol=0, atol=2e-6, err_msg=str((case, B, N)))
+    assert tried >= 30

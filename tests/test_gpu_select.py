@@ -172,3 +172,40 @@ def test_several_workgroups_per_object_select_what_one_workgroup_selects(B, H, W
     assert torch.equal(many[3], one[3])
     live = torch.arange(N, device=dev)[None, :] < one[3][:, None]
     assert torch.equal(many[4][live], one[4][live]) and torch.equal(many[1][live[..., None].expand_as(many[1])], one[1][live[..., None].expand_as(one[1])])
+
+
+def test_split_selection_soak_over_random_shapes():
+    """Forty random batches (objects, map sizes, strides, offsets, modes, quantiles, element types): several workgroups per object select exactly what
+    one workgroup selects -- counts, indices, rows."""
+    from lc_amd import _lib
+    from lc_amd.dense import dense_front_end_select
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    lib = _lib.load()
+    tried = 0
+    for case in range(60):
+        B = int(torch.randint(1, 129, (1,), generator=g))
+        H, W = (int(v) for v in torch.randint(48, 161, (2,), generator=g))
+        sample = int(torch.randint(1, 3, (1,), generator=g))
+        top, left = (int(v) for v in torch.randint(0, sample, (2,), generator=g))
+        if lib.lc_dense_frontend_select_workspace_bytes(B, H, W, top, left, sample) == 0:
+            continue
+        tried += 1
+        dtype = (torch.float32, torch.bfloat16, torch.float16)[case % 3]
+        mode = ("quantile_in_mask", "quantile", "mask")[(case // 3) % 3]
+        q = float(torch.rand(1, generator=g))
+        wl = (torch.randn(B, 2, H, W, generator=g) * 2).to(dev, dtype)
+        vl = (torch.randn(B, 1, H, W, generator=g) * 2 + 0.5).to(dev, dtype)
+        xyz = torch.randn(B, 3, H, W, generator=g).to(dev, dtype)
+        ws = (torch.rand(B, generator=g) + 0.5).to(dev)
+        kw = dict(seg_thresh=0.5, sample=sample, top_left=(top, left), quantile=q, min_count=5, seed=case)
+        one = dense_front_end_select(xyz, wl, ws, None, vl, mode, split=False, **kw)
+        many = dense_front_end_select(xyz, wl, ws, None, vl, mode, split=True, **kw)
+        assert torch.equal(many[3], one[3]), (case, B, H, W, sample, mode, q)
+        live = torch.arange(one[0].shape[1], device=dev)[None, :] < one[3][:, None]
+        for x, y in zip(many, one):
+            if x.dim() >= 2:
+                m = live if x.dim() == 2 else live[..., None].expand_as(x)
+                assert torch.equal(x[m], y[m]), (case, B, H, W, sample, mode, q)
+    assert tried >= 20
