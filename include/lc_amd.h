@@ -74,6 +74,9 @@ int lc_pnp_lm_f32(const float *K, const float *pts3d, const float *pts2d, const 
  * options = 0, pose_mod = 0 with sqrtL or weights_diag is lc_pnp_lm_f32. */
 #define LC_PNP_WEIGHTS_ARE_ICOV 1
 #define LC_PNP_NAN_TO_NUM 2
+/* with LC_PNP_WEIGHTS_ARE_ICOV: weights_diag holds the predicted standard DEVIATIONS of the sparse head (test.py:52 `inv_cov2d = 1/(pts2d_std**2)`):
+ * 1 / (s * s) is formed at the load with the float operations torch uses, then filtered and rooted as inverse variances are */
+#define LC_PNP_WEIGHTS_ARE_STD 4
 int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
                    const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,
                    int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod,

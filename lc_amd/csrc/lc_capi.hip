@@ -198,8 +198,9 @@ static int pnp_params(const float* K, const float* pts3d, const float* pts2d, co
     }
     if ((sqrtL != nullptr) + (weights_diag != nullptr) + (weight_mask != nullptr) != 1)
         return fail(1, "exactly one of sqrtL / weights_diag / weight_mask must be given");
-    if (options & ~(LC_PNP_WEIGHTS_ARE_ICOV | LC_PNP_NAN_TO_NUM)) return fail(1, "unknown option bit");
+    if (options & ~(LC_PNP_WEIGHTS_ARE_ICOV | LC_PNP_NAN_TO_NUM | LC_PNP_WEIGHTS_ARE_STD)) return fail(1, "unknown option bit");
     if ((options & LC_PNP_WEIGHTS_ARE_ICOV) && !weights_diag) return fail(1, "LC_PNP_WEIGHTS_ARE_ICOV needs weights_diag");
+    if ((options & LC_PNP_WEIGHTS_ARE_STD) && !(options & LC_PNP_WEIGHTS_ARE_ICOV)) return fail(1, "LC_PNP_WEIGHTS_ARE_STD goes with LC_PNP_WEIGHTS_ARE_ICOV (deviations -> inverse variances -> factor)");
     if (pose_mod > 0 && (!start || start == states)) return fail(1, "pose_mod needs a separate start array");
     if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, pts2d, weights_diag);

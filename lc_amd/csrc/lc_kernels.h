@@ -71,7 +71,9 @@ int split_parts_for(int units);      // 8 / 4 / 2 workgroups per unit of work wh
 int pnp_split_parts(int B, int Nmax);  // workgroups per pose of the split form: 1 (not worth it / grid would not be resident at once), 2, 4, 8
 size_t pnp_split_workspace_bytes(int B, int Nmax);
 enum PnpOptions { kPnpWeightsAreIcov = 1,  // sqrt_diag holds inverse VARIANCES: take the square root at the load (cer_solver.py:33-36)
-                  kPnpNanToNum = 2 };      // torch.nan_to_num on K, points, weights and start at the load (cer_solver.py:29-31)
+                  kPnpNanToNum = 2,        // torch.nan_to_num on K, points, weights and start at the load (cer_solver.py:29-31)
+                  kPnpWeightsAreStd = 4 }; // (with kPnpWeightsAreIcov) sqrt_diag holds standard DEVIATIONS: 1 / (s s) first (test.py:52 `1/(pts2d_std**2)`, torch's own
+                                           // float operations), then as for inverse variances
 int launch_pnp_lm(const PnpParams& p, hipStream_t stream);
 // launch_pnp_lm(a) then launch_pnp_lm(b) -- as one launch where the shapes allow (include/lc_amd.h: lc_pnp_lm_chain_f32)
 int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stream);

@@ -84,6 +84,8 @@ int launch_pnp_lm_chain(const PnpParams& a, const PnpParams& b, hipStream_t stre
     // a first job in the in-place form (its states are both start and result) solved by SEVERAL second-stage workgroups would let one of
     // them read a start the other has already overwritten: one launch only when every first-stage pose has one solver, or a separate start
     const bool first_is_safe = a.start != nullptr || b.B == a.B;
+    if (a.B > 0 && b.B > 0 && a.Nmax <= 64 && b.Nmax <= 64 && b.B <= kLatencyGridMax && b.B % a.B == 0 && rows_match && first_is_safe)
+        return launch_pnp_lm_chain_latency(a, b, b_start == a.states ? 1 : 0, stream);  // the sparse head's two solves
     if (a.B > 0 && b.B > 0 && wide4(a) && wide4(b) && b.B % a.B == 0 && rows_match && first_is_safe) {
         hipLaunchKernelGGL(lc_pnp_lm_chain_kernel, dim3(b.B), dim3(256), 0, stream, a, b, b_start == a.states ? 1 : 0);
         return hipGetLastError() == hipSuccess ? 0 : 2;

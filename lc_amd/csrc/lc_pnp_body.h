@@ -217,6 +217,7 @@ __device__ __forceinline__ RawPoint load_raw_point(const PnpParams& p, size_t ba
         o.a = L.x; o.b = 0.f; o.c = L.y;
     }
     if constexpr (OPTS) {
+        if (p.options & kPnpWeightsAreStd) { o.a = 1.f / (o.a * o.a); o.c = 1.f / (o.c * o.c); }  // the sparse head's predicted deviations -> inverse variances (test.py:52)
         if (p.options & kPnpNanToNum) {
             o.u.x = nan_to_num(o.u.x); o.u.y = nan_to_num(o.u.y);
             o.X[0] = nan_to_num(o.X[0]); o.X[1] = nan_to_num(o.X[1]); o.X[2] = nan_to_num(o.X[2]);

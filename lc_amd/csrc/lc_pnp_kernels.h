@@ -17,5 +17,6 @@ __global__ __launch_bounds__(64, WPS) void lc_pnp_lm_kernel(const PnpParams p) {
 }  // namespace
 
 int launch_pnp_lm_latency(const PnpParams& p, hipStream_t stream);  // N <= 64, B <= kLatencyGridMax (lc_pnp_latency.hip)
+int launch_pnp_lm_chain_latency(const PnpParams& a, const PnpParams& b, int second_starts_from_first, hipStream_t stream);  // both jobs N <= 64, b.B <= kLatencyGridMax
 
 }  // namespace lc

@@ -9,6 +9,24 @@
 
 namespace lc {
 
+namespace {
+// Two dependent one-wavefront solves in one launch (lc_pnp_lm_chain_f32 at the sparse head's shape: the RANSAC's inlier refinement, then the weighted
+// solve on all keypoints, test.py:55-59): workgroup w solves pose w % a.B of the first job -- its outputs written by ONE workgroup per pose -- hands the
+// refined state on through LDS and goes on with pose w of the second.  Same arithmetic as the two launches: same bits.
+__global__ __launch_bounds__(64, 1) void lc_pnp_lm_chain_small_kernel(const PnpParams a, const PnpParams b, const int second_starts_from_first) {
+    __shared__ __attribute__((aligned(16))) double bc[pnp::kPnpLdsDoubles<1>];
+    __shared__ float refined[8];
+    pnp::solve_pose<true, 1, false, true>(a, (int)(blockIdx.x % (unsigned)a.B), threadIdx.x, bc, blockIdx.x < (unsigned)a.B, refined);
+    __syncthreads();
+    pnp::solve_pose<true, 1, false, true>(b, blockIdx.x, threadIdx.x, bc, true, nullptr, second_starts_from_first ? refined : nullptr);
+}
+}  // namespace
+
+int launch_pnp_lm_chain_latency(const PnpParams& a, const PnpParams& b, int second_starts_from_first, hipStream_t stream) {
+    hipLaunchKernelGGL(lc_pnp_lm_chain_small_kernel, dim3(b.B), dim3(64), 0, stream, a, b, second_starts_from_first);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int launch_pnp_lm_latency(const PnpParams& p, hipStream_t stream) {
     if (p.options || p.weight_mask || p.pose_mod > 0) hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1, true>), dim3(p.B), dim3(64), 0, stream, p);
     else hipLaunchKernelGGL((lc_pnp_lm_kernel<true, 1>), dim3(p.B), dim3(64), 0, stream, p);

@@ -60,8 +60,12 @@ def solve_pnp(cfg, out_dict, gt_dict):
         return solve_pnp_dense(cfg, out_dict, gt_dict)
     K, pts3d = gt_dict["out_K"], gt_dict["pts3d"]
     pts2d, std = out_dict["pts2d"], out_dict["pts2d_std"]
-    start, _inl, _bad = gpu_solver.solve_device(K, pts3d, pts2d, **_reprojection_threshold(cfg, gt_dict, 2))
-    return {"weighted": _weighted(K, pts3d, pts2d, std.pow(-2), start), "ransac": start}
+    # RANSAC, then its inlier refinement and the weighted solve on all keypoints as ONE launch (`lc_pnp_lm_chain_f32`); `1 / std**2` (test.py:52), the NaN
+    # filter and the square root of cer_solver.py:29-36 are formed at the solve's loads, not by element-wise launches in front of it
+    _ransac, _inl, _bad, refine = gpu_solver.solve_device(K, pts3d, pts2d, refine="defer", **_reprojection_threshold(cfg, gt_dict, 2))
+    (start, _, _), (weighted, _, _) = pnp_ceres.solve_chain_device(
+        refine, dict(cam_mat=K, pts3d=pts3d, pts2d=pts2d, sqrtL=std, weights_are_std=True, nan_to_num=True, start="first"))
+    return {"weighted": weighted, "ransac": start}
 
 
 _SIDE_STREAMS = {}  # device index -> streams the sub-batches of a wide test-time batch run on

@@ -22,7 +22,7 @@ def _to_np(val):
     return val
 
 
-LC_PNP_WEIGHTS_ARE_ICOV, LC_PNP_NAN_TO_NUM = 1, 2  # include/lc_amd.h
+LC_PNP_WEIGHTS_ARE_ICOV, LC_PNP_NAN_TO_NUM, LC_PNP_WEIGHTS_ARE_STD = 1, 2, 4  # include/lc_amd.h
 
 
 SPLIT_WORKSPACE_MAX_BYTES = splitws.PNP_MAX_BYTES
@@ -43,13 +43,14 @@ def split_workspace(dev, *shapes, split=None):
 
 
 def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6,
-                 return_iters=False, trace_rows=0, weights_are_icov=False, nan_to_num=False, weight_mask=None, shared_poses=0, split=None):
+                 return_iters=False, trace_rows=0, weights_are_icov=False, nan_to_num=False, weight_mask=None, shared_poses=0, split=None,
+                 weights_are_std=False):
     """Device route. cam_mat (B,3,3) pts3d (B,N,3) pts2d (B,N,2) start (B,7); sqrtL (B,N,2,2) lower factor or
     (B,N,2) diagonal; n_points (B,) int or None.  trace_rows > 0 runs the diagnostic twin of the kernel and appends the
     (B,trace_rows,8) float64 per-iteration schedule (`lc_pnp_lm_trace_f32`, include/lc_amd.h) to the returned tuple.
 
     Folded into the kernel's loads instead of separate element-wise launches (`lc_pnp_lm2_f32`): weights_are_icov (the diagonal
-    tensor holds inverse variances), nan_to_num (torch.nan_to_num on every input; an invalid job returns the filtered start),
+    tensor holds inverse variances), weights_are_std (it holds standard deviations: `1/(std**2)` of test.py:52 formed at the load), nan_to_num (torch.nan_to_num on every input; an invalid job returns the filtered start),
     weight_mask (B,N) uint8/bool in place of sqrtL: unit information where set; shared_poses = P > 0: cam_mat and start have P rows
     and pose b of the B = k P correspondence sets reads row b % P (several selections of the same objects in one launch).
     split (default: on, LC_AMD_PNP_SPLIT=0 turns it off): batches of at most 128 poses with rows wider than 2048 are solved by several
@@ -77,7 +78,7 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     tr = torch.empty(B, device=dev, dtype=torch.float32)
     ret = torch.empty(B, device=dev, dtype=torch.int32)
     iters = torch.empty(B, device=dev, dtype=torch.int32) if return_iters else None
-    opts = (LC_PNP_WEIGHTS_ARE_ICOV if weights_are_icov else 0) | (LC_PNP_NAN_TO_NUM if nan_to_num else 0)
+    opts = (LC_PNP_WEIGHTS_ARE_ICOV if weights_are_icov or weights_are_std else 0) | (LC_PNP_NAN_TO_NUM if nan_to_num else 0) | (LC_PNP_WEIGHTS_ARE_STD if weights_are_std else 0)
     if trace_rows > 0:
         if opts or M is not None or shared_poses:
             raise ValueError("the diagnostic trace takes plain inputs")
@@ -108,7 +109,7 @@ class _Job(ctypes.Structure):  # include/lc_amd.h: lc_pnp_lm_job
 
 
 def _job(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=50, function_tolerance=1e-6, weights_are_icov=False,
-         nan_to_num=False, weight_mask=None, shared_poses=0):
+         nan_to_num=False, weight_mask=None, shared_poses=0, weights_are_std=False):
     """The arguments of `solve_device` as an lc_pnp_lm_job + its output tensors (state, tr, ret) + the tensors the job points into."""
     K = _lib.require_hip_f32("cam_mat", cam_mat)
     X = _lib.require_hip_f32("pts3d", pts3d)
@@ -131,7 +132,7 @@ def _job(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=5
     counts = None if n_points is None else torch.as_tensor(n_points).to(device=dev, dtype=torch.int32).contiguous()
     tr = torch.empty(B, device=dev, dtype=torch.float32)
     ret = torch.empty(B, device=dev, dtype=torch.int32)
-    opts = (LC_PNP_WEIGHTS_ARE_ICOV if weights_are_icov else 0) | (LC_PNP_NAN_TO_NUM if nan_to_num else 0)
+    opts = (LC_PNP_WEIGHTS_ARE_ICOV if weights_are_icov or weights_are_std else 0) | (LC_PNP_NAN_TO_NUM if nan_to_num else 0) | (LC_PNP_WEIGHTS_ARE_STD if weights_are_std else 0)
     P = _lib.ptr
     job = _Job(P(K), P(X), P(U), P(L) if full else None, P(L) if (L is not None and not full) else None, P(M), P(counts), P(start), P(state),
                P(tr), P(ret), None, B, N, int(max_iter_count), float(function_tolerance), opts, int(shared_poses))

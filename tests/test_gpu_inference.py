@@ -75,3 +75,25 @@ def test_graphed_dense_pipeline_replays_on_new_inputs():
     with pytest.raises(ValueError):
         bad = dict(out, xyz_noc=out["xyz_noc"][:2])
         solver(bad, gt)
+
+
+def test_sparse_pipeline_one_launch_solves_equal_the_separate_calls():
+    """The sparse head's chain (test.py:47-64): the RANSAC's inlier refinement and the weighted solve as ONE launch, with `1 / std**2` formed at the solve's
+    loads (LC_PNP_WEIGHTS_ARE_STD), against the separate calls on `std.pow(-2)`: the same poses bit for bit -- incl. a keypoint with a NaN deviation."""
+    from lc_amd import synth
+    from lc_amd.config import AttrDict
+    from lc_amd.inference import _weighted, solve_pnp
+    from lc_amd.pnp import gpu_solver
+
+    dev = torch.device("cuda:0")
+    b = synth.make_batch(64, 16, seed=9, noise_px=0.5, outlier_frac=0.05)
+    std = (1 / b["inv_std"]).to(dev)
+    std[3, 5, 0] = float("nan")
+    std[4, 2, 1] = float("inf")
+    out = dict(pts2d=b["pts2d"].to(dev), pts2d_std=std)
+    gt = dict(out_K=b["K"].to(dev), pts3d=b["pts3d"].to(dev))
+    res = solve_pnp(AttrDict(solvers=["ransac", "weighted"]), out, gt)
+    start, _inl, _bad = gpu_solver.solve_device(gt["out_K"], gt["pts3d"], out["pts2d"], reprojectionError=2)
+    want = _weighted(gt["out_K"], gt["pts3d"], out["pts2d"], std.pow(-2), start)
+    assert torch.equal(res["ransac"], start)
+    assert torch.equal(res["weighted"], want)
