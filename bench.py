@@ -613,12 +613,17 @@ def main():
             cfg = dict(dense_point_select="quantile_in_mask", quantile=0.5, dense_sample=2, solvers=["weighted", "weighted_filtered"])
             key, what = "weighted", "64x64 maps, stride 2 (1024 candidates), quantile_in_mask 0.5, solvers weighted + weighted_filtered (rounds 2-3's hybrid)"
         else:
+            half = name.endswith("_bf16")  # the same chain on the maps a bf16-autocast backbone hands over (BASELINE.json configs[2]): read natively, no cast
+            name = name[:-5] if half else name
             cfg, gt, net = synth.test_time_inputs(name, B=objects, seed=3)
+            if half:
+                net = {k: (v.to(torch.bfloat16) if v.is_floating_point() and k != "xyz_weights_scale" else v) for k, v in net.items()}
             spec = synth.TEST_TIME_CONFIGS[name]
             stride = cfg.get("dense_sample", 2)
             key = "weighted-filtered" if "weighted_filtered" in cfg["solvers"] else "weighted"
             what = (f"{spec['H']}x{spec['W']} maps, stride {stride} ({-(-spec['H'] // stride) * -(-spec['W'] // stride)} candidates), {cfg['dense_point_select']} "
-                    f"{cfg['quantile']}, solvers {cfg['solvers']}" + (f", {sum(spec['bits'])} code planes + model_transform, rel_reproj_err" if spec["bits"] else ""))
+                    f"{cfg['quantile']}, solvers {cfg['solvers']}" + (f", {sum(spec['bits'])} code planes + model_transform, rel_reproj_err" if spec["bits"] else "")
+                    + (", bf16 maps" if half else ""))
         cfg = AttrDict(cfg)
         gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
         net = {k: v.to(dev).contiguous() for k, v in net.items()}  # a convolution's output is contiguous NCHW
@@ -744,7 +749,7 @@ def main():
             out["dense"] = {k: dense_block(k, *v) for k, v in DENSE_WORKLOADS.items() if args.workload in ("all", k)}
         if world == 1 and args.workload == "all":
             out["test_time"] = {}
-            for tt in ("zlmo", "glmo", "gsplmo", "hybrid_r03"):
+            for tt in ("zlmo", "zlmo_bf16", "glmo", "gsplmo", "hybrid_r03"):
                 try:  # auxiliary blocks: whatever happens in one, the headline above is printed
                     out["test_time"][tt] = test_time_block(tt)
                 except Exception as e:  # noqa: BLE001

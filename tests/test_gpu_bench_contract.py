@@ -61,7 +61,8 @@ def test_single_gpu_line_has_the_contract_keys():
             assert blk[k]["traffic"] > 0 and blk[k]["counters_from"]["file"].startswith("profiles/") and 0 < blk[k]["valu_active_share_of_wave_cycles"] < 1
     # the test-time chain (8f rows f1 + f2 + a24), replayed as one graph
     # ... at the reference's own knobs: configs/zlmo.yaml:30-37 (16 384 candidates per object, weighted_filtered) and configs/glmo.yaml:28-32
-    assert set(d["test_time"]) == {"zlmo", "glmo", "gsplmo", "hybrid_r03"}
+    assert set(d["test_time"]) == {"zlmo", "zlmo_bf16", "glmo", "gsplmo", "hybrid_r03"}
+    assert "bf16 maps" in d["test_time"]["zlmo_bf16"]["workload"] and d["test_time"]["zlmo_bf16"]["us_per_call_replayed_200"] <= d["test_time"]["zlmo"]["us_per_call_replayed_200"] * 1.05
     assert "16 keypoints" in d["test_time"]["gsplmo"]["workload"] and d["test_time"]["gsplmo"]["solver"] == "weighted"
     assert "16384 candidates" in d["test_time"]["zlmo"]["workload"] and "quantile_in_mask 0.2" in d["test_time"]["zlmo"]["workload"]
     assert "1024 candidates" in d["test_time"]["glmo"]["workload"] and "quantile 0.3" in d["test_time"]["glmo"]["workload"]
