@@ -19,6 +19,8 @@ cfg, gt, out = synth.test_time_inputs(name, B=B, seed=3)
 cfg = AttrDict(cfg)
 gt = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
 out = {k: v.to(dev).contiguous() for k, v in out.items()}
+if os.environ.get("MAPS") == "bf16":  # the maps a bf16-autocast backbone hands over, read natively
+    out = {k: (v.to(torch.bfloat16) if v.is_floating_point() and k != "xyz_weights_scale" else v) for k, v in out.items()}
 
 
 def timeit(fn, n=100):
