@@ -32,6 +32,8 @@ fn.argtypes = [ctypes.c_void_p]
 cfg, gt, out = synth.test_time_inputs("zlmo", B=64, seed=3)
 xyz = torch.randn(64, 3, 128, 128).to(dev)
 wl, ws, vl = out["xyz_weight_logits"].to(dev), out["xyz_weights_scale"].to(dev), out["msk_vis_logits"].to(dev)
+if os.environ.get("MAPS") == "bf16":
+    xyz, wl, vl = xyz.to(torch.bfloat16), wl.to(torch.bfloat16), vl.to(torch.bfloat16)
 SPLIT = os.environ.get("LC_SELECT_SPLIT") == "1"  # four workgroups per object (part 0 of object 0 holds the clock)
 rows = []
 for it in range(24):
