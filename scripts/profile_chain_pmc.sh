@@ -9,7 +9,7 @@ export CFG=${2:-zlmo}
 OUT=$ROOT/gpurun_out/chain_pmc_${TAG}_$CFG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-TT="python3 $ROOT/scripts/ubench/config_test_time.py"
+TT="python3 $ROOT/${PMC_SCRIPT:-scripts/ubench/config_test_time.py}"  # PMC_SCRIPT=bench_next.py: the f-row kernels instead of the chain
 i=0
 for GROUP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT"; do
     i=$((i + 1))
