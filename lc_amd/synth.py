@@ -174,13 +174,16 @@ TEST_TIME_CONFIGS = {
 }
 
 
-def test_time_inputs(name: str, B: int = 64, seed: int = 0, flip: float = 0.02):
+def test_time_inputs(name: str, B: int = 64, seed: int = 0, flip: float = 0.02, train: bool = False):
     """Synthetic network outputs of the dense heads at test time, shaped like the named config's: every object is an ellipsoid with the
     LM-O extents seen under a random pose, rendered by ray casting (so pixel <-> model point correspondences are exact up to the noise
     added below and the visible region is a blob of ~20-30 % of the crop); zlmo: 21 code planes (Gray code of the
     model-transformed, scaled coordinates, `flip` of the bits wrong: gross outliers for the RANSAC), glmo: the continuous xyz head.
     Weight logits are higher on the object, visibility logits follow the silhouette with a few errors at its rim.
-    -> (cfg dict for AttrDict, gt_dict, out_dict) of CPU tensors; gt_dict['pose_best'] is the pose to recover."""
+    -> (cfg dict for AttrDict, gt_dict, out_dict) of CPU tensors; gt_dict['pose_best'] is the pose to recover.
+    `train=True` adds what `Loss_fn.forward` reads at training time (`losses.py:49-67,132-139`: `msk_noc`, `xyz_noc_tgt` or the code
+    targets `xyz_noc_bin_tgt / _raw`), an occluder over part of `msk_vis`, and gross errors on a few pixels of the xyz head; every extra
+    random draw comes after the test-time ones, so the test-time tensors of a (name, B, seed) do not depend on the flag."""
     from . import floatbits as fb
 
     spec = TEST_TIME_CONFIGS[name]
@@ -237,4 +240,46 @@ def test_time_inputs(name: str, B: int = 64, seed: int = 0, flip: float = 0.02):
         logits = (mod_bits.float() * 2 - 1) * (torch.rand(B, C, H, W, generator=g) * 3 + 0.2)
         out["xyz_noc_bin"] = torch.where(torch.rand(B, C, H, W, generator=g) < flip, -logits, logits).contiguous()
         gt.update(bit_cnt=list(bits), model_transform=T.float())
+    if train:
+        # an occluder: a rectangle of the crop is not visible (msk_vis is a subset of msk_noc, dataset.py:453-458); the heads do not know it
+        x0, y0 = (torch.rand(B, generator=g) * 0.6 * W).long(), (torch.rand(B, generator=g) * 0.6 * H).long()
+        x1, y1 = x0 + (torch.rand(B, generator=g) * 0.4 * W).long() + 2, y0 + (torch.rand(B, generator=g) * 0.4 * H).long() + 2
+        ysl, xsl = torch.arange(H)[None, :, None], torch.arange(W)[None, None, :]
+        occ = (xsl >= x0[:, None, None]) & (xsl < x1[:, None, None]) & (ysl >= y0[:, None, None]) & (ysl < y1[:, None, None])
+        gt["msk_noc"] = hit
+        gt["msk_vis"] = (hit & ~occ).float()
+        if bits is None:
+            gt["xyz_noc_tgt"] = (noc.permute(0, 3, 1, 2) * hit[:, None]).float().contiguous()
+            gross = (torch.rand(B, 1, H, W, generator=g) < 0.03).float() * 0.3
+            out["xyz_noc"] = (out["xyz_noc"] + gross * torch.randn(B, 3, H, W, generator=g)).contiguous()
+        else:
+            # the label of a pixel off the object is the code of the coordinate 0 (losses.py:58-62: the transformed points are masked)
+            tgt = ((Xt * hit.reshape(B, H * W, 1)) / noc_scale[:, None]).reshape(B, H, W, 3).float()
+            gt["xyz_noc_bin_tgt"], gt["xyz_noc_bin_raw"] = fb.nn_noc2target(tgt, list(bits))
     return dict(spec["pnp_solver"]), gt, out
+
+
+# ---- Loss_fn.forward at the reference's own training shapes (configs/glmo.yaml:9,63-65,72-79, configs/zlmo.yaml:74-83,
+# configs/gsplmo.yaml loss block); tests/golden/gen_golden_lossfn.py runs the reference class on exactly these tensors ----
+
+TRAIN_LOSS_CONFIGS = {
+    # loss block of configs/glmo.yaml:72-79 (dense_sample defaults to 2 => N = 32 x 32 = 1024 of the 64x64 maps)
+    "dense_glmo": dict(pose_loss_cfg=dict(clip_weight_grad=True), pose_loss_start_step=2000, pose_loss_start_epoch=1, w_loss_pose=0.02,
+                       w_loss_seg=0.25, w_loss_noc=1),
+    # loss block of configs/zlmo.yaml:74-83 (128x128 maps, dense_sample 3 => N = 43 x 43 = 1849; 7+7+7 code planes)
+    "bin_zlmo": dict(pose_loss_cfg=dict(dense_sample=3, clip_weight_grad=True), seg_loss_type="L1", pose_loss_start_step=3000,
+                     pose_loss_start_epoch=0, w_loss_pose=0.03, w_loss_noc_bin=3, w_loss_seg=1),
+    # loss block of configs/gsplmo.yaml at BASELINE's B=256, N=64 keypoints
+    "sparse_metric": dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True), pose_loss_start_step=4000, pose_loss_start_epoch=1,
+                          w_loss_kpts=1, w_loss_pose=0.7),
+}
+
+
+def train_inputs(kind: str, seed: int = 0, B: int = None):
+    """(gt_dict, out_dict) of `Loss_fn.forward` for one of TRAIN_LOSS_CONFIGS' kinds, CPU tensors."""
+    if kind == "sparse_metric":
+        return sparse_inputs(B=B or 256, N=64, seed=seed)
+    name = {"dense_glmo": "glmo", "bin_zlmo": "zlmo"}[kind]
+    _cfg, gt, out = test_time_inputs(name, B=B or 4, seed=seed + 20, flip=0.08, train=True)
+    gt.pop("out_pix_scale")
+    return gt, out

@@ -1,5 +1,6 @@
 """Golden trajectories of the reference's `losses.Loss_fn.forward` (sparse and dense branch), see gen_golden.py."""
 import os
+import re
 import sys
 
 import numpy as np
@@ -25,19 +26,42 @@ DENSE_CFG = dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scal
                  w_loss_noc=1, w_loss_seg=1, w_loss_pose=0.05, seg_loss_type="L1")
 
 
-def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None):
-    """Shared by the generator (reference class) and the tests (lc_amd class): returns a flat record of the trajectory."""
-    cfg = AttrDict({"sparse": SPARSE_CFG, "dense": DENSE_CFG, "bin": BIN_CFG}[kind])
-    fn = Loss_fn_cls(cfg, AttrDict(), 17 if kind == "bin" else 0)
+# the reference's own training shapes: kind -> (steps, steps_per_epoch, total code planes).  The steps span the warm-up ramp
+# `(step + 1) / max(pose_loss_start_step, pose_loss_start_epoch * steps_per_epoch)` (losses.py:272-276,296-302) and every call moves the
+# NormClipper's max_norm (lib/utils/grad.py:19-30), so each record is also a >= 3-call trajectory of that buffer.
+TRAIN_KINDS = {
+    "dense_glmo": ([0, 1249, 2498, 2499, 3000], 2500, 0),   # the epoch term wins: full step 2500; factors 4e-4, 0.5, 0.9996, 1, 1
+    # full step 3000; factors 0.5, 3.3e-4, 1 -- deliberately not monotonic: the first call sets max_norm from a mid-ramp gradient, the
+    # second is NOT clipped (norm far below max_norm), the third is clipped with an unsaturated EMA update, whereas dense_glmo's natural
+    # order starts from a near-zero factor and then grows max_norm by the saturated 1.189 per call -- both branches of grad.py:19-30
+    "bin_zlmo": ([1499, 0, 2999], 1000, 21),
+    "sparse_metric": ([0, 1999, 3999, 4500], 1500, 0),      # full step 4000; factors 2.5e-4, 0.5, 1, 1
+}
+
+
+def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None, head_dtype=None):
+    """Shared by the generator (reference class) and the tests (lc_amd class): returns a flat record of the trajectory.
+    `head_dtype`: the network outputs are handed over in that type (a mixed-precision backbone's fp16 / bf16 heads)."""
+    if kind in TRAIN_KINDS:
+        cfg, (_, steps_per_epoch, total_bits) = AttrDict(synth.TRAIN_LOSS_CONFIGS[kind]), TRAIN_KINDS[kind]
+        cfg["pose_loss_cfg"] = AttrDict(cfg["pose_loss_cfg"])
+        make = lambda seed: synth.train_inputs(kind, seed=seed)  # noqa: E731
+    else:
+        cfg, steps_per_epoch, total_bits = AttrDict({"sparse": SPARSE_CFG, "dense": DENSE_CFG, "bin": BIN_CFG}[kind]), 10, 17 if kind == "bin" else 0
+        make = lambda seed: {"sparse": sparse_inputs, "dense": dense_inputs, "bin": bin_inputs}[kind](seed=seed)  # noqa: E731
+    fn = Loss_fn_cls(cfg, AttrDict(), total_bits)
     if device is not None:
         fn = fn.to(device)
     rec = {}
     for i, step in enumerate(steps):
-        gt, out = {"sparse": sparse_inputs, "dense": dense_inputs, "bin": bin_inputs}[kind](seed=i)
+        gt, out = make(i)
         gt = {k: ((v.to(dtype) if v.is_floating_point() else v).to(device) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
-        leaves = {k: v.to(dtype).to(device).clone().requires_grad_(True) for k, v in out.items()}
+        leaves = {k: v.to(dtype).to(device).clone() for k, v in out.items()}
+        if head_dtype is not None:  # the per-sample scale stays fp32 (an exp of a Linear under autocast, ptnet.py:69-80)
+            leaves = {k: (v if k == "xyz_weights_scale" else v.to(head_dtype)) for k, v in leaves.items()}
+        leaves = {k: v.requires_grad_(True) for k, v in leaves.items()}
         np.random.seed(1000 + i)  # random sub-sampling phase (losses.py:152)
-        loss_dict, w_loss_dict = fn(gt, leaves, 0, step, 10)
+        loss_dict, w_loss_dict = fn(gt, leaves, 0, step, steps_per_epoch)
         total = sum(w_loss_dict.values())
         grads = torch.autograd.grad(total, list(leaves.values()), allow_unused=True)
         for k, v in loss_dict.items():
@@ -65,5 +89,31 @@ def gen_lossfn():
             print(kind, tag, {k: float(v) for k, v in rec.items() if k.startswith("s0_loss_")}, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_lossfn_train_shapes():
+    """One file per kind: the reference class in float64 (scalars and states as float64, gradients ROUNDED TO float32 for storage -- the
+    truth the fp32 kernels are measured against) + the reference's own float32 run's scalars and states under `f32_*` (its drift from
+    float64, for the tolerance's context)."""
+    sys.path.insert(0, os.environ.get("LC_REFERENCE", "/root/reference"))
+    import time
+
+    import losses as ref_losses
+
+    for kind, (steps, _spe, _bits) in TRAIN_KINDS.items():
+        t0 = time.time()
+        r64 = run(ref_losses.Loss_fn, kind, steps, torch.float64)
+        r32 = run(ref_losses.Loss_fn, kind, steps, torch.float32)
+        rec = {k: (v.astype(np.float32) if "_grad_" in k else v) for k, v in r64.items()}
+        rec.update({"f32_" + k: v for k, v in r32.items() if "_grad_" not in k and k != "steps"})
+        path = os.path.join(HERE, f"lossfn_{kind}.npz")
+        np.savez_compressed(path, **rec)
+        drift = max(abs(float(r32[k]) - float(r64[k])) / max(1.0, abs(float(r64[k]))) for k in r64 if re.match(r"s\d+_w?loss_", k))
+        print(kind, {k: float(v) for k, v in rec.items() if k.startswith("s0_loss_")}, "max_norm",
+              [float(rec[f"s{i}_state_weight_grad_clipper.max_norm"]) for i in range(len(steps))], f"f32 drift {drift:.2e}",
+              os.path.getsize(path) // 1024, "KiB", f"{time.time() - t0:.0f} s")
+
+
 if __name__ == "__main__":
-    gen_lossfn()
+    if "--train-shapes" in sys.argv[1:] or "--all" in sys.argv[1:]:
+        gen_lossfn_train_shapes()
+    if "--train-shapes" not in sys.argv[1:]:
+        gen_lossfn()

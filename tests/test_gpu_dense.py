@@ -92,6 +92,62 @@ def test_bin_loss_fn_end_to_end_on_gpu():
             assert rel_err(rec[k], z[k]) <= 1e-3, k
 
 
+def _train_shape_record(kind, head_dtype=None):
+    import os
+    from lc_amd.losses import Loss_fn
+    from tests.golden.gen_golden_lossfn import TRAIN_KINDS, run
+    from tests.util import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, f"lossfn_{kind}.npz"))
+    assert list(z["steps"]) == TRAIN_KINDS[kind][0]
+    rec = run(Loss_fn, kind, list(z["steps"]), torch.float32, device=torch.device("cuda:0"), head_dtype=head_dtype)
+    assert set(rec) == {k for k in z.files if not k.startswith("f32_")}
+    return z, rec
+
+
+@pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo", "sparse_metric"])
+def test_loss_fn_at_the_reference_training_shapes(kind):
+    """`Loss_fn.forward` + backward at the shapes the reference's training configs execute against trajectories of the
+    UNMODIFIED reference class in float64 (`tests/golden/lossfn_<kind>.npz`, `gen_golden_lossfn.py --train-shapes`):
+    dense_glmo -- B=4, 64x64 maps, stride 2 => N=1024: the many-workgroups-per-sample front end and the TILED loss kernel with its cached
+    workspace inside autograd, NormClipper hooks over the weight-logit gradient maps, aux losses, warm-up blend (configs/glmo.yaml:72-79);
+    bin_zlmo -- B=4, 128x128 maps, stride 3 => N=1849, 7+7+7 code planes decoded with ground-truth bits, model transform, L1 segmentation,
+    `Loss_xyz_bin` with its EMA histogram (configs/zlmo.yaml:74-83);  sparse_metric -- B=256, N=64 keypoints (gsplmo's loss block).
+    Same tolerances as the 16x16 trajectories above: 1e-4 on every loss, 2e-3 of a gradient map's largest entry, 1e-3 on the states."""
+    z, rec = _train_shape_record(kind)
+    for k in rec:
+        if k == "steps":
+            continue
+        if re.match(r"s\d+_w?loss_", k):
+            assert abs(float(rec[k]) - float(z[k])) <= 1e-4 * max(1.0, abs(float(z[k]))), (k, float(rec[k]), float(z[k]))
+        elif "_grad_" in k:
+            assert np.isfinite(rec[k]).all() and rel_err(rec[k], z[k]) <= 2e-3, (k, rel_err(rec[k], z[k]))
+        else:
+            assert rel_err(rec[k], z[k]) <= 1e-3, (k, rec[k], z[k])
+    if kind != "sparse_metric":  # the trajectory did exercise the clipper: max_norm moved at every call
+        mn = [float(rec[f"s{i}_state_weight_grad_clipper.max_norm"]) for i in range(len(z["steps"]))]
+        assert all(m > 0 for m in mn) and len(set(mn)) == len(mn)
+
+
+@pytest.mark.parametrize("head_dtype,loss_tol,grad_tol", [(torch.float16, 2e-3, 1e-2), (torch.bfloat16, 2e-2, 5e-2)], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo"])
+def test_loss_fn_at_training_shapes_with_half_precision_heads(kind, head_dtype, loss_tol, grad_tol):
+    """BASELINE configs[2] / [4]: a mixed-precision backbone hands fp16 / bf16 maps to `Loss_fn`; the step is checked against the SAME
+    reference trajectories (float64, full-precision inputs), at the map type's accuracy -- inputs rounded to 11 / 8 significant bits and
+    gradients of a map written in the map's type: losses to 2e-3 (fp16) / 2e-2 (bf16) relative, gradients to 1e-2 / 5e-2 of a map's
+    largest entry, max_norm and the code histogram to 5e-2."""
+    z, rec = _train_shape_record(kind, head_dtype)
+    for k in rec:
+        if k == "steps":
+            continue
+        if re.match(r"s\d+_w?loss_", k):
+            assert abs(float(rec[k]) - float(z[k])) <= loss_tol * max(1.0, abs(float(z[k]))), (k, float(rec[k]), float(z[k]))
+        elif "_grad_" in k:
+            assert np.isfinite(rec[k]).all() and rel_err(rec[k], z[k]) <= grad_tol, (k, rel_err(rec[k], z[k]))
+        else:
+            assert rel_err(rec[k], z[k]) <= 5e-2, (k, rec[k], z[k])
+
+
 @pytest.mark.parametrize("thr", [0.5, 0.3, 0.9])
 def test_front_end_visibility_mask_equals_torch(thr):
     """dense_front_end_with_visibility: the mask of the sampled pixels from the front-end launch is torch's

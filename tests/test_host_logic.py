@@ -146,6 +146,30 @@ def test_loss_fn_matches_reference_trajectory(oracle_backend, kind):
             assert abs(float(rec32[k]) - float(z32[k])) <= 1e-4 * max(1.0, abs(float(z32[k]))), k
 
 
+@pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo", "sparse_metric"])
+def test_loss_fn_matches_reference_at_training_shapes(oracle_backend, kind):
+    """The same host logic + oracle at the reference's own training shapes (configs/glmo.yaml: 64x64 maps, stride 2, N=1024;
+    configs/zlmo.yaml: 128x128 maps, stride 3, N=1849, 21 code planes; gsplmo's loss block at B=256 N=64) against the trajectories the
+    unmodified reference class produced (tests/golden/gen_golden_lossfn.py --train-shapes): float64 losses / states to 1e-8, gradients
+    (stored rounded to float32) to 1e-6 of their largest entry; the float32 run against the reference's float32 scalars to 1e-4."""
+    from lc_amd.losses import Loss_fn
+    from tests.golden.gen_golden_lossfn import TRAIN_KINDS, run
+
+    z = np.load(os.path.join(GOLDEN, f"lossfn_{kind}.npz"))
+    assert list(z["steps"]) == TRAIN_KINDS[kind][0]
+    rec = run(Loss_fn, kind, list(z["steps"]), torch.float64)
+    assert set(rec) == {k for k in z.files if not k.startswith("f32_")}
+    for k in rec:
+        if k != "steps":
+            assert rel_err(rec[k], z[k]) <= (1e-6 if "_grad_" in k else 1e-8), k
+    rec32 = run(Loss_fn, kind, list(z["steps"]), torch.float32)
+    for k in z.files:
+        if re.match(r"f32_s\d+_w?loss_", k):
+            assert abs(float(rec32[k[4:]]) - float(z[k])) <= 1e-4 * max(1.0, abs(float(z[k]))), k
+        elif k.startswith("f32_") and "_state_" in k:
+            assert rel_err(rec32[k[4:]], z[k]) <= 1e-3, k
+
+
 def test_loss_fn_state_dict_keys_match_reference_checkpoints():
     from lc_amd.config import AttrDict
     from lc_amd.losses import Loss_fn
