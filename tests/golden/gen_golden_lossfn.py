@@ -39,9 +39,12 @@ TRAIN_KINDS = {
 }
 
 
-def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None, head_dtype=None):
+def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None, head_dtype=None, loss_scale=1.0, round_heads_to=None):
     """Shared by the generator (reference class) and the tests (lc_amd class): returns a flat record of the trajectory.
-    `head_dtype`: the network outputs are handed over in that type (a mixed-precision backbone's fp16 / bf16 heads)."""
+    `head_dtype`: the network outputs are handed over in that type (a mixed-precision backbone's fp16 / bf16 heads); `loss_scale`: what a
+    GradScaler does around an fp16 step (the total is multiplied before backward; the recorded gradients and the clippers' max_norm --
+    which live in scaled units, as they do in a GradScaler-driven training loop -- are divided by it again); `round_heads_to`: the network
+    outputs carry that type's values but are handed over in `dtype` (the full-precision twin of a `head_dtype` run)."""
     if kind in TRAIN_KINDS:
         cfg, (_, steps_per_epoch, total_bits) = AttrDict(synth.TRAIN_LOSS_CONFIGS[kind]), TRAIN_KINDS[kind]
         cfg["pose_loss_cfg"] = AttrDict(cfg["pose_loss_cfg"])
@@ -57,13 +60,16 @@ def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None, head_dtype=N
         gt, out = make(i)
         gt = {k: ((v.to(dtype) if v.is_floating_point() else v).to(device) if isinstance(v, torch.Tensor) else v) for k, v in gt.items()}
         leaves = {k: v.to(dtype).to(device).clone() for k, v in out.items()}
-        if head_dtype is not None:  # the per-sample scale stays fp32 (an exp of a Linear under autocast, ptnet.py:69-80)
-            leaves = {k: (v if k == "xyz_weights_scale" else v.to(head_dtype)) for k, v in leaves.items()}
+        if head_dtype is not None or round_heads_to is not None:  # the per-sample scale stays fp32 (an exp of a Linear under autocast, ptnet.py:69-80)
+            leaves = {k: (v if k == "xyz_weights_scale" else v.to(head_dtype) if head_dtype is not None else v.to(round_heads_to).to(dtype))
+                      for k, v in leaves.items()}
         leaves = {k: v.requires_grad_(True) for k, v in leaves.items()}
         np.random.seed(1000 + i)  # random sub-sampling phase (losses.py:152)
         loss_dict, w_loss_dict = fn(gt, leaves, 0, step, steps_per_epoch)
         total = sum(w_loss_dict.values())
-        grads = torch.autograd.grad(total, list(leaves.values()), allow_unused=True)
+        grads = torch.autograd.grad(total * loss_scale if loss_scale != 1.0 else total, list(leaves.values()), allow_unused=True)
+        if loss_scale != 1.0:
+            grads = [None if gk is None else gk.float() / loss_scale for gk in grads]
         for k, v in loss_dict.items():
             rec[f"s{i}_loss_{k}"] = v.detach().double().cpu().numpy()
         for k, v in w_loss_dict.items():
@@ -72,7 +78,8 @@ def run(Loss_fn_cls, kind, steps, dtype=torch.float32, device=None, head_dtype=N
             if gk is not None:
                 rec[f"s{i}_grad_{k}"] = gk.double().cpu().numpy()
         for k, v in fn.state_dict().items():
-            rec[f"s{i}_state_{k}"] = v.detach().double().cpu().numpy().copy()  # copy: the state may be updated in place
+            v = v.detach().double().cpu().numpy().copy()  # copy: the state may be updated in place
+            rec[f"s{i}_state_{k}"] = v / loss_scale if k.endswith("clipper.max_norm") and float(v) > 0 else v
     rec["steps"] = np.asarray(steps)
     return rec
 

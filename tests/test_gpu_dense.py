@@ -92,7 +92,7 @@ def test_bin_loss_fn_end_to_end_on_gpu():
             assert rel_err(rec[k], z[k]) <= 1e-3, k
 
 
-def _train_shape_record(kind, head_dtype=None):
+def _train_shape_record(kind, head_dtype=None, loss_scale=1.0, round_heads_to=None):
     import os
     from lc_amd.losses import Loss_fn
     from tests.golden.gen_golden_lossfn import TRAIN_KINDS, run
@@ -100,7 +100,7 @@ def _train_shape_record(kind, head_dtype=None):
 
     z = np.load(os.path.join(GOLDEN, f"lossfn_{kind}.npz"))
     assert list(z["steps"]) == TRAIN_KINDS[kind][0]
-    rec = run(Loss_fn, kind, list(z["steps"]), torch.float32, device=torch.device("cuda:0"), head_dtype=head_dtype)
+    rec = run(Loss_fn, kind, list(z["steps"]), torch.float32, device=torch.device("cuda:0"), head_dtype=head_dtype, loss_scale=loss_scale, round_heads_to=round_heads_to)
     assert set(rec) == {k for k in z.files if not k.startswith("f32_")}
     return z, rec
 
@@ -129,23 +129,48 @@ def test_loss_fn_at_the_reference_training_shapes(kind):
         assert all(m > 0 for m in mn) and len(set(mn)) == len(mn)
 
 
-@pytest.mark.parametrize("head_dtype,loss_tol,grad_tol", [(torch.float16, 2e-3, 1e-2), (torch.bfloat16, 2e-2, 5e-2)], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("head_dtype,loss_scale,tol", [
+    (torch.float16, 4096.0, dict(loss=2e-3, grad=3e-2, grad_xyz_noc=3e-2, state=5e-3, twin_loss=1e-4, twin_grad=2e-3)),
+    (torch.bfloat16, 1.0, dict(loss=2e-2, grad=6e-2, grad_xyz_noc=3e-1, state=5e-2, twin_loss=1e-4, twin_grad=1.2e-2))], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo"])
-def test_loss_fn_at_training_shapes_with_half_precision_heads(kind, head_dtype, loss_tol, grad_tol):
-    """BASELINE configs[2] / [4]: a mixed-precision backbone hands fp16 / bf16 maps to `Loss_fn`; the step is checked against the SAME
-    reference trajectories (float64, full-precision inputs), at the map type's accuracy -- inputs rounded to 11 / 8 significant bits and
-    gradients of a map written in the map's type: losses to 2e-3 (fp16) / 2e-2 (bf16) relative, gradients to 1e-2 / 5e-2 of a map's
-    largest entry, max_norm and the code histogram to 5e-2."""
-    z, rec = _train_shape_record(kind, head_dtype)
+def test_loss_fn_at_training_shapes_with_half_precision_heads(kind, head_dtype, loss_scale, tol):
+    """BASELINE configs[2] / [4]: a mixed-precision backbone hands fp16 / bf16 maps to `Loss_fn`.  Two comparisons per step:
+
+    (1) against the SAME reference trajectories as the fp32 test (float64, full-precision inputs), at what rounding the INPUTS to 11 / 8
+    significant bits does to each quantity: losses 2e-3 / 2e-2, gradient maps 3e-2 / 6e-2 of their largest entry, max_norm and the code
+    histogram 5e-3 / 5e-2.  The gradient of the xyz head under bf16 gets 0.3: its largest entries are the LC loss's, proportional to a
+    pixel's reprojection error (~0.2 px here), and a bf16 coordinate is off by up to 0.09 mm = 0.04 px -- a property of the inputs, not of
+    the kernels (measured 0.19; fp16, 8x finer: 0.015).  Excluded, and counted: the sign of `loss_noc`'s L1 gradient (losses.py:281-283)
+    at pixels whose coordinate error is smaller than the rounding of the coordinate.
+    (2) against the fp32 HIP step on the same ROUNDED values (itself pinned to the reference by the test above): what is left is the
+    16-bit write of a map's gradient -- 2e-3 / 1.2e-2 of the largest entry, losses 1e-4.
+
+    fp16 runs under a loss scale of 4096, as a GradScaler-driven step does (gradients of 5e-8 at the start of the warm-up ramp are below
+    fp16's subnormal step otherwise); gradients and max_norm are compared after un-scaling."""
+    from lc_amd import synth
+
+    z, rec = _train_shape_record(kind, head_dtype, loss_scale)
+    _, twin = _train_shape_record(kind, None, loss_scale, round_heads_to=head_dtype)
     for k in rec:
         if k == "steps":
             continue
         if re.match(r"s\d+_w?loss_", k):
-            assert abs(float(rec[k]) - float(z[k])) <= loss_tol * max(1.0, abs(float(z[k]))), (k, float(rec[k]), float(z[k]))
+            assert abs(float(rec[k]) - float(z[k])) <= tol["loss"] * max(1.0, abs(float(z[k]))), (k, float(rec[k]), float(z[k]))
+            assert abs(float(rec[k]) - float(twin[k])) <= tol["twin_loss"] * max(1.0, abs(float(twin[k]))), (k, float(rec[k]), float(twin[k]))
         elif "_grad_" in k:
-            assert np.isfinite(rec[k]).all() and rel_err(rec[k], z[k]) <= grad_tol, (k, rel_err(rec[k], z[k]))
+            got, want = np.asarray(rec[k], np.float64), np.asarray(z[k], np.float64)
+            assert np.isfinite(got).all()
+            assert rel_err(got, twin[k]) <= tol["twin_grad"], (k, "vs the fp32 step on the rounded values", rel_err(got, twin[k]))
+            if k.endswith("_grad_xyz_noc"):
+                gt, out = synth.train_inputs(kind, seed=int(k[1:k.index("_")]))
+                m, x, t = gt["msk_noc"][:, None].float(), out["xyz_noc"], gt["xyz_noc_tgt"]
+                flips = (torch.sign(x * m - t) != torch.sign(x.to(head_dtype).float() * m - t)).numpy()
+                assert flips.sum() <= 0.05 * float(m.sum()) * 3, (k, int(flips.sum()))
+                got, want = np.where(flips, 0.0, got), np.where(flips, 0.0, want)
+            err = np.abs(got - want).max() / np.abs(want).max()
+            assert err <= tol["grad_xyz_noc" if k.endswith("_grad_xyz_noc") else "grad"], (k, err)
         else:
-            assert rel_err(rec[k], z[k]) <= 5e-2, (k, rec[k], z[k])
+            assert rel_err(rec[k], z[k]) <= tol["state"], (k, rec[k], z[k])
 
 
 @pytest.mark.parametrize("thr", [0.5, 0.3, 0.9])
