@@ -145,10 +145,19 @@ def _compile(out: str, flags, verbose: bool) -> str:
     return out
 
 
+VARIANT_DIR = os.path.join(os.path.dirname(PKG), "build", "variants")  # diagnostics stay out of the package (build/ is git-ignored)
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(VARIANT_DIR, f"liblc_amd_{name}.so")
+
+
 def build_variant(name: str, flags, verbose: bool = False) -> str:
-    """An experiment build of the same sources with extra compiler flags (-D switches) next to the shipped library:
-    lc_amd/_C/liblc_amd_<name>.so; select it with LC_AMD_LIB=<path>.  Used by the A/B scripts under scripts/ only."""
-    return _locked(lambda: _compile(os.path.join(OUT_DIR, f"liblc_amd_{name}.so"), list(flags), verbose))
+    """An experiment build of the same sources with extra compiler flags (-D switches), OUTSIDE the package:
+    build/variants/liblc_amd_<name>.so; select it with LC_AMD_LIB=<path>.  Used by the A/B scripts under scripts/ and by the tests
+    that need a diagnostic build only."""
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    return _locked(lambda: _compile(variant_path(name), list(flags), verbose))
 
 
 if __name__ == "__main__":

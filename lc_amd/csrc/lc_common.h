@@ -306,28 +306,59 @@ __device__ __forceinline__ void block_sum_waves4(double (&v)[K], double* lds, in
 // rewritten every second sum (two rows, by sum parity: a workgroup can be one sum ahead of the slowest, not two -- it cannot finish sum s+1
 // before every part has written its s+1 words, i.e. finished reading the rows of sum s), so what a reader finds there is older than the
 // ticket it waits for, or it.  Zeroed workspace = ticket 0 everywhere, first sum = ticket 1.
-// The wait is bounded (~1 s): workgroups of one launch that are not all resident at the same time (more spinning launches in flight than the
-// chip holds -- pnp_split_parts() sizes grids to at most one workgroup per CU) end as a failed solve, not as a hung device.
-constexpr int kSplitMaxParts = 8, kSplitMaxPolls = 1 << 20;
+// The wait is bounded (kSplitMaxPolls polls, a few ms) and NOTHING depends on the parts being resident together: a part that has waited
+// that long stops for good -- it writes no further exchange word -- and raises the pose's `dirty` word; part 0, whose sums decide the solve
+// and which alone stores the pose, reports status 2 ("a part never arrived") when IT ran out of patience.  The rescue launch that follows
+// every split launch on the same stream (lc_pnp.hip: lc_pnp_lm_split_rescue_kernel; all parts have ended by then, there are no stragglers)
+// re-zeroes the region of a dirty pose -- tickets and epoch start over, so whatever height the abandoned launch left behind cannot be taken
+// for a current word -- and re-solves a pose of status 2 with ONE workgroup that plays the G parts one after the other: the same per-thread
+// shares, the same wave / workgroup / part order of every sum (block_sum_parts_serial below), hence the bits the parts would have produced.
+// So co-residency (pnp_split_parts() sizes grids to at most one workgroup per CU) is what makes the split form FAST; other streams, other
+// processes or a CU mask taking compute units away make it slow, never wrong and never different.
+// Tail of a pose's region (its last 128 bytes): word 0 epoch, word 1 dirty, word 2 rescues so far (diagnostics: tests read it).
+constexpr int kSplitMaxParts = 8;
+#ifndef LC_SPLIT_MAX_POLLS
+#define LC_SPLIT_MAX_POLLS (1 << 11)
+#endif
+constexpr int kSplitMaxPolls = LC_SPLIT_MAX_POLLS;
 constexpr int kSplitRowWords = 64;                                                             // 32 totals x 2 words
-constexpr size_t kSplitPoseBytes = 2 * kSplitMaxParts * kSplitRowWords * sizeof(unsigned long long) + 128;  // two rows per part + the epoch's line
+constexpr size_t kSplitPoseBytes = 2 * kSplitMaxParts * kSplitRowWords * sizeof(unsigned long long) + 128;  // two rows per part + the tail's line
 constexpr int kSplitLdsDoubles = 128 + 64 + 2;
+constexpr int kSplitSerialLdsDoubles = 128 + 32 * kSplitMaxParts + 32;  // block_sum_parts_serial: wave rows, one row per part, the totals
 struct SplitSum {
     unsigned long long* exch;  // this pose's [2][kSplitMaxParts][64] words
-    unsigned* epoch;           // this pose's epoch word
+    unsigned* epoch;           // this pose's tail: epoch, dirty, rescues
     int G, part;
     unsigned base;             // *epoch on entry
     unsigned seq;              // sums finished in this launch
     bool timed_out;
 };
-__device__ __forceinline__ SplitSum split_sum_enter(void* pose_region, int G, int part) {
-    char* q = static_cast<char*>(pose_region);
-    unsigned* epoch = reinterpret_cast<unsigned*>(q + kSplitPoseBytes - 128);
-    return SplitSum{reinterpret_cast<unsigned long long*>(q), epoch, G, part, xcd_load(epoch), 0u, false};
+__device__ __forceinline__ unsigned* split_tail(void* region, size_t region_bytes) {
+    return reinterpret_cast<unsigned*>(static_cast<char*>(region) + region_bytes - 128);
 }
-// one thread of part 0, after its last sum.  A launch that timed out leaves tickets of unknown height behind: jump well past them
+__device__ __forceinline__ SplitSum split_sum_enter(void* pose_region, int G, int part) {
+    unsigned* epoch = split_tail(pose_region, kSplitPoseBytes);
+    return SplitSum{reinterpret_cast<unsigned long long*>(pose_region), epoch, G, part, xcd_load(epoch), 0u, false};
+}
+// one thread of every part, after its last sum: part 0 of a launch that met every time moves the epoch on; a part that gave up marks the region
 __device__ __forceinline__ void split_sum_leave(const SplitSum& sx) {
-    if (sx.part == 0 && sx.seq > 0) xcd_store(sx.epoch, sx.base + sx.seq + (sx.timed_out ? 4096u : 0u));
+    if (sx.timed_out) xcd_store(sx.epoch + 1, 1u);
+    else if (sx.part == 0 && sx.seq > 0) xcd_store(sx.epoch, sx.base + sx.seq);
+}
+// The rescue launch's entry, all threads of the workgroup that owns the region: false = nothing to do here.  A dirty region is zeroed
+// (every word, the tail's rescue counter excepted); `redo` = the unit has to be computed again by this workgroup.
+__device__ __forceinline__ bool split_rescue_enter(void* region, size_t region_bytes, bool redo, int tid, int threads) {
+    unsigned* tail = split_tail(region, region_bytes);
+    const bool dirty = xcd_load(tail + 1) != 0u;
+    if (!dirty && !redo) return false;
+    __syncthreads();  // every thread has read the tail before it is rewritten
+    if (dirty) {
+        unsigned long long* w = static_cast<unsigned long long*>(region);
+        for (size_t i = tid; i < (region_bytes - 128) / 8; i += threads) xcd_store(w + i, 0ull);
+        if (tid < 2) xcd_store(tail + tid, 0u);
+    }
+    if (redo && tid == 0) xcd_store(tail + 2, xcd_load(tail + 2) + 1u);
+    return redo;
 }
 
 template <int K>
@@ -342,6 +373,11 @@ __device__ __forceinline__ void block_sum_split(double (&v)[K], double* lds, int
     double* tot = lds + 128 + 32 * phase;    // [2][32]
     int* arrived_ok = reinterpret_cast<int*>(lds + 192);
     phase ^= 1;
+    if (sx.timed_out) {  // (uniform) this part has given up: it stays silent, its caller is on its way out
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = 0.0;
+        return;
+    }
     if ((lane & 3) == 0) *reinterpret_cast<double2*>(part + 32 * wave + scatter16_base(lane, 2)) = make_double2(w[0], w[1]);
     __syncthreads();
     if (tid < 32) {
@@ -383,6 +419,38 @@ __device__ __forceinline__ void block_sum_split(double (&v)[K], double* lds, int
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = tot[k];
     ++sx.seq;
+}
+
+// block_sum_split played by ONE workgroup for the rescue launch: called once per part g = 0 .. G-1 with the values of that part's share
+// (the same threads own the same correspondences as in workgroup g of the split launch), it forms the part's 32 totals exactly as
+// block_sum_split does -- wave reduce-scatter, the four wave rows added in wave order -- and keeps them in LDS row g; the call for the last
+// part adds the G rows in part order and hands every thread the totals.  lds: kSplitSerialLdsDoubles.
+template <int K>
+__device__ __forceinline__ void block_sum_parts_serial(double (&v)[K], double* lds, int tid, int g, int G) {
+    static_assert(K <= 32, "one reduce-scatter of 32");
+    const int lane = tid & 63, wave = tid >> 6;
+    double w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = k < K ? v[k] : 0.0;
+    wave_reduce_scatter16<32>(w, lane);
+    double* part = lds;                               // [4][32]
+    double* rows = lds + 128;                         // [G][32]
+    double* tot = lds + 128 + 32 * kSplitMaxParts;    // [32]
+    if ((lane & 3) == 0) *reinterpret_cast<double2*>(part + 32 * wave + scatter16_base(lane, 2)) = make_double2(w[0], w[1]);
+    __syncthreads();
+    if (tid < 32) {
+        rows[32 * g + tid] = ((part[tid] + part[32 + tid]) + part[64 + tid]) + part[96 + tid];
+        if (g == G - 1) {
+            double s = 0.0;
+            for (int h = 0; h < G; ++h) s += rows[32 * h + tid];  // in part order
+            tot[tid] = s;
+        }
+    }
+    __syncthreads();
+    if (g == G - 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = tot[k];
+    }
 }
 
 #ifndef LC_HORNER_ASM

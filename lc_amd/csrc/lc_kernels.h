@@ -53,7 +53,7 @@ struct PnpParams {
     const float* start;   // (B,7) start poses, or null: read them from `states` (in-place form)
     float* states;        // (B,7) out: optimum if converged, else the start pose
     float* result_tr;     // (B,) final trust-region radius
-    int* rets;            // (B,) 0 ok / 1 invalid
+    int* rets;            // (B,) 0 ok / 1 invalid (between a split launch and its rescue launch also kPnpPartNeverArrived)
     int* iters;           // (B,) LM iterations used, or null
     int B, Nmax, max_iter;
     float ftol;
@@ -66,6 +66,10 @@ struct PnpParams {
     int split_parts;      // pnp_split_parts(B, Nmax) when split_ws is given
 };
 constexpr int kSplitMinPoints = 2048;
+// rets[b] of a split launch whose part 0 waited in vain for another part: "not solved yet", as opposed to 1 = "did not converge"
+// (ceres.cpp:134-138).  launch_pnp_lm always follows a split launch by the rescue launch, which re-solves exactly these poses, so the value
+// never reaches a caller.
+constexpr int kPnpPartNeverArrived = 2;
 int device_compute_units();          // of the current device, cached
 int split_parts_for(int units);      // 8 / 4 / 2 workgroups per unit of work while units x parts fits the device's compute units, else 1  // rows up to here: one workgroup per pose (the exchange between the parts would cost more than it saves)
 int pnp_split_parts(int B, int Nmax);  // workgroups per pose of the split form: 1 (not worth it / grid would not be resident at once), 2, 4, 8

@@ -54,8 +54,23 @@ __global__ __launch_bounds__(256) void lc_pnp_lm_split_kernel(const PnpParams p)
     if (b >= p.B) return;
     SplitSum sx = split_sum_enter(static_cast<char*>(p.split_ws) + (size_t)b * kSplitPoseBytes, p.split_parts, part);
     if (threadIdx.x == 0) *reinterpret_cast<int*>(bc + 192) = 1;  // block_sum_split's "all parts arrived" (its first barrier orders this)
-    pnp::solve_pose<false, 4, false, OPTS, 8, true, true>(p, b, threadIdx.x, bc, part == 0, nullptr, nullptr, &sx);
+    pnp::solve_pose<false, 4, false, OPTS, 8, true, 1>(p, b, threadIdx.x, bc, part == 0, nullptr, nullptr, &sx);
     if (threadIdx.x == 0) split_sum_leave(sx);
+}
+
+// The launch behind every split launch (same stream: all its workgroups have ended): one workgroup per pose, which leaves at once unless a
+// part of the pose gave up waiting -- then the pose's exchange region starts over from zeroes, and if the pose itself is unsolved (status
+// kPnpPartNeverArrived; its row of `states` still holds the start) this workgroup solves it, playing the parts in turn: the same bits the
+// split launch produces when its parts do meet (lc_common.h: block_sum_parts_serial).  Nothing flagged: ~2 us of workgroups that read two words.
+template <bool OPTS>
+__global__ __launch_bounds__(256) void lc_pnp_lm_split_rescue_kernel(const PnpParams p) {
+    __shared__ __attribute__((aligned(16))) double bc[kSplitSerialLdsDoubles];
+    const int b = (int)blockIdx.x;
+    char* region = static_cast<char*>(p.split_ws) + (size_t)b * kSplitPoseBytes;
+    const bool redo = __hip_atomic_load(p.rets + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kPnpPartNeverArrived;
+    if (!split_rescue_enter(region, kSplitPoseBytes, redo, (int)threadIdx.x, 256)) return;
+    SplitSum sx{nullptr, nullptr, p.split_parts, 0, 0u, 0u, false};
+    pnp::solve_pose<false, 4, false, OPTS, 0, false, 2>(p, b, threadIdx.x, bc, true, nullptr, nullptr, &sx);
 }
 
 // diagnostic twins that also record the per-iteration trace (tests/test_gpu_pnp_trace.py)
@@ -123,8 +138,13 @@ int launch_pnp_lm(const PnpParams& p, hipStream_t stream) {
     if (p.B <= 0) return 0;
     if (p.split_ws && p.split_parts > 1) {
         const dim3 grid((unsigned)((p.B + 7) / 8 * 8 * p.split_parts));
-        if (p.options || p.weight_mask || p.pose_mod > 0) hipLaunchKernelGGL(lc_pnp_lm_split_kernel<true>, grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL(lc_pnp_lm_split_kernel<false>, grid, dim3(256), 0, stream, p);
+        if (p.options || p.weight_mask || p.pose_mod > 0) {
+            hipLaunchKernelGGL(lc_pnp_lm_split_kernel<true>, grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(lc_pnp_lm_split_rescue_kernel<true>, dim3((unsigned)p.B), dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL(lc_pnp_lm_split_kernel<false>, grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(lc_pnp_lm_split_rescue_kernel<false>, dim3((unsigned)p.B), dim3(256), 0, stream, p);
+        }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     const bool big = p.B > kLatencyGridMax;

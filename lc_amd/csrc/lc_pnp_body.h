@@ -266,15 +266,18 @@ __device__ __forceinline__ double norm6(const double (&v)[6]) {
 // store / handoff / start_override (the chained launch, lc_pnp.hip): store = false keeps the job's outputs in registers (a workgroup that
 // repeats a solve another workgroup owns must not write the owner's rows a second time); handoff (7 floats of LDS) receives the state the
 // solve would leave in p.states[b]; start_override replaces the start pose (7 floats, e.g. a previous solve's handoff).
-// SPLIT (NW = 4, PPT > 0): workgroup sx->part of the sx->G that share pose b -- it owns the correspondences part * 64 NW + lane + k * 64 NW G,
-// the block sum runs across the G workgroups (lc_common.h: block_sum_split), everything else is replicated; part 0 stores.
-template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0, bool TAIL = false, bool SPLIT = false>
+// SPLIT = 1 (NW = 4, PPT > 0): workgroup sx->part of the sx->G that share pose b -- it owns the correspondences part * 64 NW + lane + k * 64 NW G,
+// the block sum runs across the G workgroups (lc_common.h: block_sum_split), everything else is replicated; part 0 stores -- status 2 when
+// its wait for another part ran out.  SPLIT = 2 (NW = 4, PPT = 0): ONE workgroup plays the sx->G parts in turn (the rescue launch of a pose
+// of status 2: block_sum_parts_serial) -- per thread the same correspondences in the same order, every sum in the same order: the same bits.
+template <bool REG, int NW = 1, bool TRACE = false, bool OPTS = false, int PPT = 0, bool TAIL = false, int SPLIT = 0>
 __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, double* bc, bool store = true, float* handoff = nullptr,
                                            const float* start_override = nullptr, [[maybe_unused]] SplitSum* sx = nullptr) {
     constexpr int kThreads = kWave * NW;  // `lane` is the thread index within the workgroup
-    static_assert(!SPLIT || (NW == 4 && !REG && PPT > 0 && !TRACE), "the split form is the four-wave cached-prefix solve");
-    const int slot = SPLIT ? lane + kThreads * sx->part : lane;  // first correspondence of this thread, and the distance to its next
-    const int stride = SPLIT ? kThreads * sx->G : kThreads;
+    static_assert(SPLIT != 1 || (NW == 4 && !REG && PPT > 0 && !TRACE), "the split form is the four-wave cached-prefix solve");
+    static_assert(SPLIT != 2 || (NW == 4 && !REG && PPT == 0 && !TRACE), "the rescue form walks memory, part by part");
+    const int slot = SPLIT == 1 ? lane + kThreads * sx->part : lane;  // first correspondence of this thread, and the distance to its next
+    const int stride = SPLIT == 1 ? kThreads * sx->G : kThreads;
 #ifdef LC_TRACE_CLOCK
     const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -374,11 +377,21 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
                 // order as the plain loop below -- same sums bit for bit; empty when the pose's count fits the prefix
                 if constexpr (TAIL)
                     for (int i = slot + PPT * stride; i < n; i += stride) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
+            } else if constexpr (SPLIT == 2) {
+                for (int g = 0; g < sx->G; ++g) {  // part g's share and its totals; the last call adds the parts in order
+                    if (g > 0) {
+#pragma unroll
+                        for (int i = 0; i < 28; ++i) acc[i] = 0;
+                    }
+                    for (int i = lane + kThreads * g; i < n; i += kThreads * sx->G) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
+                    block_sum_parts_serial<28>(acc, bc, lane, g, sx->G);
+                }
             } else {
                 for (int i = lane; i < n; i += kThreads) accumulate_point<false>(load_point<OPTS>(p, base, i, cam), rt, t, cam, sc, acc);
             }
             LC_PSTAMP(3);
-            if constexpr (SPLIT) block_sum_split<28>(acc, bc, lane, sum_phase, *sx);
+            if constexpr (SPLIT == 2) {}
+            else if constexpr (SPLIT == 1) block_sum_split<28>(acc, bc, lane, sum_phase, *sx);
             else if constexpr (NW == 4 && LC_WIDE_SUM_REGS) block_sum_waves4<28>(acc, bc, lane, sum_phase);
             else block_sum_bcast_lds<28, NW>(acc, bc, lane);
         }
@@ -393,8 +406,8 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
 #pragma unroll
         for (int i = 0; i < 6; ++i) chk += H[tri6(i, i)];
         LC_PSTAMP(5);
-        if constexpr (SPLIT) {
-            if (sx->timed_out) return false;  // a workgroup of this pose never arrived: the solve fails (lc_common.h: SplitSum)
+        if constexpr (SPLIT == 1) {
+            if (sx->timed_out) return false;  // a workgroup of this pose never arrived: this launch gives the pose up (lc_common.h: SplitSum)
         }
         return chk <= DBL_MAX;
     };
@@ -493,6 +506,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
         // a rejected step -- rare -- restores them by re-evaluating at x
         double cost_c;
         const bool cand_ok = evaluate(xc, scale, H, g, cost_c);
+        if constexpr (SPLIT == 1) {
+            if (sx->timed_out) { failed = true; break; }
+        }
         if (!cand_ok) cost_c = DBL_MAX;
         if (ptol_hit) {  // ParameterToleranceReached
             converged = true; trace(3, cost, cost_c, mcc, 0.0, step_norm); break;
@@ -538,6 +554,9 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     if (lane == 0) {
         if (store) {
             p.rets[b] = invalid ? 1 : 0;
+            if constexpr (SPLIT == 1) {
+                if (sx->timed_out) p.rets[b] = kPnpPartNeverArrived;  // never leaves the launch pair: the rescue launch re-solves the pose
+            }
             p.result_tr[b] = (float)radius;
 #ifndef LC_STAMPS
             if (p.iters) p.iters[b] = iter;

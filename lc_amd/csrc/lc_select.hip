@@ -459,6 +459,9 @@ __device__ __forceinline__ void select_row_wide(const SelectParams& p, int b, Ma
     LC_FS_STAMP(5);
 }
 
+constexpr int kSelRowWords = 256;  // the split form's exchange rows (below)
+constexpr size_t kSelSplitPoseBytes = 2 * kSplitMaxParts * kSelRowWords * sizeof(unsigned long long) + 128;
+
 template <typename T, typename TX, bool WIDE>
 __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(const SelectParams p, const DenseParams d) {
     extern __shared__ float srt[];
@@ -474,6 +477,11 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
     src.lse = 0.f;
     src.scale = map_scalar_at(d.wscale, d.wscale_dtype, b);
     for (int k = 0; k < 3; ++k) src.ns[k] = d.noc_scale ? d.noc_scale[3 * b + k] : 1.f;
+    if (p.split_ws) {  // (uniform) the rescue launch behind a split launch: only the objects a part gave up on
+        char* region = static_cast<char*>(p.split_ws) + (size_t)b * kSelSplitPoseBytes;
+        const bool marked = xcd_load(split_tail(region, kSelSplitPoseBytes) + 1) != 0u;
+        if (!split_rescue_enter(region, kSelSplitPoseBytes, marked, tid, kThreads)) return;
+    }
     if constexpr (WIDE) {
         select_row_wide(p, b, src, 2 * HW, red, srt);
     } else {
@@ -500,10 +508,11 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
 //      the upper order statistic is read off the last pass' merged bins (exact keys) -- or, the rank closing its prefix, one more meeting;
 //   3. compaction: the parts' survivor counts meet, part g writes behind the parts before it.
 // Every value is formed by the expressions of the one-workgroup kernels and every decision is taken on the same integers: outputs bit for bit
-// those of lc_dense_frontend_select_kernel (tests/test_gpu_select.py).  The parts wait for each other (bounded; an object whose parts never
-// all arrive gets count 0) and the grid is sized to one workgroup per compute unit: one such launch at a time per device.
-constexpr int kSelRowWords = 256;
-constexpr size_t kSelSplitPoseBytes = 2 * kSplitMaxParts * kSelRowWords * sizeof(unsigned long long) + 128;
+// those of lc_dense_frontend_select_kernel (tests/test_gpu_select.py).  The parts wait for each other, for a bounded time: a part that has
+// waited in vain marks the object's region (lc_common.h: SplitSum's tail) and leaves; the launch is always followed by the one-workgroup
+// kernel in its rescue role (p.split_parts < 0), whose workgroups leave at once unless their object is marked -- then they zero its region
+// and select it themselves, bit for bit what the parts would have written.  The grid is sized to one workgroup per compute unit so that the
+// parts normally do meet; anything else holding compute units costs time, not objects.
 
 // The parts of an object meet: threads tid < nw publish word tid of this part (`mine`); the nw x G words of all parts are then fetched by the
 // workgroup's threads one word each (thread t: word t % nw of part t / nw -- one or two registers per thread, not G) and handed to
@@ -590,11 +599,8 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_split_kerne
         __syncthreads();
         return never_arrived == 0;
     };
-    auto give_up = [&]() {  // (uniform) an object whose parts did not all arrive: no points -- the RANSAC behind flags it invalid
-        if (part == 0 && tid == 0) {
-            p.counts[b] = 0;
-            xcd_store(sx.epoch, sx.base + sx.seq + 4096u);
-        }
+    auto give_up = [&]() {  // (uniform) this part waited in vain for another: the object is marked, the rescue launch behind this one selects it again
+        if (tid == 0) xcd_store(sx.epoch + 1, 1u);
     };
     {
         unsigned mine = 0u;
@@ -787,10 +793,12 @@ int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d_in,
     const size_t lds = p.mode == 0 ? 0 : (size_t)P * sizeof(float);
     if (d.xyz_dtype != d.map_dtype && d.xyz_dtype != kMapF32) return 2;
     int rc = 0;
+    bool rescue = false;
+    SelectParams pr;
     auto go = [&](auto* kernel) {
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             rc = 2;
-        else hipLaunchKernelGGL(kernel, dim3(p.B), dim3(kThreads), lds, stream, p, d);
+        else hipLaunchKernelGGL(kernel, dim3(p.B), dim3(kThreads), lds, stream, pr, d);
     };
     if (p.split_ws) {
         const int parts = dense_select_split_parts(p.B, p.N);
@@ -800,9 +808,12 @@ int launch_dense_frontend_select(const SelectParams& p, const DenseParams& d_in,
             auto split = [&](auto* kernel) { hipLaunchKernelGGL(kernel, dim3((unsigned)p.B * parts), dim3(kThreads), 0, stream, ps, d); };
             LC_MAP_DISPATCH(d.map_dtype, if (d.xyz_dtype == d.map_dtype) split(lc_dense_frontend_select_split_kernel<T, T>);
                                          else split(lc_dense_frontend_select_split_kernel<T, float>));
-            return hipGetLastError() == hipSuccess ? 0 : 2;
+            if (hipGetLastError() != hipSuccess) return 2;
+            rescue = true;  // ... and the one-workgroup kernel behind it, for the objects a part gave up on (p.split_ws stays set)
         }
     }
+    pr = p;
+    if (!rescue) pr.split_ws = nullptr;
     const bool wide = p.N > kCache * kThreads;  // more candidates per thread than the register cache of the one-entry-at-a-time walk holds
     LC_MAP_DISPATCH(d.map_dtype,
                     if (d.xyz_dtype == d.map_dtype) { if (wide) go(lc_dense_frontend_select_kernel<T, T, true>); else go(lc_dense_frontend_select_kernel<T, T, false>); }

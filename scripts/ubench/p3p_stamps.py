@@ -1,6 +1,6 @@
 """Phase clock of the RANSAC hypothesis kernel (one wavefront = 64 P3P hypotheses): diagnostic build -DLC_P3P_STAMPS, shader cycles.
 
-    python scripts/ubench/p3p_stamps.py            # builds lc_amd/_C/liblc_amd_p3pstamps.so here, run on the GPU box
+    python scripts/ubench/p3p_stamps.py            # builds build/variants/liblc_amd_p3pstamps.so here, run on the GPU box
 """
 import ctypes
 import os
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from lc_amd import build  # noqa: E402
 
-LIB = os.path.join(ROOT, "lc_amd", "_C", "liblc_amd_p3pstamps.so")
+LIB = build.variant_path("p3pstamps")
 if "--build" in sys.argv or not os.path.exists(LIB):
     build.build_variant("p3pstamps", ["-DLC_P3P_STAMPS"])
     if "--build" in sys.argv:

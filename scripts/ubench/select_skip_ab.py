@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from lc_amd import build  # noqa: E402
 
-LIB = os.path.join(ROOT, "lc_amd", "_C", "liblc_amd_skipsearch.so")
+LIB = build.variant_path("skipsearch")
 if "--build" in sys.argv:
     build.build_variant("skipsearch", ["-DLC_SELECT_SKIP_SEARCH"])
     sys.exit(0)

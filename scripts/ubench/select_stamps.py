@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from lc_amd import build  # noqa: E402
 
-LIB = os.path.join(ROOT, "lc_amd", "_C", "liblc_amd_selstamps.so")
+LIB = build.variant_path("selstamps")
 if "--build" in sys.argv or not os.path.exists(LIB):
     build.build_variant("selstamps", ["-DLC_SELECT_STAMPS"])
     if "--build" in sys.argv:

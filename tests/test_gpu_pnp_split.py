@@ -13,7 +13,7 @@ from oracle import pnp_oracle
 from .test_gpu_pnp import pose_err
 
 pytestmark = pytest.mark.gpu
-POSE_BYTES = 2 * 8 * 64 * 8 + 128  # lc_common.h kSplitPoseBytes: two rows of 8 x 32 partial sums (two ticketed words each) + the epoch word's line
+POSE_BYTES = 2 * 8 * 64 * 8 + 128  # lc_common.h kSplitPoseBytes: two rows of 8 x 32 partial sums (two ticketed words each) + the tail's line (epoch, dirty, rescues)
 
 
 def _batch(B, N, seed, noise_px=0.7, outlier_frac=0.05):
@@ -116,17 +116,18 @@ def test_chain_call_with_a_workspace_equals_the_two_split_solves():
 
 
 @pytest.mark.timeout(180)
-def test_split_launches_side_by_side_end_instead_of_hanging():
-    """What include/lc_amd.h warns about, exercised: split solves launched on TWO streams at once (each with a workspace of its own).  A split launch is
-    sized to one workgroup per compute unit, so two of them can hold units the other's missing workgroups need; the wait for a part is bounded, and
-    a pose whose parts never all arrived is reported invalid with its start pose returned.  The contract checked here: the calls END, every pose that
-    is reported valid carries the one-launch-at-a-time result, and the workspaces are usable afterwards."""
+def test_split_launches_side_by_side_lose_no_pose():
+    """Split solves launched on TWO streams at once (each with a workspace of its own).  A split launch is sized to one workgroup per compute
+    unit, so two of them can hold units the other's missing workgroups need; a part's wait is bounded and the rescue launch behind every
+    split launch re-solves what its parts gave up on (tests/test_gpu_contention.py has the forced case).  The contract: every call returns the
+    one-launch-at-a-time result bit for bit -- no pose is reported invalid because of scheduling -- and the workspaces stay usable."""
     B, N = 64, 4096
     b = _batch(B, N, seed=41)
     counts = torch.full((B,), 3000, dtype=torch.int32, device="cuda:0")
     args = (b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"], counts)
     want = pnp_ceres.solve_device(*args, split=True)
     torch.cuda.synchronize()
+    assert int(want[2].sum()) == 0
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     outs = [[], []]
     for rep in range(6):
@@ -134,14 +135,9 @@ def test_split_launches_side_by_side_end_instead_of_hanging():
             with torch.cuda.stream(st):
                 outs[k].append(pnp_ceres.solve_device(*args, split=True))
     torch.cuda.synchronize()
-    failed = 0
     for per_stream in outs:
-        for state, _tr, ret in per_stream:
-            ok = ret == 0
-            failed += int((~ok).sum())
-            assert torch.equal(state[ok], want[0][ok]), "a pose reported valid is the pose of the undisturbed solve"
-            assert torch.equal(state[~ok], b["start"][~ok]), "a failed pose returns its start"
-    print(f"poses failed by the bounded wait under two overlapping split launches: {failed} of {2 * 6 * B}")
+        for state, tr, ret in per_stream:
+            assert torch.equal(ret, want[2]) and torch.equal(state, want[0]) and torch.equal(tr, want[1])
     for st in streams:  # the workspaces survive: an undisturbed solve on either stream is exact again
         with torch.cuda.stream(st):
             again = pnp_ceres.solve_device(*args, split=True)
