@@ -90,11 +90,16 @@ int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const
  *       or more poses than half the device's compute units -- B > 128 on an MI355X: the grid would not fit the chip at one workgroup per CU).
  *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller; after that it belongs to these calls (each leaves it ready for
  *       the next of any shape on the same stream; calls that may run concurrently need a workspace each).  NULL: lc_pnp_lm2_f32.
- * Results: those of lc_pnp_lm2_f32 up to the order of the fp64 sums over the correspondences (tests/test_gpu_pnp_split.py).
- * The workgroups of a pose wait for each other, and such a launch is sized to fill the chip by itself (one workgroup per compute unit): run
- * these calls one at a time per device.  Two of them admitted side by side (different streams) can each hold compute units the other's
- * missing workgroups need; the wait is bounded (about a second), after which the poses concerned are reported invalid (rets = 1) -- a failed
- * solve, not a hung device.  Callers that overlap solves on several streams pass workspace = NULL. */
+ * Results: those of lc_pnp_lm2_f32 up to the order of the fp64 sums over the correspondences (tests/test_gpu_pnp_split.py); rets keeps
+ * the reference's meaning -- 0 solved, 1 not usable / did not converge (ceres.cpp:134-138) -- and nothing else.
+ * Scheduling: the workgroups of a pose wait for each other, and the launch is sized to one workgroup per compute unit so that they normally
+ * all run at once.  Nothing DEPENDS on that: a workgroup that has waited a few milliseconds in vain stops, and the call always enqueues a
+ * second launch behind the first that (a) re-zeroes the exchange region of every pose a workgroup gave up on and (b) solves those poses
+ * with one workgroup each, adding the partial sums in the order the several workgroups would have -- the SAME bits.  Other streams, other
+ * processes or a CU mask holding compute units therefore cost time, never a pose, and never change a result
+ * (tests/test_gpu_contention.py).  What a C caller must do: zero the workspace once; give concurrent calls (different streams) a workspace
+ * each; nothing else.  Callers that overlap many solves on several streams may still prefer workspace = NULL (one workgroup per pose):
+ * contended split launches are correct but slow. */
 size_t lc_pnp_lm_workspace_bytes(int B, int Nmax);
 int lc_pnp_lm3_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
                    const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,
@@ -474,8 +479,9 @@ int lc_dense_frontend_select2(const void *xyz, const void *wlogits, const void *
  * one workgroup pulling the object's maps through one compute unit.  Every output bit for bit that of lc_dense_frontend_select2.
  *   lc_dense_frontend_select_workspace_bytes: bytes that shape needs (0: one workgroup per object anyway).
  *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller, then owned by these calls (each leaves it ready for the next on the
- *       same stream).  NULL: lc_dense_frontend_select2.  As for lc_pnp_lm3_f32: the workgroups of an object wait for each other (bounded; an
- *       object whose parts never all arrive gets count 0) and the launch fills the chip -- one such call at a time per device. */
+ *       same stream).  NULL: lc_dense_frontend_select2.  Scheduling as for lc_pnp_lm3_f32: the workgroups of an object wait for each other
+ *       for a bounded time, and the call always enqueues the one-workgroup kernel behind them, which selects again -- bit for bit -- every
+ *       object a workgroup gave up on and re-zeroes its region: contention costs time, never an object (tests/test_gpu_contention.py). */
 size_t lc_dense_frontend_select_workspace_bytes(int B, int H, int W, int top, int left, int sample);
 int lc_dense_frontend_select3(const void *xyz, const void *wlogits, const void *wscale, const float *noc_scale,
                               const void *vis_logits, float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left,

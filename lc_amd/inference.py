@@ -105,7 +105,7 @@ def solve_pnp_dense(cfg, out_dict, gt_dict):
     results = []
     for (b0, b1), side in zip(bounds, pool):
         side.wait_stream(cur)  # the network's outputs are ready on the caller's stream
-        with torch.cuda.stream(side), splitws.no_split():  # concurrent launches: no forms whose workgroups wait for each other
+        with torch.cuda.stream(side), splitws.no_split():  # concurrent launches: forms whose workgroups wait for each other would stay correct (rescue launch) but crawl
             results.append(_solve_pnp_dense(cfg, cut(out_dict, b0, b1), cut(gt_dict, b0, b1), b0))
     for side in pool[:parts]:
         cur.wait_stream(side)
@@ -245,7 +245,7 @@ class GraphedSolvePnP:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         # the workspaces of the split launches (few objects x thousands of points: selection, solves): zeroed once here, kept consistent by the launches themselves -- no fill node in the graph
-        self._split_ws = (torch.zeros(splitws.PNP_MAX_BYTES, device=dev, dtype=torch.uint8), torch.zeros(splitws.SELECT_MAX_BYTES, device=dev, dtype=torch.uint8))
+        self._split_ws = (torch.zeros(splitws.max_bytes("pnp", dev), device=dev, dtype=torch.uint8), torch.zeros(splitws.max_bytes("select", dev), device=dev, dtype=torch.uint8))
         torch.cuda.synchronize(dev)
         with quiet_capture(), torch.cuda.graph(self.graph), splitws.owned(pnp=self._split_ws[0], select=self._split_ws[1]):
             self._res = solve_pnp(cfg, self._out, self._gt)

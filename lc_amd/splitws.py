@@ -1,8 +1,10 @@
 """Workspaces of the launches that give ONE unit of work to SEVERAL workgroups (the weighted-PnP solve of thousands of points per pose:
 `lc_pnp_lm3_f32`; front end + selection of thousands of candidates per object: `lc_dense_frontend_select3`).  Such a workspace is zeroed once
 and then belongs to those launches -- each leaves it ready for the next on the same stream -- so it is cached per (kind, device, stream), or
-owned by a captured graph.  The workgroups of such a launch wait for each other and the launch fills the chip: callers that overlap launches on
-several streams turn the forms off (`no_split`, or LC_AMD_PNP_SPLIT=0 for the process)."""
+owned by a captured graph.  The workgroups of such a launch wait for each other (bounded), and every such launch is followed by a rescue
+launch that recomputes -- bit for bit -- the units whose workgroups did not all meet (lc_amd/csrc/lc_common.h: SplitSum), so results never depend
+on what else holds compute units; contended split launches are merely slow, which is why callers that overlap many launches on several
+streams may turn the forms off (`no_split`, or LC_AMD_PNP_SPLIT=0 for the process)."""
 from __future__ import annotations
 
 import contextlib
@@ -26,7 +28,8 @@ def is_off() -> bool:
 def no_split():
     """Launches inside the block take one workgroup per unit whatever their shape.  For callers that run several of them CONCURRENTLY on one
     device (side streams): a split launch fills the chip by itself (its workgroups take a compute unit each), and two of them admitted half and
-    half would wait for workgroups that cannot start -- until the wait's bound (about a second) fails the units concerned."""
+    half would wait for workgroups that cannot start until the wait's bound (milliseconds) hands the units concerned to the rescue launch --
+    correct, but slower than one workgroup per unit from the start."""
     global _OFF
     _OFF += 1
     try:
@@ -57,8 +60,15 @@ def get(kind: str, dev, need: int, split=None):
     if need <= 0 or split is False or (split is None and is_off()) or _OFF:
         return None
     ws = _OWNED.get(kind)
-    if ws is not None and ws.device == dev and ws.numel() >= need:
-        return ws
+    if ws is not None:
+        index = lambda d: d.index if d.index is not None else torch.cuda.current_device()  # noqa: E731  (torch.device("cuda") == the current device)
+        if ws.is_cuda and index(ws.device) == index(dev) and ws.numel() >= need:
+            return ws
+        import warnings
+
+        warnings.warn(f"lc_amd.splitws: the owned '{kind}' workspace ({ws.numel()} bytes on {ws.device}) does not serve a launch that needs {need} bytes "
+                      f"on {dev}; falling back to a {'zero-filled tensor inside the capture' if torch.cuda.is_current_stream_capturing() else 'per-stream workspace'}",
+                      RuntimeWarning, stacklevel=3)
     if torch.cuda.is_current_stream_capturing():  # a graph owns its workspace; without `owned` its zero-fill is a node of the graph
         return torch.zeros(need, device=dev, dtype=torch.uint8)
     key = (kind, dev.index if dev.index is not None else torch.cuda.current_device(), _lib.raw_stream(dev))
@@ -70,5 +80,16 @@ def get(kind: str, dev, need: int, split=None):
     return ws
 
 
-PNP_MAX_BYTES = 128 * (2 * 8 * 64 * 8 + 128)       # lc_pnp_lm_workspace_bytes at its largest batch (include/lc_amd.h)
-SELECT_MAX_BYTES = 128 * (2 * 8 * 256 * 8 + 128)   # lc_dense_frontend_select_workspace_bytes likewise
+PNP_POSE_BYTES = 2 * 8 * 64 * 8 + 128        # lc_common.h kSplitPoseBytes (tests/test_gpu_pnp_split.py checks it against lc_pnp_lm_workspace_bytes)
+SELECT_POSE_BYTES = 2 * 8 * 256 * 8 + 128    # lc_select.hip kSelSplitPoseBytes
+
+
+def max_bytes(kind: str, dev=None) -> int:
+    """The largest workspace launches of `kind` ('pnp' | 'select') can ask for on `dev`: the split forms admit at most half as many units as the device
+    has compute units (two workgroups per unit at least) -- 128 on a 256-CU MI355X, more on a larger device, fewer on a partition."""
+    cus = torch.cuda.get_device_properties(dev if dev is not None else torch.cuda.current_device()).multi_processor_count
+    return max(cus // 2, 1) * (PNP_POSE_BYTES if kind == "pnp" else SELECT_POSE_BYTES)
+
+
+PNP_MAX_BYTES = 128 * PNP_POSE_BYTES         # on a 256-CU device (kept for callers that size buffers without a device at hand)
+SELECT_MAX_BYTES = 128 * SELECT_POSE_BYTES
