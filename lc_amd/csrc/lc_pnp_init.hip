@@ -337,23 +337,35 @@ __device__ __forceinline__ bool hypothesis_pose(const int (&idx)[4], PointFn&& p
     return true;
 }
 
-// one correspondence against one hypothesis (fp32): inlier flag and squared reprojection error in normalised coordinates.
-// Every fused multiply-add is written out: the pair form below performs the same operations in the same order, so the single
-// launch and the split form see the same inlier bits.
-__device__ __forceinline__ void score_point(const float (&R)[9], const float (&t)[3], float X, float Y, float Z, float u, float v,
-                                            float thr2, int& cnt, float& err) {
+// One correspondence against one hypothesis, in fp32 and WITHOUT a division, so that every bit is reproducible off the chip
+// (oracle/p3p_ransac_oracle.py: score_f32 restates these lines operation by operation; v_rcp_f32's last bit cannot be restated):
+//   c = R X + t by three fma chains that start from t;   r = (cx - u cz, cy - v cz);   q = ry ry + rx rx   (one fma over one product);
+//   inlier  <=>  cz > 0  and  q < (thr2 cz) cz                  -- | c_xy / cz - u |^2 < thr2 with both sides multiplied by cz^2;
+//   the inlier error of a hypothesis (the tie-break of equal counts) adds q over its inliers -- even / odd points of a 64-point chunk in
+//   two sums, (even + odd) x 1 / (tz tz) per chunk (chunk_error: squared residuals in the camera plane at the hypothesis' own depth tz,
+//   IEEE operations only), chunk values in chunk order.  Every launch form performs exactly these operations in exactly this order.
+__device__ __forceinline__ bool inlier_q(const float (&R)[9], const float (&t)[3], float X, float Y, float Z, float u, float v, float thr2, float& q) {
     const float cz = __builtin_fmaf(R[8], Z, __builtin_fmaf(R[7], Y, __builtin_fmaf(R[6], X, t[2])));
     const float cx = __builtin_fmaf(R[2], Z, __builtin_fmaf(R[1], Y, __builtin_fmaf(R[0], X, t[0])));
     const float cy = __builtin_fmaf(R[5], Z, __builtin_fmaf(R[4], Y, __builtin_fmaf(R[3], X, t[1])));
-    const float icz = __builtin_amdgcn_rcpf(cz);  // 1 ulp: scoring only
-    const float ex = __builtin_fmaf(cx, icz, -u), ey = __builtin_fmaf(cy, icz, -v);
-    const float e = __builtin_fmaf(ey, ey, ex * ex);
-    const bool in = cz > 0 && e < thr2;
+    const float rx = __builtin_fmaf(-u, cz, cx), ry = __builtin_fmaf(-v, cz, cy);
+    q = __builtin_fmaf(ry, ry, rx * rx);
+    return cz > 0 && q < (thr2 * cz) * cz;
+}
+__device__ __forceinline__ void score_point(const float (&R)[9], const float (&t)[3], float X, float Y, float Z, float u, float v,
+                                            float thr2, int& cnt, float& err) {
+    float q;
+    const bool in = inlier_q(R, t, X, Y, Z, u, v, thr2, q);
     cnt += in ? 1 : 0;
-    err += in ? e : 0.f;
+    err += in ? q : 0.f;
+}
+// (even + odd) sums of a chunk -> the chunk's contribution to the hypothesis' inlier error
+__device__ __forceinline__ float chunk_error(float even, float odd, float tz) {
+    const float scale = tz > 0.f ? 1.f / (tz * tz) : 1.f;  // IEEE division (hipcc's default for fp32), once per hypothesis and chunk
+    return (even + odd) * scale;
 }
 
-// two correspondences per instruction (v_pk_fma_f32): X, Y, Z, nu = -u, nv = -v hold the same coordinate of points i and i+1
+// two correspondences per instruction (v_pk_fma_f32 / v_pk_mul_f32): X, Y, Z, nu = -u, nv = -v hold the same coordinate of points i and i+1
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f_t bc2(float a) { return v2f_t{a, a}; }
 __device__ __forceinline__ void score_pair(const float (&R)[9], const float (&t)[3], v2f_t X, v2f_t Y, v2f_t Z, v2f_t nu, v2f_t nv,
@@ -361,12 +373,12 @@ __device__ __forceinline__ void score_pair(const float (&R)[9], const float (&t)
     const v2f_t cz = __builtin_elementwise_fma(bc2(R[8]), Z, __builtin_elementwise_fma(bc2(R[7]), Y, __builtin_elementwise_fma(bc2(R[6]), X, bc2(t[2]))));
     const v2f_t cx = __builtin_elementwise_fma(bc2(R[2]), Z, __builtin_elementwise_fma(bc2(R[1]), Y, __builtin_elementwise_fma(bc2(R[0]), X, bc2(t[0]))));
     const v2f_t cy = __builtin_elementwise_fma(bc2(R[5]), Z, __builtin_elementwise_fma(bc2(R[4]), Y, __builtin_elementwise_fma(bc2(R[3]), X, bc2(t[1]))));
-    const v2f_t icz = {__builtin_amdgcn_rcpf(cz.x), __builtin_amdgcn_rcpf(cz.y)};
-    const v2f_t ex = __builtin_elementwise_fma(cx, icz, nu), ey = __builtin_elementwise_fma(cy, icz, nv);
-    const v2f_t e = __builtin_elementwise_fma(ey, ey, ex * ex);
-    const bool in0 = cz.x > 0 && e.x < thr2, in1 = cz.y > 0 && e.y < thr2;
+    const v2f_t rx = __builtin_elementwise_fma(nu, cz, cx), ry = __builtin_elementwise_fma(nv, cz, cy);
+    const v2f_t q = __builtin_elementwise_fma(ry, ry, rx * rx);
+    const v2f_t lim = (bc2(thr2) * cz) * cz;
+    const bool in0 = cz.x > 0 && q.x < lim.x, in1 = cz.y > 0 && q.y < lim.y;
     cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
-    err += v2f_t{in0 ? e.x : 0.f, in1 ? e.y : 0.f};
+    err += v2f_t{in0 ? q.x : 0.f, in1 ? q.y : 0.f};
 }
 
 // (count, -error, -hypothesis id) ordering of the hypotheses of a pose
@@ -481,10 +493,8 @@ __device__ __forceinline__ void write_result(const RansacParams& p, int b, int n
                 if (i < n) {
                     float ux, uy;
                     kin.normalise(q.pu[k], q.pv[k], ux, uy);
-                    const float cz = R[6] * q.X[k] + R[7] * q.Y[k] + R[8] * q.Z[k] + t[2];
-                    const float ex = (R[0] * q.X[k] + R[1] * q.Y[k] + R[2] * q.Z[k] + t[0]) / cz - ux,
-                                ey = (R[3] * q.X[k] + R[4] * q.Y[k] + R[5] * q.Z[k] + t[1]) / cz - uy;
-                    in[k] = cz > 0 && (ex * ex + ey * ey) < thr2;
+                    float qq;  // the scoring's own expression: the mask's count IS the winner's count
+                    in[k] = inlier_q(R, t, q.X[k], q.Y[k], q.Z[k], ux, uy, thr2, qq);
                     mask[i] = in[k] ? 1 : 0;
                 }
                 bal[k] = __ballot(in[k]);
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(64 * kRansacMaxWaves) void lc_pnp_ransac_kernel(con
                     score_point(R, t, sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], su[2 * i], su[2 * i + 1], thr2, cnt, e0);
                     if (i + 1 < i1) score_point(R, t, sx[3 * i + 3], sx[3 * i + 4], sx[3 * i + 5], su[2 * i + 2], su[2 * i + 3], thr2, cnt, e1);
                 }
-                err += e0 + e1;
+                err += chunk_error(e0, e1, t[2]);
             }
         }
         if (active && (cnt > best_cnt || (cnt == best_cnt && err < best_err))) {
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_kerne
         }
     }
     const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
-    w.part[o] = pack_partial(cnt, err2.x + err2.y);
+    w.part[o] = pack_partial(cnt, chunk_error(err2.x, err2.y, t[2]));
 }
 
 // Rows wider than 4096 candidates (zlmo's test-time shape: 16 384 per object, of which a pose's count keeps a fifth): one wavefront per
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_wide_
                 score_pair(R, t, X1.zw, Y1.zw, Z1.zw, U1.zw, V1.zw, thr2, cnt, err2);
             }
         }
-        w.part[((size_t)b * w.C + c) * w.H + hyp] = pack_partial(cnt, err2.x + err2.y);
+        w.part[((size_t)b * w.C + c) * w.H + hyp] = pack_partial(cnt, chunk_error(err2.x, err2.y, t[2]));
         __builtin_amdgcn_wave_barrier();  // the chunk's LDS reads precede the next chunk's writes (one wavefront: program order)
         cur = nxt;
     }
@@ -945,7 +955,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_live_
                 score_pair(R, t, X1.zw, Y1.zw, Z1.zw, U1.zw, V1.zw, thr2, cnt, err2);
             }
         }
-        w.part[((size_t)b * w.C + c) * w.H + hyp] = pack_partial(cnt, err2.x + err2.y);
+        w.part[((size_t)b * w.C + c) * w.H + hyp] = pack_partial(cnt, chunk_error(err2.x, err2.y, t[2]));
         __builtin_amdgcn_wave_barrier();  // the unit's LDS reads precede the next unit's writes (one wavefront: program order)
     }
 }
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(kWave * kRansacMaxWaves) void lc_ransac_score_selec
             X = Xn; Y = Yn; Z = Zn; U = Un; V = Vn;
         }
         const size_t o = ((size_t)b * w.C + c) * w.H + hyp;
-        xcd_store(w.part + o, pack_partial(cnt, err2.x + err2.y));
+        xcd_store(w.part + o, pack_partial(cnt, chunk_error(err2.x, err2.y, t[2])));
     }
     xcd_stores_done();
     __syncthreads();  // every wave's partials have been acknowledged

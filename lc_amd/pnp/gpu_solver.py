@@ -14,8 +14,22 @@ from .. import _lib
 from . import cer_solver, pnp_ceres
 
 
+def workspace_views(ws, B, N, iterations):
+    """Diagnostics (the oracle tests): the split form's workspace as tensors -- hyp64 (B,H,12) double and hyp32 (B,H,12) float, every
+    hypothesis' [R row-major | t], and the chunk partials (B,C,H) as (count int32, error float32); layout of lc_pnp_init.hip: carve_workspace."""
+    H, C = (int(iterations) + 63) // 64 * 64, max(1, (N + 63) // 64)
+    raw = ws.view(torch.uint8)
+    o = 16 * ((B + 3) // 4)
+    hyp64 = raw[o:o + 8 * 12 * B * H].view(torch.float64).view(B, H, 12)
+    o += 8 * 12 * B * H
+    hyp32 = raw[o:o + 4 * 12 * B * H].view(torch.float32).view(B, H, 12)
+    o += 4 * 12 * B * H
+    part = raw[o:o + 8 * B * C * H].view(torch.int32).view(B, C, H, 2)
+    return hyp64, hyp32, part[..., 0], part[..., 1].view(torch.float32)
+
+
 def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionError=3.0, iterations=150, seed=0, refine=True,
-                 return_hypothesis=False, split=None, ticketed=False, select=None, reproj_divisor=None, pose_index_offset=0):
+                 return_hypothesis=False, split=None, ticketed=False, select=None, reproj_divisor=None, pose_index_offset=0, workspace_out=None):
     """Batched tensors (B,3,3), (B,N,3), (B,N,2) [+ n_points (B)] -> states (B,7), inlier_mask (B,N) bool, invalid (B) bool
     [+ best_hyp (B) int32, n_inliers (B) int32 with return_hypothesis: the integer outputs the oracle test compares exactly].
     pose_index_offset: this batch is the slice [offset, offset + B) of a larger one -- hypothesis streams and padding draws are those of the
@@ -32,6 +46,7 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
     select['result'].  ticketed: the split form with the selection inside the scoring launch (two launches instead of three, same
     outputs, tests compare the two) -- measured 2.9 us SLOWER per call on MI355X (profiles/r03/test_time/ransac_forms.txt), hence off.
 
+    workspace_out: a list that receives the split form's workspace tensor (see `workspace_views`; diagnostics).
     split: None picks the launch form from the shape -- the single launch keeps a pose on one compute unit (its scoring loop costs
     ~0.07 us per point, times ceil(B/256) when the poses outnumber the compute units), the split form pays ~17 us of extra launches
     and fixed work but spreads the points of a pose over the chip (scripts/ubench/ransac_forms.py: (64, 1024) 83 -> 37 us,
@@ -81,6 +96,8 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
         if split:  # hypotheses / scoring / selection as launches over a workspace: spreads one pose over many compute units
             nbytes = int(lib.lc_pnp_ransac_workspace_bytes(B, N, int(iterations)))
             ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
+            if workspace_out is not None:
+                workspace_out.append(ws)
         head = (_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError), _lib.ptr(per_pose),
                 int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask), _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp),
                 _lib.ptr(rows), _lib.ptr(ws), nbytes)

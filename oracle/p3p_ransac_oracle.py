@@ -14,6 +14,14 @@ contract, with integer outputs compared exactly:
     definition in float64; `decided` reports for which poses the float32 kernel MUST pick the same hypothesis: the winner's count lead
     exceeds the number of points that it and the rival have within `margin` of the inlier threshold, and no error-sum tie within
     `margin`; `mask_unsure` lists the points of the winner's inlier mask that float32 may decide either way (the rest is exact).
+
+Round 5 -- the float32-faithful mode (`score_f32`, `ransac_f32`).  The kernel's scoring is division-free IEEE float32 (fused
+multiply-adds and multiplies in a fixed order, lc_pnp_init.hip: inlier_q / chunk_error), so it can be restated operation by operation:
+`fma32` below is an exactly rounded float32 fma built from float64 arithmetic, the error sums are added in the kernel's association
+(even / odd points of a 64-point chunk, (even + odd) / tz^2 per chunk, chunks in order).  Given the float32 hypotheses (the kernel's own,
+read back from its workspace -- a different P3P algorithm agrees with them to 1e-10, not to the bit), per-hypothesis counts, error sums,
+the winner, its inlier count and its inlier mask are compared with EQUALITY for every pose; the float64 run above stays as the sanity
+bound on the hypotheses themselves.
 """
 from __future__ import annotations
 
@@ -138,13 +146,15 @@ def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3)
             continue
         R, t = pick
         c = Xs[:nl] @ R.T + t
-        e = ((c[:, :2] / c[:, 2:3] - un[:nl]) ** 2).sum(1)
-        inl = (c[:, 2] > 0) & (e < thr2)
+        # the kernel's division-free form (lc_pnp_init.hip: inlier_q): q = |c_xy - u cz|^2 < thr2 cz^2; inlier error = sum of q / tz^2
+        e = ((c[:, :2] - un[:nl] * c[:, 2:3]) ** 2).sum(1)
+        lim = thr2 * c[:, 2] ** 2
+        inl = (c[:, 2] > 0) & (e < lim)
         # points the float32 kernel may legitimately put on the other side of the threshold (or of the camera plane): the hypothesis'
         # count is known up to that many
-        n_unsure = int(((np.abs(e - thr2) < margin * thr2) | (np.abs(c[:, 2]) < 1e-6)).sum())
+        n_unsure = int(((np.abs(e - lim) < margin * lim) | (np.abs(c[:, 2]) < 1e-6)).sum())
         ambiguous_pick = pick_gap < margin * max(pick_e, 1e-12)
-        cand.append((int(inl.sum()), float(e[inl].sum()), hyp, R, t, n_unsure, ambiguous_pick))
+        cand.append((int(inl.sum()), float(e[inl].sum() / t[2] ** 2) if t[2] > 0 else float(e[inl].sum()), hyp, R, t, n_unsure, ambiguous_pick))
     best = max(cand, key=lambda c: (c[0], -c[1], -c[2]))
     ok = best[0] >= 4
     out = dict(invalid=0 if ok else 1, best_hyp=best[2], best_count=best[0], per_hyp_count=np.array([c[0] for c in cand]))
@@ -169,13 +179,113 @@ def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3)
     Rf, tf = R.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
     c = X.astype(np.float32).astype(np.float64) @ Rf.T + tf
     un_all = np.stack(((k[4] * du - k[1] * dv) * idet, (-k[3] * du + k[0] * dv) * idet), -1).astype(np.float32).astype(np.float64)
-    e = ((c[:, :2] / c[:, 2:3] - un_all) ** 2).sum(1)
-    inl = (c[:, 2] > 0) & (e < thr2)
+    e = ((c[:, :2] - un_all * c[:, 2:3]) ** 2).sum(1)
+    lim = thr2 * c[:, 2] ** 2
+    inl = (c[:, 2] > 0) & (e < lim)
     # mask_unsure: the points of the winner's inlier mask float32 may decide either way; everywhere else the mask is exact
-    mask_unsure = np.nonzero((np.abs(e - thr2) < margin * thr2) | (np.abs(c[:, 2]) < 1e-6))[0]
+    mask_unsure = np.nonzero((np.abs(e - lim) < margin * lim) | (np.abs(c[:, 2]) < 1e-6))[0]
     out.update(n_inliers=int(inl.sum()), inliers=np.nonzero(inl)[0], R=R, t=t, decided=decided, mask_decided=decided and len(mask_unsure) == 0,
                mask_unsure=mask_unsure)
     return out
+
+
+# ---- float32-faithful scoring (the kernel's arithmetic, operation by operation) ------------------------------------------------------
+
+def fma32(a, b, c):
+    """round-to-nearest-even float32 of a * b + c for float32 arrays, EXACTLY (one rounding): the product of two float32 is exact in
+    float64; the float64 sum is rounded once, its rounding error recovered by TwoSum, and the second rounding (to float32) is corrected
+    where the float64 sum sits exactly on a float32 midpoint and the discarded error decides the side."""
+    a, b, c = (np.asarray(v, np.float32).astype(np.float64) for v in (a, b, c))
+    p = a * b
+    s = p + c
+    with np.errstate(invalid="ignore"):
+        bb = s - p
+        err = (p - (s - bb)) + (c - bb)
+    r = s.astype(np.float32)
+    fin = np.isfinite(s) & np.isfinite(err)
+    bits = np.ascontiguousarray(s).view(np.int64)
+    mid = fin & ((bits & ((1 << 29) - 1)) == (1 << 28)) & (err != 0)
+    if mid.any():
+        r64 = r.astype(np.float64)
+        up = np.where(r64 > s, r, np.nextafter(r, np.float32(np.inf)))
+        down = np.where(r64 < s, r, np.nextafter(r, np.float32(-np.inf)))
+        r = np.where(mid, np.where(err > 0, up, down), r)
+    return r.astype(np.float32)
+
+
+def normalised_points_f32(K, pts2d):
+    """CamInv::normalise: K^-1 (u, v, 1) formed in double precision and rounded to float32 once (the subtraction inside is contracted to one
+    fma by the build's -ffp-contract=on: the products are formed here in extended precision, where they are exact)."""
+    k = np.asarray(K, np.float32).astype(np.float64).reshape(-1)
+    idet = 1.0 / (k[0] * k[4] - k[1] * k[3])  # products of two floats are exact in double
+    du = pts2d[:, 0].astype(np.float64) - k[2]
+    dv = pts2d[:, 1].astype(np.float64) - k[5]
+    ld = np.longdouble
+    ux = ((ld(k[4]) * du.astype(ld) - (k[1] * dv).astype(ld)).astype(np.float64) * idet).astype(np.float32)
+    uy = ((ld(-k[3]) * du.astype(ld) + (k[0] * dv).astype(ld)).astype(np.float64) * idet).astype(np.float32)
+    return np.stack((ux, uy), -1), idet
+
+
+def threshold2_f32(reproj_err_px, idet):
+    thr = np.float32(reproj_err_px) * np.float32(np.sqrt(abs(idet)))
+    return np.float32(thr * thr)
+
+
+def inlier_q_f32(hyp32, X, un, thr2):
+    """lc_pnp_init.hip inlier_q for hypotheses hyp32 (H,12) x points X (n,3), un (n,2), all float32 -> (inlier (H,n) bool, q (H,n) float32)."""
+    R, t = hyp32[:, None, :9], hyp32[:, None, 9:]
+    Xx, Xy, Xz = X[None, :, 0], X[None, :, 1], X[None, :, 2]
+    cz = fma32(R[..., 8], Xz, fma32(R[..., 7], Xy, fma32(R[..., 6], Xx, t[..., 2])))
+    cx = fma32(R[..., 2], Xz, fma32(R[..., 1], Xy, fma32(R[..., 0], Xx, t[..., 0])))
+    cy = fma32(R[..., 5], Xz, fma32(R[..., 4], Xy, fma32(R[..., 3], Xx, t[..., 1])))
+    with np.errstate(invalid="ignore", over="ignore"):
+        rx, ry = fma32(-un[None, :, 0], cz, cx), fma32(-un[None, :, 1], cz, cy)
+        q = fma32(ry, ry, (rx * rx).astype(np.float32))
+        lim = ((np.float32(thr2) * cz).astype(np.float32) * cz).astype(np.float32)
+        return (cz > 0) & (q < lim), q
+
+
+def score_f32(hyp32, X, un, thr2):
+    """Every hypothesis against every point of the pose, as the scoring kernels do it: -> (count (H,) int, error (H,) float32)."""
+    hyp32, X, un = np.asarray(hyp32, np.float32), np.asarray(X, np.float32), np.asarray(un, np.float32)
+    H, n = len(hyp32), len(X)
+    inl, q = inlier_q_f32(hyp32, X, un, thr2)
+    C = (n + 63) // 64
+    qi = np.zeros((H, C * 64), np.float32)
+    qi[:, :n] = np.where(inl, q, np.float32(0))
+    qi = qi.reshape(H, C, 32, 2)
+    even, odd = np.zeros((H, C), np.float32), np.zeros((H, C), np.float32)
+    for k in range(32):  # sequential float32 adds, even and odd points apart
+        even = (even + qi[:, :, k, 0]).astype(np.float32)
+        odd = (odd + qi[:, :, k, 1]).astype(np.float32)
+    tz = hyp32[:, 11]
+    with np.errstate(divide="ignore", over="ignore"):
+        scale = np.where(tz > 0, np.float32(1) / (tz * tz).astype(np.float32), np.float32(1)).astype(np.float32)
+    chunk = ((even + odd).astype(np.float32) * scale[:, None]).astype(np.float32)
+    err = np.zeros(H, np.float32)
+    for c in range(C):  # chunk order
+        err = (err + chunk[:, c]).astype(np.float32)
+    return inl.sum(1).astype(np.int64), err
+
+
+def ransac_f32(K, pts3d, pts2d, count, reproj_err_px, hyp32):
+    """The kernel's RANSAC decision for one pose given its float32 hypotheses (H,12) = [R row-major | t]: every integer output exactly.
+    -> dict(invalid, best_hyp, n_inliers, inlier_mask (over the row), per_hyp_count, per_hyp_err)."""
+    N = len(pts3d)
+    n = int(min(count, N))
+    if n < 4:
+        return dict(invalid=1, best_hyp=-1, n_inliers=0, inlier_mask=np.zeros(N, bool), per_hyp_count=None, per_hyp_err=None)
+    un, idet = normalised_points_f32(K, np.asarray(pts2d[:n], np.float32))
+    thr2 = threshold2_f32(reproj_err_px, idet)
+    X = np.asarray(pts3d[:n], np.float32)
+    cnt, err = score_f32(hyp32, X, un, thr2)
+    order = sorted(range(len(cnt)), key=lambda h: (-int(cnt[h]), float(err[h]), h))  # (count, -error, -id) arg-max: better_hyp
+    win = order[0]
+    ok = cnt[win] >= 4
+    mask = np.zeros(N, bool)
+    if ok:
+        mask[:n] = inlier_q_f32(np.asarray(hyp32, np.float32)[win:win + 1], X, un, thr2)[0][0]
+    return dict(invalid=0 if ok else 1, best_hyp=int(win) if ok else -1, n_inliers=int(mask.sum()), inlier_mask=mask, per_hyp_count=cnt, per_hyp_err=err)
 
 
 def rot_to_quat(R):
