@@ -249,9 +249,10 @@ int lc_dense_frontend_bwd_f32(const float *wlogits, const float *wscale, const f
  * (2g) PnP initialiser -- takes the place of lib/pnp/cv2_solver.py:69-88 (cv2.solvePnPRansac, EPnP,
  *      iterationsCount=150) in front of the weighted solve: RANSAC over P3P minimal samples, one wavefront per pose,
  *      `iterations` hypotheses rounded up to a multiple of 64.  Same zero-padded batch layout as (2a).
- *      reproj_err in pixels: the scalar; with reproj_err_per_pose != NULL (B floats) the per-pose value when reproj_err <= 0, and
- *      reproj_err / reproj_err_per_pose[b] when reproj_err > 0 -- test.py:56-57,115-116's `2 / gt_dict['out_pix_scale']`
- *      (rel_reproj_err) formed inside the launch.
+ *      reproj_err in pixels: the scalar; with reproj_err_per_pose != NULL (B floats) the per-pose value IS the threshold of pose b
+ *      (lc_pnp_ransac_init_f32 .. init4_f32, whatever the scalar).  lc_pnp_ransac_init5_f32 ONLY: with reproj_err > 0 the per-pose value
+ *      is a DIVISOR, threshold = reproj_err / reproj_err_per_pose[b] -- test.py:56-57,115-116's `2 / gt_dict['out_pix_scale']`
+ *      (rel_reproj_err) formed inside the launch; a divisor that is not positive leaves reproj_err itself.
  *      -> states (B,7) w,x,y,z,tx,ty,tz; inlier_mask (B,Nmax) uint8; n_inliers (B); invalid (B) (1: fewer than 4 points
  *      or no hypothesis with >= 4 inliers; states is then the identity pose like the reference's zero rvec/tvec).
  * ------------------------------------------------------------------------------------------------ */

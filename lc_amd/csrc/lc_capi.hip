@@ -522,11 +522,12 @@ int lc_pnp_ransac_init3_f32(const float* K, const float* pts3d, const float* pts
     return rc ? fail(11, "ransac kernel launch failed") : 0;
 }
 
-int lc_pnp_ransac_init5_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
-                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
-                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
-                            size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
-                            float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, int pose_index_offset, void* stream) {
+static int ransac_init_any(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+                           float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
+                           unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
+                           size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
+                           float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, int pose_index_offset, int per_pose_divides,
+                           void* stream) {
     if (B < 0 || Nmax < 0 || iterations <= 0 || sel_min_count < 0) return fail(1, "bad size");
     if (B == 0) return 0;
     if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
@@ -538,10 +539,22 @@ int lc_pnp_ransac_init5_f32(const float* K, const float* pts3d, const float* pts
     LC_REQUIRE_ALIGNED(8, pts2d);
     lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
                        (iterations + 63) / 64, reproj_err, seed, best_hyp, valid_counts, workspace, workspace_bytes,
-                       sel_w, sel_in_index, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, sel_min_count, sel_seed, (workspace && ticketed) ? 1 : 0, pose_index_offset};
+                       sel_w, sel_in_index, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, sel_min_count, sel_seed, (workspace && ticketed) ? 1 : 0, pose_index_offset,
+                       per_pose_divides};
     const int rc = lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream));
     if (rc == 3) return fail(1, "workspace smaller than lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)");
     return rc ? fail(11, "ransac kernel launch failed") : 0;
+}
+
+int lc_pnp_ransac_init5_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
+                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
+                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
+                            size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
+                            float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, int pose_index_offset, void* stream) {
+    // the one entry point on which a positive scalar next to per-pose values means "divide" (include/lc_amd.h)
+    return ransac_init_any(K, pts3d, pts2d, counts, B, Nmax, reproj_err, reproj_err_per_pose, iterations, seed, states, inlier_mask, n_inliers, invalid, best_hyp,
+                           valid_counts, workspace, workspace_bytes, ticketed, sel_w, sel_in_index, sel_min_count, sel_seed, sel_pts2d, sel_w_out, sel_pts3d, sel_index,
+                           sel_counts, pose_index_offset, (reproj_err_per_pose && reproj_err > 0.f) ? 1 : 0, stream);
 }
 
 int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
@@ -549,7 +562,8 @@ int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts
                             unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
                             size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
                             float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, void* stream) {
-    return lc_pnp_ransac_init5_f32(K, pts3d, pts2d, counts, B, Nmax, reproj_err, reproj_err_per_pose, iterations, seed, states, inlier_mask, n_inliers, invalid, best_hyp, valid_counts, workspace, workspace_bytes, ticketed, sel_w, sel_in_index, sel_min_count, sel_seed, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, 0, stream);
+    // init .. init4 keep their original meaning: per-pose values, when given, ARE the thresholds (whatever the scalar)
+    return ransac_init_any(K, pts3d, pts2d, counts, B, Nmax, reproj_err, reproj_err_per_pose, iterations, seed, states, inlier_mask, n_inliers, invalid, best_hyp, valid_counts, workspace, workspace_bytes, ticketed, sel_w, sel_in_index, sel_min_count, sel_seed, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, 0, 0, stream);
 }
 
 static int bits_check(int B, int C, int H, int W, int n0, int n1, int n2, int top, int left, int sample) {

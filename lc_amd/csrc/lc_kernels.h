@@ -122,7 +122,7 @@ struct RansacParams {
     const float* pts3d;    // (B,Nmax,3)
     const float* pts2d;    // (B,Nmax,2)
     const int* counts;     // (B,) or null
-    const float* reproj_err_per_pose;  // (B,) or null (use reproj_err)
+    const float* reproj_err_per_pose;  // (B,) or null (use reproj_err); see per_pose_divides
     float* states;         // (B,7) out
     unsigned char* inlier_mask;  // (B,Nmax) out
     int* n_inliers;        // (B,) out
@@ -150,6 +150,8 @@ struct RansacParams {
     int pose0;                 // index of the batch's first pose in the caller's numbering: the hypothesis stream and the padding draw of pose b are
                                // those of pose pose0 + b, so a batch solved in several sub-batches (concurrently, on several streams) gives the
                                // results of the one call
+    int per_pose_divides;      // 0: reproj_err_per_pose[b] IS the threshold of pose b (lc_pnp_ransac_init .. init4); 1 (init5 with reproj_err > 0):
+                               // the threshold is reproj_err / reproj_err_per_pose[b], a non-positive divisor leaving reproj_err itself
 };
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);  // 3: workspace too small
 size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds);

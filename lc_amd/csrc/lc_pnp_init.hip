@@ -399,13 +399,15 @@ struct CamInv {
     }
 };
 
-// Inlier threshold of pose b in pixels: the scalar, a per-pose value, or scalar / per-pose value -- test.py:56-57,115-116's
-// `2 / gt_dict['out_pix_scale']` (rel_reproj_err) formed here instead of by two element-wise launches in front of the pipeline
-// (IEEE division: the float torch's `2 / t` produces)
+// Inlier threshold of pose b in pixels: the scalar; a per-pose value; or (per_pose_divides, lc_pnp_ransac_init5_f32 only) scalar / per-pose
+// value -- test.py:56-57,115-116's `2 / gt_dict['out_pix_scale']` (rel_reproj_err) formed here instead of by two element-wise launches in front
+// of the pipeline (IEEE division: the float torch's `2 / t` produces).  A divisor that is not positive leaves the scalar (an infinite
+// threshold would call every point an inlier).
 __device__ __forceinline__ float threshold_px(const RansacParams& p, int b) {
     if (!p.reproj_err_per_pose) return p.reproj_err;
     const float v = p.reproj_err_per_pose[b];
-    return p.reproj_err > 0.f ? p.reproj_err / v : v;
+    if (!p.per_pose_divides) return v;
+    return v > 0.f ? p.reproj_err / v : p.reproj_err;
 }
 
 __device__ __forceinline__ RowCopy selection_rows(const RansacParams& p) {

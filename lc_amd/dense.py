@@ -55,18 +55,28 @@ def _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample, vis_logits=N
     return (pts2d, inv_std, pts3d, lse) if vis_logits is None else (pts2d, inv_std, pts3d, lse, vis)
 
 
-def _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, shape, top, left, sample, need):
+def _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, shape, top, left, sample, need, xyz_dtype=None):
     lib = _lib.load()
     B, H, W = shape
     (wlogits,), (ws_,), code = _lib.hip_maps(xyz_weight_logits=wlogits)
     m = dict(device=wlogits.device, dtype=wlogits.dtype)  # the gradient of a map in the map's own type (dense)
-    d_xyz = torch.empty(B, 3, H, W, **m) if need[0] else None
+    # an fp32 coordinate map next to 16-bit weight logits (`_head_maps`): its gradient is written in ITS type by a launch of its own --
+    # the kernel writes both gradient maps in one element type, and rounding an fp32 leaf's gradient to fp16 can flush it to zero
+    xyz_apart = need[0] and xyz_dtype is not None and xyz_dtype != wlogits.dtype
+    d_xyz = torch.empty(B, 3, H, W, **m) if need[0] and not xyz_apart else None
     d_wl = torch.empty(B, 2, H, W, **m) if need[1] else None
     d_ws = torch.empty(B, device=wlogits.device, dtype=wscale.dtype) if need[2] else None
     with _lib.on_device(wlogits.device):
-        rc = lib.lc_dense_frontend_bwd2(_lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(lse), _lib.ptr(g_inv_std),
-                                        _lib.ptr(g_pts3d), code, _lib.MAP_DTYPES[wscale.dtype], ws_, B, H, W, top, left, sample, _lib.ptr(d_xyz), _lib.ptr(d_wl), _lib.ptr(d_ws),
-                                        _lib.stream_ptr(wlogits.device))
+        rc = 0
+        if d_xyz is not None or d_wl is not None or d_ws is not None:
+            rc = lib.lc_dense_frontend_bwd2(_lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(lse), _lib.ptr(g_inv_std),
+                                            _lib.ptr(g_pts3d), code, _lib.MAP_DTYPES[wscale.dtype], ws_, B, H, W, top, left, sample, _lib.ptr(d_xyz), _lib.ptr(d_wl), _lib.ptr(d_ws),
+                                            _lib.stream_ptr(wlogits.device))
+        if rc == 0 and xyz_apart:  # no weight gradient asked for: the logits are not read, only the scatter of g_pts3d x noc_scale runs
+            d_xyz = torch.empty(B, 3, H, W, device=wlogits.device, dtype=xyz_dtype)
+            rc = lib.lc_dense_frontend_bwd2(_lib.ptr(wlogits), _lib.ptr(wscale), _lib.ptr(noc_scale), _lib.ptr(lse), None, _lib.ptr(g_pts3d),
+                                            _lib.MAP_DTYPES[xyz_dtype], _lib.MAP_DTYPES[wscale.dtype], ws_, B, H, W, top, left, sample, _lib.ptr(d_xyz), None, None,
+                                            _lib.stream_ptr(wlogits.device))
     _lib.check(rc, "lc_dense_frontend_bwd2")
     return d_xyz, d_wl, d_ws
 
@@ -77,6 +87,7 @@ class _DenseFrontEndFn(torch.autograd.Function):
         pts2d, inv_std, pts3d, lse = _launch_fwd(xyz, wlogits, wscale, noc_scale, top, left, sample)
         ctx.save_for_backward(wlogits, wscale, noc_scale, lse)
         ctx.cfg = (wlogits.shape[0], wlogits.shape[2], wlogits.shape[3], top, left, sample)
+        ctx.xyz_dtype = None if xyz is None else xyz.dtype
         ctx.mark_non_differentiable(pts2d)
         if pts3d is None:  # binary-code heads: no continuous xyz input
             pts3d = wlogits.new_zeros(0)
@@ -92,7 +103,7 @@ class _DenseFrontEndFn(torch.autograd.Function):
             g_pts3d, need[0] = None, False
         g_inv_std = None if g_inv_std is None else g_inv_std.contiguous().to(torch.float32)
         g_pts3d = None if g_pts3d is None else g_pts3d.contiguous().to(torch.float32)
-        d_xyz, d_wl, d_ws = _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, (B, H, W), top, left, sample, need)
+        d_xyz, d_wl, d_ws = _launch_bwd(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, (B, H, W), top, left, sample, need, ctx.xyz_dtype)
         return d_xyz, d_wl, d_ws, None, None, None, None
 
 

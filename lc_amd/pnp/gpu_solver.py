@@ -101,7 +101,7 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
         head = (_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError), _lib.ptr(per_pose),
                 int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask), _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp),
                 _lib.ptr(rows), _lib.ptr(ws), nbytes)
-        if ticketed or select is not None or pose_index_offset:
+        if ticketed or select is not None or pose_index_offset or reproj_divisor is not None:  # (the divisor form of the threshold exists on init5 only)
             name = "lc_pnp_ransac_init5_f32"
             rc = lib.lc_pnp_ransac_init5_f32(*head, int(bool(ticketed)), _lib.ptr(sel_w), _lib.ptr(sel_idx), int(select.get("min_count", 4)) if select else 0,
                                              (int(select.get("seed", 0)) if select else 0) & 0xFFFFFFFF, *(_lib.ptr(sel_out[k]) for k in (0, 1, 2, 4, 3)),  # C order: rows, index, counts

@@ -189,3 +189,31 @@ def test_test_time_path_on_16bit_network_outputs(name, dtype):
     _no_copies(names)
     want = solve_pnp(cfg, {k: (v.float().contiguous() if k in keys else v) for k, v in half.items()}, gt)
     assert list(got) == list(want) and all(torch.equal(got[k], want[k]) for k in got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fp32_coordinate_map_next_to_16bit_logits_keeps_an_fp32_gradient(dtype):
+    """the differentiable front end with an fp32 `xyz_noc` next to 16-bit weight logits.  The coordinate gradient is the
+    scatter of `g_pts3d * noc_scale` -- it does not involve the logits -- so it must come back in fp32 and bit-identical to the all-fp32
+    call, tiny values included (written in fp16 they would flush to zero); the logits' gradient stays in the logits' type."""
+    from lc_amd.dense import dense_front_end
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, H, W, s = 3, 32, 36, 2
+    xyz = torch.randn(B, 3, H, W, generator=g).to(dev)
+    wl = (torch.randn(B, 2, H, W, generator=g) * 2).to(dev)
+    ws = (torch.rand(B, 1, 1, 1, generator=g) + 0.5).to(dev)
+    ns = (torch.rand(B, 3, generator=g) + 0.5).to(dev)
+    cot = (torch.randn(B, (H // s) * (W // s), 3, generator=g) * 1e-9).to(dev)  # far below fp16's smallest subnormal (6e-8)
+    cs = torch.randn(B, (H // s) * (W // s), 2, generator=g).to(dev)
+    grads = {}
+    for name, wl_t in (("mixed", wl.to(dtype)), ("fp32", wl.to(dtype).float())):
+        x, l = xyz.clone().requires_grad_(True), wl_t.clone().requires_grad_(True)
+        _, inv_std, p3 = dense_front_end(x, l, ws, ns, sample=s, top_left=(1, 0))
+        gx, gl = torch.autograd.grad([p3, inv_std], [x, l], [cot, cs])
+        grads[name] = (gx, gl)
+    gx, gl = grads["mixed"]
+    assert gx.dtype == torch.float32 and gl.dtype == dtype
+    assert torch.equal(gx, grads["fp32"][0]) and float(gx.abs().max()) > 0 and float(gx.abs().max()) < 6e-8
+    assert (gl.float() - grads["fp32"][1]).abs().max() <= (8e-3 if dtype == torch.bfloat16 else 1e-3) * grads["fp32"][1].abs().max()

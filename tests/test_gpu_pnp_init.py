@@ -71,3 +71,45 @@ def test_ragged_lists_and_too_few_points():
     assert all(int(inliers[i].max()) < n[i] for i in (0, 2, 3))
     inv1, st1, inl1 = gpu_solver.solve(b["K"][0].to(dev), p3[0], p2[0], reprojectionError=2.0)  # un-batched form
     assert inv1 is False and st1.shape == (7,) and torch.equal(st1, states[0])
+
+
+def test_per_pose_threshold_is_a_threshold_on_the_old_entry_points_and_a_divisor_on_init5_only():
+    """`lc_pnp_ransac_init_f32 .. init4_f32` keep their original meaning -- per-pose values ARE the thresholds, whatever the scalar
+    next to them -- and only `lc_pnp_ransac_init5_f32` reads a positive scalar next to per-pose values as scalar / value (rel_reproj_err,
+    test.py:56-57); a divisor that is not positive leaves the scalar instead of an infinite threshold."""
+    from lc_amd import _lib
+    from lc_amd.pnp import gpu_solver
+
+    dev = torch.device("cuda:0")
+    B, N = 12, 96
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, N, seed=4, outlier_frac=0.2, noise_px=1.0).items()}
+    lib = _lib.load()
+    per = (torch.rand(B, generator=torch.Generator().manual_seed(1)) * 3 + 0.5).to(dev)
+
+    def raw(entry, scalar, per_pose):
+        st, mask = torch.empty(B, 7, device=dev), torch.empty(B, N, device=dev, dtype=torch.uint8)
+        n_in, bad, hyp = (torch.empty(B, device=dev, dtype=torch.int32) for _ in range(3))
+        head = (_lib.ptr(b["K"]), _lib.ptr(b["pts3d"]), _lib.ptr(b["pts2d"]), None, B, N, float(scalar), _lib.ptr(per_pose), 150, 7, _lib.ptr(st), _lib.ptr(mask),
+                _lib.ptr(n_in), _lib.ptr(bad), _lib.ptr(hyp), None, None, 0)
+        with _lib.on_device(dev):
+            if entry == 3:
+                rc = lib.lc_pnp_ransac_init3_f32(*head, _lib.stream_ptr(dev))
+            else:
+                rc = lib.lc_pnp_ransac_init5_f32(*head, 0, None, None, 0, 0, None, None, None, None, None, 0, _lib.stream_ptr(dev))
+        assert rc == 0
+        return st, mask, n_in, hyp
+
+    want = gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], reprojectionError=per, seed=7, refine=False, return_hypothesis=True, split=False)
+    for scalar in (0.0, 2.0):  # the scalar next to per-pose thresholds is ignored by init3
+        st, mask, n_in, hyp = raw(3, scalar, per)
+        assert torch.equal(st, want[0]) and torch.equal(mask.bool(), want[1]) and torch.equal(n_in, want[4]) and torch.equal(hyp, want[3])
+    # init5: 2 / divisor -- equal to the per-pose thresholds 2 / divisor handed to init3; a zero / negative divisor -> the scalar 2
+    div = per.clone()
+    div[3], div[5] = 0.0, -1.0
+    thr = torch.where(div > 0, 2.0 / div, torch.full_like(div, 2.0))
+    a, c = raw(5, 2.0, div), raw(3, 0.0, thr)
+    assert all(torch.equal(x, y) for x, y in zip(a, c))
+    st, inl, bad, hyp, n_in = gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], reprojectionError=2.0, reproj_divisor=div, seed=7, refine=False,
+                                                      return_hypothesis=True, split=False)
+    assert torch.equal(st, a[0]) and torch.equal(n_in, a[2])
+    assert int(a[2][3]) < N  # not "every point is an inlier"
