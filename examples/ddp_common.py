@@ -24,6 +24,12 @@ def init(args):
     """-> (world, rank, device, group or None)."""
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     local = 0 if args.share_gpu else local
+    # The synthetic blobs are built by torch CPU ops every step.  With torch's default of one OpenMP thread per physical core (128 on the
+    # GPU boxes) the pool those ops wake keeps spinning after them and competes with the ONE thread that launches the step's kernels:
+    # a quarter of the dense steps then took 75 ms instead of 16 (profiles/r04/g1: p75 74.5 ms; the stall sits in the forward or the
+    # backward, never in the lc_* launches; profiles/r05/step_stall.txt: 9 of 37 steps slow at 128 threads, 0 of 37 at 4).  A real
+    # data loader runs in worker processes; here the host side is told to stay small.
+    torch.set_num_threads(max(1, min(4, torch.get_num_threads())))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None

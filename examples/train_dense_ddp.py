@@ -150,8 +150,8 @@ def main():
         tail = sorted(times[2:])
         t = tail[len(tail) // 2]
         q = lambda f: tail[min(len(tail) - 1, int(f * len(tail)))] * 1e3  # noqa: E731
-        # (on the shared pool a fraction of the steps carries a ~55-70 ms stall that is also there when the step is a single graph
-        # replay with no host work in it; the quartiles show both modes)
+        # (round 4's summaries showed p75 = 74 ms next to a 16 ms median: the host's 128-thread OpenMP pool, woken by the per-step CPU blob
+        # construction, spinning beside the launch thread -- ddp_common.init now caps it; profiles/r05/step_stall.txt has the A/B)
         print(f"quartiles of the step time [ms]: min {q(0):.1f}  p25 {q(0.25):.1f}  median {q(0.5):.1f}  p75 {q(0.75):.1f}  max {q(1):.1f}")
         print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), {args.dtype} backbone, "
               f"{'binary-code' if args.bin else 'continuous-xyz'} dense head, N=1024 correspondences per sample")

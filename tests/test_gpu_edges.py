@@ -156,7 +156,7 @@ def test_misaligned_pointers_are_rejected():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_half_precision_network_outputs_are_upcast(dtype):
+def test_half_precision_keypoint_tensors_get_gradients_in_their_own_dtype(dtype):
     """bf16 / fp16 heads (mixed-precision training): same loss as fp32 on the rounded values, gradients return in the head's dtype."""
     from lc_amd import synth
     from lc_amd.cov_mixed import Loss_cov_mixed
