@@ -45,7 +45,7 @@ def main(out_dir=os.path.join(ROOT, "gpurun_out")):
             for c in range(C):
                 cnt[b] += pc[b, c]
                 err[b] = (err[b] + pe[b, c]).astype(np.float32)
-        path = os.path.join(out_dir, f"ransac_f32_{name}.npz")
+        path = os.path.join(out_dir, f"kernel_ransac_f32_{name}.npz")
         np.savez_compressed(path, problem_set=np.asarray(f"ransac_{name}.npz"), hyp32=hyp32, hyp64_winner=np.stack([hyp64[b, max(int(hyp[b]), 0)] for b in range(B)]),
                             per_hyp_count=cnt, per_hyp_err_bits=err.view(np.uint32), best_hyp=hyp.astype(np.int32), n_inliers=n_in.astype(np.int32),
                             inlier_mask=inl.astype(np.uint8), invalid=bad.astype(np.uint8), states=st)

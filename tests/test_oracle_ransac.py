@@ -106,10 +106,10 @@ def test_float32_scoring_agrees_with_the_float64_scoring_away_from_the_threshold
 
 
 def test_float32_oracle_reproduces_the_kernel_records():
-    """tests/golden/ransac_f32_*.npz are records of the HIP kernels (gen_golden_ransac_f32.py, taken on an MI355X): their float32 hypotheses, their
+    """tests/golden/kernel_ransac_f32_*.npz are records of the HIP kernels (gen_golden_ransac_f32.py, taken on an MI355X): their float32 hypotheses, their
     per-hypothesis counts and inlier-error bits, their winners, inlier counts, masks and validity flags.  The float32-faithful oracle must
     reproduce every integer and every error bit from the hypotheses alone -- here, on the CPU."""
-    files = sorted(glob.glob(os.path.join(GOLDEN, "ransac_f32_*.npz")))
+    files = sorted(glob.glob(os.path.join(GOLDEN, "kernel_ransac_f32_*.npz")))
     assert len(files) >= 3
     for path in files:
         k = np.load(path)
