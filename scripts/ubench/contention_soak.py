@@ -17,6 +17,7 @@ from lc_amd.config import AttrDict  # noqa: E402
 from lc_amd.inference import GraphedSolvePnP, solve_pnp  # noqa: E402
 
 rounds, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 40), (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+FILLER = sys.argv[3] if len(sys.argv) > 3 else "held-units"  # | matmul | head-backward: a second stream of real work instead of the helper kernel
 so = os.path.join(ROOT, "build", "tests", "liboccupy.so")
 if not os.path.exists(so):
     import subprocess
@@ -50,13 +51,27 @@ def rescues():
 bad = 0
 slow = []
 r0 = rescues()
+if FILLER == "matmul":
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+elif FILLER == "head-backward":
+    from lc_amd.ptnet import spatial_softargmax_2d_std
+    logits = synth.make_head_logits(64, 64, 64, 64, seed=1).to(dev).requires_grad_(True)
 for it in range(rounds):
-    how = ("waves", "lds")[int(torch.randint(0, 2, (1,), generator=g))]
-    free = int(torch.randint(1, 65, (1,), generator=g))
-    ms = float(torch.rand(1, generator=g)) * 40 + 5
-    rc = lib.occupy(2 * (cus - free) if how == "waves" else cus - free, 1024 if how == "waves" else 256, 0 if how == "waves" else 160 * 1024, int(ms * 1e5),
-                    ctypes.c_void_p(side.cuda_stream))
-    assert rc == 0
+    if FILLER == "held-units":
+        how = ("waves", "lds")[int(torch.randint(0, 2, (1,), generator=g))]
+        free = int(torch.randint(1, 65, (1,), generator=g))
+        ms = float(torch.rand(1, generator=g)) * 40 + 5
+        rc = lib.occupy(2 * (cus - free) if how == "waves" else cus - free, 1024 if how == "waves" else 256, 0 if how == "waves" else 160 * 1024, int(ms * 1e5),
+                        ctypes.c_void_p(side.cuda_stream))
+        assert rc == 0
+    else:
+        with torch.cuda.stream(side):
+            for _ in range(30):
+                if FILLER == "matmul":
+                    a @ a
+                else:
+                    m_, s_ = spatial_softargmax_2d_std(logits)
+                    torch.autograd.grad(m_.sum() + s_.sum(), logits)
     t0 = time.perf_counter()
     eager = solve_pnp(cfg, out, gt)["weighted-filtered"]
     replay = solver(out, gt)["weighted-filtered"].clone()
@@ -66,7 +81,7 @@ for it in range(rounds):
     side.synchronize()
 r1 = rescues()
 assert torch.equal(solve_pnp(cfg, out, gt)["weighted-filtered"], want)
-print(f"{rounds} rounds (seed {seed}) of the zlmo chain, eager + replayed, beside a helper holding all but 1..64 compute units for 5..45 ms:")
+print(f"{rounds} rounds (seed {seed}) of the zlmo chain, eager + replayed, beside " + ("a helper holding all but 1..64 compute units for 5..45 ms:" if FILLER == "held-units" else f"a second stream of 30 x {FILLER}:"))
 print(f"results that differ from the undisturbed call: {bad} of {2 * rounds}")
 print(f"units (poses / objects) recomputed by rescue launches: {r1 - r0}")
 print(f"wall clock of a disturbed pair of calls [ms]: median {sorted(slow)[len(slow) // 2]:.1f}, max {max(slow):.1f}  (undisturbed: ~0.3)")
