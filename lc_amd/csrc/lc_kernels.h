@@ -345,7 +345,8 @@ struct SelectParams {
     int square, min_count;
     unsigned seed;
     int pose0;                  // as RansacParams::pose0: the padding draw of row b is that of row pose0 + b
-    void* split_ws;             // launch_dense_frontend_select only, or null: dense_select_split_workspace_bytes(B, N) bytes, zeroed once
+    void* split_ws;             // launch_dense_frontend_select only, or null: dense_select_split_workspace_bytes(B, N) bytes, zeroed once.  Seen by the
+                                // one-workgroup kernel it means "rescue role": only objects whose region is marked are selected (lc_select.hip)
     int split_parts;            // set by the launch: workgroups per object (dense_select_split_parts), 1 = one workgroup per object
 };
 int dense_select_split_parts(int B, int N);  // 1 (rows of up to 4096 candidates / more than 128 objects: the grid would not be resident at once), 2, 4, 8

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void lc_dense_frontend_select_kernel(cons
 // Every value is formed by the expressions of the one-workgroup kernels and every decision is taken on the same integers: outputs bit for bit
 // those of lc_dense_frontend_select_kernel (tests/test_gpu_select.py).  The parts wait for each other, for a bounded time: a part that has
 // waited in vain marks the object's region (lc_common.h: SplitSum's tail) and leaves; the launch is always followed by the one-workgroup
-// kernel in its rescue role (p.split_parts < 0), whose workgroups leave at once unless their object is marked -- then they zero its region
+// kernel in its rescue role (its SelectParams keep split_ws), whose workgroups leave at once unless their object is marked -- then they zero its region
 // and select it themselves, bit for bit what the parts would have written.  The grid is sized to one workgroup per compute unit so that the
 // parts normally do meet; anything else holding compute units costs time, not objects.
 
