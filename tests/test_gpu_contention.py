@@ -87,15 +87,20 @@ def test_split_solve_is_bit_identical_when_its_parts_cannot_all_be_resident(occu
     # room for a quarter of the launch's workgroups only: the others cannot start before the first have given up
     parts = next(p for p in (8, 4, 2) if (B + 7) // 8 * 8 * p <= occupy.cus)  # lc_pnp.hip: pnp_split_parts
     free = max(2, (B * parts) // 4 // 8)  # a free compute unit takes at most 8 of these 256-thread workgroups (32 wave slots)
-    side = occupy(free, 60.0)
-    got = pnp_ceres.solve_device(*args, return_iters=True, split=True)
-    torch.cuda.synchronize()
-    for name, x, y in zip(("states", "result_tr", "rets", "iters"), got, want):
-        assert torch.equal(x, y), name
-    assert int(got[2].max()) <= 1, "the internal 'a part never arrived' status never leaves the launch pair"
-    _, dirty, resc = _tail(ws, B, PNP_POSE_BYTES)
-    assert int(dirty.sum()) == 0, "the rescue launch leaves every region clean"
-    rescued = int((resc - resc0).sum())
+    rescued = 0
+    for attempt in range(4):  # (the helper and the launch under test race for the dispatcher: if the launch got in first, once more)
+        side = occupy(free, 60.0)
+        got = pnp_ceres.solve_device(*args, return_iters=True, split=True)
+        torch.cuda.synchronize()
+        for name, x, y in zip(("states", "result_tr", "rets", "iters"), got, want):
+            assert torch.equal(x, y), (name, attempt)
+        assert int(got[2].max()) <= 1, "the internal 'a part never arrived' status never leaves the launch pair"
+        _, dirty, resc = _tail(ws, B, PNP_POSE_BYTES)
+        assert int(dirty.sum()) == 0, "the rescue launch leaves every region clean"
+        rescued = int((resc - resc0).sum())
+        if rescued > 0:
+            break
+        side.synchronize()
     print(f"B={B} N={N}: {rescued} of {B} poses solved by the rescue launch while {occupy.cus - free} compute units were held")
     assert rescued > 0, "the contention did not bite: the test does not exercise the rescue path"
     # and the workspace is good for the next launch, which meets again (no rescue)
@@ -135,20 +140,26 @@ def test_split_selection_is_bit_identical_when_its_parts_cannot_all_be_resident(
     torch.cuda.synchronize()
     work = splitws.get("select", torch.device(DEV), _lib.load().lc_dense_frontend_select_workspace_bytes(B, H, W, 0, 0, 1), True)
     _, _, resc0 = _tail(work, B, SEL_POSE_BYTES)
-    side = occupy(2, 100.0, "lds")  # two compute units left: never the four parts of an object at once
-    got = dense_front_end_select(xyz, wl, ws_, ns, vl, mode, split=True, **kw)
-    torch.cuda.synchronize()
     cnt = want[3]
-    assert torch.equal(got[3], cnt)
     live = torch.arange(want[0].shape[1], device=DEV)[None, :] < cnt[:, None]
-    for x, y in zip(got, want):
-        if x.dim() >= 2:
-            m = live if x.dim() == 2 else live[..., None].expand_as(x)
-            assert torch.equal(x[m], y[m])
-    _, dirty, resc = _tail(work, B, SEL_POSE_BYTES)
-    rescued = int((resc - resc0).sum())
+    rescued = 0
+    for attempt in range(4):  # (the helper and the launch under test race for the dispatcher: if the launch got in first, once more)
+        side = occupy(2, 100.0, "lds")  # two compute units left: never the four parts of an object at once
+        got = dense_front_end_select(xyz, wl, ws_, ns, vl, mode, split=True, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(got[3], cnt)
+        for x, y in zip(got, want):
+            if x.dim() >= 2:
+                m = live if x.dim() == 2 else live[..., None].expand_as(x)
+                assert torch.equal(x[m], y[m])
+        _, dirty, resc = _tail(work, B, SEL_POSE_BYTES)
+        assert int(dirty.sum()) == 0
+        rescued = int((resc - resc0).sum())
+        if rescued > 0:
+            break
+        side.synchronize()
     print(f"{mode}: {rescued} of {B} objects selected by the rescue launch")
-    assert int(dirty.sum()) == 0 and rescued > 0
+    assert rescued > 0
     side.synchronize()
     again = dense_front_end_select(xyz, wl, ws_, ns, vl, mode, split=True, **kw)
     torch.cuda.synchronize()
