@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Soak of the claim "the RANSAC's integer outputs are exact for EVERY pose": random batches (poses, row length, ragged counts, noise, gross outlier
+"""(Lives under tests/ like fuzz_parity.py: it uses the oracle as its checker, which only tests may import.)
+Soak of the claim "the RANSAC's integer outputs are exact for EVERY pose": random batches (poses, row length, ragged counts, noise, gross outlier
 share, iterations, per-pose thresholds), both launch forms, every checked pose against oracle/p3p_ransac_oracle.py: ransac_f32 on the kernel's
 own float32 hypotheses -- winner, inlier count, inlier mask, validity, per-hypothesis counts and the bits of the per-hypothesis inlier error.
-    python scripts/ubench/ransac_exact_soak.py [batches=60] [seed=1]      (on the MI355X; ~3 min)"""
+    python tests/soak_ransac_exact.py [batches=60] [seed=1]      (on the MI355X; ~3 min)"""
 import os
 import sys
 import time
@@ -10,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lc_amd import synth  # noqa: E402
 from lc_amd.pnp import gpu_solver  # noqa: E402
