@@ -57,6 +57,13 @@ def test_split_solve_fits_one_workgroup_per_compute_unit(res):
     for d in _find(res, "lc_pnp_lm_split_kernel"):
         assert d.get("private_segment_fixed_size", 0) == 0, (d["name"], "scratch")
         assert d["vgpr_count"] <= 512 and d.get("group_segment_fixed_size", 0) <= 8 * 1024, d["name"]
+    # the rescue launch behind it (round 5): it must be startable while the chip is held by others -- one 256-thread workgroup per pose, no scratch,
+    # a few KB of LDS; and the scoring kernels of the RANSAC, whose division-free form must not have cost them their occupancy
+    for d in _find(res, "lc_pnp_lm_split_rescue_kernel"):
+        assert d.get("private_segment_fixed_size", 0) == 0 and d["vgpr_count"] <= 512 and d.get("group_segment_fixed_size", 0) <= 8 * 1024, d["name"]
+    for name in ("lc_ransac_score_kernel", "lc_ransac_score_live_kernel", "lc_ransac_score_wide_kernel"):
+        for d in _find(res, name):
+            assert d.get("private_segment_fixed_size", 0) == 0 and d["waves_per_simd_by_registers"] >= 4, d["name"]
 
 
 def test_head_kernels_keep_their_occupancy(res):
