@@ -99,6 +99,33 @@ def _check_hypotheses_against_float64_p3p(K, X, U, counts, thr_px, iterations, s
     return checked
 
 
+def _check_all_hypotheses_against_float64_p3p(K, X, U, counts, seed, views, poses):
+    """EVERY hypothesis of the given poses, not only the winner: a pose the kernel formed is one of the independent float64 P3P's solutions of
+    the same three correspondences (within 1e-6), and where the kernel formed none the float64 P3P has no solution in front of the camera for
+    the fourth point either.  -> (hypotheses with a pose, of which matched, hypotheses without a pose, of which confirmed)."""
+    hyp64 = views[0]
+    have = matched = none = confirmed = 0
+    for b in poses:
+        n = int(counts[b])
+        un, _ = O.normalised_points_f32(K[b], U[b, :n].astype(np.float32))
+        un = un.astype(np.float64)
+        Xb = X[b].astype(np.float64)
+        for h in range(hyp64.shape[1]):
+            idx = O.sample_indices(seed, b, h, n)
+            yb = np.concatenate((un[idx[:3]], np.ones((3, 1))), 1)
+            yb /= np.linalg.norm(yb, axis=1, keepdims=True)
+            sols = O.p3p_grunert(yb, Xb[idx[:3]])
+            Rk, tk = hyp64[b, h, :9].reshape(3, 3), hyp64[b, h, 9:]
+            if not Rk.any():  # the kernel's "no usable solution" marker (R = 0, t = (0, 0, -1))
+                none += 1
+                confirmed += not any((R @ Xb[idx[3]] + t)[2] > 0 for R, t in sols)
+            else:
+                have += 1
+                gap = min((np.abs(R - Rk).max() + np.abs(t - tk).max() / max(1.0, np.abs(tk).max()) for R, t in sols), default=np.inf)
+                matched += gap < 1e-6
+    return have, matched, none, confirmed
+
+
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[7:-4] for p in FILES])
 def test_ransac_integers_equal_the_float32_oracle_on_the_fixtures(path):
     z = np.load(path)
@@ -111,6 +138,11 @@ def test_ransac_integers_equal_the_float32_oracle_on_the_fixtures(path):
     _check_exact(K, X, U, counts, thr_px, single, views, "single launch")
     _check_partials(counts, views, res, os.path.basename(path))
     assert _check_hypotheses_against_float64_p3p(K, X, U, counts, thr_px, iters, seed, views, res) >= 1
+    # what the exact comparison takes as given -- the hypotheses -- held against the independent float64 P3P one by one (two poses per fixture)
+    poses = [b for b in range(len(K)) if counts[b] >= 4][:2]
+    have, matched, none, confirmed = _check_all_hypotheses_against_float64_p3p(K, X, U, counts, seed, views, poses)
+    print(f"{os.path.basename(path)}: {matched} of {have} kernel hypotheses are float64 P3P solutions of their sample (1e-6); {confirmed} of {none} 'no solution' confirmed")
+    assert have > 100 and matched >= 0.995 * have and confirmed >= 0.9 * none
 
 
 @pytest.mark.parametrize("B,N,noise,outl,iters", [(6, 16, 0.5, 0.1, 150), (12, 16, 0.0, 0.0, 150), (4, 3300, 0.4, 0.25, 150), (3, 16384, 0.3, 0.3, 150),
