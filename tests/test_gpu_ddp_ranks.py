@@ -1,4 +1,5 @@
-"""Two-rank DistributedDataParallel steps on the REAL kernels (both ranks on the one GPU of the test box, collectives over gloo):
+"""Two- and EIGHT-rank DistributedDataParallel steps on the REAL kernels (all ranks on the one GPU of the test box, collectives over gloo; eight is
+the rank count of BASELINE configs[3] / [4], whose 8-GPU form cannot be run from here):
 examples/train_sparse_ddp.py and examples/train_dense_ddp.py against the single-process run on the concatenated crops.
 
 What a sharded job must preserve (reference: train.py:57-67 is one process; lib/utils/grad.py:19-30,66-68 takes the clipping norm
@@ -28,31 +29,35 @@ def _port():
         return s.getsockname()[1]
 
 
-def _run(script, extra, dump, ranks):
+def _run(script, extra, dump, ranks, emulate=2):
     common = [os.path.join(ROOT, "examples", script), "--steps", str(STEPS), "--batch", "4", "--width", "16", "--bn-eval", "--dump", dump, *extra]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     if ranks > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(_port()), *common, "--backend", "gloo", "--share-gpu"]
     else:
-        cmd = [sys.executable, *common, "--emulate-ranks", "2"]
+        cmd = [sys.executable, *common, "--emulate-ranks", str(emulate)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     return [torch.load(f"{dump}.rank{r}.pt") for r in range(ranks)]
 
 
-@pytest.mark.parametrize("script,extra", [("train_sparse_ddp.py", ["--sparse-cnt", "16", "--fp32"]),
-                                          ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3"])], ids=["sparse", "dense"])
-def test_two_ranks_match_the_single_process_run(tmp_path, script, extra):
-    r0, r1 = _run(script, extra, str(tmp_path / "two"), 2)
-    (one,) = _run(script, extra, str(tmp_path / "one"), 1)
+@pytest.mark.parametrize("script,extra,world", [("train_sparse_ddp.py", ["--sparse-cnt", "16", "--fp32"], 2),
+                                                ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3"], 2),
+                                                ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3"], 8),
+                                                ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3", "--bin"], 8)],
+                         ids=["sparse-2", "dense-2", "dense-8", "binary-code-8"])
+def test_ranks_match_the_single_process_run(tmp_path, script, extra, world):
+    ranks = _run(script, extra, str(tmp_path / "many"), world)
+    (one,) = _run(script, extra, str(tmp_path / "one"), 1, emulate=world)
+    r0, r1 = ranks[0], ranks[-1]
     # (i)
-    for d in (r0, r1, one):
+    for d in (*ranks, one):
         assert len(d["losses"]) == STEPS and all(map(lambda v: v == v and abs(v) < 1e9, d["losses"]))
-    # (ii) bit for bit
-    assert torch.equal(r0["params"], r1["params"])
+    # (ii) bit for bit, every rank
+    assert all(torch.equal(r0["params"], r["params"]) for r in ranks[1:])
     # (iii)
-    assert r0["clip_states"] == r1["clip_states"]
+    assert all(r0["clip_states"] == r["clip_states"] for r in ranks[1:])
     if "dense" in script:
         assert any(v > 0 for v in r0["final_clip"].values())  # the hooks ran
     for a, b in zip(r0["clip_states"], one["clip_states"]):
@@ -60,7 +65,7 @@ def test_two_ranks_match_the_single_process_run(tmp_path, script, extra):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
     # (iv)
-    job = [(x + y) / 2 for x, y in zip(r0["losses"], r1["losses"])]
+    job = [sum(r["losses"][i] for r in ranks) / world for i in range(STEPS)]
     for x, y in zip(job, one["losses"]):
         assert abs(x - y) <= 2e-3 * max(abs(y), 1.0), (job, one["losses"])
     # Adam normalises every gradient entry, so round-off in a near-zero entry moves its weight by up to lr per step in either run:
