@@ -31,10 +31,10 @@ DENSE_CFG = dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scal
 # NormClipper's max_norm (lib/utils/grad.py:19-30), so each record is also a >= 3-call trajectory of that buffer.
 TRAIN_KINDS = {
     "dense_glmo": ([0, 1249, 2498, 2499, 3000], 2500, 0),   # the epoch term wins: full step 2500; factors 4e-4, 0.5, 0.9996, 1, 1
-    # full step 3000; factors 0.5, 3.3e-4, 1 -- deliberately not monotonic: the first call sets max_norm from a mid-ramp gradient, the
+    # full step 3000; factors 0.5, 3.3e-4, 1 (the plateau: no blend with the weight-segmentation term) -- deliberately not monotonic: the first call sets max_norm from a mid-ramp gradient, the
     # second is NOT clipped (norm far below max_norm), the third is clipped with an unsaturated EMA update, whereas dense_glmo's natural
     # order starts from a near-zero factor and then grows max_norm by the saturated 1.189 per call -- both branches of grad.py:19-30
-    "bin_zlmo": ([1499, 0, 2999], 1000, 21),
+    "bin_zlmo": ([1499, 0, 3000], 1000, 21),
     "sparse_metric": ([0, 1999, 3999, 4500], 1500, 0),      # full step 4000; factors 2.5e-4, 0.5, 1, 1
 }
 
