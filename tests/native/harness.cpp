@@ -179,6 +179,61 @@ int main(int argc, char** argv) {
         for (int i = 1; i < hc[0]; ++i) EXPECT(hidx[i] > hidx[i - 1]);
         std::printf("select: counts %d %d %d %d\n", hc[0], hc[1], hc[2], hc[3]);
     }
+    if (all || std::string(which) == "split") {
+        // Few poses x thousands of correspondences (the test-time solves behind the dense heads): what a C caller does for lc_pnp_lm3_f32 --
+        // ask for the workspace size, zero the workspace ONCE, keep it for the following calls on the stream -- and what it gets: the
+        // one-workgroup solve's poses (up to the order of the fp64 sums), flags 0 / 1 only, the same answer call after call (include/lc_amd.h)
+        const int Bs = 8, Ns = 2304;
+        std::vector<float> K2(Bs * 9), X2(Bs * Ns * 3), U2(Bs * Ns * 2), S2(Bs * Ns * 2), st0(Bs * 7);
+        for (int b = 0; b < Bs; ++b) {
+            for (int i = 0; i < 9; ++i) K2[b * 9 + i] = K[i];
+            const float* p = &pose[(b % B) * 7];
+            for (int i = 0; i < 7; ++i) st0[b * 7 + i] = p[i];
+            st0[b * 7 + 6] *= 1.03f;
+            float q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            float R[9] = {1 - 2 * (q2 * q2 + q3 * q3), 2 * (q1 * q2 - q3 * q0), 2 * (q1 * q3 + q2 * q0),
+                          2 * (q1 * q2 + q3 * q0), 1 - 2 * (q1 * q1 + q3 * q3), 2 * (q2 * q3 - q1 * q0),
+                          2 * (q1 * q3 - q2 * q0), 2 * (q2 * q3 + q1 * q0), 1 - 2 * (q1 * q1 + q2 * q2)};
+            for (int n = 0; n < Ns; ++n) {
+                float* x = &X2[((size_t)b * Ns + n) * 3];
+                for (int d = 0; d < 3; ++d) x[d] = 40 * rnd();
+                float c[3];
+                for (int d = 0; d < 3; ++d) c[d] = R[3 * d] * x[0] + R[3 * d + 1] * x[1] + R[3 * d + 2] * x[2] + p[4 + d];
+                U2[((size_t)b * Ns + n) * 2] = 250 * c[0] / c[2] + 32 + rnd();
+                U2[((size_t)b * Ns + n) * 2 + 1] = 250 * c[1] / c[2] + 32 + rnd();
+                S2[((size_t)b * Ns + n) * 2] = 1 + 0.5f * rnd();
+                S2[((size_t)b * Ns + n) * 2 + 1] = 1 + 0.5f * rnd();
+            }
+        }
+        float *dK2 = to_dev(K2), *dX2 = to_dev(X2), *dU2 = to_dev(U2), *dS2 = to_dev(S2), *dSt0 = to_dev(st0);
+        float *stA, *stB, *trA, *trB; int *retA, *retB, *itA, *itB;
+        CK(hipMalloc(&stA, Bs * 28)); CK(hipMalloc(&stB, Bs * 28)); CK(hipMalloc(&trA, Bs * 4)); CK(hipMalloc(&trB, Bs * 4));
+        CK(hipMalloc(&retA, Bs * 4)); CK(hipMalloc(&retB, Bs * 4)); CK(hipMalloc(&itA, Bs * 4)); CK(hipMalloc(&itB, Bs * 4));
+        const size_t need = lc_pnp_lm_workspace_bytes(Bs, Ns);
+        EXPECT(need > 0 && lc_pnp_lm_workspace_bytes(Bs, 64) == 0);  // this shape takes several workgroups per pose; the metric's shape does not
+        void* ws = nullptr;
+        CK(hipMalloc(&ws, need ? need : 128));
+        CK(hipMemset(ws, 0, need ? need : 128));  // once
+        int rc1 = lc_pnp_lm2_f32(dK2, dX2, dU2, nullptr, dS2, nullptr, nullptr, dSt0, stA, trA, retA, itA, Bs, Ns, 50, 1e-6f, 0, 0, nullptr);
+        std::vector<float> a(Bs * 7), b2(Bs * 7); std::vector<int> ra(Bs), rb(Bs), ia(Bs), ib(Bs);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(a.data(), stA, Bs * 28, hipMemcpyDeviceToHost)); CK(hipMemcpy(ra.data(), retA, Bs * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ia.data(), itA, Bs * 4, hipMemcpyDeviceToHost));
+        EXPECT(rc1 == 0);
+        for (int rep = 0; rep < 3; ++rep) {
+            int rc = lc_pnp_lm3_f32(dK2, dX2, dU2, nullptr, dS2, nullptr, nullptr, dSt0, stB, trB, retB, itB, Bs, Ns, 50, 1e-6f, 0, 0, ws, need, nullptr);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(b2.data(), stB, Bs * 28, hipMemcpyDeviceToHost)); CK(hipMemcpy(rb.data(), retB, Bs * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ib.data(), itB, Bs * 4, hipMemcpyDeviceToHost));
+            EXPECT(rc == 0);
+            for (int b = 0; b < Bs; ++b) {
+                EXPECT(rb[b] == ra[b] && rb[b] == 0 && ib[b] == ia[b]);
+                for (int i = 0; i < 7; ++i) EXPECT(std::fabs(b2[b * 7 + i] - a[b * 7 + i]) <= 2e-6f * (i < 4 ? 1.f : 1000.f));
+            }
+        }
+        // a workspace that is too small or misaligned is refused with a message, nothing is launched
+        EXPECT(lc_pnp_lm3_f32(dK2, dX2, dU2, nullptr, dS2, nullptr, nullptr, dSt0, stB, trB, retB, itB, Bs, Ns, 50, 1e-6f, 0, 0, ws, need - 1, nullptr) != 0);
+        EXPECT(lc_pnp_lm3_f32(dK2, dX2, dU2, nullptr, dS2, nullptr, nullptr, dSt0, stB, trB, retB, itB, Bs, Ns, 50, 1e-6f, 0, 0, (char*)ws + 8, need, nullptr) != 0);
+        std::printf("split: %zu workspace bytes for %d poses x %d points, iterations %d %d %d ...\n", need, Bs, Ns, ib[0], ib[1], ib[2]);
+    }
     std::printf("harness done, %d check(s) failed\n", g_failed);
     return g_failed;
 }
