@@ -165,7 +165,8 @@ def dense_front_end_select(xyz_noc: Tensor, xyz_weight_logits: Tensor, xyz_weigh
     returns -- (pts2d, weights, pts3d, counts, index), bit for bit.  xyz_noc = None: the selection alone -- pts3d comes back unwritten, for the
     caller to fill from `index` / `counts` (binary-code heads: `floatbits.decode_selected_rows`, which decodes the selected pixels only).
     split (default: on unless `splitws.no_split()` / LC_AMD_PNP_SPLIT=0): rows of more than 4096 candidates of at most 128 objects are selected by
-    several workgroups per object (`lc_dense_frontend_select3` + workspace) -- the same outputs bit for bit."""
+    several workgroups per object (`lc_dense_frontend_select3` + workspace) -- the same outputs bit for bit, also when something else holds compute units
+    (the one-workgroup kernel behind the split launch selects again whatever object's workgroups did not all meet)."""
     lib = _lib.load()
     top, left = top_left
     B, _, H, W = xyz_weight_logits.shape

@@ -54,7 +54,8 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     weight_mask (B,N) uint8/bool in place of sqrtL: unit information where set; shared_poses = P > 0: cam_mat and start have P rows
     and pose b of the B = k P correspondence sets reads row b % P (several selections of the same objects in one launch).
     split (default: on, LC_AMD_PNP_SPLIT=0 turns it off): batches of at most 128 poses with rows wider than 2048 are solved by several
-    workgroups per pose (`lc_pnp_lm3_f32`) -- the same solve up to the order of the fp64 sums."""
+    workgroups per pose (`lc_pnp_lm3_f32`) -- the same solve up to the order of the fp64 sums.  The result never depends on whether those
+    workgroups got to run together: a rescue launch behind the split launch re-solves, bit for bit, whatever did not meet (include/lc_amd.h)."""
     lib = _lib.load()
     K = _lib.require_hip_f32("cam_mat", cam_mat)
     X = _lib.require_hip_f32("pts3d", pts3d)
