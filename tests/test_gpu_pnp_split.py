@@ -172,3 +172,29 @@ def test_split_solve_soak_over_random_shapes():
         assert torch.equal(one[2], many[2]) and torch.equal(one[3], many[3]), (case, B, N)
         np.testing.assert_allclose(many[0].cpu().numpy(), one[0].cpu().numpy(), rtol=0, atol=2e-6, err_msg=str((case, B, N)))
     assert tried >= 30
+
+
+def test_owned_workspaces_are_sized_from_the_device_and_a_rejected_one_warns():
+    """`GraphedSolvePnP` sized its split workspaces from constants for a 256-CU device and `splitws.get` silently fell back when an owned
+    workspace did not fit.  Now `max_bytes` follows the device's compute units, devices are compared by index (torch.device('cuda') is the current
+    device), and a rejected owned workspace warns before the fallback -- which still solves correctly."""
+    import warnings
+
+    from lc_amd import splitws
+
+    dev = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert splitws.max_bytes("pnp", dev) == (cus // 2) * POSE_BYTES and splitws.max_bytes("select") == (cus // 2) * splitws.SELECT_POSE_BYTES
+    B, N = 16, 2500
+    b = _batch(B, N, seed=3)
+    args = (b["K"], b["pts3d"], b["pts2d"], b["inv_std"], b["start"])
+    want = pnp_ceres.solve_device(*args, split=True)
+    big = torch.zeros(splitws.max_bytes("pnp", dev), device=torch.device("cuda"), dtype=torch.uint8)  # no index: still this device
+    with splitws.owned(pnp=big), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = pnp_ceres.solve_device(*args, split=True)
+    assert all(torch.equal(x, y) for x, y in zip(got, want)) and int(big.view(torch.int32).view(-1, POSE_BYTES // 4)[:B, -32].min()) > 0  # the owned one was used
+    small = torch.zeros(B * POSE_BYTES - 128, device=dev, dtype=torch.uint8)
+    with splitws.owned(pnp=small), pytest.warns(RuntimeWarning, match="does not serve"):
+        got = pnp_ceres.solve_device(*args, split=True)
+    assert all(torch.equal(x, y) for x, y in zip(got, want)) and int(small.sum()) == 0  # ... and the small one was not touched
