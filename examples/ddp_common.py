@@ -72,4 +72,5 @@ def dump(args, rank, model, loss_fn, losses, clip_states, params_at_start=None):
         return
     flat = flat_params(model)
     torch.save({"params": flat, "params_at_start": params_at_start, "losses": losses, "clip_states": clip_states,
-                "final_clip": {k: float(v) for k, v in loss_fn.state_dict().items() if k.endswith("max_norm")}}, f"{args.dump}.rank{rank}.pt")
+                "final_clip": {k: float(v) for k, v in loss_fn.state_dict().items() if k.endswith("max_norm")},
+                "loss_state": {k: v.detach().cpu() for k, v in loss_fn.state_dict().items()}}, f"{args.dump}.rank{rank}.pt")

@@ -128,18 +128,38 @@ class Loss_xyz_bin(nn.Module):
     """`losses.py:196-216`: per-bit weighted BCE on the code logits with an EMA histogram of per-bit Hamming errors
     (`histogram` buffer: rides in the checkpoint as `loss_fn.xyz_bin_loss_fn.histogram`)."""
 
-    def __init__(self, total_bit_cnt: int, momentum=0.05) -> None:
+    def __init__(self, total_bit_cnt: int, momentum=0.05, group=None) -> None:
         super().__init__()
         self.register_buffer("histogram", torch.full((total_bit_cnt,), 0.5))
         self.momentum = momentum
+        self.group = group  # the batch is sharded over this process group: the histogram is the WHOLE batch's (SURVEY.md 8e, collective 4)
+
+    def _sharded(self) -> bool:
+        import torch.distributed as dist
+
+        return self.group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def forward(self, noc_xyz_bin_logits: Tensor, noc_xyz_bin_gt: Tensor, msk_vis_logits: Tensor):
-        if dense_aux.fused_path_ok(noc_xyz_bin_logits, msk_vis_logits, self.histogram) and self.histogram.numel() <= 128:
+        sharded = self._sharded()
+        if not sharded and dense_aux.fused_path_ok(noc_xyz_bin_logits, msk_vis_logits, self.histogram) and self.histogram.numel() <= 128:
             # one pass over the logits instead of ~12 (lc_amd/csrc/lc_dense_aux.hip); the histogram buffer is updated in place
             return dense_aux.xyz_bin_loss(noc_xyz_bin_logits, noc_xyz_bin_gt, msk_vis_logits, self.histogram, self.momentum)
+        if sharded and noc_xyz_bin_logits.dtype in (torch.float16, torch.bfloat16):  # 16-bit heads: the fused kernel computes in fp32, so does this route
+            noc_xyz_bin_logits, msk_vis_logits = noc_xyz_bin_logits.float(), msk_vis_logits.float()
         msk_hard = msk_vis_logits > 0
         hamm = (noc_xyz_bin_logits > 0).logical_xor(noc_xyz_bin_gt.to(torch.bool)).logical_and(msk_hard)
-        hist = hamm.sum([0, 2, 3]) / (msk_hard.sum() + 1)
+        if sharded:
+            # The reference is one process: its histogram update (losses.py:203-208) sees the Hamming errors and the visible pixels of the whole
+            # batch.  Per-rank updates would let the checkpointed buffer -- and with it the bit weights and the gradient -- depend on the GPU
+            # count, so the C error counts and the pixel count are all-reduced (one vector of C + 1 floats: integers below 2^24, exact) and
+            # every rank applies the single process' update.  (The loss itself stays the rank's mean: DDP averages the ranks.)
+            import torch.distributed as dist
+
+            counts = torch.cat((hamm.sum([0, 2, 3]).float(), msk_hard.sum().float().reshape(1)))
+            dist.all_reduce(counts, group=self.group)
+            hist = counts[:-1] / (counts[-1] + 1)
+        else:
+            hist = hamm.sum([0, 2, 3]) / (msk_hard.sum() + 1)
         self.histogram.mul_(1 - self.momentum).add_(hist * self.momentum)
         hist_soft = torch.minimum(self.histogram, 0.51 - self.histogram)
         bin_weights = (hist_soft * 3).softmax(dim=-1)
@@ -188,7 +208,7 @@ def pose_loss_factor(cfg, step, steps_per_epoch) -> float:
 class Loss_fn(nn.Module):
     """Drop-in for `losses.Loss_fn` (`losses.py:239-386`): `forward(gt_dict, out_dict, epoch, step, steps_per_epoch)`
     -> `(loss_dict, w_loss_dict)`.  `group`: optional process group; when the batch is sharded over ranks the
-    NormClippers all-reduce their squared norm over it; `shard_loss_scale`: lc_amd/grad.py (1 / world_size under
+    NormClippers all-reduce their squared norm over it and `Loss_xyz_bin` the error counts of its histogram (collectives 2 and 4); `shard_loss_scale`: lc_amd/grad.py (1 / world_size under
     DistributedDataParallel)."""
 
     def __init__(self, cfg, cfg_global, total_bit_cnt=0, group=None, shard_loss_scale=1.0) -> None:
@@ -201,7 +221,7 @@ class Loss_fn(nn.Module):
         self.pts_grad_clipper = NormClipper(rel_thresh=2, **kw) if pose_cfg.get("clip_pts_grad", False) else None
         self.cfg_global = cfg_global
         if total_bit_cnt > 0:
-            self.xyz_bin_loss_fn = Loss_xyz_bin(total_bit_cnt)
+            self.xyz_bin_loss_fn = Loss_xyz_bin(total_bit_cnt, group=group)
         seg_loss_type = cfg.get("seg_loss_type", "BCE")
         self.seg_loss_type = seg_loss_type.lower()
         if seg_loss_type.lower() == "bce":

@@ -165,3 +165,65 @@ def test_bench_timing_aggregation_two_ranks():
 
     one = lcd.aggregate_regions([0.3, 0.1, 0.2], steps=100)
     assert one["ranks_seen"] == 1 and one["backend"] == "none" and abs(one["ms_per_step"] - 2.0) < 1e-12
+
+
+def _bin_inputs(B, C=9, H=12, W=10):
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(B, C, H, W, generator=g, dtype=torch.float64) * 2
+    bits = (logits > 0) ^ (torch.rand(B, C, H, W, generator=g) < 0.25)
+    vis = torch.randn(B, 1, H, W, generator=g, dtype=torch.float64)
+    return logits, bits, vis
+
+
+def _bin_worker(rank, world, port, B, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lc_amd import dist as lcd
+        from lc_amd.losses import Loss_xyz_bin
+
+        logits, bits, vis = _bin_inputs(B)
+        lo, hi = lcd.shard_range(B, rank, world)
+        fn = Loss_xyz_bin(logits.shape[1], group=dist.group.WORLD).double()
+        hists, losses, grads = [], [], []
+        for step in range(3):
+            x = (logits[lo:hi] * (1 + 0.3 * step)).clone().requires_grad_(True)
+            loss = fn(x, bits[lo:hi], vis[lo:hi])
+            loss.backward()
+            hists.append(fn.histogram.clone().numpy())
+            losses.append(float(loss))
+            grads.append(x.grad.clone().numpy())
+        ret[rank] = (hists, losses, grads, (lo, hi))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_code_histogram_under_sharding_is_the_single_process_histogram():
+    """SURVEY.md 8(e), collective 4: `Loss_xyz_bin.histogram` (losses.py:203-208, a checkpointed EMA of per-bit Hamming errors over the visible
+    pixels of the WHOLE batch).  Two ranks with three of six samples each, three steps: the buffer on every rank equals the single process' on the
+    concatenated batch, the mean of the ranks' losses is the single process' loss, and each rank's gradient x 1/world (what DDP's averaging makes
+    of it) is its slice of the single process' gradient -- the bit weights come from the shared histogram."""
+    B, world = 6, 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_bin_worker, args=(r, world, port, B, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    from lc_amd.losses import Loss_xyz_bin
+
+    logits, bits, vis = _bin_inputs(B)
+    fn = Loss_xyz_bin(logits.shape[1]).double()
+    for step in range(3):
+        x = (logits * (1 + 0.3 * step)).clone().requires_grad_(True)
+        loss = fn(x, bits, vis)
+        loss.backward()
+        for r in range(world):
+            hists, losses, grads, (lo, hi) = ret[r]
+            np.testing.assert_allclose(hists[step], fn.histogram.numpy(), rtol=0, atol=1e-12)
+            np.testing.assert_allclose(grads[step] / world, x.grad[lo:hi].numpy(), rtol=1e-9, atol=1e-15)
+        assert abs(sum(ret[r][1][step] for r in range(world)) / world - float(loss)) <= 1e-12
+    assert float(np.abs(ret[0][0][-1] - 0.5).max()) > 1e-3  # the EMA moved

@@ -8,6 +8,7 @@ over the whole batch and keeps it in a checkpointed buffer):
   (ii)  identical parameters on both ranks after the steps (DDP's all-reduced gradients);
   (iii) NormClipper.max_norm equal on both ranks AND equal to the single-process run on the concatenated batch -- the squared norm
         is all-reduced and scaled to the job's mean loss (`shard_loss_scale`), so the buffer does not depend on the GPU count;
+  (iii') the ZebraPose code histogram (`Loss_xyz_bin.histogram`, also checkpointed) likewise: error and pixel counts all-reduced (SURVEY.md 8e, 4);
   (iv)  the job's loss (mean over ranks) and parameters follow the single-process run (batch-norm statistics frozen: per-rank batch
         statistics are the one thing a sharded step cannot share without SyncBN)."""
 import os
@@ -64,6 +65,10 @@ def test_ranks_match_the_single_process_run(tmp_path, script, extra, world):
         assert a.keys() == b.keys()
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
+    if "--bin" in extra:  # the code histogram (losses.py:203-208, a checkpointed buffer): the whole batch's on every rank, i.e. the single process'
+        h = [r["loss_state"]["xyz_bin_loss_fn.histogram"] for r in ranks]
+        assert all(torch.equal(h[0], x) for x in h[1:]) and float((h[0] - 0.5).abs().max()) > 1e-3
+        assert (h[0] - one["loss_state"]["xyz_bin_loss_fn.histogram"]).abs().max() <= 1e-6
     # (iv)
     job = [sum(r["losses"][i] for r in ranks) / world for i in range(STEPS)]
     for x, y in zip(job, one["losses"]):
