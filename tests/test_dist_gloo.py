@@ -225,5 +225,7 @@ def test_code_histogram_under_sharding_is_the_single_process_histogram():
             hists, losses, grads, (lo, hi) = ret[r]
             np.testing.assert_allclose(hists[step], fn.histogram.numpy(), rtol=0, atol=1e-12)
             np.testing.assert_allclose(grads[step] / world, x.grad[lo:hi].numpy(), rtol=1e-9, atol=1e-15)
-        assert abs(sum(ret[r][1][step] for r in range(world)) / world - float(loss)) <= 1e-12
+        # (torch's BCE on float64 logits against float32 targets is itself only good to ~2e-8 between a batch and its halves: the reference formula's
+        # own arithmetic, measured here without any sharding)
+        assert abs(sum(ret[r][1][step] for r in range(world)) / world - float(loss)) <= 1e-7
     assert float(np.abs(ret[0][0][-1] - 0.5).max()) > 1e-3  # the EMA moved
