@@ -90,13 +90,14 @@ def main():
     ap.add_argument("--bin", action="store_true", help="ZebraPose binary-code head (zlmo/zycbv) instead of the continuous xyz head")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--graphs", action="store_true", help="replay the Loss_fn step as hipGraphs (one per sub-sampling phase; eager inside the warm-up ramp)")
-    ap.add_argument("--np-seed", type=int, default=None, help="seed of the sub-sampling phase draws (losses.py:152); default: the rank")
+    ap.add_argument("--np-seed", type=int, default=0, help="seed of the sub-sampling phase draws (losses.py:152), the SAME on every rank: the reference's one "
+                    "process draws one (top, left) phase per step for the whole batch, so the ranks of a sharded step must draw the same one")
     ddp_common.add_args(ap)
     args = ap.parse_args()
     world, rank, dev, group = ddp_common.init(args)
     local = dev.index
     torch.manual_seed(0)
-    np.random.seed(rank if args.np_seed is None else args.np_seed)
+    np.random.seed(args.np_seed)
     model = DenseNet(sum(BITS) if args.bin else 3, args.width).to(dev).to(memory_format=torch.channels_last)
     cfg = AttrDict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True, clip_scale_grad=True, clip_pts_grad=not args.bin, dense_sample=2,
                                       max_err_len=32), pose_loss_start_step=4, pose_loss_start_epoch=0, loss_pose_nz_step=0,
