@@ -109,6 +109,10 @@ def main():
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    report = None
+    if args.report_comm and world > 1:
+        report = ddp_common.CommReport(world, rank, group, args.backend)
+        report.attach(net)
     if args.bn_eval:
         ddp_common.freeze_bn(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -120,6 +124,8 @@ def main():
                                      for r in ddp_common.data_ranks(args, world, rank)])
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
+        if report is not None:
+            report.begin_step()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
             logits = net(blob["rgb_in"].contiguous(memory_format=torch.channels_last))
         out = sparse_head(logits)  # fused HIP head (ptnet.py:59-66) on the bf16 logits as they are: fp32 statistics, bf16 gradient
@@ -137,6 +143,8 @@ def main():
         opt.step()
         torch.cuda.synchronize(dev)
         times.append(time.perf_counter() - t0)
+        if report is not None:
+            report.end_step(times[-1] * 1e3)
         losses.append(float(loss))
         clip_states.append({k: float(v) for k, v in loss_fn.state_dict().items() if k.endswith("max_norm")})
         if rank == 0:
@@ -151,6 +159,8 @@ def main():
         print(f"quartiles of the step time [ms]: min {q(0):.1f}  p25 {q(0.25):.1f}  median {q(0.5):.1f}  p75 {q(0.75):.1f}  max {q(1):.1f}")
         print(f"median step {t * 1e3:.1f} ms -> {args.batch * world / t:.0f} crops/s on {world} GPU(s), bf16 backbone, fp32/fp64 LC loss")
     ddp_common.dump(args, rank, model, loss_fn, losses, clip_states, params_at_start)
+    if report is not None:
+        report.finish(f"{args.dump}.comm.json" if args.dump else None)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -515,6 +515,20 @@ int lc_dense_aux_bwd2(const void *xyz, const unsigned char *msk_noc_u8, const fl
 int lc_xyz_bin_loss_fwd2(const void *logits, const unsigned char *gt_bits, const void *msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride, int B,
                          int C, int HW, float momentum, float *histogram, float *loss, float *bin_weights, double *partials,
                          unsigned *ticket, void *stream);
+/* Loss_xyz_bin when the batch is SHARDED over ranks (collective 4): the reference is one process, so its histogram update
+ * (losses.py:203-208) sees the whole batch's Hamming errors and visible pixels.  The one-launch forward above splits in two around the
+ * caller's all-reduce, the same streaming pass and the same closing arithmetic (one device function), so a world of one gives the bits of
+ * lc_xyz_bin_loss_fwd2:
+ *   lc_xyz_bin_loss_counts: the pass over this rank's logits; counts (C + 1 64-bit integers, 8-byte aligned) <- per-bit errors inside the hard
+ *     mask, then the mask's population; bce_mean (C) <- this rank's per-bit BCE means (stay on the device).  partials / ticket as above.
+ *   -- the caller sums `counts` over the ranks (integers: exact at any batch size) --
+ *   lc_xyz_bin_loss_finish: histogram (C, read and updated in place) from the summed counts, bin_weights (C), loss (1) = this rank's loss.
+ * Backward: lc_xyz_bin_loss_bwd2 with those bin_weights. */
+int lc_xyz_bin_loss_counts(const void *logits, const unsigned char *gt_bits, const void *msk_vis_logits, int map_dtype, long long logits_bstride,
+                           long long vis_bstride, int B, int C, int HW, long long *counts, float *bce_mean, double *partials, unsigned *ticket,
+                           void *stream);
+int lc_xyz_bin_loss_finish(const long long *counts, const float *bce_mean, int C, float momentum, float *histogram, float *loss,
+                           float *bin_weights, void *stream);
 /* The NormClipper pair (lc_sqnorm_f32, lc_norm_clip_apply_f32) on a gradient of any map type: the hooks sit on the heads' outputs
  * (losses.py:343-352), so under mixed precision the gradient they clip is 16-bit; read and written in place of a cast each way. */
 int lc_sqnorm(const void *x, int dtype, long long n, double *partials, unsigned *ticket, float *sq, int accumulate,

@@ -93,6 +93,8 @@ _SIGNATURES = {
     "lc_dense_aux_fwd2": (c_int, [c_void_p] * 7 + [c_int] + [ctypes.c_longlong] * 3 + [c_int] * 3 + [c_void_p] * 4),
     "lc_dense_aux_bwd2": (c_int, [c_void_p] * 7 + [c_int] + [ctypes.c_longlong] * 3 + [c_int] * 3 + [c_void_p] * 7),
     "lc_xyz_bin_loss_fwd2": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong, ctypes.c_longlong] + [c_int] * 3 + [c_float] + [c_void_p] * 6),
+    "lc_xyz_bin_loss_counts": (c_int, [c_void_p] * 3 + [c_int, ctypes.c_longlong, ctypes.c_longlong] + [c_int] * 3 + [c_void_p] * 5),
+    "lc_xyz_bin_loss_finish": (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 4),
     "lc_xyz_bin_loss_bwd2": (c_int, [c_void_p] * 5 + [c_int, ctypes.c_longlong, ctypes.c_longlong] + [c_int] * 3 + [c_void_p] * 2),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -860,9 +860,9 @@ int lc_dense_aux_bwd_f32(const float* xyz, const unsigned char* msk_noc_u8, cons
     return lc_dense_aux_bwd2(xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, 0 /* LC_F32 */, 0, 0, 0, B, HW, seg_type, g_noc, g_seg, g_wseg, d_xyz, d_seg, d_wlogits, stream);
 }
 
-int lc_xyz_bin_loss_fwd2(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride, int B, int C, int HW,
-                            float momentum, float* histogram, float* loss, float* bin_weights, double* partials, unsigned* ticket,
-                            void* stream) {
+static int xyz_bin_fwd_common(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride,
+                              int B, int C, int HW, float momentum, float* histogram, float* loss, float* bin_weights, long long* counts, float* bce_mean,
+                              double* partials, unsigned* ticket, void* stream) {
     if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
     if (logits_bstride < 0 || vis_bstride < 0) return fail(1, "negative batch stride");
     if ((logits_bstride && logits_bstride < (long long)C * HW) || (vis_bstride && vis_bstride < HW)) return fail(1, "batch stride smaller than a sample");
@@ -871,11 +871,44 @@ int lc_xyz_bin_loss_fwd2(const void* logits, const unsigned char* gt_bits, const
     if (C > lc::kBinMaxChannels) return fail(1, "more than 128 code bits");
     if ((long long)B * C * HW >= (1ll << 31)) return fail(1, "logits of 2^31 elements or more");
     if (B == 0) return 0;
-    if (!logits || !gt_bits || !msk_vis_logits || !histogram || !loss || !bin_weights || !partials || !ticket) return fail(1, "null pointer");
+    if (!logits || !gt_bits || !msk_vis_logits || !partials || !ticket) return fail(1, "null pointer");
+    if (counts ? !bce_mean : (!histogram || !loss || !bin_weights)) return fail(1, "null pointer");
     LC_REQUIRE_ALIGNED(8, partials);
+    if (counts) LC_REQUIRE_ALIGNED(8, counts);
     const int vec = HW % 4 == 0 && ((logits_bstride | vis_bstride) & 3) == 0 && !misaligned(map_dtype ? 8 : 16, logits, msk_vis_logits) && !misaligned(4, gt_bits);
-    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, histogram, momentum, loss, bin_weights, partials, ticket, nullptr, nullptr, B, C, HW, vec, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * HW, vis_bstride ? vis_bstride : 1ll * HW};
+    lc::BinLossParams p{};
+    p.logits = logits; p.gt_bits = gt_bits; p.msk_vis_logits = msk_vis_logits;
+    p.histogram = histogram; p.momentum = momentum; p.loss = loss; p.bin_weights = bin_weights;
+    p.partials = partials; p.ticket = ticket; p.counts_out = counts; p.bce_mean = bce_mean;
+    p.B = B; p.C = C; p.HW = HW; p.vec = vec; p.map_dtype = map_dtype;
+    p.logits_bs = logits_bstride ? logits_bstride : (long long)C * HW;
+    p.vis_bs = vis_bstride ? vis_bstride : 1ll * HW;
     return lc::launch_xyz_bin_loss_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss launch failed") : 0;
+}
+
+int lc_xyz_bin_loss_fwd2(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride, int B, int C, int HW,
+                            float momentum, float* histogram, float* loss, float* bin_weights, double* partials, unsigned* ticket,
+                            void* stream) {
+    return xyz_bin_fwd_common(logits, gt_bits, msk_vis_logits, map_dtype, logits_bstride, vis_bstride, B, C, HW, momentum, histogram, loss, bin_weights, nullptr, nullptr,
+                              partials, ticket, stream);
+}
+
+int lc_xyz_bin_loss_counts(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride, int B, int C,
+                           int HW, long long* counts, float* bce_mean, double* partials, unsigned* ticket, void* stream) {
+    if (!counts) return fail(1, "null pointer");
+    return xyz_bin_fwd_common(logits, gt_bits, msk_vis_logits, map_dtype, logits_bstride, vis_bstride, B, C, HW, 0.f, nullptr, nullptr, nullptr, counts, bce_mean, partials,
+                              ticket, stream);
+}
+
+int lc_xyz_bin_loss_finish(const long long* counts, const float* bce_mean, int C, float momentum, float* histogram, float* loss, float* bin_weights, void* stream) {
+    if (C <= 0) return fail(1, "bad size");
+    if (C > lc::kBinMaxChannels) return fail(1, "more than 128 code bits");
+    if (!counts || !bce_mean || !histogram || !loss || !bin_weights) return fail(1, "null pointer");
+    LC_REQUIRE_ALIGNED(8, counts);
+    lc::BinLossParams p{};
+    p.counts_in = counts; p.bce_mean = const_cast<float*>(bce_mean); p.C = C; p.momentum = momentum;
+    p.histogram = histogram; p.loss = loss; p.bin_weights = bin_weights;
+    return lc::launch_xyz_bin_loss_finish(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss finish launch failed") : 0;
 }
 
 int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, int B, int C, int HW,
@@ -895,7 +928,11 @@ int lc_xyz_bin_loss_bwd2(const void* logits, const unsigned char* gt_bits, const
     if (B == 0) return 0;
     if (!logits || !gt_bits || !msk_vis_logits || !bin_weights || !g_loss || !d_logits) return fail(1, "null pointer");
     const int vec = HW % 4 == 0 && ((logits_bstride | vis_bstride) & 3) == 0 && !misaligned(map_dtype ? 8 : 16, logits, msk_vis_logits, d_logits) && !misaligned(4, gt_bits);
-    lc::BinLossParams p{logits, gt_bits, msk_vis_logits, nullptr, 0.f, nullptr, const_cast<float*>(bin_weights), nullptr, nullptr, g_loss, d_logits, B, C, HW, vec, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * HW, vis_bstride ? vis_bstride : 1ll * HW};
+    lc::BinLossParams p{};
+    p.logits = logits; p.gt_bits = gt_bits; p.msk_vis_logits = msk_vis_logits; p.bin_weights = const_cast<float*>(bin_weights);
+    p.g_loss = g_loss; p.d_logits = d_logits; p.B = B; p.C = C; p.HW = HW; p.vec = vec; p.map_dtype = map_dtype;
+    p.logits_bs = logits_bstride ? logits_bstride : (long long)C * HW;
+    p.vis_bs = vis_bstride ? vis_bstride : 1ll * HW;
     return lc::launch_xyz_bin_loss_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss backward launch failed") : 0;
 }
 

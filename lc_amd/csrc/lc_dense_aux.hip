@@ -245,6 +245,43 @@ constexpr int kBinThreads = 1024;  // of 1024 threads each: every workgroup ends
 // to ~1e-7 absolute on log1p(e), e in (0, 1] -- terms of a MEAN of order 0.1-1 that is compared at 1e-6
 __device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - __logf(1.f + __expf(-fabsf(z)))); }
 
+// The end of Loss_xyz_bin.forward from the per-bit error counts (losses.py:205-213), shared by the one-launch kernel (its last workgroup)
+// and by the weights-in kernel of the sharded form, so that both give the same bits: histogram EMA in place, soft histogram, softmax
+// over the C <= 128 bits, the weighted sum of the per-bit BCE means parked in `ws`.  Called by every thread of the workgroup
+// (blockDim >= C); hamm / ws hold C valid entries and are visible (a barrier has been passed).
+__device__ __forceinline__ void bin_loss_finish(const BinLossParams& p, const long long* hamm, long long vis_total, float* zs, float* ws, int tid) {
+    __shared__ float es[kBinMaxChannels];
+    if (tid < p.C) {
+        // losses.py:205-208 in the reference's fp32 operation order (integer tensors divide as float32)
+        const float hist = (float)hamm[tid] / (float)(vis_total + 1);
+        float h = p.histogram[tid];
+        h = h * (1.f - p.momentum);
+        h = h + hist * p.momentum;
+        p.histogram[tid] = h;
+        zs[tid] = fminf(h, 0.51f - h) * 3.f;
+    }
+    __syncthreads();
+    // one thread per bit for the exponentials, sums in index order (every thread forms them for itself from LDS): the one-thread
+    // version cost ~3 us of serial expf at the very end of the launch
+    float m = -INFINITY;
+    for (int ch = 0; ch < p.C; ++ch) m = fmaxf(m, zs[ch]);
+    if (tid < p.C) es[tid] = expf(zs[tid] - m);
+    __syncthreads();
+    float sum = 0.f;
+    for (int ch = 0; ch < p.C; ++ch) sum += es[ch];
+    if (tid < p.C) {
+        const float w = es[tid] / sum;
+        p.bin_weights[tid] = w;
+        ws[tid] *= w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float loss = 0.f;
+        for (int ch = 0; ch < p.C; ++ch) loss += ws[ch];
+        *p.loss = loss;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const BinLossParams p) {
     const T* const logits = static_cast<const T*>(p.logits);
@@ -317,6 +354,8 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
     const int tid = threadIdx.x;
     __shared__ double stage[32][2][kBinChunks];
     __shared__ double vis_part[kBinChunks];
+    __shared__ long long hamm_s[kBinMaxChannels];
+    __shared__ long long vis_s;
     if (tid < chunks) vis_part[tid] = xcd_load(p.partials + 3 * tid + 2);  // channel 0's chunks
     for (int g0 = 0; g0 < p.C; g0 += 32) {
         for (int v = tid; v < 32 * 2 * chunks; v += kBinThreads) {
@@ -328,39 +367,32 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
             const int ch = g0 + tid;
             double hamm = 0, bce = 0, vis_total = 0;
             for (int k = 0; k < chunks; ++k) { hamm += stage[tid][0][k]; bce += stage[tid][1][k]; vis_total += vis_part[k]; }
-            // losses.py:205-210 in the reference's fp32 operation order
-            const float hist = (float)(long long)hamm / (float)((long long)vis_total + 1);
-            float h = p.histogram[ch];
-            h = h * (1.f - p.momentum);
-            h = h + hist * p.momentum;
-            p.histogram[ch] = h;
-            zs[ch] = fminf(h, 0.51f - h) * 3.f;
+            hamm_s[ch] = (long long)hamm;  // integers below 2^53: exact
+            if (ch == 0) vis_s = (long long)vis_total;
             ws[ch] = (float)(bce / (double)n);  // loss_raw.mean([0, 2, 3]) of this bit, parked until the weights exist
         }
         __syncthreads();
     }
     __syncthreads();
-    // softmax over the C <= 128 bits and the weighted sum: one thread per bit for the exponentials, sums in index order (every
-    // thread forms them for itself from LDS): the one-thread version cost ~3 us of serial expf at the very end of the launch
-    __shared__ float es[kBinMaxChannels];
-    float m = -INFINITY;
-    for (int ch = 0; ch < p.C; ++ch) m = fmaxf(m, zs[ch]);
-    if (tid < p.C) es[tid] = expf(zs[tid] - m);
-    __syncthreads();
-    float sum = 0.f;
-    for (int ch = 0; ch < p.C; ++ch) sum += es[ch];
-    if (tid < p.C) {
-        const float w = es[tid] / sum;
-        p.bin_weights[tid] = w;
-        ws[tid] *= w;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float loss = 0.f;
-        for (int ch = 0; ch < p.C; ++ch) loss += ws[ch];
-        *p.loss = loss;
+    if (p.counts_out) {
+        // counts-out form (the batch is sharded over ranks): this rank's C error counts + its visible-pixel count leave as 64-bit integers
+        // for the all-reduce, the rank's per-bit BCE means wait in `bce_mean` for lc_xyz_bin_loss_finish_kernel
+        if (tid < p.C) { p.counts_out[tid] = hamm_s[tid]; p.bce_mean[tid] = ws[tid]; }
+        if (tid == 0) p.counts_out[p.C] = vis_s;
+    } else {
+        bin_loss_finish(p, hamm_s, vis_s, zs, ws, tid);
     }
     arrival_reset(p.ticket, tid);
+}
+
+// weights-in half of the sharded form: the all-reduced counts -> histogram EMA, bit weights, this rank's loss (one small workgroup)
+__global__ __launch_bounds__(kBinMaxChannels) void lc_xyz_bin_loss_finish_kernel(const BinLossParams p) {
+    __shared__ float zs[kBinMaxChannels], ws[kBinMaxChannels];
+    __shared__ long long hamm_s[kBinMaxChannels];
+    const int tid = threadIdx.x;
+    if (tid < p.C) { hamm_s[tid] = p.counts_in[tid]; ws[tid] = p.bce_mean[tid]; }
+    __syncthreads();
+    bin_loss_finish(p, hamm_s, p.counts_in[p.C], zs, ws, tid);
 }
 
 template <typename T>
@@ -464,6 +496,13 @@ int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream) {
     q.chunks = (int)std::min<long long>(kBinChunks, std::max<long long>(1, (req + 4 * kBinThreads - 1) / (4 * kBinThreads)));
     q.chunks = std::min(q.chunks, std::max(1, 512 / q.C));  // one round of workgroups: two of 1024 threads fit a compute unit
     LC_MAP_DISPATCH(q.map_dtype, hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel<T>, dim3(q.C * q.chunks), dim3(kBinThreads), 0, stream, q));
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_xyz_bin_loss_finish(const BinLossParams& p, hipStream_t stream) {
+    if (p.C <= 0) return 0;
+    if (p.C > kBinMaxChannels) return 3;
+    hipLaunchKernelGGL(lc_xyz_bin_loss_finish_kernel, dim3(1), dim3(kBinMaxChannels), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -281,6 +281,11 @@ struct BinLossParams {
     float* bin_weights;             // (C) out (forward), in (backward)
     double* partials;               // (C * 32, 3) workspace (forward)
     unsigned* ticket;               // kArrivalWords (lc_common.h), zero between launches (forward)
+    // sharded form (the batch is split over ranks, the histogram is the whole batch's): forward with counts_out != null stops after the
+    // counts; the caller all-reduces them; launch_xyz_bin_loss_finish takes counts_in and does the rest
+    long long* counts_out;          // (C + 1) out: per-bit Hamming errors inside the hard visibility mask, then the mask's population
+    const long long* counts_in;     // (C + 1) in (finish)
+    float* bce_mean;                // (C) this rank's per-bit BCE means: out of the counts launch, in to the finish launch
     const float* g_loss;            // device scalar (backward)
     void* d_logits;                 // (B,C,HW) (backward), element type map_dtype
     int B, C, HW;
@@ -290,6 +295,7 @@ struct BinLossParams {
     long long logits_bs, vis_bs;    // elements between consecutive samples of logits / msk_vis_logits (channel slices in place); d_logits dense
 };
 int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream);  // 3: more than kBinMaxChannels bits
+int launch_xyz_bin_loss_finish(const BinLossParams& p, hipStream_t stream);  // reads counts_in, bce_mean, histogram; writes histogram, bin_weights, loss
 int launch_xyz_bin_loss_bwd(const BinLossParams& p, hipStream_t stream);
 
 constexpr int kClipMaxBlocks = 512;  // length of the caller-provided `partials` workspace of lc_sqnorm_f32

@@ -103,7 +103,7 @@ def dense_aux_losses(xyz_noc: Tensor, msk_noc: Tensor, xyz_noc_tgt: Tensor, msk_
 
 class _XyzBinLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, gt_bits, msk_vis_logits, histogram, momentum: float):
+    def forward(ctx, logits, gt_bits, msk_vis_logits, histogram, momentum: float, group=None):
         lib = _lib.load()
         B, C = logits.shape[:2]
         HW = logits.numel() // (B * C)
@@ -119,10 +119,27 @@ class _XyzBinLoss(torch.autograd.Function):
         if partials.numel() < C * 32 * 3:
             raise ValueError("Loss_xyz_bin: more than 128 code bits")
         P = _lib.ptr
-        with _lib.on_device(dev):
-            rc = lib.lc_xyz_bin_loss_fwd2(P(x), P(t), P(v), code, ls, vs, B, C, HW, float(momentum), P(histogram), P(loss), P(weights), P(partials),
-                                          P(ticket), _lib.stream_ptr(dev))
-        _lib.check(rc, "lc_xyz_bin_loss_fwd2")
+        if group is None:
+            with _lib.on_device(dev):
+                rc = lib.lc_xyz_bin_loss_fwd2(P(x), P(t), P(v), code, ls, vs, B, C, HW, float(momentum), P(histogram), P(loss), P(weights), P(partials),
+                                              P(ticket), _lib.stream_ptr(dev))
+            _lib.check(rc, "lc_xyz_bin_loss_fwd2")
+        else:
+            # The batch is sharded over `group`: the same pass stops after the counts, the C + 1 integers are summed over the ranks (int64: exact
+            # at any batch size, as the reference's integer sums are -- losses.py:203-204), and a one-workgroup launch closes with the arithmetic
+            # the one-launch kernel ends with.  Two launches + one latency-sized all-reduce instead of ~15 element-wise torch launches.
+            import torch.distributed as dist
+
+            counts = torch.empty(C + 1, device=dev, dtype=torch.int64)
+            bce_mean = torch.empty(C, device=dev, dtype=torch.float32)
+            with _lib.on_device(dev):
+                rc = lib.lc_xyz_bin_loss_counts(P(x), P(t), P(v), code, ls, vs, B, C, HW, P(counts), P(bce_mean), P(partials), P(ticket),
+                                                _lib.stream_ptr(dev))
+            _lib.check(rc, "lc_xyz_bin_loss_counts")
+            dist.all_reduce(counts, group=group)
+            with _lib.on_device(dev):
+                rc = lib.lc_xyz_bin_loss_finish(P(counts), P(bce_mean), C, float(momentum), P(histogram), P(loss), P(weights), _lib.stream_ptr(dev))
+            _lib.check(rc, "lc_xyz_bin_loss_finish")
         ctx.map_args = (code, ls, vs)
         ctx.save_for_backward(x, t, v, weights)
         ctx.shape = logits.shape
@@ -141,9 +158,11 @@ class _XyzBinLoss(torch.autograd.Function):
         with _lib.on_device(x.device):
             rc = lib.lc_xyz_bin_loss_bwd2(P(x), P(t), P(v), P(weights), P(g), code, ls, vs, B, C, HW, P(d), _lib.stream_ptr(x.device))
         _lib.check(rc, "lc_xyz_bin_loss_bwd2")
-        return d.view(ctx.shape), None, None, None, None
+        return d.view(ctx.shape), None, None, None, None, None
 
 
-def xyz_bin_loss(noc_xyz_bin_logits: Tensor, noc_xyz_bin_gt: Tensor, msk_vis_logits: Tensor, histogram: Tensor, momentum: float) -> Tensor:
-    """`Loss_xyz_bin.forward` (`losses.py:196-216`) as one launch each way; `histogram` (the module's buffer) is updated in place."""
-    return _XyzBinLoss.apply(noc_xyz_bin_logits, noc_xyz_bin_gt, msk_vis_logits, histogram, momentum)
+def xyz_bin_loss(noc_xyz_bin_logits: Tensor, noc_xyz_bin_gt: Tensor, msk_vis_logits: Tensor, histogram: Tensor, momentum: float, group=None) -> Tensor:
+    """`Loss_xyz_bin.forward` (`losses.py:196-216`) as one launch each way; `histogram` (the module's buffer) is updated in place.
+    `group`: the batch is sharded over this process group -- the histogram update takes the whole batch's counts (counts launch, int64
+    all-reduce, finish launch); the returned loss is this rank's (DistributedDataParallel averages the ranks)."""
+    return _XyzBinLoss.apply(noc_xyz_bin_logits, noc_xyz_bin_gt, msk_vis_logits, histogram, momentum, group)

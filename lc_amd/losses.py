@@ -32,6 +32,12 @@ from .dense import dense_front_end
 from .grad import NormClipper
 from .kpt import kpt_nll_mean
 
+# A/B switch for profiles only (scripts/bench_xyz_bin_routes.py): LC_AMD_XYZ_BIN_TORCH=1 sends HIP maps through the torch formulas of
+# Loss_xyz_bin, the route a sharded job took up to round 5
+import os as _os
+
+_TORCH_SHARDED_ROUTE = _os.environ.get("LC_AMD_XYZ_BIN_TORCH") == "1"
+
 
 def _reference_losses():
     """The reference's own `losses` module, for the label-preparation names this package does not rebuild."""
@@ -137,33 +143,36 @@ class Loss_xyz_bin(nn.Module):
     def _sharded(self) -> bool:
         import torch.distributed as dist
 
-        return self.group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        # a group of one rank takes the sharded form too (its all-reduce is the identity): the same launches whatever the GPU count
+        return self.group is not None and dist.is_available() and dist.is_initialized()
 
     def forward(self, noc_xyz_bin_logits: Tensor, noc_xyz_bin_gt: Tensor, msk_vis_logits: Tensor):
         sharded = self._sharded()
-        if not sharded and dense_aux.fused_path_ok(noc_xyz_bin_logits, msk_vis_logits, self.histogram) and self.histogram.numel() <= 128:
-            # one pass over the logits instead of ~12 (lc_amd/csrc/lc_dense_aux.hip); the histogram buffer is updated in place
-            return dense_aux.xyz_bin_loss(noc_xyz_bin_logits, noc_xyz_bin_gt, msk_vis_logits, self.histogram, self.momentum)
-        if sharded and noc_xyz_bin_logits.dtype in (torch.float16, torch.bfloat16):  # 16-bit heads: the fused kernel computes in fp32, so does this route
-            noc_xyz_bin_logits, msk_vis_logits = noc_xyz_bin_logits.float(), msk_vis_logits.float()
-        msk_hard = msk_vis_logits > 0
+        if dense_aux.fused_path_ok(noc_xyz_bin_logits, msk_vis_logits, self.histogram) and self.histogram.numel() <= 128 and not _TORCH_SHARDED_ROUTE:
+            # one pass over the logits instead of ~12 (lc_amd/csrc/lc_dense_aux.hip); the histogram buffer is updated in place.  Sharded: the same
+            # pass, split around the all-reduce of the C + 1 counts -- the same kernels and numerics for every map type and GPU count
+            return dense_aux.xyz_bin_loss(noc_xyz_bin_logits, noc_xyz_bin_gt, msk_vis_logits, self.histogram, self.momentum,
+                                          group=self.group if sharded else None)
+        # the reference's torch formulas (maps that are not HIP tensors: the world-size-2 gloo tests on the CPU)
+        msk_hard = msk_vis_logits > 0  # the comparisons need no up-cast of a 16-bit map
         hamm = (noc_xyz_bin_logits > 0).logical_xor(noc_xyz_bin_gt.to(torch.bool)).logical_and(msk_hard)
+        counts = torch.cat((hamm.sum([0, 2, 3]), msk_hard.sum().reshape(1)))  # int64, like the reference's sums
         if sharded:
             # The reference is one process: its histogram update (losses.py:203-208) sees the Hamming errors and the visible pixels of the whole
             # batch.  Per-rank updates would let the checkpointed buffer -- and with it the bit weights and the gradient -- depend on the GPU
-            # count, so the C error counts and the pixel count are all-reduced (one vector of C + 1 floats: integers below 2^24, exact) and
-            # every rank applies the single process' update.  (The loss itself stays the rank's mean: DDP averages the ranks.)
+            # count, so the C error counts and the pixel count are all-reduced as integers (exact at any batch size) and every rank applies the
+            # single process' update.  (The loss itself stays the rank's mean: DDP averages the ranks.)
             import torch.distributed as dist
 
-            counts = torch.cat((hamm.sum([0, 2, 3]).float(), msk_hard.sum().float().reshape(1)))
             dist.all_reduce(counts, group=self.group)
-            hist = counts[:-1] / (counts[-1] + 1)
-        else:
-            hist = hamm.sum([0, 2, 3]) / (msk_hard.sum() + 1)
+        hist = counts[:-1] / (counts[-1] + 1)
         self.histogram.mul_(1 - self.momentum).add_(hist * self.momentum)
         hist_soft = torch.minimum(self.histogram, 0.51 - self.histogram)
         bin_weights = (hist_soft * 3).softmax(dim=-1)
-        loss_raw = F.binary_cross_entropy_with_logits(noc_xyz_bin_logits * msk_hard, noc_xyz_bin_gt.float(), reduction="none")
+        masked = noc_xyz_bin_logits * msk_hard
+        if masked.dtype in (torch.float16, torch.bfloat16):  # 16-bit heads: the BCE in fp32, as the fused kernel computes it
+            masked = masked.float()
+        loss_raw = F.binary_cross_entropy_with_logits(masked, noc_xyz_bin_gt.to(masked.dtype), reduction="none")
         return (loss_raw.mean([0, 2, 3]) * bin_weights).sum(-1).mean()
 
 
