@@ -46,8 +46,9 @@ def _run(script, extra, dump, ranks, emulate=2):
 @pytest.mark.parametrize("script,extra,world", [("train_sparse_ddp.py", ["--sparse-cnt", "16", "--fp32"], 2),
                                                 ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3"], 2),
                                                 ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3"], 8),
-                                                ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3", "--bin"], 8)],
-                         ids=["sparse-2", "dense-2", "dense-8", "binary-code-8"])
+                                                ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3", "--bin"], 8),
+                                                ("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3", "--zlmo", "--batch", "2"], 8)],
+                         ids=["sparse-2", "dense-2", "dense-8", "binary-code-8", "zlmo-shape-8"])
 def test_ranks_match_the_single_process_run(tmp_path, script, extra, world):
     ranks = _run(script, extra, str(tmp_path / "many"), world)
     (one,) = _run(script, extra, str(tmp_path / "one"), 1, emulate=world)
@@ -65,7 +66,7 @@ def test_ranks_match_the_single_process_run(tmp_path, script, extra, world):
         assert a.keys() == b.keys()
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
-    if "--bin" in extra:  # the code histogram (losses.py:203-208, a checkpointed buffer): the whole batch's on every rank, i.e. the single process'
+    if "--bin" in extra or "--zlmo" in extra:  # the code histogram (losses.py:203-208, a checkpointed buffer): the whole batch's on every rank, i.e. the single process'
         h = [r["loss_state"]["xyz_bin_loss_fn.histogram"] for r in ranks]
         assert all(torch.equal(h[0], x) for x in h[1:]) and float((h[0] - 0.5).abs().max()) > 1e-3
         assert (h[0] - one["loss_state"]["xyz_bin_loss_fn.histogram"]).abs().max() <= 1e-6

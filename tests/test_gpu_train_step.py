@@ -22,15 +22,21 @@ def test_example_train_step_runs(extra):
 
 
 @pytest.mark.parametrize("extra", [[], ["--bin"], ["--dtype", "bf16"], ["--dtype", "bf16", "--bin"], ["--dtype", "bf16", "--graphs"],
-                                   ["--dtype", "bf16", "--width", "64", "--batch", "8", "--steps", "5"]],
-                         ids=["xyz-fp16", "binary-code-fp16", "xyz-bf16", "binary-code-bf16", "xyz-bf16-graphed-loss", "xyz-bf16-resnet34-width"])
+                                   ["--dtype", "bf16", "--width", "64", "--batch", "8", "--steps", "5"],
+                                   ["--zlmo"], ["--zlmo", "--graphs", "--steps", "14"], ["--zlmo", "--width", "64", "--batch", "8", "--steps", "5"]],
+                         ids=["xyz-fp16", "binary-code-fp16", "xyz-bf16", "binary-code-bf16", "xyz-bf16-graphed-loss", "xyz-bf16-resnet34-width",
+                              "binary-code-fp16-zlmo-shape", "binary-code-fp16-zlmo-shape-graphed-loss", "binary-code-fp16-zlmo-shape-resnet34-width"])
 def test_example_dense_train_step_runs(extra):
-    """BASELINE configs[2]/[4] plumbing: dense heads (continuous xyz / ZebraPose codes), fp16 (GradScaler) or bf16 autocast backbone,
-    clippers; Loss_fn eager or replayed as hipGraphs; the last case runs the ResNet-34-width backbone (64-128-256-512 channels) in bf16."""
+    """BASELINE configs[2]/[4]: dense heads (continuous xyz / ZebraPose codes), fp16 (GradScaler) or bf16 autocast backbone,
+    clippers; Loss_fn eager or replayed as hipGraphs; `resnet34-width` runs the 64-128-256-512-channel backbone in bf16.
+    `zlmo-shape`: configs/zlmo.yaml's own step -- output-stride-8 dilated trunk + atrous pyramid (examples/os8_trunk.py), 128x128 maps, 7+7+7
+    code planes, dense_sample 3 => N = 1849, fp16 + GradScaler, zlmo.yaml:74-83's loss block; graphed: one hipGraph per sub-sampling phase (nine)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_dense_ddp.py"), "--steps", "6", "--batch", "4", "--width", "16"]
                          + extra, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "median step" in out.stdout and "nan" not in out.stdout.lower()
+    if "--zlmo" in extra:
+        assert "os8 trunk, 128x128 maps, binary-code (21 planes) dense head, N=1849 correspondences per sample" in out.stdout
 
 
 @pytest.mark.parametrize("kind", ["sparse", "dense", "bin"])

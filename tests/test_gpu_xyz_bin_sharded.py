@@ -103,7 +103,8 @@ def _worker(rank, world, port, shape, dt, ret):
         fn = Loss_xyz_bin(C, group=dist.group.WORLD).to(dev)
         hists, losses, grads = [], [], []
         for step in range(3):
-            x = (logits[lo:hi] * (1 + 0.3 * step)).clone().requires_grad_(True)
+            # (scaled as the whole batch, then sliced: torch's fp16 `tensor * python float` rounds a few elements differently for another tensor size)
+            x = (logits * (1 + 0.3 * step))[lo:hi].clone().requires_grad_(True)
             loss = fn(x, bits[lo:hi], vis[lo:hi])
             (loss * SCALE).backward()
             hists.append(fn.histogram.cpu().numpy().copy())
