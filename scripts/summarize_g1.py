@@ -42,7 +42,39 @@ def first(pattern):
 
 
 print("# g1: real-width training step around the hot path (one MI355X, bf16 autocast backbone, synthetic data)\n")
-for tag, title in (("dense", "dense head (glmo shape, configs[2]): ResNet-34-width encoder + decoder, B=32, 64x64 maps, N=1024 correspondences"),
+def hbm_table(rows, B=32, S=128, C=21, e=2, sample=3):
+    """The lc_* kernels of the zlmo-shaped step that stream maps: algorithmic bytes (what the operation must move once) / time / 8 TB/s."""
+    HW, N = S * S, (-(-S // sample)) ** 2
+    algo = {  # kernel -> (bytes, what)
+        "lc_xyz_bin_loss_fwd_kernel": (B * C * HW * (e + 1) + B * HW * e, "code logits + target bits + visibility logits, once"),
+        "lc_xyz_bin_loss_bwd_kernel": (B * C * HW * (e + 1 + e) + B * HW * e, "the same + the logits' gradient"),
+        "lc_bits_decode_gt_fwd_kernel": (B * N * (C * (e + 1) + 1 + 12), "sampled pixels only: C logits + C raw bits + mask in, 3 floats out (whole sampled rows "
+                                         "at sector granularity: %.1f MB)" % (B * C * (-(-S // sample)) * S * (e + 1) / 1e6)),
+        "lc_bits_decode_gt_bwd_kernel": (B * C * HW * e + B * N * (C * (e + 1) + 1 + 12), "the logits' gradient map (zero off the sampled pixels) + the forward's reads + the cotangent"),
+        "lc_dense_frontend_fwd_kernel": (B * 2 * HW * e + B * N * 16, "weight logits (joint softmax over 2HW) in, pts2d + inv_std out"),
+        "lc_dense_frontend_bwd_kernel": (B * 2 * HW * e * 2 + B * N * 8, "weight logits in, their gradient out, the cotangent of inv_std"),
+        "lc_dense_aux_fwd_kernel": (B * HW * (e + 4), "visibility logits + mask"),
+        "lc_dense_aux_bwd_kernel": (B * HW * (e + 4 + e), "the same + the gradient"),
+        "lc_sqnorm_kernel": (B * 2 * HW * e, "the weight logits' gradient"),
+        "lc_clip_apply_kernel": (B * 2 * HW * e * 2, "the gradient in and out"),
+    }
+    print(f"HBM view of the lc_* kernels that stream maps (B={B}, {S}x{S} maps, {C} planes, {e}-byte elements, N={N}); algorithmic bytes = what the operation must move once:\n")
+    print("| kernel | avg us | algorithmic MB | GB/s | of 8 TB/s | bytes counted |")
+    print("|---|---|---|---|---|---|")
+    for r in rows:
+        k = short(r["Name"])
+        if k in algo:
+            by, what = algo[k]
+            us = float(r["AverageNs"]) / 1e3
+            print(f"| {k} | {us:.1f} | {by / 1e6:.2f} | {by / us / 1e3:.0f} | {100 * by / us / 1e3 / 8000:.1f} % | {what} |")
+    print()
+
+
+for tag, title in (("zlmo", "binary-code head at zlmo's own shape (configs[4], configs/zlmo.yaml): output-stride-8 dilated ResNet-34-width encoder + atrous pyramid + skip "
+                            "decoder (examples/os8_trunk.py), fp16 autocast + GradScaler, B=32, 128x128 maps, 7+7+7 code planes, dense_sample 3 => N=1849"),
+                   ("zlmo2", "the same step SHARDED: two ranks of B=32 on this one GPU over gloo (rank 0 profiled) -- which launches a sharded job adds, not how long they "
+                             "take (the ranks' kernels share the GPU and gloo stages every collective through the host)"),
+                   ("dense", "dense head (glmo shape, configs[2]): ResNet-34-width encoder + decoder, B=32, 64x64 maps, N=1024 correspondences"),
                    ("sparse", "sparse head: same backbone, B=256, 64 keypoint maps of 64x64 (the metric's B=256, N=64 inside a training step)")):
     print(f"## {title}\n")
     for mode in ("eager", "graphs"):
@@ -52,6 +84,11 @@ for tag, title in (("dense", "dense head (glmo shape, configs[2]): ResNet-34-wid
             d = [ln.strip() for ln in open(f) if ln.startswith("quartiles of the step time")]
             print(f"* wall clock, Loss_fn {mode}: {m[-1] if m else 'no result (see log)'}{' [' + d[-1] + ']' if d else ''}")
     print()
+    if tag == "zlmo2":
+        for ln in open(os.path.join(out, "zlmo_2rank_r0.log")) if os.path.exists(os.path.join(out, "zlmo_2rank_r0.log")) else []:
+            if ln.startswith(("median step", "comm summary")):
+                print("* " + ln.strip())
+        print()
     f = first(f"{tag}_trace/**/*kernel_stats.csv")
     if not f:
         print("(no kernel stats)\n")
@@ -73,6 +110,8 @@ for tag, title in (("dense", "dense head (glmo shape, configs[2]): ResNet-34-wid
         if i < 14 or family(r["Name"]).startswith("lc_"):
             print(f"| {short(r['Name'])} | {family(r['Name']).split(' ')[0]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
     print()
+    if tag == "zlmo":
+        hbm_table(rows)
     f = first(f"{tag}_pmc/**/*counter_collection.csv")
     if f:
         acc = defaultdict(lambda: defaultdict(float))
