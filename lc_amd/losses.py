@@ -172,7 +172,7 @@ class Loss_xyz_bin(nn.Module):
         masked = noc_xyz_bin_logits * msk_hard
         if masked.dtype in (torch.float16, torch.bfloat16):  # 16-bit heads: the BCE in fp32, as the fused kernel computes it
             masked = masked.float()
-        loss_raw = F.binary_cross_entropy_with_logits(masked, noc_xyz_bin_gt.to(masked.dtype), reduction="none")
+        loss_raw = F.binary_cross_entropy_with_logits(masked, noc_xyz_bin_gt.float(), reduction="none")  # losses.py:213: the targets in float32 whatever the logits' type
         return (loss_raw.mean([0, 2, 3]) * bin_weights).sum(-1).mean()
 
 

@@ -171,6 +171,9 @@ TEST_TIME_CONFIGS = {
                                  solvers=["weighted_filtered"]), H=128, W=128, bits=(7, 7, 7), model_transform=True),
     "glmo": dict(pnp_solver=dict(dense_point_select="quantile", quantile=0.3, solvers=["weighted"]), H=64, W=64, bits=None,
                  model_transform=False),
+    # BASELINE configs[0], "reference plumbing": glmo on 128x128 crops => 32x32 maps (the stride-4 decoder), stride 2 => N = 256 correspondences
+    "plumb": dict(pnp_solver=dict(dense_point_select="quantile", quantile=0.3, solvers=["weighted"]), H=32, W=32, bits=None,
+                  model_transform=False),
 }
 
 
@@ -227,7 +230,7 @@ def test_time_inputs(name: str, B: int = 64, seed: int = 0, flip: float = 0.02, 
     noc = (Xt / noc_scale[:, None]).reshape(B, H, W, 3)
     msk_vis = hit.float()
     wl = torch.randn(B, 2, H, W, generator=g) + 6 * msk_vis[:, None]  # background weights e^-6 of the object's
-    out = dict(xyz_weight_logits=wl, xyz_weights_scale=torch.exp(torch.randn(B, 1, 1, 1, generator=g) * 0.2 + (3.0 if name == "glmo" else 4.5)),
+    out = dict(xyz_weight_logits=wl, xyz_weights_scale=torch.exp(torch.randn(B, 1, 1, 1, generator=g) * 0.2 + (3.0 if bits is None else 4.5)),
                msk_vis_logits=(msk_vis[:, None] * 2 - 1) * 4 + torch.randn(B, 1, H, W, generator=g) * 2)
     gt = dict(pose_best=torch.cat((q, t), -1).float(), out_K=K.float(), noc_scale=noc_scale.float(), msk_vis=msk_vis,
               bbox_3d=bbox3d_from_scale(ext).expand(B, 8, 3).contiguous().float(),
@@ -269,6 +272,9 @@ TRAIN_LOSS_CONFIGS = {
     # loss block of configs/zlmo.yaml:74-83 (128x128 maps, dense_sample 3 => N = 43 x 43 = 1849; 7+7+7 code planes)
     "bin_zlmo": dict(pose_loss_cfg=dict(dense_sample=3, clip_weight_grad=True), seg_loss_type="L1", pose_loss_start_step=3000,
                      pose_loss_start_epoch=0, w_loss_pose=0.03, w_loss_noc_bin=3, w_loss_seg=1),
+    # BASELINE configs[0] (16 crops of 128x128 through glmo: 32x32 maps, stride 2 => N = 256, the one-workgroup kernel's largest size): glmo's block
+    "dense_plumb": dict(pose_loss_cfg=dict(clip_weight_grad=True), pose_loss_start_step=2000, pose_loss_start_epoch=1, w_loss_pose=0.02,
+                        w_loss_seg=0.25, w_loss_noc=1),
     # loss block of configs/gsplmo.yaml at BASELINE's B=256, N=64 keypoints
     "sparse_metric": dict(pose_loss_cfg=dict(type="cov", clip_weight_grad=True), pose_loss_start_step=4000, pose_loss_start_epoch=1,
                           w_loss_kpts=1, w_loss_pose=0.7),
@@ -279,7 +285,7 @@ def train_inputs(kind: str, seed: int = 0, B: int = None):
     """(gt_dict, out_dict) of `Loss_fn.forward` for one of TRAIN_LOSS_CONFIGS' kinds, CPU tensors."""
     if kind == "sparse_metric":
         return sparse_inputs(B=B or 256, N=64, seed=seed)
-    name = {"dense_glmo": "glmo", "bin_zlmo": "zlmo"}[kind]
-    _cfg, gt, out = test_time_inputs(name, B=B or 4, seed=seed + 20, flip=0.08, train=True)
+    name = {"dense_glmo": "glmo", "bin_zlmo": "zlmo", "dense_plumb": "plumb"}[kind]
+    _cfg, gt, out = test_time_inputs(name, B=B or (16 if kind == "dense_plumb" else 4), seed=seed + 20, flip=0.08, train=True)
     gt.pop("out_pix_scale")
     return gt, out

@@ -36,6 +36,9 @@ TRAIN_KINDS = {
     # order starts from a near-zero factor and then grows max_norm by the saturated 1.189 per call -- both branches of grad.py:19-30
     "bin_zlmo": ([1499, 0, 3000], 1000, 21),
     "sparse_metric": ([0, 1999, 3999, 4500], 1500, 0),      # full step 4000; factors 2.5e-4, 0.5, 1, 1
+    # BASELINE configs[0]'s shape: B=16, 32x32 maps, stride 2 => N = 256 = the last size of the one-workgroup loss kernel;
+    # glmo's block, three calls over the ramp (factors 4e-4, 0.5, 1)
+    "dense_plumb": ([0, 1249, 2500], 2500, 0),
 }
 
 
@@ -105,7 +108,10 @@ def gen_lossfn_train_shapes():
 
     import losses as ref_losses
 
+    only = [a for a in sys.argv[1:] if a in TRAIN_KINDS]
     for kind, (steps, _spe, _bits) in TRAIN_KINDS.items():
+        if only and kind not in only:
+            continue
         t0 = time.time()
         r64 = run(ref_losses.Loss_fn, kind, steps, torch.float64)
         r32 = run(ref_losses.Loss_fn, kind, steps, torch.float32)

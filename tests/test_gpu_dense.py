@@ -105,14 +105,16 @@ def _train_shape_record(kind, head_dtype=None, loss_scale=1.0, round_heads_to=No
     return z, rec
 
 
-@pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo", "sparse_metric"])
+@pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo", "sparse_metric", "dense_plumb"])
 def test_loss_fn_at_the_reference_training_shapes(kind):
     """`Loss_fn.forward` + backward at the shapes the reference's training configs execute against trajectories of the
     UNMODIFIED reference class in float64 (`tests/golden/lossfn_<kind>.npz`, `gen_golden_lossfn.py --train-shapes`):
     dense_glmo -- B=4, 64x64 maps, stride 2 => N=1024: the many-workgroups-per-sample front end and the TILED loss kernel with its cached
     workspace inside autograd, NormClipper hooks over the weight-logit gradient maps, aux losses, warm-up blend (configs/glmo.yaml:72-79);
     bin_zlmo -- B=4, 128x128 maps, stride 3 => N=1849, 7+7+7 code planes decoded with ground-truth bits, model transform, L1 segmentation,
-    `Loss_xyz_bin` with its EMA histogram (configs/zlmo.yaml:74-83);  sparse_metric -- B=256, N=64 keypoints (gsplmo's loss block).
+    `Loss_xyz_bin` with its EMA histogram (configs/zlmo.yaml:74-83);  sparse_metric -- B=256, N=64 keypoints (gsplmo's loss block);
+    dense_plumb -- BASELINE configs[0]'s shape: B=16, 32x32 maps, stride 2 => N=256, the LAST size the one-workgroup loss kernel takes
+    (four correspondences per lane; `lc_loss.hip` switches to the tiled kernel above it).
     Same tolerances as the 16x16 trajectories above: 1e-4 on every loss, 2e-3 of a gradient map's largest entry, 1e-3 on the states."""
     z, rec = _train_shape_record(kind)
     for k in rec:

@@ -62,9 +62,11 @@ def test_loss_kernel_vs_golden(path, autograd):
         assert rel_err(Hinv, z["f64_Hinv"]) <= 1e-4
 
 
-@pytest.mark.parametrize("B,N,seed", [(1, 3, 0), (7, 5, 1), (3, 64, 2), (2, 65, 3), (2, 200, 4), (2, 257, 5), (1, 1849, 6), (33, 100, 7)])
+@pytest.mark.parametrize("B,N,seed", [(1, 3, 0), (7, 5, 1), (3, 64, 2), (2, 65, 3), (2, 200, 4), (3, 255, 8), (16, 256, 9), (2, 257, 5), (1, 1849, 6), (33, 100, 7)])
 def test_loss_kernel_vs_oracle_shapes(B, N, seed):
-    """Ragged / odd sizes through both kernel variants (registers: N<=256, block-stride: N>256), with a valid mask."""
+    """Ragged / odd sizes through both kernel variants (registers: N<=256, block-stride: N>256), with a valid mask.  255 / 256 / 257 sit on
+    the switch between the two (`lc_loss.hip`: one workgroup with four points per lane up to N = 256, tiles beyond); B=16, N=256 is
+    BASELINE configs[0]'s loss shape (16 crops, 32x32 maps, stride 2)."""
     from lc_amd import synth
     from oracle import lc_loss_oracle as orc
 

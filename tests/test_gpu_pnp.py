@@ -29,8 +29,11 @@ def make(B, N, seed, **kw):
     return b, torch.diag_embed(b["inv_std"])
 
 
-@pytest.mark.parametrize("B,N,seed", [(256, 64, 0), (16, 16, 1), (8, 4, 2), (5, 100, 3), (3, 1024, 4), (3, 1849, 5), (2, 2500, 6), (2, 4096, 7)])
+@pytest.mark.parametrize("B,N,seed", [(256, 64, 0), (16, 16, 1), (8, 4, 2), (5, 100, 3), (3, 1024, 4), (3, 1849, 5), (2, 2500, 6), (2, 4096, 7),
+                                      (4, 65, 8), (3, 255, 9), (16, 256, 10), (3, 257, 11)])
 def test_pnp_device_route_vs_oracle(B, N, seed):
+    """(the last four: either side of the one-wavefront / four-wavefront switch at N = 64 and of four correspondences per thread at N = 256;
+    B=16, N=256 is BASELINE configs[0]'s shape: 16 crops, 32x32 maps, stride 2)"""
     from lc_amd.pnp import pnp_ceres
 
     b, L = make(B, N, seed)

@@ -146,10 +146,11 @@ def test_loss_fn_matches_reference_trajectory(oracle_backend, kind):
             assert abs(float(rec32[k]) - float(z32[k])) <= 1e-4 * max(1.0, abs(float(z32[k]))), k
 
 
-@pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo", "sparse_metric"])
+@pytest.mark.parametrize("kind", ["dense_glmo", "bin_zlmo", "sparse_metric", "dense_plumb"])
 def test_loss_fn_matches_reference_at_training_shapes(oracle_backend, kind):
     """The same host logic + oracle at the reference's own training shapes (configs/glmo.yaml: 64x64 maps, stride 2, N=1024;
-    configs/zlmo.yaml: 128x128 maps, stride 3, N=1849, 21 code planes; gsplmo's loss block at B=256 N=64) against the trajectories the
+    configs/zlmo.yaml: 128x128 maps, stride 3, N=1849, 21 code planes; gsplmo's loss block at B=256 N=64; BASELINE configs[0]'s plumbing
+    case: 16 crops, 32x32 maps, stride 2, N=256) against the trajectories the
     unmodified reference class produced (tests/golden/gen_golden_lossfn.py --train-shapes): float64 losses / states to 1e-8, gradients
     (stored rounded to float32) to 1e-6 of their largest entry; the float32 run against the reference's float32 scalars to 1e-4."""
     from lc_amd.losses import Loss_fn
@@ -335,7 +336,7 @@ def test_training_shape_fixtures_span_the_warm_up_ramp_and_the_reference_shapes(
     from lc_amd.losses import pose_loss_factor
     from tests.golden.gen_golden_lossfn import TRAIN_KINDS
 
-    shapes = {"dense_glmo": ((4, 3, 64, 64), 2, 1024), "bin_zlmo": ((4, 21, 128, 128), 3, 1849)}
+    shapes = {"dense_glmo": ((4, 3, 64, 64), 2, 1024), "bin_zlmo": ((4, 21, 128, 128), 3, 1849), "dense_plumb": ((16, 3, 32, 32), 2, 256)}
     for kind, (steps, spe, bits) in TRAIN_KINDS.items():
         cfg = AttrDict(synth.TRAIN_LOSS_CONFIGS[kind])
         f = [pose_loss_factor(cfg, s, spe) for s in steps]
