@@ -17,6 +17,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
+def in_training_head_times():
+    """The head kernels' rocprofv3 averages INSIDE a training step (sparse example, B=256, 64 maps of 64x64 in bf16, freshly written by the
+    backbone), read from the newest committed `profiles/<round>/g1/sparse_kernel_stats.csv` -- never a literal.  None if no such file."""
+    import csv
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "g1", "sparse_kernel_stats.csv")), reverse=True):
+        fwd = bwd = None
+        for r in csv.DictReader(open(path)):
+            if "lc_head_fwd" in r["Name"]:
+                fwd = float(r["AverageNs"]) / 1e3
+            elif "lc_head_bwd" in r["Name"]:
+                bwd = float(r["AverageNs"]) / 1e3
+        if fwd and bwd:
+            by = 256 * 64 * 64 * 64 * 2  # bf16 maps
+            return {"fwd_us": round(fwd, 2), "bwd_us": round(bwd, 2), "fwd_frac_of_hbm": round(by / fwd / 1e3 / HBM_PEAK_GBS, 3),
+                    "bwd_frac_of_hbm": round(2 * by / bwd / 1e3 / HBM_PEAK_GBS, 3),
+                    "source": os.path.relpath(path, ROOT) + " (rocprofv3 --kernel-trace --stats of examples/train_sparse_ddp.py, B=256, bf16 maps)"}
+    return None
+
+
 def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3, dtype="f32"):
     from lc_amd import _lib
 
@@ -96,11 +117,10 @@ def measure_head(dev, B=256, S=64, H=64, W=64, steps=20, warmup=3, dtype="f32"):
                      "timing": "events around each kernel inside the alternating fwd;bwd loop (median)",
                      "cache_note": "same-buffer, Infinity-Cache-assisted: the loop re-reads ONE 268 MB logits buffer with a 256 MiB Infinity "
                                    "Cache behind it (non-temporal gradient stores leave part of it resident), which is how the step gets above "
-                                   "the 6.29 TB/s copy ceiling; inside a training step, where the maps are freshly written by the backbone, "
-                                   "rocprofv3 measured fwd 31.2 / bwd 51.2 us on bf16 maps against 25-26 / 42 us in this loop "
-                                   "(profiles/r02/g1/G1_SUMMARY.md) -- 1.2x: quote that ratio with any use of this figure",
-                     "in_training_rocprof_bf16_us": {"fwd": 31.2, "bwd": 51.2, "this_loop_fwd": [25.0, 26.0], "this_loop_bwd": 42.3,
-                                                     "source": "profiles/r02/g1/G1_SUMMARY.md (sparse head, B=256, bf16 maps)"},
+                                   "the 6.29 TB/s copy ceiling; inside a training step the maps are freshly written by the backbone: "
+                                   "`in_training_rocprof_bf16` holds the kernels' averages there (from the newest committed g1 profile) -- "
+                                   "quote those with any use of this figure",
+                     "in_training_rocprof_bf16": in_training_head_times(),
                      "fwd": {"kernel": "lc_head_fwd_wave64_kernel" if (H, W) == (64, 64) else "lc_head_fwd_rows_kernel",
                              "achieved": gbs(by_f, t_f), "frac": gbs(by_f, t_f) / HBM_PEAK_GBS, "ms": t_f},
                      "bwd_ms": t_b,

@@ -4,8 +4,10 @@
  * One shared library (liblc_amd.so, built from lc_amd/csrc/ by `python __graft_entry__.py build`) exports
  *   (1) the reference's OWN native entry point, symbol-for-symbol, so the reference's cffi binding
  *       (lib/pnp/pnp_ceres.py:93-140) can load this library instead of its Ceres extension, and
- *   (2) device-pointer entry points for the three fused kernels, which the Python host layer (lc_amd/ *.py,
- *       mirroring lib/cov_mixed.py, lib/pnp/cer_solver.py, ptnet.py) binds with ctypes.
+ *   (2) device-pointer entry points -- ONE per operation -- for the fused kernels, which the Python host layer (lc_amd/ *.py,
+ *       mirroring lib/cov_mixed.py, lib/pnp/cer_solver.py, ptnet.py, losses.py, floatbits.py) binds with ctypes.
+ * Names keep the generation suffix they had when they superseded an earlier form (lc_pnp_lm3_f32, lc_cov_loss3_fwd_bwd_f32, ...): the
+ * earlier forms are not exported any more, every one of them is the surviving call with NULL / 0 in the arguments it lacked.
  * Plain pointers and sizes only; no torch types.  All `float*`/`int*` of the device API are DEVICE pointers,
  * `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream.
  * Return value: 0 on success, non-zero on error (lc_amd_last_error() gives the text).
@@ -22,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LC_AMD_VERSION 1
+#define LC_AMD_VERSION 2 /* 2: one entry point per operation (the superseded generations of version 1 are gone) */
 #define LC_AMD_LOSS_AUX_STRIDE 40 /* per sample: prior_error, cov_err, linear_err, not_spd, Hinv[36] */
 
 int lc_amd_version(void);
@@ -52,45 +54,37 @@ void pnp_ceres_f32_omp(float **init_states, float **cam_Ks, float **pts2ds, floa
  * (2a) Batched weighted PnP on device-resident, zero-padded batches -- the GPU form of what
  *      lib/pnp/cer_solver.py:22-44 builds before calling the solver (so no device->host round trip).
  *      K (B,3,3)  pts3d (B,Nmax,3)  pts2d (B,Nmax,2)  counts (B) or NULL (= Nmax)
- *      exactly one of: sqrtL (B,Nmax,2,2) lower factor | sqrt_diag (B,Nmax,2) its diagonal (cer_solver.py:37-40)
+ *      exactly one of: sqrtL (B,Nmax,2,2) lower factor | weights_diag (B,Nmax,2) its diagonal (cer_solver.py:37-40) | weight_mask
  *      start (B,7) or NULL; states (B,7): with start==NULL (or start==states) the reference's in-place rule applies
  *      (states holds the start pose on entry and is overwritten only for converged jobs); with a separate start,
  *      states is output only: the optimum for converged jobs, a copy of start otherwise (cer_solver.py:51-52).
  *      result_tr (B), rets (B), iters (B) or NULL
- * ------------------------------------------------------------------------------------------------ */
-int lc_pnp_lm_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *sqrt_diag,
-                  const int *counts, const float *start, float *states, float *result_tr, int *rets, int *iters, int B,
-                  int Nmax, int max_iter, float function_tolerance, void *stream);
-
-/* lc_pnp_lm_f32 with the element-wise work of its callers folded into the load (each was a separate launch in front of the solve):
+ *  The element-wise work of the callers is folded into the load (each was a separate launch in front of the solve):
  *   weights_diag + LC_PNP_WEIGHTS_ARE_ICOV: the (B,Nmax,2) tensor holds inverse VARIANCES; their square root is the information
  *       factor (lib/pnp/cer_solver.py:33-36 `icovs.sqrt()`);
  *   LC_PNP_NAN_TO_NUM: torch.nan_to_num (NaN -> 0, +-inf -> +-FLT_MAX) on K, pts3d, pts2d, the weights and start
  *       (cer_solver.py:29-31 `filter_input_nan`); an invalid job returns the FILTERED start;
  *   weight_mask (B,Nmax) uint8: unit information on the flagged correspondences, none on the others (the RANSAC inlier
- *       refinement of lc_amd/pnp/gpu_solver.py); exactly one of sqrtL / weights_diag / weight_mask is given.
+ *       refinement of lc_amd/pnp/gpu_solver.py);
  *   pose_mod > 0: K and start have pose_mod rows and pose b reads row b % pose_mod -- several solves of the same objects on
  *       different correspondence selections (test.py:120,133 'weighted' and 'weighted-filtered') as ONE launch of B = k pose_mod poses.
- * options = 0, pose_mod = 0 with sqrtL or weights_diag is lc_pnp_lm_f32. */
+ *  options = 0, pose_mod = 0, workspace = NULL: the plain solve.
+ * ------------------------------------------------------------------------------------------------ */
 #define LC_PNP_WEIGHTS_ARE_ICOV 1
 #define LC_PNP_NAN_TO_NUM 2
 /* with LC_PNP_WEIGHTS_ARE_ICOV: weights_diag holds the predicted standard DEVIATIONS of the sparse head (test.py:52 `inv_cov2d = 1/(pts2d_std**2)`):
  * 1 / (s * s) is formed at the load with the float operations torch uses, then filtered and rooted as inverse variances are */
 #define LC_PNP_WEIGHTS_ARE_STD 4
-int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
-                   const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,
-                   int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod,
-                   void *stream);
 
-/* lc_pnp_lm2_f32 for batches of FEW poses with THOUSANDS of correspondences each (the test-time solves behind the dense heads,
+/* Batches of FEW poses with THOUSANDS of correspondences each (the test-time solves behind the dense heads,
  * test.py:120-133 with 64 objects x ~3000 selected pixels): given a workspace, such a batch is solved by several workgroups per pose
  * -- each sums its share of the correspondences, the partial normal equations meet in the workspace, and all of them take the same
  * LM steps -- instead of one workgroup per pose on a quarter of the chip.
  *   lc_pnp_lm_workspace_bytes(B, Nmax): bytes that shape needs; 0 when it is solved by one workgroup per pose anyway (Nmax <= 2048,
  *       or more poses than half the device's compute units -- B > 128 on an MI355X: the grid would not fit the chip at one workgroup per CU).
  *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller; after that it belongs to these calls (each leaves it ready for
- *       the next of any shape on the same stream; calls that may run concurrently need a workspace each).  NULL: lc_pnp_lm2_f32.
- * Results: those of lc_pnp_lm2_f32 up to the order of the fp64 sums over the correspondences (tests/test_gpu_pnp_split.py); rets keeps
+ *       the next of any shape on the same stream; calls that may run concurrently need a workspace each).  NULL: one workgroup per pose.
+ * Results: those of the one-workgroup solve up to the order of the fp64 sums over the correspondences (tests/test_gpu_pnp_split.py); rets keeps
  * the reference's meaning -- 0 solved, 1 not usable / did not converge (ceres.cpp:134-138) -- and nothing else.
  * Scheduling: the workgroups of a pose wait for each other, and the launch is sized to one workgroup per compute unit so that they normally
  * all run at once.  Nothing DEPENDS on that: a workgroup that has waited a few milliseconds in vain stops, and the call always enqueues a
@@ -101,14 +95,19 @@ int lc_pnp_lm2_f32(const float *K, const float *pts3d, const float *pts2d, const
  * each; nothing else.  Callers that overlap many solves on several streams may still prefer workspace = NULL (one workgroup per pose):
  * contended split launches are correct but slow. */
 size_t lc_pnp_lm_workspace_bytes(int B, int Nmax);
+/* How often a rescue launch had to recompute a unit over the life of a split-form workspace: kind 0 = lc_pnp_lm3_f32's, 1 =
+ * lc_dense_frontend_select3's.  A non-zero count says the launches were contended (results are unaffected, time is not): such a caller
+ * does better with workspace = NULL.  Synchronises `stream`, reads the counters off the device (a diagnostic, not for a hot loop);
+ * -1 on error. */
+long long lc_split_workspace_rescues(const void *workspace, size_t workspace_bytes, int kind, void *stream);
 int lc_pnp_lm3_f32(const float *K, const float *pts3d, const float *pts2d, const float *sqrtL, const float *weights_diag,
                    const unsigned char *weight_mask, const int *counts, const float *start, float *states, float *result_tr,
                    int *rets, int *iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod,
                    void *workspace, size_t workspace_bytes, void *stream);
 
 /* Two solves, the second starting where the first ends -- the RANSAC inlier refinement followed by the weighted solve(s) of
- * test.py:120,133 -- as ONE call.  A job is the argument list of lc_pnp_lm2_f32; the call is defined as
- *     lc_pnp_lm2_f32(first ...);  lc_pnp_lm2_f32(second ...);      on `stream`
+ * test.py:120,133 -- as ONE call.  A job is the argument list of lc_pnp_lm3_f32 up to pose_mod; the call is defined as
+ *     lc_pnp_lm3_f32(first ..., workspace, workspace_bytes, stream);  lc_pnp_lm3_f32(second ..., workspace, workspace_bytes, stream);
  * and returns what those return.  Where the shapes allow (both 256 < Nmax <= 1024, second->B a multiple of first->B, and
  * second->start either unrelated to first->states or reading its row b % first->B: pose_mod == first->B, or pose_mod == 0 with equal
  * B) it is ONE launch: workgroup b solves pose b % first->B of the first job, then pose b of the second -- a pose of the first job
@@ -126,8 +125,7 @@ typedef struct lc_pnp_lm_job {
     float function_tolerance;
     int options, pose_mod;
 } lc_pnp_lm_job;
-int lc_pnp_lm_chain_f32(const lc_pnp_lm_job *first, const lc_pnp_lm_job *second, void *stream);
-/* the same with a workspace for jobs that take the split form: max over the two jobs of lc_pnp_lm_workspace_bytes(B, Nmax) bytes */
+/* workspace (NULL: none) for jobs that take the split form: max over the two jobs of lc_pnp_lm_workspace_bytes(B, Nmax) bytes */
 int lc_pnp_lm_chain2_f32(const lc_pnp_lm_job *first, const lc_pnp_lm_job *second, void *workspace, size_t workspace_bytes, void *stream);
 
 /* (2a') Parity diagnostics of (2a): the same solve (same template body, so the same arithmetic) that also records the
@@ -146,28 +144,19 @@ int lc_pnp_lm_trace_f32(const float *K, const float *pts3d, const float *pts2d, 
  *      lib/cov_mixed.py:100-150 Loss_cov_mixed (cov_2d=False).  K (B,3,3) pose (B,7) pts3d (B,N,3) pts2d (B,N,2)
  *      inv_std (B,N,2) valid (B,N)|NULL bbox_3d (B,8,3) grad_out (B)|NULL(=1)
  *      -> loss (B); d_pts2d,d_inv_std (B,N,2) (both NULL = forward only); d_pts3d (B,N,3)|NULL; aux (B,40)|NULL
- *      Gradients are d(sum_b grad_out[b]*loss[b]) / d(input).
+ *      Gradients are d(sum_b grad_out[b]*loss[b]) / d(input).  cov_2d: the switch of cov_mixed.py:111,125-130 (covariance of the
+ *      PROJECTED bbox corners; no reference call site enables it, losses.py:333,383).
+ *      Declared below as lc_cov_loss3_fwd_bwd_f32 (with the optional workspace of the dense shapes).
  * ------------------------------------------------------------------------------------------------ */
-int lc_cov_loss_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,
-                            const float *inv_std, const float *valid, const float *bbox_3d, const float *grad_out,
-                            int B, int N, float max_err_len, float rel_thresh, float w_e_thresh, float *loss,
-                            float *d_pts2d, float *d_inv_std, float *d_pts3d, float *aux, void *stream);
-
 /* ------------------------------------------------------------------------------------------------
  * (2b') One "pose unit" per pose in ONE launch: (2b) on B samples and (2a) on the same B correspondence sets
  *      (diagonal information factor pnp_sqrt_diag (B,N,2), start poses pnp_start (B,7) -> pnp_states (B,7)), N <= 64.
  *      The two computations are independent; sharing a grid fills the chip at small B (bench.py's headline step).
  * ------------------------------------------------------------------------------------------------ */
-int lc_pose_unit_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d, const float *inv_std,
-                     const float *valid, const float *bbox_3d, const float *grad_out, int B, int N, float max_err_len,
-                     float rel_thresh, float w_e_thresh, float *loss, float *d_pts2d, float *d_inv_std, float *d_pts3d,
-                     const float *pnp_sqrt_diag, const float *pnp_start, float *pnp_states, float *pnp_result_tr,
-                     int *pnp_rets, int pnp_max_iter, float pnp_function_tolerance, void *stream);
-
-/* Round 3: the pose unit for the dense shapes as well.  N <= 64: lc_pose_unit_f32 (workspace unused).  256 < N <= 2048 with
+/* N <= 64: one wavefront per pose for each half (workspace unused: NULL, 0).  The dense shapes as well: 256 < N <= 2048 with
  * workspace = lc_cov_loss_workspace_bytes(B, N) > 0 bytes (256-byte aligned like lc_cov_loss3_fwd_bwd_f32's, zero-filled once, left zero): the tiled loss's
  * workgroups and the four-wave solve's share one grid (B = 32, N = 1024: 128 + 32 workgroups at the same time instead of two launches
- * back to back).  Other shapes: return code 3 -- launch lc_cov_loss3_fwd_bwd_f32 and lc_pnp_lm_f32 separately.  pnp_iters (B)|NULL.
+ * back to back).  Other shapes: return code 3 -- launch lc_cov_loss3_fwd_bwd_f32 and lc_pnp_lm3_f32 separately.  pnp_iters (B)|NULL.
  * Results bit for bit those of the two stand-alone launches. */
 int lc_pose_unit2_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d, const float *inv_std,
                       const float *valid, const float *bbox_3d, const float *grad_out, int B, int N, float max_err_len,
@@ -176,14 +165,7 @@ int lc_pose_unit2_f32(const float *K, const float *pose, const float *pts3d, con
                       int *pnp_rets, int *pnp_iters, int pnp_max_iter, float pnp_function_tolerance, void *workspace,
                       size_t workspace_bytes, void *stream);
 
-/* same with the cov_2d switch of cov_mixed.py:111,125-130 (covariance of the PROJECTED bbox corners; no reference call site
- * enables it, losses.py:333,383) */
-int lc_cov_loss2_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,
-                             const float *inv_std, const float *valid, const float *bbox_3d, const float *grad_out,
-                             int B, int N, float max_err_len, float rel_thresh, float w_e_thresh, int cov_2d, float *loss,
-                             float *d_pts2d, float *d_inv_std, float *d_pts3d, float *aux, void *stream);
-
-/* (2b'') The same with a caller workspace, which lets the dense shapes (N > 256: configs/glmo.yaml N = 1024, zlmo N = 1849;
+/* (2b'') The loss kernel (2b).  A caller workspace lets the dense shapes (N > 256: configs/glmo.yaml N = 1024, zlmo N = 1849;
  * losses.py:336-386) spread ONE sample over several compute units: the sample's 64-correspondence tiles are dealt to 256-thread
  * workgroups (4, 8 or 16 tiles each) that exchange the partial sums of the normal equations once through the workspace.
  * Results are bit-identical to the workspace-less call (all forms add the per-sample sums in the same tile order).
@@ -191,7 +173,7 @@ int lc_cov_loss2_fwd_bwd_f32(const float *K, const float *pose, const float *pts
  *   chip anyway).  The caller zero-fills the workspace ONCE per (B, N); every launch leaves it zeroed except word 2 of its header,
  *   which counts hand-offs that timed out (none can, by construction); a sample any of whose workgroups timed out returns loss = NaN
  *   (its gradients are then undefined): re-zero the workspace after that.  One workspace serves the launches of ONE stream (or of graphs replayed
- *   one at a time); concurrent launches need one each.  workspace == NULL is (2b'). */
+ *   one at a time); concurrent launches need one each.  workspace == NULL: one workgroup per sample. */
 size_t lc_cov_loss_workspace_bytes(int B, int N);
 int lc_cov_loss3_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d, const float *pts2d,
                              const float *inv_std, const float *valid, const float *bbox_3d, const float *grad_out,
@@ -208,13 +190,7 @@ int lc_scale_rows_f32(const float *scale, int B, const float *src0, float *dst0,
  *      spatial softmax of ptnet.py:61 is fused) or probabilities (is_prob=1; ptnet.softargmax_2d_std itself).
  *      -> mean (M,2) [x,y], std (M,2), stats (M,4) saved for backward.
  * ------------------------------------------------------------------------------------------------ */
-int lc_softargmax2d_fwd_f32(const float *in, int M, int H, int W, int is_prob, float *mean, float *std, float *stats,
-                            void *stream);
-int lc_softargmax2d_bwd_f32(const float *in, const float *mean, const float *std, const float *stats,
-                            const float *g_mean, const float *g_std, int M, int H, int W, int is_prob, float *g_in,
-                            void *stream);
-/* The same pair for maps in the element type a mixed-precision backbone emits (BASELINE.json configs 3, 5): `in` and `g_in`
- * are (M,H,W) of `dtype`; statistics, mean/std and their cotangents stay fp32, arithmetic is fp32, the gradient is rounded
+/* `in` and `g_in` are (M,H,W) of `dtype` -- fp32, or the element type a mixed-precision backbone emits (BASELINE.json configs 3, 5); statistics, mean/std and their cotangents stay fp32, arithmetic is fp32, the gradient is rounded
  * to nearest even into the map's type.  16-bit maps halve the HBM bytes of this bandwidth-bound pair. */
 #define LC_F32 0
 #define LC_F16 1
@@ -232,57 +208,43 @@ int lc_softargmax2d_bwd(const void *in, int dtype, const float *mean, const floa
  *      xyz (B,3,H,W) wlogits (B,2,H,W) wscale (B) noc_scale (B,3)|NULL -> pts2d,inv_std (B,N,2) pts3d (B,N,3) lse (B)
  *      with N = ceil((H-top)/sample) * ceil((W-left)/sample).  Backward: cotangents of inv_std / pts3d (either NULL)
  *      -> d_xyz (B,3,H,W), d_wlogits (B,2,H,W), d_wscale (B) (any NULL to skip).
+ *      Forward + the test-time visibility mask of the sampled pixels (test.py:88-90: sigmoid(msk_vis_logits) > seg_thresh, then the
+ *      stride slice): vis_logits (B,H,W), vis_thresh -> vis_mask (B,N) uint8; both NULL = none.
+ *      Declared in (2i) as lc_dense_frontend_fwd3 / lc_dense_frontend_bwd2 (any map element type, batch strides).
  * ------------------------------------------------------------------------------------------------ */
-int lc_dense_frontend_fwd_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale, int B,
-                              int H, int W, int top, int left, int sample, float *pts2d, float *inv_std, float *pts3d,
-                              float *lse, void *stream);
-/* Forward + the test-time visibility mask of the sampled pixels (test.py:88-90: sigmoid(msk_vis_logits) > seg_thresh, then the
- * stride slice): vis_logits (B,H,W), vis_thresh -> vis_mask (B,N) uint8; both NULL = lc_dense_frontend_fwd_f32. */
-int lc_dense_frontend_fwd2_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale,
-                               const float *vis_logits, float vis_thresh, int B, int H, int W, int top, int left, int sample,
-                               float *pts2d, float *inv_std, float *pts3d, float *lse, unsigned char *vis_mask, void *stream);
-int lc_dense_frontend_bwd_f32(const float *wlogits, const float *wscale, const float *noc_scale, const float *lse,
-                              const float *g_inv_std, const float *g_pts3d, int B, int H, int W, int top, int left,
-                              int sample, float *d_xyz, float *d_wlogits, float *d_wscale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2g) PnP initialiser -- takes the place of lib/pnp/cv2_solver.py:69-88 (cv2.solvePnPRansac, EPnP,
  *      iterationsCount=150) in front of the weighted solve: RANSAC over P3P minimal samples, one wavefront per pose,
  *      `iterations` hypotheses rounded up to a multiple of 64.  Same zero-padded batch layout as (2a).
- *      reproj_err in pixels: the scalar; with reproj_err_per_pose != NULL (B floats) the per-pose value IS the threshold of pose b
- *      (lc_pnp_ransac_init_f32 .. init4_f32, whatever the scalar).  lc_pnp_ransac_init5_f32 ONLY: with reproj_err > 0 the per-pose value
- *      is a DIVISOR, threshold = reproj_err / reproj_err_per_pose[b] -- test.py:56-57,115-116's `2 / gt_dict['out_pix_scale']`
- *      (rel_reproj_err) formed inside the launch; a divisor that is not positive leaves reproj_err itself.
+ *      reproj_err in pixels: the scalar.  With reproj_err_per_pose != NULL (B floats): reproj_err > 0 makes the per-pose value a DIVISOR,
+ *      threshold = reproj_err / reproj_err_per_pose[b] -- test.py:56-57,115-116's `2 / gt_dict['out_pix_scale']` (rel_reproj_err) formed
+ *      inside the launch, a divisor that is not positive leaves reproj_err itself; reproj_err <= 0: the per-pose value IS the threshold.
  *      -> states (B,7) w,x,y,z,tx,ty,tz; inlier_mask (B,Nmax) uint8; n_inliers (B); invalid (B) (1: fewer than 4 points
  *      or no hypothesis with >= 4 inliers; states is then the identity pose like the reference's zero rvec/tvec).
+ *      best_hyp (B)|NULL: the index of the winning hypothesis of every pose (-1 when invalid).  Hypothesis h of pose b draws its four
+ *      point indices from a counter-based hash of (seed, b, h) -- oracle/p3p_ransac_oracle.py restates the stream bit for bit, which
+ *      makes best_hyp, n_inliers and inlier_mask integer outputs that are compared EXACTLY.
+ *      Ranking of hypotheses: (inlier count, error, hypothesis index); the error that breaks count ties is the camera-plane residual
+ *      at the hypothesis' depth -- sum over the inliers of |c_xy - u c_z|^2, divided by t_z^2 (c = R X + t, u the normalised pixel;
+ *      division-free IEEE float32 in a fixed order: reproducible off the chip) -- not the pixel reprojection error; a hypothesis with
+ *      t_z <= 0 ranks last among equal counts (error = +inf).  cv2.solvePnPRansac has no such tie-break.
  * ------------------------------------------------------------------------------------------------ */
-int lc_pnp_ransac_init_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
-                           float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
-                           float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, void *stream);
-
-/* Same, plus best_hyp (B)|NULL: the index of the winning hypothesis of every pose (-1 when invalid).  Hypothesis h of pose b
- * draws its four point indices from a counter-based hash of (seed, b, h) -- oracle/p3p_ransac_oracle.py restates the stream
- * bit for bit, which makes best_hyp, n_inliers and inlier_mask integer outputs that are compared EXACTLY. */
-int lc_pnp_ransac_init2_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
-                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
-                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
-                            void *stream);
-
 /* Split form of the same RANSAC for batches that do not fill the chip with one workgroup per pose (64 objects x 150 hypotheses
  * x 1000+ dense correspondences): three launches -- hypotheses (one lane each), scoring (point chunks x hypotheses, spread over
  * all compute units), selection -- over a caller-provided device workspace of lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)
  * bytes (16-byte aligned; contents undefined before and after; B x ceil(Nmax / 64) x hypotheses x 8 bytes of chunk partials: EVERY
  * point of a pose is sampled from and scored, as cv2.solvePnPRansac does, cv2_solver.py:72-75).  Same hypothesis stream, same per-point arithmetic and the same
- * (count, error, hypothesis index) ordering as the single launch; results do not depend on scheduling (no atomics).
- * workspace == NULL runs the single launch through this entry.  valid_counts (B)|NULL: the pose's point count, 0 when the pose is
- * invalid -- handed as `counts` to a following lc_pnp_lm2_f32 refinement it makes that solve skip the failed poses. */
+ * (count, error, hypothesis index) ordering as the single launch (workspace == NULL); results do not depend on scheduling (no atomics).
+ * valid_counts (B)|NULL: the pose's point count, 0 when the pose is invalid -- handed as `counts` to a following lc_pnp_lm3_f32
+ * refinement it makes that solve skip the failed poses.
+ * lc_pnp_ransac_workspace_layout (diagnostics: the tests that re-check the kernel's hypotheses and chunk partials on the CPU): byte
+ * offsets into that workspace of out[0] the hypotheses as doubles (B,H,12: R row-major | t), out[1] the same as floats (B,H,12),
+ * out[2] the chunk partials (B,C,H) of 8 bytes {inlier count int32 | error-sum float32}; out[3] = H (hypotheses, a multiple of 64),
+ * out[4] = C (chunks of 64 points), out[5] = total bytes.  Returns 0, or 1 for a bad size. */
 size_t lc_pnp_ransac_workspace_bytes(int B, int Nmax, int iterations);
-int lc_pnp_ransac_init3_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
-                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
-                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
-                            int *valid_counts, void *workspace, size_t workspace_bytes, void *stream);
-
-/* Round 3: init3 plus (a) the inlier re-selection inside the selection step and (b) an optional two-launch split form.
+int lc_pnp_ransac_workspace_layout(int B, int Nmax, int iterations, size_t out[6]);
+/* Further options: (a) the inlier re-selection inside the selection step and (b) an optional two-launch split form.
  *  - sel_w != NULL: second-stage selection by the inlier mask (test.py:129-133, the 'weighted-filtered' solve's input) written by
  *    the workgroup that writes the mask: the inliers of every pose compacted, order kept, to the front of sel_pts2d (B,Nmax,2),
  *    sel_w_out (B,Nmax,2) <- sel_w (B,Nmax,2, the weights travelling with the correspondences), sel_pts3d (B,Nmax,3),
@@ -292,18 +254,12 @@ int lc_pnp_ransac_init3_f32(const float *K, const float *pts3d, const float *pts
  *    of its own (tests/test_gpu_pnp_init_oracle.py); works with either launch form.
  *  - ticketed != 0 and workspace != NULL: TWO launches (hypotheses; scoring + selection).  One workgroup per (pose, chunk of 64
  *    points) scores, counts itself in, and the workgroup that completes the pose's count selects; nobody waits.  The chunk partials
- *    are still summed in chunk order: every output equals the three launches'.  Same workspace contract as init3 (the arrival
+ *    are still summed in chunk order: every output equals the three launches'.  Same workspace contract (the arrival
  *    counters in it are zeroed by the hypotheses launch).  Measured slower than the three launches on MI355X (profiles/r03/NOTES.md 8): an
  *    option for the record, not the default of the Python host side. */
-int lc_pnp_ransac_init4_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
-                            float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
-                            float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
-                            int *valid_counts, void *workspace, size_t workspace_bytes, int ticketed, const float *sel_w,
-                            const int *sel_in_index, int sel_min_count, unsigned sel_seed, float *sel_pts2d, float *sel_w_out,
-                            float *sel_pts3d, int *sel_index, int *sel_counts, void *stream);
-/* init4 for a batch that is a slice [pose_index_offset, pose_index_offset + B) of a larger one: the hypothesis stream and the padding draw of
+/* pose_index_offset: the batch is a slice [pose_index_offset, pose_index_offset + B) of a larger one: the hypothesis stream and the padding draw of
  * pose b are those of pose pose_index_offset + b, so sub-batches solved concurrently on several streams (lc_amd/inference.py) return what the
- * one call over the whole batch returns.  lc_dense_frontend_select2 takes the same offset for its padding draw. */
+ * one call over the whole batch returns.  lc_dense_frontend_select3 takes the same offset for its padding draw. */
 int lc_pnp_ransac_init5_f32(const float *K, const float *pts3d, const float *pts2d, const int *counts, int B, int Nmax,
                             float reproj_err, const float *reproj_err_per_pose, int iterations, unsigned seed,
                             float *states, unsigned char *inlier_mask, int *n_inliers, int *invalid, int *best_hyp,
@@ -317,33 +273,13 @@ int lc_pnp_ransac_init5_f32(const float *K, const float *pts3d, const float *pts
  *      lc_bits_decode_gt_*: floatbits.py:130-160 + :108-118 (training decode against the raw ground-truth bits gt_bits
  *      (B,C,H,W) uint8 and the object mask gt_msk (B,H,W) uint8|NULL), evaluated on the strided pixel subset
  *      (top,left,sample) of losses.py:163-184 -> noc (B,N,3); backward writes the full (B,C,H,W) logit gradient.
- *      lc_bits_decode_f32: floatbits.py:194-223 + :162-180 (inference Gray decode) -> noc (B,H,W,3).
- *      (2d) accepts xyz = pts3d = NULL for these heads (weights / pixel grid only).
+ *      lc_bits_decode3: floatbits.py:194-223 + :162-180 (inference Gray decode) -> noc (B,H,W,3), with the callers' coordinate map
+ *      folded in (nn_out_to_xyz(..., inference=True), losses.py:17-47) and, with planar != 0, written as (B,3,H,W) planes -- what the dense
+ *      front end reads: out = noc * out_scale (B,3)|NULL, then (. - T[:3,3]) @ T[:3,:3] with out_xform (B,4,4)|NULL.
+ *      The training decode folds the same map in (losses.py:17-47,163-184): out (B,N,3) = (noc * out_scale - T[:3,3]) @ T[:3,:3]; the
+ *      backward form takes the cotangent of `out`; out_scale = out_xform = NULL: the normalised coordinates themselves.
+ *      (2d) accepts xyz = pts3d = NULL for these heads (weights / pixel grid only).  Declared in (2i).
  * ------------------------------------------------------------------------------------------------ */
-int lc_bits_decode_gt_fwd_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk, int B, int C,
-                              int H, int W, int n0, int n1, int n2, int black_background, int top, int left, int sample,
-                              float *noc, void *stream);
-int lc_bits_decode_gt_bwd_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
-                              const float *g_noc, int B, int C, int H, int W, int n0, int n1, int n2, int black_background,
-                              int top, int left, int sample, float *d_logits, void *stream);
-/* Round 3: the inference decode with the callers' coordinate map folded in (nn_out_to_xyz(..., inference=True), losses.py:17-47) and,
- * with planar != 0, written as (B,3,H,W) planes -- what lc_dense_frontend_*_f32 read -- instead of (B,H,W,3): out = noc * out_scale
- * (B,3)|NULL, then (. - T[:3,3]) @ T[:3,:3] with out_xform (B,4,4)|NULL. */
-int lc_bits_decode2_f32(const float *logits, const float *out_scale, const float *out_xform, int B, int C, int H, int W, int n0,
-                        int n1, int n2, int black_background, int planar, float *out, void *stream);
-
-/* Round 3: the training decode with the callers' coordinate map folded in (nn_out_to_xyz, losses.py:17-47,163-184): out (B,N,3) =
- * noc * out_scale (B,3), and with out_xform (B,4,4) = the model transform T: (noc * out_scale - T[:3,3]) @ T[:3,:3]; the backward form
- * takes the cotangent of `out`.  out_scale = out_xform = NULL is lc_bits_decode_gt_{fwd,bwd}_f32. */
-int lc_bits_decode_gt_fwd2_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
-                               const float *out_scale, const float *out_xform, int B, int C, int H, int W, int n0, int n1, int n2,
-                               int black_background, int top, int left, int sample, float *out, void *stream);
-int lc_bits_decode_gt_bwd2_f32(const float *logits, const unsigned char *gt_bits, const unsigned char *gt_msk,
-                               const float *out_scale, const float *out_xform, const float *g_out, int B, int C, int H, int W,
-                               int n0, int n1, int n2, int black_background, int top, int left, int sample, float *d_logits,
-                               void *stream);
-int lc_bits_decode_f32(const float *logits, int B, int C, int H, int W, int n0, int n1, int n2, int black_background,
-                       float *noc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2e) Pose-error metrics -- lib/utils/error6d.py:87-154 (add, adi, re, te) bundled as
@@ -357,23 +293,19 @@ int lc_pose_errors_f32(const float *R_est, const float *t_est, const float *R_gt
 /* ------------------------------------------------------------------------------------------------
  * (2h) EMA-adaptive gradient-norm clipping -- lib/utils/grad.py:5-30 (NormClipper.clip) + :33-83 (clip_norm), the
  *      backward hook of the dense heads (losses.py:343-352,378-381), without host synchronisation:
- *        lc_sqnorm_f32            sq (device float) = [sq +] sum x^2.  partials: LC_SQNORM_BLOCKS doubles of workspace,
+ *        lc_sqnorm                sq (device float) = [sq +] sum x^2.  partials: LC_SQNORM_BLOCKS doubles of workspace,
  *                                 ticket: one zero-initialised unsigned (left at zero); both owned by the caller.
  *                                 state/state_snapshot (both or neither): *state_snapshot = *state, so that the apply step
  *                                 can take state_in = state_snapshot and state_out = state, i.e. update the running
  *                                 maximum IN PLACE (fixed addresses: the pair can be replayed inside a hipGraph).
  *        [all-reduce sq over the data-parallel group when the batch is sharded]
- *        lc_norm_clip_apply_f32   norm = sqrt(sq);  limit = state_in <= 0 ? initial_max_norm : state_in;
+ *        lc_norm_clip_apply       norm = sqrt(sq);  limit = state_in <= 0 ? initial_max_norm : state_in;
  *                                 out = grad * min(limit / (norm + 1e-6), 1);
  *                                 state_out = state_in <= 0 ? norm*scale
  *                                           : state_in*(1-momentum) + momentum*scale*min(norm, state_in*scale)
  *                                 (state_out / norm_out may be NULL: scale a further tensor of the same hook call).
  * ------------------------------------------------------------------------------------------------ */
-#define LC_SQNORM_BLOCKS 512
-int lc_sqnorm_f32(const float *x, long long n, double *partials, unsigned *ticket, float *sq, int accumulate,
-                  const float *state, float *state_snapshot, void *stream);
-int lc_norm_clip_apply_f32(const float *grad, long long n, const float *sq, const float *state_in, float initial_max_norm,
-                           float scale, double momentum, float *out, float *state_out, float *norm_out, void *stream);
+#define LC_SQNORM_BLOCKS 512 /* declared in (2i): the gradient may have any map element type */
 
 /* ------------------------------------------------------------------------------------------------
  * (2g) Keypoint NLL of the sparse heads -- losses.py:318-326 sparse_kpt_loss: per-sample
@@ -392,7 +324,7 @@ int lc_kpt_nll_fwd_bwd_f32(const float *K, const float *pose, const float *pts3d
  *        mode 1: keep w >= torch.quantile(w, q)       with w = inv_std[:,0] + inv_std[:,1]
  *        mode 2: q_b = 1 - (1-q) * mean(mask);  keep (w*mask >= torch.quantile(w*mask, q_b)) & mask
  *      Survivors are written in source order to the front of out_* (B,N,.); out_weights = inv_std, squared when
- *      square_weights (the inverse covariance lc_pnp_lm_f32 takes as sqrt_diag^2 -- pass 0 to keep inv_std);
+ *      square_weights (the inverse covariance lc_pnp_lm3_f32 takes with LC_PNP_WEIGHTS_ARE_ICOV -- pass 0 to keep inv_std);
  *      counts[b] = survivors, padded to min_count with seeded pseudo-random source indices when fewer survive
  *      (np.random.choice in the reference).  out_index may be NULL.
  * ------------------------------------------------------------------------------------------------ */
@@ -401,17 +333,11 @@ int lc_dense_select_f32(const float *pts2d, const float *inv_std, const float *p
                         int square_weights, int min_count, unsigned seed, float *out_pts2d, float *out_weights,
                         float *out_pts3d, int *out_index, int *counts, void *stream);
 
-/* Round 3: the dense front end (2d, lc_dense_frontend_fwd2_f32) and the selection above in ONE launch for the test-time pipeline,
+/* The dense front end (2d) and the selection above in ONE launch for the test-time pipeline (declared in (2i) as lc_dense_frontend_select3),
  * one workgroup per object, for N = ceil((H-top)/sample) * ceil((W-left)/sample) <= 16384 sampled pixels (128x128 maps at stride 1,
  * configs/zlmo.yaml:30-37's test-time shape; more: an error, use the two launches).  The front end's (B,N,.) rows are never written; every selected value, count and index
- * equals what lc_dense_frontend_fwd2_f32 followed by lc_dense_select_f32(mask = the visibility mask) returns, bit for bit
+ * equals what lc_dense_frontend_fwd3 followed by lc_dense_select_f32(mask = the visibility mask) returns, bit for bit
  * (tests/test_gpu_select.py).  xyz (B,3,H,W) required; vis_logits (B,H,W) required by modes 0 and 2. */
-int lc_dense_frontend_select_f32(const float *xyz, const float *wlogits, const float *wscale, const float *noc_scale,
-                                 const float *vis_logits, float vis_thresh, int B, int H, int W, int top, int left, int sample,
-                                 int mode, double quantile, int square_weights, int min_count, unsigned seed,
-                                 float *out_pts2d, float *out_weights, float *out_pts3d, int *out_index, int *counts,
-                                 void *stream);
-
 /* ------------------------------------------------------------------------------------------------
  * (2h) The dense heads' auxiliary losses of Loss_fn.forward (losses.py:281-316), one launch each way:
  *        losses[0] loss_noc        = mean |xyz * msk_noc - noc_tgt|                        (F.l1_loss, losses.py:293-295)
@@ -423,35 +349,22 @@ int lc_dense_frontend_select_f32(const float *xyz, const float *wlogits, const f
  *      unsigned (the workgroups' arrival counters, sharded over 128-byte lines), zero before the first call (the kernel leaves them
  *      zero); sums in double precision, block partials added in block order.
  *      Backward: g_* = device scalars (the cotangents of the three means, NULL = none), d_* (same shapes as the inputs)|NULL.
+ *      Declared in (2i) as lc_dense_aux_fwd2 / lc_dense_aux_bwd2.
  * ------------------------------------------------------------------------------------------------ */
 #define LC_ARRIVAL_WORDS 544 /* (1 + 16 shards) x 32 words: lc_common.h kArrivalWords */
-int lc_dense_aux_fwd_f32(const float *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
-                         const float *seg_logits, const float *msk_vis, const float *wlogits, int B, int HW, int seg_type,
-                         float *losses, double *partials, unsigned *ticket, void *stream);
-int lc_dense_aux_bwd_f32(const float *xyz, const unsigned char *msk_noc_u8, const float *msk_noc_f32, const float *noc_tgt,
-                         const float *seg_logits, const float *msk_vis, const float *wlogits, int B, int HW, int seg_type,
-                         const float *g_noc, const float *g_seg, const float *g_wseg, float *d_xyz, float *d_seg,
-                         float *d_wlogits, void *stream);
-
 /* Loss_xyz_bin (losses.py:196-216), the ZebraPose heads' code loss: per-bit BCE-with-logits on logits * (msk_vis_logits > 0),
  * weighted by softmax(3 * min(h, 0.51 - h)) of the EMA histogram h of per-bit Hamming error rates inside that mask.  logits (B,C,HW),
  * gt_bits (B,C,HW) bool bytes, msk_vis_logits (B,HW), C <= 128.  Forward (one pass over the logits): histogram (C) is read and updated in
  * place (h <- h (1 - momentum) + rate momentum), loss (1), bin_weights (C) for the backward pass; partials = C * 32 * 3 doubles, ticket =
- * LC_ARRIVAL_WORDS unsigned, zero before the first call (left zero).  Backward: d_logits = g_loss (device scalar) * d loss / d logits. */
-int lc_xyz_bin_loss_fwd_f32(const float *logits, const unsigned char *gt_bits, const float *msk_vis_logits, int B, int C, int HW,
-                            float momentum, float *histogram, float *loss, float *bin_weights, double *partials,
-                            unsigned *ticket, void *stream);
-int lc_xyz_bin_loss_bwd_f32(const float *logits, const unsigned char *gt_bits, const float *msk_vis_logits,
-                            const float *bin_weights, const float *g_loss, int B, int C, int HW, float *d_logits, void *stream);
-
+ * LC_ARRIVAL_WORDS unsigned, zero before the first call (left zero).  Backward: d_logits = g_loss (device scalar) * d loss / d logits.
+ * Declared in (2i) as lc_xyz_bin_loss_fwd2 / lc_xyz_bin_loss_bwd2 (+ the counts / finish pair of a sharded batch). */
 /* ------------------------------------------------------------------------------------------------
- * (2i) Round 4: the f1 / f3 entry points above for network outputs in the element type a mixed-precision backbone emits
+ * (2i) The f1 / f3 entry points and the Loss_fn glue for network outputs in any element type: fp32, or what a mixed-precision backbone emits
  *      (BASELINE.json configs[2] bf16, configs[4] fp16; ptnet.py:68-82 hands the heads' outputs over in the autocast type,
  *      losses.py:163-184,355-356 and floatbits.py:130-160,194-223 consume them).  map_dtype = LC_F32 | LC_F16 | LC_BF16 is the element
  *      type of EVERY `const void *` map argument and of every `void *` gradient map; everything else (per-sample scales, targets, masks,
- *      the (B,N,.) rows, cotangents of the rows, losses) stays fp32 / bytes exactly as in the `_f32` entry point of the same name, which
- *      is this function with map_dtype = LC_F32.  Arithmetic is fp32 for every type and the element order of every reduction does not
- *      depend on it: a 16-bit map gives bit for bit the fp32 entry point's result on the up-cast values; a gradient map is that fp32
+ *      the (B,N,.) rows, cotangents of the rows, losses) stays fp32 / bytes.  Arithmetic is fp32 for every type and the element order of
+ *      every reduction does not depend on it: a 16-bit map gives bit for bit the LC_F32 result on the up-cast values; a gradient map is that fp32
  *      gradient rounded to nearest even into the map's type.  No up-cast copy exists anywhere.  Four-element (8-byte) accesses need
  *      W (HW) % 4 == 0 and 8-byte aligned maps, else one element per access.
  *      wscale_dtype: the element type of the (B,) weight scale and of its gradient (fp32 under autocast, where exp is an fp32 op; the
@@ -469,18 +382,13 @@ int lc_dense_frontend_fwd3(const void *xyz, const void *wlogits, const void *wsc
 int lc_dense_frontend_bwd2(const void *wlogits, const void *wscale, const float *noc_scale, const float *lse,
                            const float *g_inv_std, const float *g_pts3d, int map_dtype, int wscale_dtype, long long wlogits_bstride, int B, int H, int W, int top, int left,
                            int sample, void *d_xyz, void *d_wlogits, void *d_wscale, void *stream);
-int lc_dense_frontend_select2(const void *xyz, const void *wlogits, const void *wscale, const float *noc_scale,
-                              const void *vis_logits, float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left,
-                              int sample, int mode, double quantile, int square_weights, int min_count, unsigned seed, int pose_index_offset,
-                              float *out_pts2d, float *out_weights, float *out_pts3d, int *out_index, int *counts,
-                              void *stream);
-/* lc_dense_frontend_select2 for FEW objects with THOUSANDS of candidates each (zlmo's test-time shape: 64 objects x 16 384): given a workspace,
+/* Front end + selection (2f).  FEW objects with THOUSANDS of candidates each (zlmo's test-time shape: 64 objects x 16 384): given a workspace,
  * rows of more than 4096 candidates of at most 128 objects are selected by several workgroups per object -- each forms its share of the
  * log-sum-exp, of the radix select's histograms and of the compaction, the shares meet through ticketed words in the workspace -- instead of
- * one workgroup pulling the object's maps through one compute unit.  Every output bit for bit that of lc_dense_frontend_select2.
+ * one workgroup pulling the object's maps through one compute unit.  Every output bit for bit that of the one-workgroup form (workspace = NULL).
  *   lc_dense_frontend_select_workspace_bytes: bytes that shape needs (0: one workgroup per object anyway).
  *   workspace: that many bytes, 128-byte aligned, ZEROED ONCE by the caller, then owned by these calls (each leaves it ready for the next on the
- *       same stream).  NULL: lc_dense_frontend_select2.  Scheduling as for lc_pnp_lm3_f32: the workgroups of an object wait for each other
+ *       same stream).  NULL: one workgroup per object.  Scheduling as for lc_pnp_lm3_f32: the workgroups of an object wait for each other
  *       for a bounded time, and the call always enqueues the one-workgroup kernel behind them, which selects again -- bit for bit -- every
  *       object a workgroup gave up on and re-zeroes its region: contention costs time, never an object (tests/test_gpu_contention.py). */
 size_t lc_dense_frontend_select_workspace_bytes(int B, int H, int W, int top, int left, int sample);
@@ -499,7 +407,7 @@ int lc_bits_decode_gt_bwd3(const void *logits, const unsigned char *gt_bits, con
 int lc_bits_decode3(const void *logits, const float *out_scale, const float *out_xform, int map_dtype, long long logits_bstride, int B, int C, int H,
                     int W, int n0, int n1, int n2, int black_background, int planar, float *out, void *stream);
 /* Inference decode of the SELECTED pixels only (test time, test.py:67-136 with binary-code heads): entry k < rows_counts[b] of row b is sampled
- * pixel rows_index[b][k] of the (top, left, sample) grid -- what lc_dense_frontend_select2 (called with xyz = out_pts3d = NULL: the selection alone)
+ * pixel rows_index[b][k] of the (top, left, sample) grid -- what lc_dense_frontend_select3 (called with xyz = out_pts3d = NULL: the selection alone)
  * leaves in out_index / counts -- and its object coordinates `(noc * out_scale - T[:3,3]) @ T[:3,:3]` go to out_pts3d[b][k] (B,rows_N,3).  The floats
  * of lc_bits_decode3 at those pixels; a fifth of its work at zlmo's test-time shape. */
 int lc_bits_decode_rows(const void *logits, const float *out_scale, const float *out_xform, int map_dtype, long long logits_bstride,
@@ -529,7 +437,7 @@ int lc_xyz_bin_loss_counts(const void *logits, const unsigned char *gt_bits, con
                            void *stream);
 int lc_xyz_bin_loss_finish(const long long *counts, const float *bce_mean, int C, float momentum, float *histogram, float *loss,
                            float *bin_weights, void *stream);
-/* The NormClipper pair (lc_sqnorm_f32, lc_norm_clip_apply_f32) on a gradient of any map type: the hooks sit on the heads' outputs
+/* The NormClipper pair (2h) on a gradient of any map type: the hooks sit on the heads' outputs
  * (losses.py:343-352), so under mixed precision the gradient they clip is 16-bit; read and written in place of a cast each way. */
 int lc_sqnorm(const void *x, int dtype, long long n, double *partials, unsigned *ticket, float *sq, int accumulate,
               const float *state, float *state_snapshot, void *stream);

@@ -24,65 +24,32 @@ _SIGNATURES = {
     "lc_amd_version": (c_int, []),
     "lc_amd_last_error": (ctypes.c_char_p, []),
     "pnp_ceres_f32_omp": (None, [_FP, _FP, _FP, _FP, _FP, _I, c_int, c_float, c_int, _F, _I, c_int, c_int]),
-    "lc_pnp_lm_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p]),
-    "lc_pnp_lm2_f32": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "lc_pnp_lm3_f32": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p]),
     "lc_pnp_lm_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "lc_split_workspace_rescues": (ctypes.c_longlong, [c_void_p, ctypes.c_size_t, c_int, c_void_p]),
     "lc_pnp_lm_chain2_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "lc_pnp_lm_trace_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
-    "lc_cov_loss_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 6),
-    "lc_cov_loss2_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float, c_int] + [c_void_p] * 6),
     "lc_cov_loss3_fwd_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float, c_int] + [c_void_p] * 6 + [ctypes.c_size_t, c_void_p]),
     "lc_cov_loss_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
-    "lc_pose_unit_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 9 +
-                         [c_int, c_float, c_void_p]),
     "lc_pose_unit2_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 10 +
                           [c_int, c_float, c_void_p, ctypes.c_size_t, c_void_p]),
     "lc_scale_rows_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_int, c_void_p]),
-    "lc_dense_frontend_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 5),
-    "lc_dense_frontend_fwd2_f32": (c_int, [c_void_p] * 5 + [c_float] + [c_int] * 6 + [c_void_p] * 6),
-    "lc_dense_frontend_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p] * 4),
-    "lc_pnp_lm_chain_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "lc_pnp_ransac_init_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 5),
-    "lc_pnp_ransac_init2_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6),
-    "lc_pnp_ransac_init3_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +
-                                [ctypes.c_size_t, c_void_p]),
-    "lc_pnp_ransac_init4_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +
-                                [ctypes.c_size_t, c_int, c_void_p, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 6),
     "lc_pnp_ransac_init5_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 7 +
                                 [ctypes.c_size_t, c_int, c_void_p, c_void_p, c_int, ctypes.c_uint] + [c_void_p] * 5 + [c_int, c_void_p]),
     "lc_pnp_ransac_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
-    "lc_bits_decode_gt_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 11 + [c_void_p, c_void_p]),
-    "lc_bits_decode_gt_bwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
-    "lc_bits_decode_gt_fwd2_f32": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p, c_void_p]),
-    "lc_bits_decode_gt_bwd2_f32": (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p, c_void_p]),
-    "lc_bits_decode_f32": (c_int, [c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
-    "lc_bits_decode2_f32": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_void_p]),
+    "lc_pnp_ransac_workspace_layout": (c_int, [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "lc_pose_errors_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_void_p]),
-    "lc_sqnorm_f32": (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "lc_norm_clip_apply_f32": (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_float, c_float, ctypes.c_double,
-                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "lc_kpt_nll_fwd_bwd_f32": (c_int, [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 4),
-    "lc_dense_frontend_select_f32": (c_int, [c_void_p] * 5 + [c_float] + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint] +
-                                     [c_void_p] * 6),
-    "lc_xyz_bin_loss_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float] + [c_void_p] * 6),
-    "lc_xyz_bin_loss_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 2),
-    "lc_dense_aux_fwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p] * 4),
-    "lc_dense_aux_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_void_p] * 7),
     "lc_dense_select_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, ctypes.c_double, c_int, c_int, ctypes.c_uint] + [c_void_p] * 6),
-    "lc_softargmax2d_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "lc_softargmax2d_bwd_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lc_softargmax2d_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lc_softargmax2d_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lc_sqnorm": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "lc_norm_clip_apply": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_float, c_float, ctypes.c_double,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
-    # round 4: the f1 / f3 entry points for maps of any element type (map_dtype) lying anywhere a sample is contiguous (batch strides)
+    # the f1 / f3 entry points: maps of any element type (map_dtype) lying anywhere a sample is contiguous (batch strides)
     "lc_dense_frontend_fwd3": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 6 + [c_void_p] * 6),
     "lc_dense_frontend_bwd2": (c_int, [c_void_p] * 6 + [c_int, c_int, ctypes.c_longlong] + [c_int] * 6 + [c_void_p] * 4),
-    "lc_dense_frontend_select2": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint, c_int] +
-                                  [c_void_p] * 6),
     "lc_dense_frontend_select3": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int] * 7 + [ctypes.c_double, c_int, c_int, ctypes.c_uint, c_int] +
                                   [c_void_p] * 5 + [c_void_p, ctypes.c_size_t, c_void_p]),
     "lc_dense_frontend_select_workspace_bytes": (ctypes.c_size_t, [c_int] * 6),

@@ -145,7 +145,19 @@ def _compile(out: str, flags, verbose: bool) -> str:
     return out
 
 
-VARIANT_DIR = os.path.join(os.path.dirname(PKG), "build", "variants")  # diagnostics stay out of the package (build/ is git-ignored)
+def _variant_dir() -> str:
+    """Where experiment builds go: LC_AMD_BUILD_DIR if set; next to a source checkout (build/variants, git-ignored) when the package sits in
+    one; a per-user cache otherwise (an installed package's parent directory is site-packages: nothing is written there)."""
+    env = os.environ.get("LC_AMD_BUILD_DIR")
+    if env:
+        return env
+    parent = os.path.dirname(PKG)
+    if os.path.exists(os.path.join(parent, "include", "lc_amd.h")) and os.access(parent, os.W_OK):
+        return os.path.join(parent, "build", "variants")
+    return os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache")), "lc_amd", "variants")
+
+
+VARIANT_DIR = _variant_dir()  # diagnostics stay out of the package
 
 
 def variant_path(name: str) -> str:

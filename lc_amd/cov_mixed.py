@@ -1,7 +1,7 @@
 """`lib.cov_mixed.Loss_cov_mixed` call surface on top of the fused HIP kernel.
 
 Same signature, kwargs, output and gradient semantics as `lib/cov_mixed.py:100-150`; the ~1000 torch ops
-of the reference become one `lc_cov_loss_fwd_bwd_f32` launch (forward + unit Jacobians) plus, in backward,
+of the reference become one `lc_cov_loss3_fwd_bwd_f32` launch (forward + unit Jacobians) plus, in backward,
 one `lc_scale_rows_f32` launch applying the incoming cotangent.
 """
 from __future__ import annotations

@@ -172,22 +172,7 @@ void pnp_ceres_f32_omp(float** init_states, float** cam_Ks, float** pts2ds, floa
     }
 }
 
-int lc_pnp_lm_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* sqrt_diag,
-                  const int* counts, const float* start, float* states, float* result_tr, int* rets, int* iters, int B, int Nmax,
-                  int max_iter, float function_tolerance, void* stream) {
-    if (B < 0 || Nmax < 0) return fail(1, "negative size");
-    if (B == 0) return 0;
-    if ((sqrtL == nullptr) == (sqrt_diag == nullptr)) return fail(1, "exactly one of sqrtL / sqrt_diag must be given");
-    if (!K || !pts3d || !pts2d || !states || !result_tr || !rets) return fail(1, "null pointer");
-    LC_REQUIRE_ALIGNED(8, pts2d, sqrt_diag);
-    LC_REQUIRE_ALIGNED(16, sqrtL);
-    lc::PnpParams p{K, pts2d, pts3d, sqrtL, sqrt_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
-                    B, Nmax, max_iter, function_tolerance};
-    if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
-    return 0;
-}
-
-// argument checks of lc_pnp_lm2_f32 -> kernel parameters; 0 / 1 (lc_amd_last_error says why)
+// argument checks of lc_pnp_lm3_f32 -> kernel parameters; 0 / 1 (lc_amd_last_error says why)
 static int pnp_params(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
                       const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
                       int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod, lc::PnpParams& p) {
@@ -207,18 +192,6 @@ static int pnp_params(const float* K, const float* pts3d, const float* pts2d, co
     LC_REQUIRE_ALIGNED(16, sqrtL);
     p = lc::PnpParams{K, pts2d, pts3d, sqrtL, weights_diag, counts, start == states ? nullptr : start, states, result_tr, rets, iters,
                       B, Nmax, max_iter, function_tolerance, nullptr, 0, options, weight_mask, pose_mod};
-    return 0;
-}
-
-int lc_pnp_lm2_f32(const float* K, const float* pts3d, const float* pts2d, const float* sqrtL, const float* weights_diag,
-                   const unsigned char* weight_mask, const int* counts, const float* start, float* states, float* result_tr, int* rets,
-                   int* iters, int B, int Nmax, int max_iter, float function_tolerance, int options, int pose_mod, void* stream) {
-    lc::PnpParams p;
-    if (int rc = pnp_params(K, pts3d, pts2d, sqrtL, weights_diag, weight_mask, counts, start, states, result_tr, rets, iters, B, Nmax, max_iter,
-                            function_tolerance, options, pose_mod, p))
-        return rc;
-    if (B == 0) return 0;
-    if (lc::launch_pnp_lm(p, static_cast<hipStream_t>(stream))) return fail(11, "pnp kernel launch failed");
     return 0;
 }
 
@@ -250,8 +223,18 @@ int lc_pnp_lm3_f32(const float* K, const float* pts3d, const float* pts2d, const
     return 0;
 }
 
-int lc_pnp_lm_chain_f32(const lc_pnp_lm_job* first, const lc_pnp_lm_job* second, void* stream) {
-    return lc_pnp_lm_chain2_f32(first, second, nullptr, 0, stream);
+long long lc_split_workspace_rescues(const void* workspace, size_t workspace_bytes, int kind, void* stream) {
+    // per-unit region size of the kind: what one unit of a shape that takes the split form asks for
+    const size_t unit = kind == 0 ? lc::pnp_split_workspace_bytes(1, 4 * lc::kSplitMinPoints) : kind == 1 ? lc::dense_select_split_workspace_bytes(1, 16384) : 0;
+    if (!workspace || unit < 128 || workspace_bytes < unit) { fail(1, "lc_split_workspace_rescues: kind 0 (pnp) | 1 (select) and a workspace of at least one unit"); return -1; }
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) { fail(11, "stream synchronisation failed"); return -1; }
+    long long total = 0;
+    for (size_t u = 0; (u + 1) * unit <= workspace_bytes; ++u) {
+        unsigned tail[3];  // epoch, dirty, rescues so far (lc_common.h: the last 128 bytes of a unit's region)
+        if (hipMemcpy(tail, static_cast<const char*>(workspace) + (u + 1) * unit - 128, sizeof(tail), hipMemcpyDeviceToHost) != hipSuccess) { fail(11, "copy failed"); return -1; }
+        total += tail[2];
+    }
+    return total;
 }
 
 int lc_pnp_lm_chain2_f32(const lc_pnp_lm_job* first, const lc_pnp_lm_job* second, void* workspace, size_t workspace_bytes, void* stream) {
@@ -285,22 +268,6 @@ int lc_pnp_lm_trace_f32(const float* K, const float* pts3d, const float* pts2d, 
     return 0;
 }
 
-int lc_cov_loss_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
-                            const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
-                            float rel_thresh, float w_e_thresh, float* loss, float* d_pts2d, float* d_inv_std, float* d_pts3d,
-                            float* aux, void* stream) {
-    return lc_cov_loss2_fwd_bwd_f32(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, B, N, max_err_len, rel_thresh,
-                                    w_e_thresh, 0, loss, d_pts2d, d_inv_std, d_pts3d, aux, stream);
-}
-
-int lc_cov_loss2_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
-                             const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
-                             float rel_thresh, float w_e_thresh, int cov_2d, float* loss, float* d_pts2d, float* d_inv_std,
-                             float* d_pts3d, float* aux, void* stream) {
-    return lc_cov_loss3_fwd_bwd_f32(K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, B, N, max_err_len, rel_thresh,
-                                    w_e_thresh, cov_2d, loss, d_pts2d, d_inv_std, d_pts3d, aux, nullptr, 0, stream);
-}
-
 size_t lc_cov_loss_workspace_bytes(int B, int N) { return lc::cov_loss_workspace_bytes(B, N); }
 
 int lc_cov_loss3_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
@@ -319,26 +286,6 @@ int lc_cov_loss3_fwd_bwd_f32(const float* K, const float* pose, const float* pts
     const int rc = lc::launch_cov_loss(p, static_cast<hipStream_t>(stream));
     if (rc == 3) return fail(3, "workspace smaller than lc_cov_loss_workspace_bytes(B, N)");
     if (rc) return fail(11, "loss kernel launch failed");
-    return 0;
-}
-
-int lc_pose_unit_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* inv_std,
-                     const float* valid, const float* bbox_3d, const float* grad_out, int B, int N, float max_err_len,
-                     float rel_thresh, float w_e_thresh, float* loss, float* d_pts2d, float* d_inv_std, float* d_pts3d,
-                     const float* pnp_sqrt_diag, const float* pnp_start, float* pnp_states, float* pnp_result_tr, int* pnp_rets,
-                     int pnp_max_iter, float pnp_function_tolerance, void* stream) {
-    if (B < 0 || N <= 0) return fail(1, "bad size");
-    if (N > 64) return fail(3, "lc_pose_unit_f32 needs N <= 64; launch the two kernels separately");
-    if (B == 0) return 0;
-    if (!K || !pose || !pts3d || !pts2d || !inv_std || !bbox_3d || !loss || !d_pts2d || !d_inv_std || !pnp_sqrt_diag ||
-        !pnp_start || !pnp_states || !pnp_result_tr || !pnp_rets)
-        return fail(1, "null pointer");
-    LC_REQUIRE_ALIGNED(8, pts2d, inv_std, d_pts2d, d_inv_std, pnp_sqrt_diag);
-    lc::LossParams lp{K, pose, pts3d, pts2d, inv_std, valid, bbox_3d, grad_out, loss, d_pts2d, d_inv_std, d_pts3d, nullptr,
-                      B, N, max_err_len, rel_thresh, w_e_thresh, 0};
-    lc::PnpParams pp{K, pts2d, pts3d, nullptr, pnp_sqrt_diag, nullptr, pnp_start == pnp_states ? nullptr : pnp_start, pnp_states,
-                     pnp_result_tr, pnp_rets, nullptr, B, N, pnp_max_iter, pnp_function_tolerance};
-    if (lc::launch_pose_unit(lp, pp, static_cast<hipStream_t>(stream))) return fail(11, "pose-unit kernel launch failed");
     return 0;
 }
 
@@ -403,15 +350,6 @@ static int head_bwd(const void* in, int dtype, const float* mean, const float* s
     return lc::launch_head_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "head backward launch failed") : 0;
 }
 
-int lc_softargmax2d_fwd_f32(const float* in, int M, int H, int W, int is_prob, float* mean, float* std, float* stats, void* stream) {
-    return head_fwd(in, 0, M, H, W, is_prob, mean, std, stats, stream);
-}
-
-int lc_softargmax2d_bwd_f32(const float* in, const float* mean, const float* std, const float* stats, const float* g_mean,
-                            const float* g_std, int M, int H, int W, int is_prob, float* g_in, void* stream) {
-    return head_bwd(in, 0, mean, std, stats, g_mean, g_std, M, H, W, is_prob, g_in, stream);
-}
-
 int lc_softargmax2d_fwd(const void* in, int dtype, int M, int H, int W, int is_prob, float* mean, float* std, float* stats, void* stream) {
     return head_fwd(in, dtype, M, H, W, is_prob, mean, std, stats, stream);
 }
@@ -419,18 +357,6 @@ int lc_softargmax2d_fwd(const void* in, int dtype, int M, int H, int W, int is_p
 int lc_softargmax2d_bwd(const void* in, int dtype, const float* mean, const float* std, const float* stats, const float* g_mean,
                         const float* g_std, int M, int H, int W, int is_prob, void* g_in, void* stream) {
     return head_bwd(in, dtype, mean, std, stats, g_mean, g_std, M, H, W, is_prob, g_in, stream);
-}
-
-int lc_dense_frontend_fwd_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, int B, int H,
-                              int W, int top, int left, int sample, float* pts2d, float* inv_std, float* pts3d, float* lse,
-                              void* stream) {
-    if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
-    if (B == 0) return 0;
-    if (!wlogits || !wscale || !pts2d || !inv_std || !lse || (xyz != nullptr) != (pts3d != nullptr)) return fail(1, "null pointer");
-    LC_REQUIRE_ALIGNED(8, pts2d, inv_std);
-    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
-    lc::DenseParams p{xyz, wlogits, wscale, noc_scale, pts2d, inv_std, pts3d, lse, B, H, W, N, top, left, sample};
-    return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
 }
 
 int lc_dense_frontend_fwd3(const void* xyz, const void* wlogits, const void* wscale, const float* noc_scale, const void* vis_logits,
@@ -452,12 +378,6 @@ int lc_dense_frontend_fwd3(const void* xyz, const void* wlogits, const void* wsc
     return lc::launch_dense_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end launch failed") : 0;
 }
 
-int lc_dense_frontend_fwd2_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
-                               float vis_thresh, int B, int H, int W, int top, int left, int sample, float* pts2d, float* inv_std,
-                               float* pts3d, float* lse, unsigned char* vis_mask, void* stream) {
-    return lc_dense_frontend_fwd3(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, 0 /* LC_F32 */, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, 0, 0, B, H, W, top, left, sample, pts2d, inv_std, pts3d, lse, vis_mask, stream);
-}
-
 int lc_dense_frontend_bwd2(const void* wlogits, const void* wscale, const float* noc_scale, const float* lse,
                               const float* g_inv_std, const float* g_pts3d, int map_dtype, int wscale_dtype, long long wlogits_bstride, int B, int H, int W, int top, int left, int sample,
                               void* d_xyz, void* d_wlogits, void* d_wscale, void* stream) {
@@ -474,52 +394,15 @@ int lc_dense_frontend_bwd2(const void* wlogits, const void* wscale, const float*
     return lc::launch_dense_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense front-end backward launch failed") : 0;
 }
 
-int lc_dense_frontend_bwd_f32(const float* wlogits, const float* wscale, const float* noc_scale, const float* lse,
-                              const float* g_inv_std, const float* g_pts3d, int B, int H, int W, int top, int left, int sample,
-                              float* d_xyz, float* d_wlogits, float* d_wscale, void* stream) {
-    return lc_dense_frontend_bwd2(wlogits, wscale, noc_scale, lse, g_inv_std, g_pts3d, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, B, H, W, top, left, sample, d_xyz, d_wlogits, d_wscale, stream);
-}
-
-int lc_pnp_ransac_init_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
-                           float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
-                           unsigned char* inlier_mask, int* n_inliers, int* invalid, void* stream) {
-    if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
-    if (B == 0) return 0;
-    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
-    lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
-                       (iterations + 63) / 64, reproj_err, seed};
-    return lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream)) ? fail(11, "ransac kernel launch failed") : 0;
-}
-
-int lc_pnp_ransac_init2_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
-                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
-                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, void* stream) {
-    if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
-    if (B == 0) return 0;
-    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
-    lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
-                       (iterations + 63) / 64, reproj_err, seed, best_hyp};
-    return lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream)) ? fail(11, "ransac kernel launch failed") : 0;
-}
-
 size_t lc_pnp_ransac_workspace_bytes(int B, int Nmax, int iterations) {
     if (B <= 0 || Nmax < 0 || iterations <= 0) return 0;
     return lc::pnp_ransac_workspace_bytes(B, Nmax, (iterations + 63) / 64);
 }
 
-int lc_pnp_ransac_init3_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
-                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
-                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
-                            size_t workspace_bytes, void* stream) {
-    if (B < 0 || Nmax < 0 || iterations <= 0) return fail(1, "bad size");
-    if (B == 0) return 0;
-    if (!K || !pts3d || !pts2d || !states || !inlier_mask || !n_inliers || !invalid) return fail(1, "null pointer");
-    LC_REQUIRE_ALIGNED(16, workspace);  // the selection reads the hypotheses as 16-byte pairs of doubles
-    lc::RansacParams p{K, pts3d, pts2d, counts, reproj_err_per_pose, states, inlier_mask, n_inliers, invalid, B, Nmax,
-                       (iterations + 63) / 64, reproj_err, seed, best_hyp, valid_counts, workspace, workspace_bytes};
-    const int rc = lc::launch_pnp_ransac(p, static_cast<hipStream_t>(stream));
-    if (rc == 3) return fail(1, "workspace smaller than lc_pnp_ransac_workspace_bytes(B, Nmax, iterations)");
-    return rc ? fail(11, "ransac kernel launch failed") : 0;
+int lc_pnp_ransac_workspace_layout(int B, int Nmax, int iterations, size_t out[6]) {
+    if (B <= 0 || Nmax < 0 || iterations <= 0 || !out) return fail(1, "bad size");
+    lc::pnp_ransac_workspace_layout(B, Nmax, (iterations + 63) / 64, out);
+    return 0;
 }
 
 static int ransac_init_any(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
@@ -551,49 +434,16 @@ int lc_pnp_ransac_init5_f32(const float* K, const float* pts3d, const float* pts
                             unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
                             size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
                             float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, int pose_index_offset, void* stream) {
-    // the one entry point on which a positive scalar next to per-pose values means "divide" (include/lc_amd.h)
+    // a positive scalar next to per-pose values means "divide" (include/lc_amd.h); a scalar <= 0: the per-pose values are the thresholds
     return ransac_init_any(K, pts3d, pts2d, counts, B, Nmax, reproj_err, reproj_err_per_pose, iterations, seed, states, inlier_mask, n_inliers, invalid, best_hyp,
                            valid_counts, workspace, workspace_bytes, ticketed, sel_w, sel_in_index, sel_min_count, sel_seed, sel_pts2d, sel_w_out, sel_pts3d, sel_index,
                            sel_counts, pose_index_offset, (reproj_err_per_pose && reproj_err > 0.f) ? 1 : 0, stream);
-}
-
-int lc_pnp_ransac_init4_f32(const float* K, const float* pts3d, const float* pts2d, const int* counts, int B, int Nmax,
-                            float reproj_err, const float* reproj_err_per_pose, int iterations, unsigned seed, float* states,
-                            unsigned char* inlier_mask, int* n_inliers, int* invalid, int* best_hyp, int* valid_counts, void* workspace,
-                            size_t workspace_bytes, int ticketed, const float* sel_w, const int* sel_in_index, int sel_min_count, unsigned sel_seed,
-                            float* sel_pts2d, float* sel_w_out, float* sel_pts3d, int* sel_index, int* sel_counts, void* stream) {
-    // init .. init4 keep their original meaning: per-pose values, when given, ARE the thresholds (whatever the scalar)
-    return ransac_init_any(K, pts3d, pts2d, counts, B, Nmax, reproj_err, reproj_err_per_pose, iterations, seed, states, inlier_mask, n_inliers, invalid, best_hyp, valid_counts, workspace, workspace_bytes, ticketed, sel_w, sel_in_index, sel_min_count, sel_seed, sel_pts2d, sel_w_out, sel_pts3d, sel_index, sel_counts, 0, 0, stream);
 }
 
 static int bits_check(int B, int C, int H, int W, int n0, int n1, int n2, int top, int left, int sample) {
     if (B < 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return fail(1, "bad size");
     if (n0 < 1 || n1 < 1 || n2 < 1 || n0 > 24 || n1 > 24 || n2 > 24 || n0 + n1 + n2 != C) return fail(1, "bad bit counts");
     return 0;
-}
-
-int lc_bits_decode_gt_fwd_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, int B, int C, int H,
-                              int W, int n0, int n1, int n2, int black_background, int top, int left, int sample, float* noc,
-                              void* stream) {
-    if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
-    if (B == 0) return 0;
-    if (!logits || !gt_bits || !noc) return fail(1, "null pointer");
-    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
-    lc::BitsParams p{logits, gt_bits, gt_msk, nullptr, noc, nullptr, B, C, H, W, N, top, left, sample, {n0, n1, n2},
-                     black_background ? -1 : 1};
-    return lc::launch_bits_decode_gt_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
-}
-
-int lc_bits_decode_gt_bwd_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* g_noc,
-                              int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top, int left,
-                              int sample, float* d_logits, void* stream) {
-    if (int rc = bits_check(B, C, H, W, n0, n1, n2, top, left, sample)) return rc;
-    if (B == 0) return 0;
-    if (!logits || !gt_bits || !g_noc || !d_logits) return fail(1, "null pointer");
-    const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
-    lc::BitsParams p{logits, gt_bits, gt_msk, g_noc, nullptr, d_logits, B, C, H, W, N, top, left, sample, {n0, n1, n2},
-                     black_background ? -1 : 1};
-    return lc::launch_bits_decode_gt_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode backward launch failed") : 0;
 }
 
 int lc_bits_decode_gt_fwd3(const void* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
@@ -612,12 +462,6 @@ int lc_bits_decode_gt_fwd3(const void* logits, const unsigned char* gt_bits, con
     return lc::launch_bits_decode_gt_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
 }
 
-int lc_bits_decode_gt_fwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
-                               const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, int top,
-                               int left, int sample, float* out, void* stream) {
-    return lc_bits_decode_gt_fwd3(logits, gt_bits, gt_msk, out_scale, out_xform, 0 /* LC_F32 */, 0, B, C, H, W, n0, n1, n2, black_background, top, left, sample, out, stream);
-}
-
 int lc_bits_decode_gt_bwd3(const void* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
                                const float* out_xform, const float* g_out, int map_dtype, long long logits_bstride, int B, int C, int H, int W, int n0, int n1, int n2,
                                int black_background, int top, int left, int sample, void* d_logits, void* stream) {
@@ -632,21 +476,6 @@ int lc_bits_decode_gt_bwd3(const void* logits, const unsigned char* gt_bits, con
     lc::BitsParams p{logits, gt_bits, gt_msk, g_out, nullptr, d_logits, B, C, H, W, N, top, left, sample, {n0, n1, n2},
                      black_background ? -1 : 1, out_scale, out_xform, 0, map_dtype, logits_bstride ? logits_bstride : (long long)C * H * W};
     return lc::launch_bits_decode_gt_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode backward launch failed") : 0;
-}
-
-int lc_bits_decode_gt_bwd2_f32(const float* logits, const unsigned char* gt_bits, const unsigned char* gt_msk, const float* out_scale,
-                               const float* out_xform, const float* g_out, int B, int C, int H, int W, int n0, int n1, int n2,
-                               int black_background, int top, int left, int sample, float* d_logits, void* stream) {
-    return lc_bits_decode_gt_bwd3(logits, gt_bits, gt_msk, out_scale, out_xform, g_out, 0 /* LC_F32 */, 0, B, C, H, W, n0, n1, n2, black_background, top, left, sample, d_logits, stream);
-}
-
-int lc_bits_decode_f32(const float* logits, int B, int C, int H, int W, int n0, int n1, int n2, int black_background, float* noc,
-                       void* stream) {
-    if (int rc = bits_check(B, C, H, W, n0, n1, n2, 0, 0, 1)) return rc;
-    if (B == 0) return 0;
-    if (!logits || !noc) return fail(1, "null pointer");
-    lc::BitsParams p{logits, nullptr, nullptr, nullptr, noc, nullptr, B, C, H, W, H * W, 0, 0, 1, {n0, n1, n2}, black_background ? -1 : 1};
-    return lc::launch_bits_decode(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode launch failed") : 0;
 }
 
 int lc_bits_decode3(const void* logits, const float* out_scale, const float* out_xform, int map_dtype, long long logits_bstride, int B, int C, int H, int W, int n0, int n1, int n2,
@@ -679,11 +508,6 @@ int lc_bits_decode_rows(const void* logits, const float* out_scale, const float*
     return lc::launch_bits_decode_rows(p, static_cast<hipStream_t>(stream)) ? fail(11, "bits decode (rows) launch failed") : 0;
 }
 
-int lc_bits_decode2_f32(const float* logits, const float* out_scale, const float* out_xform, int B, int C, int H, int W, int n0, int n1, int n2,
-                        int black_background, int planar, float* out, void* stream) {
-    return lc_bits_decode3(logits, out_scale, out_xform, 0 /* LC_F32 */, 0, B, C, H, W, n0, n1, n2, black_background, planar, out, stream);
-}
-
 int lc_pose_errors_f32(const float* R_est, const float* t_est, const float* R_gt, const float* t_gt, const float* pts,
                        const int* pts_off, const int* pts_cnt, int B, int M, int want_adi, float* out, void* stream) {
     if (B < 0 || M < 0) return fail(1, "bad size");
@@ -706,11 +530,6 @@ int lc_sqnorm(const void* x, int dtype, long long n, double* partials, unsigned*
     return lc::launch_sqnorm(p, static_cast<hipStream_t>(stream)) ? fail(11, "sqnorm launch failed") : 0;
 }
 
-int lc_sqnorm_f32(const float* x, long long n, double* partials, unsigned* ticket, float* sq, int accumulate, const float* state,
-                  float* state_snapshot, void* stream) {
-    return lc_sqnorm(x, 0 /* LC_F32 */, n, partials, ticket, sq, accumulate, state, state_snapshot, stream);
-}
-
 int lc_norm_clip_apply(const void* grad, int dtype, long long n, const float* sq, const float* state_in, float initial_max_norm, float scale,
                        double momentum, void* out, float* state_out, float* norm_out, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(1, "dtype must be LC_F32, LC_F16 or LC_BF16");
@@ -721,11 +540,6 @@ int lc_norm_clip_apply(const void* grad, int dtype, long long n, const float* sq
     p.initial_max_norm = initial_max_norm; p.scale = scale; p.keep = (float)(1.0 - momentum); p.gain = (float)(momentum * (double)scale);
     p.out = out; p.state_out = state_out; p.norm_out = norm_out; p.dtype = dtype;
     return lc::launch_clip_apply(p, static_cast<hipStream_t>(stream)) ? fail(11, "clip launch failed") : 0;
-}
-
-int lc_norm_clip_apply_f32(const float* grad, long long n, const float* sq, const float* state_in, float initial_max_norm, float scale,
-                           double momentum, float* out, float* state_out, float* norm_out, void* stream) {
-    return lc_norm_clip_apply(grad, 0 /* LC_F32 */, n, sq, state_in, initial_max_norm, scale, momentum, out, state_out, norm_out, stream);
 }
 
 int lc_kpt_nll_fwd_bwd_f32(const float* K, const float* pose, const float* pts3d, const float* pts2d, const float* pts2d_std, int B,
@@ -755,14 +569,6 @@ int lc_dense_select_f32(const float* pts2d, const float* inv_std, const float* p
     return rc ? fail(11, "dense select launch failed") : 0;
 }
 
-int lc_dense_frontend_select2(const void* xyz, const void* wlogits, const void* wscale, const float* noc_scale, const void* vis_logits,
-                                 float vis_thresh, int map_dtype, int xyz_dtype, int wscale_dtype, long long xyz_bstride, long long wlogits_bstride, long long vis_bstride, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
-                                 int square_weights, int min_count, unsigned seed, int pose_index_offset, float* out_pts2d, float* out_weights, float* out_pts3d,
-                                 int* out_index, int* counts, void* stream) {
-    return lc_dense_frontend_select3(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, map_dtype, xyz_dtype, wscale_dtype, xyz_bstride, wlogits_bstride, vis_bstride, B, H, W, top, left, sample, mode, quantile,
-                                     square_weights, min_count, seed, pose_index_offset, out_pts2d, out_weights, out_pts3d, out_index, counts, nullptr, 0, stream);
-}
-
 size_t lc_dense_frontend_select_workspace_bytes(int B, int H, int W, int top, int left, int sample) {
     if (B <= 0 || H <= 0 || W <= 0 || sample <= 0 || top < 0 || left < 0 || top >= H || left >= W) return 0;
     return lc::dense_select_split_workspace_bytes(B, ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample));
@@ -781,7 +587,7 @@ int lc_dense_frontend_select3(const void* xyz, const void* wlogits, const void* 
     const int N = ((H - top + sample - 1) / sample) * ((W - left + sample - 1) / sample);
     if (mode < 0 || mode > 2 || min_count < 0 || min_count > N) return fail(1, "bad size or mode");
     if (mode != 0 && !(quantile >= 0.0 && quantile <= 1.0)) return fail(1, "quantile outside [0,1]");
-    if (N > 16384) return fail(1, "more than 16384 sampled pixels per object: use lc_dense_frontend_fwd2_f32 + lc_dense_select_f32");
+    if (N > 16384) return fail(1, "more than 16384 sampled pixels per object: use lc_dense_frontend_fwd3 + lc_dense_select_f32");
     if (B == 0) return 0;
     if (!wlogits || !wscale || !out_pts2d || !out_weights || !counts) return fail(1, "null pointer");
     if ((xyz == nullptr) != (out_pts3d == nullptr)) return fail(1, "xyz and out_pts3d go together (both NULL: the selection alone, lc_bits_decode_rows fills the points)");
@@ -800,13 +606,6 @@ int lc_dense_frontend_select3(const void* xyz, const void* wlogits, const void* 
     lc::DenseParams d{xyz, wlogits, wscale, noc_scale, nullptr, nullptr, nullptr, nullptr, B, H, W, N, top, left, sample, vis_logits, vis_thresh, nullptr, map_dtype, wscale_dtype, xyz_dtype,
                        xyz_bstride ? xyz_bstride : 3ll * H * W, wlogits_bstride ? wlogits_bstride : 2ll * H * W, vis_bstride ? vis_bstride : 1ll * H * W};
     return lc::launch_dense_frontend_select(p, d, static_cast<hipStream_t>(stream)) ? fail(11, "front end + select launch failed") : 0;
-}
-
-int lc_dense_frontend_select_f32(const float* xyz, const float* wlogits, const float* wscale, const float* noc_scale, const float* vis_logits,
-                                 float vis_thresh, int B, int H, int W, int top, int left, int sample, int mode, double quantile,
-                                 int square_weights, int min_count, unsigned seed, float* out_pts2d, float* out_weights, float* out_pts3d,
-                                 int* out_index, int* counts, void* stream) {
-    return lc_dense_frontend_select2(xyz, wlogits, wscale, noc_scale, vis_logits, vis_thresh, 0 /* LC_F32 */, 0 /* LC_F32 */, 0 /* LC_F32 */, 0, 0, 0, B, H, W, top, left, sample, mode, quantile, square_weights, min_count, seed, 0, out_pts2d, out_weights, out_pts3d, out_index, counts, stream);
 }
 
 int lc_dense_aux_fwd2(const void* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
@@ -828,12 +627,6 @@ int lc_dense_aux_fwd2(const void* xyz, const unsigned char* msk_noc_u8, const fl
     return lc::launch_dense_aux_fwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense aux loss launch failed") : 0;
 }
 
-int lc_dense_aux_fwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
-                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type, float* losses,
-                         double* partials, unsigned* ticket, void* stream) {
-    return lc_dense_aux_fwd2(xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, 0 /* LC_F32 */, 0, 0, 0, B, HW, seg_type, losses, partials, ticket, stream);
-}
-
 int lc_dense_aux_bwd2(const void* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
                          const void* seg_logits, const float* msk_vis, const void* wlogits, int map_dtype, long long xyz_bstride, long long seg_bstride, long long wlogits_bstride, int B, int HW, int seg_type,
                          const float* g_noc, const float* g_seg, const float* g_wseg, void* d_xyz, void* d_seg, void* d_wlogits,
@@ -851,13 +644,6 @@ int lc_dense_aux_bwd2(const void* xyz, const unsigned char* msk_noc_u8, const fl
                          g_noc, g_seg, g_wseg, d_xyz, d_seg, d_wlogits, B, HW, map_dtype,
                          xyz_bstride ? xyz_bstride : 3ll * HW, seg_bstride ? seg_bstride : 1ll * HW, wlogits_bstride ? wlogits_bstride : 2ll * HW};
     return lc::launch_dense_aux_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "dense aux loss backward launch failed") : 0;
-}
-
-int lc_dense_aux_bwd_f32(const float* xyz, const unsigned char* msk_noc_u8, const float* msk_noc_f32, const float* noc_tgt,
-                         const float* seg_logits, const float* msk_vis, const float* wlogits, int B, int HW, int seg_type,
-                         const float* g_noc, const float* g_seg, const float* g_wseg, float* d_xyz, float* d_seg, float* d_wlogits,
-                         void* stream) {
-    return lc_dense_aux_bwd2(xyz, msk_noc_u8, msk_noc_f32, noc_tgt, seg_logits, msk_vis, wlogits, 0 /* LC_F32 */, 0, 0, 0, B, HW, seg_type, g_noc, g_seg, g_wseg, d_xyz, d_seg, d_wlogits, stream);
 }
 
 static int xyz_bin_fwd_common(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, int map_dtype, long long logits_bstride, long long vis_bstride,
@@ -911,12 +697,6 @@ int lc_xyz_bin_loss_finish(const long long* counts, const float* bce_mean, int C
     return lc::launch_xyz_bin_loss_finish(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss finish launch failed") : 0;
 }
 
-int lc_xyz_bin_loss_fwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, int B, int C, int HW,
-                            float momentum, float* histogram, float* loss, float* bin_weights, double* partials, unsigned* ticket,
-                            void* stream) {
-    return lc_xyz_bin_loss_fwd2(logits, gt_bits, msk_vis_logits, 0 /* LC_F32 */, 0, 0, B, C, HW, momentum, histogram, loss, bin_weights, partials, ticket, stream);
-}
-
 int lc_xyz_bin_loss_bwd2(const void* logits, const unsigned char* gt_bits, const void* msk_vis_logits, const float* bin_weights,
                             const float* g_loss, int map_dtype, long long logits_bstride, long long vis_bstride, int B, int C, int HW, void* d_logits, void* stream) {
     if (map_dtype < 0 || map_dtype > 2) return fail(1, "map_dtype must be LC_F32, LC_F16 or LC_BF16");
@@ -934,11 +714,6 @@ int lc_xyz_bin_loss_bwd2(const void* logits, const unsigned char* gt_bits, const
     p.logits_bs = logits_bstride ? logits_bstride : (long long)C * HW;
     p.vis_bs = vis_bstride ? vis_bstride : 1ll * HW;
     return lc::launch_xyz_bin_loss_bwd(p, static_cast<hipStream_t>(stream)) ? fail(11, "code loss backward launch failed") : 0;
-}
-
-int lc_xyz_bin_loss_bwd_f32(const float* logits, const unsigned char* gt_bits, const float* msk_vis_logits, const float* bin_weights,
-                            const float* g_loss, int B, int C, int HW, float* d_logits, void* stream) {
-    return lc_xyz_bin_loss_bwd2(logits, gt_bits, msk_vis_logits, bin_weights, g_loss, 0 /* LC_F32 */, 0, 0, B, C, HW, d_logits, stream);
 }
 
 }  // extern "C"

@@ -306,7 +306,9 @@ __device__ __forceinline__ void block_sum_waves4(double (&v)[K], double* lds, in
 // rewritten every second sum (two rows, by sum parity: a workgroup can be one sum ahead of the slowest, not two -- it cannot finish sum s+1
 // before every part has written its s+1 words, i.e. finished reading the rows of sum s), so what a reader finds there is older than the
 // ticket it waits for, or it.  Zeroed workspace = ticket 0 everywhere, first sum = ticket 1.
-// The wait is bounded (kSplitMaxPolls polls, a few ms) and NOTHING depends on the parts being resident together: a part that has waited
+// The wait is bounded in TIME (kSplitWaitTicks of the constant 100 MHz s_memrealtime clock = LC_SPLIT_WAIT_US microseconds, the same budget
+// for every split form whatever its polling loop costs; the clock is read once every 16 unsuccessful polls, never on the path of a hand-off
+// that arrives) and NOTHING depends on the parts being resident together: a part that has waited
 // that long stops for good -- it writes no further exchange word -- and raises the pose's `dirty` word; part 0, whose sums decide the solve
 // and which alone stores the pose, reports status 2 ("a part never arrived") when IT ran out of patience.  The rescue launch that follows
 // every split launch on the same stream (lc_pnp.hip: lc_pnp_lm_split_rescue_kernel; all parts have ended by then, there are no stragglers)
@@ -317,10 +319,17 @@ __device__ __forceinline__ void block_sum_waves4(double (&v)[K], double* lds, in
 // processes or a CU mask taking compute units away make it slow, never wrong and never different.
 // Tail of a pose's region (its last 128 bytes): word 0 epoch, word 1 dirty, word 2 rescues so far (diagnostics: tests read it).
 constexpr int kSplitMaxParts = 8;
-#ifndef LC_SPLIT_MAX_POLLS
-#define LC_SPLIT_MAX_POLLS (1 << 11)
+#ifndef LC_SPLIT_WAIT_US
+#define LC_SPLIT_WAIT_US 2000
 #endif
-constexpr int kSplitMaxPolls = LC_SPLIT_MAX_POLLS;
+constexpr unsigned long long kSplitWaitTicks = 100ull * LC_SPLIT_WAIT_US;
+// One unsuccessful poll more: true when the wait's budget is spent.  `t0` = 0 until the first clock read (the 16th unsuccessful poll).
+__device__ __forceinline__ bool split_wait_expired(int polls, unsigned long long& t0) {
+    if ((polls & 15) != 15) return false;
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) { t0 = now; return false; }
+    return now - t0 > kSplitWaitTicks;
+}
 constexpr int kSplitRowWords = 64;                                                             // 32 totals x 2 words
 constexpr size_t kSplitPoseBytes = 2 * kSplitMaxParts * kSplitRowWords * sizeof(unsigned long long) + 128;  // two rows per part + the tail's line
 constexpr int kSplitLdsDoubles = 128 + 64 + 2;
@@ -392,6 +401,7 @@ __device__ __forceinline__ void block_sum_split(double (&v)[K], double* lds, int
         // all G rows requested at once, again until every word carries the ticket (a row that is already there costs one read)
         unsigned long long lo[kSplitMaxParts], hi[kSplitMaxParts];
         bool ok = true;
+        unsigned long long t0 = 0;
         for (int polls = 0;; ++polls) {
 #pragma unroll
             for (int g = 0; g < kSplitMaxParts; ++g)
@@ -404,7 +414,7 @@ __device__ __forceinline__ void block_sum_split(double (&v)[K], double* lds, int
             for (int g = 0; g < kSplitMaxParts; ++g)
                 if (g < sx.G) late |= ((lo[g] ^ ticket) | (hi[g] ^ ticket)) >> 32;
             if (late == 0) break;
-            if (polls >= kSplitMaxPolls) { ok = false; break; }
+            if (split_wait_expired(polls, t0)) { ok = false; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         double s = 0.0;

@@ -155,6 +155,7 @@ struct RansacParams {
 };
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream);  // 3: workspace too small
 size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds);
+void pnp_ransac_workspace_layout(int B, int Nmax, int rounds, size_t out[6]);  // byte offsets of hyp64, hyp32, partials; H, C; total bytes
 
 struct BitsParams {
     const void* logits;           // (B,C,H,W) code logits of element type map_dtype (lc_map.h), C = bits[0]+bits[1]+bits[2]

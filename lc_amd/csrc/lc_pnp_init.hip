@@ -342,7 +342,7 @@ __device__ __forceinline__ bool hypothesis_pose(const int (&idx)[4], PointFn&& p
 //   c = R X + t by three fma chains that start from t;   r = (cx - u cz, cy - v cz);   q = ry ry + rx rx   (one fma over one product);
 //   inlier  <=>  cz > 0  and  q < (thr2 cz) cz                  -- | c_xy / cz - u |^2 < thr2 with both sides multiplied by cz^2;
 //   the inlier error of a hypothesis (the tie-break of equal counts) adds q over its inliers -- even / odd points of a 64-point chunk in
-//   two sums, (even + odd) x 1 / (tz tz) per chunk (chunk_error: squared residuals in the camera plane at the hypothesis' own depth tz,
+//   two sums, (even + odd) x 1 / (tz tz) per chunk (chunk_error: squared residuals in the camera plane at the hypothesis' own depth tz; +inf for tz <= 0;
 //   IEEE operations only), chunk values in chunk order.  Every launch form performs exactly these operations in exactly this order.
 __device__ __forceinline__ bool inlier_q(const float (&R)[9], const float (&t)[3], float X, float Y, float Z, float u, float v, float thr2, float& q) {
     const float cz = __builtin_fmaf(R[8], Z, __builtin_fmaf(R[7], Y, __builtin_fmaf(R[6], X, t[2])));
@@ -360,8 +360,11 @@ __device__ __forceinline__ void score_point(const float (&R)[9], const float (&t
     err += in ? q : 0.f;
 }
 // (even + odd) sums of a chunk -> the chunk's contribution to the hypothesis' inlier error
+// (a hypothesis whose origin lies behind the camera, tz <= 0, has no depth to scale by: it ranks LAST among equal counts, error = +inf,
+// instead of mixing an unscaled sum into the ordering)
 __device__ __forceinline__ float chunk_error(float even, float odd, float tz) {
-    const float scale = tz > 0.f ? 1.f / (tz * tz) : 1.f;  // IEEE division (hipcc's default for fp32), once per hypothesis and chunk
+    if (!(tz > 0.f)) return __builtin_inff();
+    const float scale = 1.f / (tz * tz);  // IEEE division (hipcc's default for fp32), once per hypothesis and chunk
     return (even + odd) * scale;
 }
 
@@ -1174,6 +1177,17 @@ size_t pnp_ransac_workspace_bytes(int B, int Nmax, int rounds) {
     const int H = rounds * kWave;
     const int C = Nmax > 0 ? (Nmax + kChunkPts - 1) / kChunkPts : 1;
     return ransac_counter_bytes(B) + (size_t)B * H * 12 * (sizeof(double) + sizeof(float)) + (size_t)B * C * H * (sizeof(int) + sizeof(float));
+}
+
+// where carve_workspace puts things, for the diagnostics that read the workspace off the device (include/lc_amd.h: lc_pnp_ransac_workspace_layout)
+void pnp_ransac_workspace_layout(int B, int Nmax, int rounds, size_t out[6]) {
+    const RansacWorkspace w = carve_workspace(nullptr, B, Nmax, rounds);
+    out[0] = reinterpret_cast<size_t>(w.hyp64);
+    out[1] = reinterpret_cast<size_t>(w.hyp32);
+    out[2] = reinterpret_cast<size_t>(w.part);
+    out[3] = (size_t)w.H;
+    out[4] = (size_t)w.C;
+    out[5] = pnp_ransac_workspace_bytes(B, Nmax, rounds);
 }
 
 int launch_pnp_ransac(const RansacParams& p, hipStream_t stream) {

@@ -528,11 +528,11 @@ __device__ __forceinline__ bool parts_meet(SplitSum& sx, int tid, int nw, unsign
     for (int idx = tid; idx < nw * sx.G; idx += kThreads) {
         const int g = idx / nw, l = idx - g * nw;
         const unsigned long long* at = rows + g * kSelRowWords + l;
-        unsigned long long word = 0;
+        unsigned long long word = 0, t0 = 0;
         for (int polls = 0;; ++polls) {  // (several reads in flight per word, a sleep apart, were measured slower: 25.6 us with one, 26.1 / 27.1 / 27.8 with 2 / 3 / 5)
             word = xcd_load(at);
             if (((word ^ ticket) >> 32) == 0) break;
-            if (polls >= kSplitMaxPolls) { ok = false; break; }
+            if (split_wait_expired(polls, t0)) { ok = false; break; }  // the same wall-clock budget as the split solve's wait (lc_common.h)
         }
         if (ok) consume(g, l, (unsigned)word);
     }

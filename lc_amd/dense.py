@@ -139,7 +139,7 @@ def dense_front_end_with_visibility(xyz_noc: Tensor, xyz_weight_logits: Tensor, 
 SELECT_MODES = {"mask": 0, "quantile": 1, "quantile_in_mask": 2}
 
 
-FUSED_SELECT_MAX_POINTS = 16384  # lc_dense_frontend_select_f32 (its keys sit in up to 64 KB of LDS): 128x128 maps at stride 1
+FUSED_SELECT_MAX_POINTS = 16384  # lc_dense_frontend_select3 (its keys sit in up to 64 KB of LDS): 128x128 maps at stride 1
 
 
 def _select_buffers(out, B, N, dev, what):

@@ -60,7 +60,7 @@ def solve_pnp(cfg, out_dict, gt_dict):
         return solve_pnp_dense(cfg, out_dict, gt_dict)
     K, pts3d = gt_dict["out_K"], gt_dict["pts3d"]
     pts2d, std = out_dict["pts2d"], out_dict["pts2d_std"]
-    # RANSAC, then its inlier refinement and the weighted solve on all keypoints as ONE launch (`lc_pnp_lm_chain_f32`); `1 / std**2` (test.py:52), the NaN
+    # RANSAC, then its inlier refinement and the weighted solve on all keypoints as ONE launch (`lc_pnp_lm_chain2_f32`); `1 / std**2` (test.py:52), the NaN
     # filter and the square root of cer_solver.py:29-36 are formed at the solve's loads, not by element-wise launches in front of it
     _ransac, _inl, _bad, refine = gpu_solver.solve_device(K, pts3d, pts2d, refine="defer", **_reprojection_threshold(cfg, gt_dict, 2))
     (start, _, _), (weighted, _, _) = pnp_ceres.solve_chain_device(
@@ -179,7 +179,7 @@ def _solve_pnp_dense(cfg, out_dict, gt_dict, pose0):
         filtered = dict(weights=icov, index=index, min_count=4, out=half(1) if both else None)
     start, inliers, _bad, refine = gpu_solver.solve_device(K, x, u, counts, select=filtered, refine="defer", pose_index_offset=pose0,
                                                            **_reprojection_threshold(cfg, gt_dict, 3))
-    # The RANSAC's inlier refinement and the weighted solve(s) that start from its result: ONE launch (`lc_pnp_lm_chain_f32`), each
+    # The RANSAC's inlier refinement and the weighted solve(s) that start from its result: ONE launch (`lc_pnp_lm_chain2_f32`), each
     # workgroup refines its object's pose and goes on with its own weighted solve.
     weighted = dict(weights_are_icov=True, nan_to_num=True, start="first")  # `_weighted` above, chained
     out = {}

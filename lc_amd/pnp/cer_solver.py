@@ -62,7 +62,7 @@ def solve(cam_mat, pts3d, pts2d, icovs, start, n_points=None, *, optimal_start=F
     elif _is_ragged(start):
         start = _pad(start, dev)
     # Device batches with a diagonal inverse covariance take the fused route: nan_to_num, the square root of the weights and the
-    # fall-back to `start` happen inside the solver launch (lc_pnp_lm2_f32) instead of ~9 element-wise launches around it.
+    # fall-back to `start` happen inside the solver launch (lc_pnp_lm3_f32) instead of ~9 element-wise launches around it.
     fused = (not optimal_start and isinstance(pts3d, Tensor) and pts3d.is_cuda and isinstance(start, Tensor) and start.dim() == 2
              and isinstance(icovs, Tensor) and icovs.dim() == pts2d.dim() and not kwargs.get("print_summary", 0))
     if fused:

@@ -16,15 +16,18 @@ from . import cer_solver, pnp_ceres
 
 def workspace_views(ws, B, N, iterations):
     """Diagnostics (the oracle tests): the split form's workspace as tensors -- hyp64 (B,H,12) double and hyp32 (B,H,12) float, every
-    hypothesis' [R row-major | t], and the chunk partials (B,C,H) as (count int32, error float32); layout of lc_pnp_init.hip: carve_workspace."""
-    H, C = (int(iterations) + 63) // 64 * 64, max(1, (N + 63) // 64)
+    hypothesis' [R row-major | t], and the chunk partials (B,C,H) as (count int32, error float32).  The section offsets come from the
+    library (`lc_pnp_ransac_workspace_layout`: what lc_pnp_init.hip's carve_workspace does), not from a copy of its arithmetic."""
+    import ctypes
+
+    lay = (ctypes.c_size_t * 6)()
+    _lib.check(_lib.load().lc_pnp_ransac_workspace_layout(int(B), int(N), int(iterations), lay), "lc_pnp_ransac_workspace_layout")
+    o64, o32, opart, H, C, total = (int(v) for v in lay)
     raw = ws.view(torch.uint8)
-    o = 16 * ((B + 3) // 4)
-    hyp64 = raw[o:o + 8 * 12 * B * H].view(torch.float64).view(B, H, 12)
-    o += 8 * 12 * B * H
-    hyp32 = raw[o:o + 4 * 12 * B * H].view(torch.float32).view(B, H, 12)
-    o += 4 * 12 * B * H
-    part = raw[o:o + 8 * B * C * H].view(torch.int32).view(B, C, H, 2)
+    assert raw.numel() >= total
+    hyp64 = raw[o64:o64 + 8 * 12 * B * H].view(torch.float64).view(B, H, 12)
+    hyp32 = raw[o32:o32 + 4 * 12 * B * H].view(torch.float32).view(B, H, 12)
+    part = raw[opart:opart + 8 * B * C * H].view(torch.int32).view(B, C, H, 2)
     return hyp64, hyp32, part[..., 0], part[..., 1].view(torch.float32)
 
 
@@ -101,15 +104,11 @@ def solve_device(cam_mat, coord_3d, coord_2d, n_points=None, *, reprojectionErro
         head = (_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(counts), B, N, float(reprojectionError), _lib.ptr(per_pose),
                 int(iterations), int(seed) & 0xFFFFFFFF, _lib.ptr(states), _lib.ptr(mask), _lib.ptr(n_in), _lib.ptr(invalid), _lib.ptr(hyp),
                 _lib.ptr(rows), _lib.ptr(ws), nbytes)
-        if ticketed or select is not None or pose_index_offset or reproj_divisor is not None:  # (the divisor form of the threshold exists on init5 only)
-            name = "lc_pnp_ransac_init5_f32"
-            rc = lib.lc_pnp_ransac_init5_f32(*head, int(bool(ticketed)), _lib.ptr(sel_w), _lib.ptr(sel_idx), int(select.get("min_count", 4)) if select else 0,
-                                             (int(select.get("seed", 0)) if select else 0) & 0xFFFFFFFF, *(_lib.ptr(sel_out[k]) for k in (0, 1, 2, 4, 3)),  # C order: rows, index, counts
-                                             int(pose_index_offset), _lib.stream_ptr(dev))
-        else:
-            name = "lc_pnp_ransac_init3_f32"
-            rc = lib.lc_pnp_ransac_init3_f32(*head, _lib.stream_ptr(dev))
-    _lib.check(rc, name)
+        # (a tensor threshold went in as per-pose values beside a zero scalar: the values ARE the thresholds; beside a positive scalar they divide it)
+        rc = lib.lc_pnp_ransac_init5_f32(*head, int(bool(ticketed)), _lib.ptr(sel_w), _lib.ptr(sel_idx), int(select.get("min_count", 4)) if select else 0,
+                                         (int(select.get("seed", 0)) if select else 0) & 0xFFFFFFFF, *(_lib.ptr(sel_out[k]) for k in (0, 1, 2, 4, 3)),  # C order: rows, index, counts
+                                         int(pose_index_offset), _lib.stream_ptr(dev))
+    _lib.check(rc, "lc_pnp_ransac_init5_f32")
     if select is not None:
         select["result"] = sel_out
     inl = mask.view(torch.bool)  # the kernel writes 0 / 1: same bytes, no launch

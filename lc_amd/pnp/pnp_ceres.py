@@ -1,7 +1,7 @@
 """`lib.pnp.pnp_ceres` call surface (`lib/pnp/pnp_ceres.py:6-140`) on the HIP batched LM solver.
 
 Two routes, same results:
-  * tensors already on the GPU  -> `lc_pnp_lm2_f32` (= `lc_pnp_lm_f32` + load-time options) on device-resident zero-padded batches (no host round trip);
+  * tensors already on the GPU  -> `lc_pnp_lm3_f32` (the solve + the callers' load-time options) on device-resident zero-padded batches (no host round trip);
   * CPU tensors / numpy arrays  -> the reference's own ABI `pnp_ceres_f32_omp` (arrays of host pointers), whose body
     in liblc_amd.so stages the jobs to the GPU.  This is exactly what the reference's cffi marshaller calls.
 Returns `(state, result_tr, invalid_flags)` like the reference (`:61`): float32 (B,7), float32 (B,), int32 (B,).
@@ -49,7 +49,7 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
     (B,N,2) diagonal; n_points (B,) int or None.  trace_rows > 0 runs the diagnostic twin of the kernel and appends the
     (B,trace_rows,8) float64 per-iteration schedule (`lc_pnp_lm_trace_f32`, include/lc_amd.h) to the returned tuple.
 
-    Folded into the kernel's loads instead of separate element-wise launches (`lc_pnp_lm2_f32`): weights_are_icov (the diagonal
+    Folded into the kernel's loads instead of separate element-wise launches (`lc_pnp_lm3_f32`): weights_are_icov (the diagonal
     tensor holds inverse variances), weights_are_std (it holds standard deviations: `1/(std**2)` of test.py:52 formed at the load), nan_to_num (torch.nan_to_num on every input; an invalid job returns the filtered start),
     weight_mask (B,N) uint8/bool in place of sqrtL: unit information where set; shared_poses = P > 0: cam_mat and start have P rows
     and pose b of the B = k P correspondence sets reads row b % P (several selections of the same objects in one launch).
@@ -91,7 +91,7 @@ def solve_device(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter
                                          _lib.ptr(trace), int(trace_rows), _lib.stream_ptr(dev))
         _lib.check(rc, "lc_pnp_lm_trace_f32")
         return (state, tr, ret, iters, trace) if return_iters else (state, tr, ret, trace)
-    with _lib.on_device(dev):  # options = 0 without a mask and without a workspace is lc_pnp_lm_f32 (same kernel instantiation)
+    with _lib.on_device(dev):  # options = 0 without a mask and without a workspace: the plain solve (same kernel instantiation)
         ws = split_workspace(dev, (B, N), split=split)
         rc = lib.lc_pnp_lm3_f32(_lib.ptr(K), _lib.ptr(X), _lib.ptr(U), _lib.ptr(L) if full else None,
                                 _lib.ptr(L) if (L is not None and not full) else None, _lib.ptr(M), _lib.ptr(counts), _lib.ptr(start),
@@ -141,7 +141,7 @@ def _job(cam_mat, pts3d, pts2d, sqrtL, start, n_points=None, *, max_iter_count=5
 
 
 def solve_chain_device(first: dict, second: dict, split=None):
-    """Two solves as one call (`lc_pnp_lm_chain_f32`): `first` and `second` are keyword arguments of `solve_device`; second['start'] may be
+    """Two solves as one call (`lc_pnp_lm_chain2_f32`): `first` and `second` are keyword arguments of `solve_device`; second['start'] may be
     the string 'first' -- the states the first solve returns (with shared_poses = the first job's batch when the second holds several
     selections of the same objects).  One launch where the shapes allow (both 256 < N <= 1024), else the two launches; the same
     results as `solve_device(**first)` followed by `solve_device(**second)` bit for bit.  Returns ((state, tr, ret), (state, tr, ret))."""

@@ -55,10 +55,18 @@ def owned(**by_kind):
                 _OWNED[k] = v
 
 
+_SEEN_RESCUES = {}
+
+
 def get(kind: str, dev, need: int, split=None):
     """-> a workspace of at least `need` bytes for launches of `kind` on the current stream of `dev`, or None (need == 0, split off)."""
     if need <= 0 or split is False or (split is None and is_off()) or _OFF:
         return None
+    if os.environ.get("LC_AMD_SPLIT_DEBUG") == "1" and not torch.cuda.is_current_stream_capturing():  # a debug log: it synchronises
+        n = rescues(kind, dev)
+        if n != _SEEN_RESCUES.get(kind, 0):
+            print(f"lc_amd.splitws: {n} unit(s) of '{kind}' launches recomputed by rescue launches so far (contended split launches: consider no_split())", flush=True)
+            _SEEN_RESCUES[kind] = n
     ws = _OWNED.get(kind)
     if ws is not None:
         index = lambda d: d.index if d.index is not None else torch.cuda.current_device()  # noqa: E731  (torch.device("cuda") == the current device)
@@ -78,6 +86,23 @@ def get(kind: str, dev, need: int, split=None):
             _CACHE.clear()
         ws = _CACHE[key] = torch.zeros(need, device=dev, dtype=torch.uint8)
     return ws
+
+
+def rescues(kind: str, dev=None) -> int:
+    """Units the rescue launches had to recompute so far on the workspaces of `kind` ('pnp' | 'select') that this process holds for `dev`
+    (`lc_split_workspace_rescues`; synchronises).  Non-zero = the split launches were contended: results are unaffected, the launches were
+    slow -- wrap the calls in `no_split()`.  LC_AMD_SPLIT_DEBUG=1 makes `get` print it whenever it grows."""
+    lib = _lib.load()
+    total = 0
+    for (k, index, _stream), ws in list(_CACHE.items()) + [((k, None, None), w) for k, w in _OWNED.items() if w is not None]:
+        if k != kind or (dev is not None and index is not None and index != (dev.index if dev.index is not None else torch.cuda.current_device())):
+            continue
+        with _lib.on_device(ws.device):
+            n = int(lib.lc_split_workspace_rescues(_lib.ptr(ws), ws.numel(), 0 if kind == "pnp" else 1, _lib.stream_ptr(ws.device)))
+        if n < 0:
+            raise RuntimeError(lib.lc_amd_last_error().decode())
+        total += n
+    return total
 
 
 PNP_POSE_BYTES = 2 * 8 * 64 * 8 + 128        # lc_common.h kSplitPoseBytes (tests/test_gpu_pnp_split.py checks it against lc_pnp_lm_workspace_bytes)

@@ -18,7 +18,7 @@ contract, with integer outputs compared exactly:
 Round 5 -- the float32-faithful mode (`score_f32`, `ransac_f32`).  The kernel's scoring is division-free IEEE float32 (fused
 multiply-adds and multiplies in a fixed order, lc_pnp_init.hip: inlier_q / chunk_error), so it can be restated operation by operation:
 `fma32` below is an exactly rounded float32 fma built from float64 arithmetic, the error sums are added in the kernel's association
-(even / odd points of a 64-point chunk, (even + odd) / tz^2 per chunk, chunks in order).  Given the float32 hypotheses (the kernel's own,
+(even / odd points of a 64-point chunk, (even + odd) / tz^2 per chunk -- +inf when tz <= 0 --, chunks in order).  Given the float32 hypotheses (the kernel's own,
 read back from its workspace -- a different P3P algorithm agrees with them to 1e-10, not to the bit), per-hypothesis counts, error sums,
 the winner, its inlier count and its inlier mask are compared with EQUALITY for every pose; the float64 run above stays as the sanity
 bound on the hypotheses themselves.
@@ -154,7 +154,7 @@ def ransac(K, pts3d, pts2d, count, reproj_err, iterations, seed, b, margin=1e-3)
         # count is known up to that many
         n_unsure = int(((np.abs(e - lim) < margin * lim) | (np.abs(c[:, 2]) < 1e-6)).sum())
         ambiguous_pick = pick_gap < margin * max(pick_e, 1e-12)
-        cand.append((int(inl.sum()), float(e[inl].sum() / t[2] ** 2) if t[2] > 0 else float(e[inl].sum()), hyp, R, t, n_unsure, ambiguous_pick))
+        cand.append((int(inl.sum()), float(e[inl].sum() / t[2] ** 2) if t[2] > 0 else float(np.inf), hyp, R, t, n_unsure, ambiguous_pick))
     best = max(cand, key=lambda c: (c[0], -c[1], -c[2]))
     ok = best[0] >= 4
     out = dict(invalid=0 if ok else 1, best_hyp=best[2], best_count=best[0], per_hyp_count=np.array([c[0] for c in cand]))
@@ -262,6 +262,7 @@ def score_f32(hyp32, X, un, thr2):
     with np.errstate(divide="ignore", over="ignore"):
         scale = np.where(tz > 0, np.float32(1) / (tz * tz).astype(np.float32), np.float32(1)).astype(np.float32)
     chunk = ((even + odd).astype(np.float32) * scale[:, None]).astype(np.float32)
+    chunk = np.where((tz > 0)[:, None], chunk, np.float32(np.inf))  # chunk_error: a hypothesis behind the camera ranks last among equal counts
     err = np.zeros(H, np.float32)
     for c in range(C):  # chunk order
         err = (err + chunk[:, c]).astype(np.float32)

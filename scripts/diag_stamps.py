@@ -40,8 +40,7 @@ states = torch.empty_like(b["start"]); tr = torch.empty(B, device=dev); ret = to
 stamps = torch.zeros(B, 16, device=dev, dtype=torch.int32)  # 8 x uint64 per pose
 P = _lib.ptr
 for rep in range(3):
-    rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), None, P(b["start"]), P(states), P(tr), P(ret),
-                           P(stamps), B, N, 50, 1e-6, None)
+    rc = lib.lc_pnp_lm3_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), None, None, P(b["start"]), P(states), P(tr), P(ret), P(stamps), B, N, 50, 1e-6, 0, 0, None, 0, None)
     torch.cuda.synchronize()
 ps = stamps.cpu().numpy().view(np.uint64).reshape(B, 8).astype(np.int64)
 iters = ps[:, 6]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Front end + point selection: the two launches against the one launch (lc_dense_frontend_select_f32), replayed as hipGraphs."""
+"""Front end + point selection: the two launches against the one launch (lc_dense_frontend_select3), replayed as hipGraphs."""
 import os
 import sys
 import time

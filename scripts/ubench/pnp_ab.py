@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of PnP-kernel build variants at the metric shape (B=256, N=64): event-timed lc_pnp_lm_f32 and lc_pose_unit_f32 launches,
+"""A/B of PnP-kernel build variants at the metric shape (B=256, N=64): event-timed lc_pnp_lm3_f32 and lc_pose_unit2_f32 launches,
 each library in its own child process (LC_AMD_LIB).  usage: pnp_ab.py name=path.so [name=path.so ...]"""
 import json
 import os
@@ -21,10 +21,9 @@ for B in (256, 65536):
     go = torch.full((B,), 1.0 / B, device=dev)
     s = _lib.stream_ptr(dev)
     def pnp():
-        assert lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), None, P(b["start"]), P(st), P(tr), P(ret), None, B, 64, 50, 1e-6, s) == 0
+        assert lib.lc_pnp_lm3_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), None, None, P(b["start"]), P(st), P(tr), P(ret), None, B, 64, 50, 1e-6, 0, 0, None, 0, s) == 0
     def unit():
-        assert lib.lc_pose_unit_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), P(go), B, 64, 32.0, 3.0, 4.0,
-                                    P(loss), P(du), P(ds), P(dx), P(b["inv_std"]), P(b["start"]), P(st), P(tr), P(ret), 50, 1e-6, s) == 0
+        assert lib.lc_pose_unit2_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), P(go), B, 64, 32.0, 3.0, 4.0, P(loss), P(du), P(ds), P(dx), P(b["inv_std"]), P(b["start"]), P(st), P(tr), P(ret), None, 50, 1e-6, None, 0, s) == 0
     for name, fn in (("pnp", pnp), ("unit", unit)):
         reps = 300 if B == 256 else 20
         for _ in range(10): fn()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of builds of the wide (N > 64) LM solve at the dense shapes: event-timed lc_pnp_lm_f32 launches (ctypes, ~6 us of host time
+"""A/B of builds of the wide (N > 64) LM solve at the dense shapes: event-timed lc_pnp_lm3_f32 launches (ctypes, ~6 us of host time
 per call: below that the figure is host-bound) and a checksum of the outputs.  usage: pnp_wide_ab.py name=path.so [...]"""
 import os
 import subprocess
@@ -19,7 +19,7 @@ for B, N, frac in ((64, 1024, 0.5), (128, 1024, 0.5), (32, 1024, 1.0), (32, 1849
     st = torch.empty_like(b["start"]); tr = torch.empty(B, device=dev); ret = torch.empty(B, device=dev, dtype=torch.int32)
     s = _lib.stream_ptr(dev)
     def pnp():
-        assert lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), P(cnt), P(b["start"]), P(st), P(tr), P(ret), None, B, N, 50, 1e-6, s) == 0
+        assert lib.lc_pnp_lm3_f32(P(b["K"]), P(b["pts3d"]), P(b["pts2d"]), None, P(b["inv_std"]), None, P(cnt), P(b["start"]), P(st), P(tr), P(ret), None, B, N, 50, 1e-6, 0, 0, None, 0, s) == 0
     for _ in range(10): pnp()
     torch.cuda.synchronize()
     best = 1e9

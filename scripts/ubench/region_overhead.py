@@ -11,8 +11,7 @@ st = torch.empty_like(b["start"]); tr = torch.empty(B, device=dev); ret = torch.
 loss = torch.empty(B, device=dev); du = torch.empty_like(b["pts2d"]); ds = torch.empty_like(b["pts2d"]); dx = torch.empty_like(b["pts3d"])
 go = torch.full((B,), 1.0 / B, device=dev)
 def unit():
-    assert lib.lc_pose_unit_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), P(go), B, 64, 32.0, 3.0, 4.0,
-                                P(loss), P(du), P(ds), P(dx), P(b["inv_std"]), P(b["start"]), P(st), P(tr), P(ret), 50, 1e-6, _lib.stream_ptr(dev)) == 0
+    assert lib.lc_pose_unit2_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), P(go), B, 64, 32.0, 3.0, 4.0, P(loss), P(du), P(ds), P(dx), P(b["inv_std"]), P(b["start"]), P(st), P(tr), P(ret), None, 50, 1e-6, None, 0, _lib.stream_ptr(dev)) == 0
 for K in (20, 200):
     s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s): unit()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The pose-unit launch (lc_pose_unit_f32: LC loss fwd+bwd + weighted PnP in one grid) over B = 256 ... 65536 poses of N = 64
+"""The pose-unit launch (lc_pose_unit2_f32: LC loss fwd+bwd + weighted PnP in one grid) over B = 256 ... 65536 poses of N = 64
 points: event-timed launch duration and poses/s per batch size, one JSON line each.  scripts/profile_round.sh also runs it under
 rocprofv3 (kernel trace; SQ counters) and scripts/summarize_prof.py groups those dispatches by grid size."""
 import json
@@ -29,9 +29,7 @@ def main():
         sd = b["inv_std"].contiguous()
 
         def one():
-            rc = lib.lc_pose_unit_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), P(go), B, N,
-                                      32.0, 3.0, 4.0, P(loss), P(o[0]), P(o[1]), P(o[2]), P(sd), P(b["start"]), P(o[3]), P(o[4]), P(o[5]), 50, 1e-6,
-                                      _lib.stream_ptr(dev))
+            rc = lib.lc_pose_unit2_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), P(go), B, N, 32.0, 3.0, 4.0, P(loss), P(o[0]), P(o[1]), P(o[2]), P(sd), P(b["start"]), P(o[3]), P(o[4]), P(o[5]), None, 50, 1e-6, None, 0, _lib.stream_ptr(dev))
             assert rc == 0
         for _ in range(3):
             one()

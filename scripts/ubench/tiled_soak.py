@@ -43,13 +43,11 @@ while time.time() - t0 < budget:
     with torch.cuda.stream(s_head):
         for _ in range(3):
             st = _lib.stream_ptr(dev)
-            lib.lc_softargmax2d_fwd_f32(P(logits), M, 64, 64, 0, P(mean), P(std), P(stats), st)
-            lib.lc_softargmax2d_bwd_f32(P(logits), P(mean), P(std), P(stats), P(gm), P(gs), M, 64, 64, 0, P(gin), st)
+            lib.lc_softargmax2d_fwd(P(logits), 0, M, 64, 64, 0, P(mean), P(std), P(stats), st)
+            lib.lc_softargmax2d_bwd(P(logits), 0, P(mean), P(std), P(stats), P(gm), P(gs), M, 64, 64, 0, P(gin), st)
     with torch.cuda.stream(s_unit):
         for _ in range(10):
-            lib.lc_pose_unit_f32(P(pu["K"]), P(pu["pose"]), P(pu["pts3d"]), P(pu["pts2d"]), P(pu["inv_std"]), None, P(pu["bbox_3d"]), P(go), 256, 64, 32.0, 3.0, 4.0,
-                                 P(pu_out[0]), P(pu_out[1]), P(pu_out[2]), P(pu_out[3]), P(pu["inv_std"]), P(pu["start"]), P(pu_out[4]), P(pu_out[5]), P(pu_out[6]), 50, 1e-6,
-                                 _lib.stream_ptr(dev))
+            lib.lc_pose_unit2_f32(P(pu["K"]), P(pu["pose"]), P(pu["pts3d"]), P(pu["pts2d"]), P(pu["inv_std"]), None, P(pu["bbox_3d"]), P(go), 256, 64, 32.0, 3.0, 4.0, P(pu_out[0]), P(pu_out[1]), P(pu_out[2]), P(pu_out[3]), P(pu["inv_std"]), P(pu["start"]), P(pu_out[4]), P(pu_out[5]), P(pu_out[6]), None, 50, 1e-6, None, 0, _lib.stream_ptr(dev))
     outs = []
     for j in range(12):
         args, ref = cases[(rounds + j) % len(cases)]

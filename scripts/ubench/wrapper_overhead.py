@@ -31,8 +31,7 @@ def timeit(fn, n=2000):
 
 
 def raw():
-    lib.lc_cov_loss_fwd_bwd_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), None, 256, 64,
-                                32.0, 3.0, 4.0, P(loss), P(du), P(ds), P(dx), None, _lib.stream_ptr(dev))
+    lib.lc_cov_loss3_fwd_bwd_f32(P(b["K"]), P(b["pose"]), P(b["pts3d"]), P(b["pts2d"]), P(b["inv_std"]), None, P(b["bbox_3d"]), None, 256, 64, 32.0, 3.0, 4.0, 0, P(loss), P(du), P(ds), P(dx), None, None, 0, _lib.stream_ptr(dev))
 
 
 def launch():

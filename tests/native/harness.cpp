@@ -84,9 +84,9 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&mean, M * 2 * 4)); CK(hipMalloc(&sd, M * 2 * 4)); CK(hipMalloc(&st, M * 4 * 4));
         CK(hipMalloc(&gi, M * H * W * 4));
         gm = to_dev(std::vector<float>(M * 2, 1.f)); gs = to_dev(std::vector<float>(M * 2, 1.f));
-        int rc = lc_softargmax2d_fwd_f32(dl, M, H, W, 0, mean, sd, st, nullptr);
+        int rc = lc_softargmax2d_fwd(dl, LC_F32, M, H, W, 0, mean, sd, st, nullptr);
         CK(hipDeviceSynchronize());
-        int rc2 = lc_softargmax2d_bwd_f32(dl, mean, sd, st, gm, gs, M, H, W, 0, gi, nullptr);
+        int rc2 = lc_softargmax2d_bwd(dl, LC_F32, mean, sd, st, gm, gs, M, H, W, 0, gi, nullptr);
         CK(hipDeviceSynchronize());
         float hm[2], hs[2];
         CK(hipMemcpy(hm, mean, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, sd, 8, hipMemcpyDeviceToHost));
@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
     if (all || std::string(which) == "pnp") {
         float* tr; int* ret; int* it;
         CK(hipMalloc(&tr, B * 4)); CK(hipMalloc(&ret, B * 4)); CK(hipMalloc(&it, B * 4));
-        int rc = lc_pnp_lm_f32(dK, dX, dU, nullptr, dS, nullptr, nullptr, dSt, tr, ret, it, B, N, 50, 1e-6f, nullptr);
+        int rc = lc_pnp_lm3_f32(dK, dX, dU, nullptr, dS, nullptr, nullptr, nullptr, dSt, tr, ret, it, B, N, 50, 1e-6f, 0, 0, nullptr, 0, nullptr);
         CK(hipDeviceSynchronize());
         std::vector<float> st(B * 7), htr(B); std::vector<int> hr(B), hi(B);
         CK(hipMemcpy(st.data(), dSt, B * 28, hipMemcpyDeviceToHost)); CK(hipMemcpy(htr.data(), tr, B * 4, hipMemcpyDeviceToHost));
@@ -126,7 +126,7 @@ int main(int argc, char** argv) {
         float *loss, *du, *ds, *dx, *aux;
         CK(hipMalloc(&loss, B * 4)); CK(hipMalloc(&du, B * N * 8)); CK(hipMalloc(&ds, B * N * 8)); CK(hipMalloc(&dx, B * N * 12));
         CK(hipMalloc(&aux, B * 40 * 4));
-        int rc = lc_cov_loss_fwd_bwd_f32(dK, dP, dX, dU, dS, nullptr, dB, nullptr, B, N, 32.f, 3.f, 4.f, loss, du, ds, dx, aux, nullptr);
+        int rc = lc_cov_loss3_fwd_bwd_f32(dK, dP, dX, dU, dS, nullptr, dB, nullptr, B, N, 32.f, 3.f, 4.f, 0, loss, du, ds, dx, aux, nullptr, 0, nullptr);
         CK(hipDeviceSynchronize());
         std::vector<float> hl(B), hdu(4);
         CK(hipMemcpy(hl.data(), loss, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdu.data(), du, 16, hipMemcpyDeviceToHost));
@@ -135,7 +135,7 @@ int main(int argc, char** argv) {
         for (int b = 0; b < B; ++b) EXPECT(std::isfinite(hl[b]) && hl[b] > -20.f && hl[b] < 20.f);
         EXPECT(std::isfinite(hdu[0]) && hdu[0] != 0.f);
         // error path: an 8-byte row pointer at a 4-byte offset is refused with a message, nothing is launched
-        rc = lc_cov_loss_fwd_bwd_f32(dK, dP, dX, dU + 1, dS, nullptr, dB, nullptr, B, N - 1, 32.f, 3.f, 4.f, loss, du, ds, dx, aux, nullptr);
+        rc = lc_cov_loss3_fwd_bwd_f32(dK, dP, dX, dU + 1, dS, nullptr, dB, nullptr, B, N - 1, 32.f, 3.f, 4.f, 0, loss, du, ds, dx, aux, nullptr, 0, nullptr);
         EXPECT(rc != 0 && std::string(lc_amd_last_error()).find("aligned") != std::string::npos);
     }
     if (all || std::string(which) == "glue") {
@@ -154,8 +154,8 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&partials, LC_SQNORM_BLOCKS * 8)); CK(hipMalloc(&ticket, 4)); CK(hipMemset(ticket, 0, 4));
         CK(hipMalloc(&sq, 4)); CK(hipMalloc(&state2, 4)); CK(hipMalloc(&norm, 4)); CK(hipMalloc(&out, n * 4));
         state = to_dev(std::vector<float>(1, -1.f));
-        rc = lc_sqnorm_f32(dU, n, partials, ticket, sq, 0, nullptr, nullptr, nullptr);
-        int rc2 = lc_norm_clip_apply_f32(dU, n, sq, state, 100.f, 1.7f, 0.1, out, state2, norm, nullptr);
+        rc = lc_sqnorm(dU, LC_F32, n, partials, ticket, sq, 0, nullptr, nullptr, nullptr);
+        int rc2 = lc_norm_clip_apply(dU, LC_F32, n, sq, state, 100.f, 1.7f, 0.1, out, state2, norm, nullptr);
         CK(hipDeviceSynchronize());
         float hsq, hs2, hnorm, ho;
         CK(hipMemcpy(&hsq, sq, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hs2, state2, 4, hipMemcpyDeviceToHost));
@@ -214,7 +214,7 @@ int main(int argc, char** argv) {
         void* ws = nullptr;
         CK(hipMalloc(&ws, need ? need : 128));
         CK(hipMemset(ws, 0, need ? need : 128));  // once
-        int rc1 = lc_pnp_lm2_f32(dK2, dX2, dU2, nullptr, dS2, nullptr, nullptr, dSt0, stA, trA, retA, itA, Bs, Ns, 50, 1e-6f, 0, 0, nullptr);
+        int rc1 = lc_pnp_lm3_f32(dK2, dX2, dU2, nullptr, dS2, nullptr, nullptr, dSt0, stA, trA, retA, itA, Bs, Ns, 50, 1e-6f, 0, 0, nullptr, 0, nullptr);
         std::vector<float> a(Bs * 7), b2(Bs * 7); std::vector<int> ra(Bs), rb(Bs), ia(Bs), ib(Bs);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(a.data(), stA, Bs * 28, hipMemcpyDeviceToHost)); CK(hipMemcpy(ra.data(), retA, Bs * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ia.data(), itA, Bs * 4, hipMemcpyDeviceToHost));

@@ -119,7 +119,7 @@ def test_decode_with_the_coordinate_map_folded_in(H, W, sample, tl, with_T):
 
 @pytest.mark.parametrize("H,W,with_T", [(64, 64, True), (30, 21, True), (128, 128, False)])
 def test_inference_decode_straight_to_xyz_planes(H, W, with_T):
-    """lc_bits_decode2_f32 (Gray decode + noc_scale + model transform, written as (B,3,H,W) planes) against
+    """lc_bits_decode3 (Gray decode + noc_scale + model transform, written as (B,3,H,W) planes) against
     `nn_out_to_xyz(..., inference=True).permute(0, 3, 1, 2)`: the decode itself bit for bit (same kernel body), the coordinate map to
     fp32 rounding of a 3-term product sum."""
     from lc_amd import floatbits as fb

@@ -150,8 +150,8 @@ def test_misaligned_pointers_are_rejected():
     odd = flat[1:]  # 4-byte offset: not 8-byte aligned
     st, tr, ret = torch.empty_like(b["start"]), torch.empty(2, device=dev), torch.empty(2, device=dev, dtype=torch.int32)
     P = _lib.ptr
-    rc = lib.lc_pnp_lm_f32(P(b["K"]), P(b["pts3d"]), P(odd), None, P(b["inv_std"]), None, P(b["start"]), P(st), P(tr), P(ret), None, 2, 8,
-                           50, 1e-6, _lib.stream_ptr(dev))
+    rc = lib.lc_pnp_lm3_f32(P(b["K"]), P(b["pts3d"]), P(odd), None, P(b["inv_std"]), None, None, P(b["start"]), P(st), P(tr), P(ret), None, 2, 8,
+                            50, 1e-6, 0, 0, None, 0, _lib.stream_ptr(dev))
     assert rc == 1 and b"aligned" in lib.lc_amd_last_error()
 
 

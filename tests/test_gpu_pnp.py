@@ -251,13 +251,13 @@ def test_pnp_full_size_permutation_and_batch_independence():
     sl = slice(2000, 2049)
     sts, trs, rets = pnp_ceres.solve_device(*(b[k][sl].contiguous() for k in ("K", "pts3d", "pts2d", "inv_std", "start")))
     assert torch.equal(sts, st[sl]) and torch.equal(trs, tr[sl]) and torch.equal(rets, ret[sl])
-    # in place: states holds the start poses on entry (lc_pnp_lm_f32 with start == NULL)
+    # in place: states holds the start poses on entry (lc_pnp_lm3_f32 with start == NULL)
     lib = _lib.load()
     inplace = b["start"].clone()
     tr2 = torch.empty(B, device=dev)
     ret2 = torch.empty(B, device=dev, dtype=torch.int32)
-    rc = lib.lc_pnp_lm_f32(_lib.ptr(b["K"]), _lib.ptr(b["pts3d"]), _lib.ptr(b["pts2d"]), None, _lib.ptr(b["inv_std"]), None, None, _lib.ptr(inplace),
-                           _lib.ptr(tr2), _lib.ptr(ret2), None, B, N, 50, 1e-6, _lib.stream_ptr(dev))
+    rc = lib.lc_pnp_lm3_f32(_lib.ptr(b["K"]), _lib.ptr(b["pts3d"]), _lib.ptr(b["pts2d"]), None, _lib.ptr(b["inv_std"]), None, None, None, _lib.ptr(inplace),
+                            _lib.ptr(tr2), _lib.ptr(ret2), None, B, N, 50, 1e-6, 0, 0, None, 0, _lib.stream_ptr(dev))
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(inplace, st) and torch.equal(tr2, tr) and torch.equal(ret2, ret)
@@ -265,8 +265,8 @@ def test_pnp_full_size_permutation_and_batch_independence():
 
 @pytest.mark.parametrize("B,N", [(37, 48), (9, 300), (5, 1500)])
 def test_fused_input_handling_equals_the_elementwise_route(B, N):
-    """lc_pnp_lm2_f32: nan_to_num, the square root of a diagonal inverse covariance and inlier-mask weights are applied at the
-    kernel's loads; results must be the bits of the route that does the same with torch element-wise ops in front of lc_pnp_lm_f32
+    """lc_pnp_lm3_f32's options: nan_to_num, the square root of a diagonal inverse covariance and inlier-mask weights are applied at the
+    kernel's loads; results must be the bits of the route that does the same with torch element-wise ops in front of the plain solve
     (cer_solver.py:29-36), including the (filtered) start returned for invalid jobs."""
     from lc_amd import synth
     from lc_amd.pnp import cer_solver, pnp_ceres
@@ -363,8 +363,8 @@ def test_fused_nan_filter_with_full_information_factor():
     counts[0] = 2  # too few points: invalid
     tr = torch.empty(B, device=dev); ret = torch.empty(B, device=dev, dtype=torch.int32)
     P = _lib.ptr
-    rc = lib.lc_pnp_lm2_f32(P(d["K"]), P(d["pts3d"]), P(d["pts2d"]), None, P(d["inv_std"]), None, P(counts), None, P(st), P(tr), P(ret), None,
-                            B, N, 50, 1e-6, pnp_ceres.LC_PNP_NAN_TO_NUM, 0, _lib.stream_ptr(dev))
+    rc = lib.lc_pnp_lm3_f32(P(d["K"]), P(d["pts3d"]), P(d["pts2d"]), None, P(d["inv_std"]), None, P(counts), None, P(st), P(tr), P(ret), None,
+                            B, N, 50, 1e-6, pnp_ceres.LC_PNP_NAN_TO_NUM, 0, None, 0, _lib.stream_ptr(dev))
     assert rc == 0
     torch.cuda.synchronize()
     assert int(ret[0]) == 1 and float(st[0, 4]) == 0.0 and bool(torch.isfinite(st).all())
@@ -404,8 +404,8 @@ def test_large_grid_build_equals_the_latency_build(hard):
 
 @pytest.mark.parametrize("B1,k,N,used", [(16, 2, 700, 400), (24, 1, 1024, 1024), (8, 3, 300, 260), (16, 2, 64, 64), (16, 2, 1500, 900)])
 def test_chained_solves_equal_the_two_calls(B1, k, N, used):
-    """lc_pnp_lm_chain_f32 (refinement on a mask, then k weighted solves per object that start from its result -- one launch where
-    256 < N <= 1024) against lc_pnp_lm2_f32 twice: states, radii and flags of BOTH jobs bit for bit; incl. an object the first job skips
+    """lc_pnp_lm_chain2_f32 (refinement on a mask, then k weighted solves per object that start from its result -- one launch where
+    256 < N <= 1024) against lc_pnp_lm3_f32 twice: states, radii and flags of BOTH jobs bit for bit; incl. an object the first job skips
     (zero point count: the second starts from the first's start) and shapes that fall back to two launches."""
     from lc_amd import synth
     from lc_amd.pnp import pnp_ceres

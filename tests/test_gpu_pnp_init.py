@@ -73,10 +73,10 @@ def test_ragged_lists_and_too_few_points():
     assert inv1 is False and st1.shape == (7,) and torch.equal(st1, states[0])
 
 
-def test_per_pose_threshold_is_a_threshold_on_the_old_entry_points_and_a_divisor_on_init5_only():
-    """`lc_pnp_ransac_init_f32 .. init4_f32` keep their original meaning -- per-pose values ARE the thresholds, whatever the scalar
-    next to them -- and only `lc_pnp_ransac_init5_f32` reads a positive scalar next to per-pose values as scalar / value (rel_reproj_err,
-    test.py:56-57); a divisor that is not positive leaves the scalar instead of an infinite threshold."""
+def test_per_pose_values_are_thresholds_beside_a_zero_scalar_and_divisors_beside_a_positive_one():
+    """`lc_pnp_ransac_init5_f32` (include/lc_amd.h): per-pose values beside a scalar <= 0 ARE the thresholds; beside a positive scalar they
+    divide it (rel_reproj_err, test.py:56-57: `2 / out_pix_scale` formed inside the launch); a divisor that is not positive leaves the scalar
+    instead of an infinite threshold."""
     from lc_amd import _lib
     from lc_amd.pnp import gpu_solver
 
@@ -86,28 +86,28 @@ def test_per_pose_threshold_is_a_threshold_on_the_old_entry_points_and_a_divisor
     lib = _lib.load()
     per = (torch.rand(B, generator=torch.Generator().manual_seed(1)) * 3 + 0.5).to(dev)
 
-    def raw(entry, scalar, per_pose):
+    def raw(scalar, per_pose):
         st, mask = torch.empty(B, 7, device=dev), torch.empty(B, N, device=dev, dtype=torch.uint8)
         n_in, bad, hyp = (torch.empty(B, device=dev, dtype=torch.int32) for _ in range(3))
         head = (_lib.ptr(b["K"]), _lib.ptr(b["pts3d"]), _lib.ptr(b["pts2d"]), None, B, N, float(scalar), _lib.ptr(per_pose), 150, 7, _lib.ptr(st), _lib.ptr(mask),
                 _lib.ptr(n_in), _lib.ptr(bad), _lib.ptr(hyp), None, None, 0)
         with _lib.on_device(dev):
-            if entry == 3:
-                rc = lib.lc_pnp_ransac_init3_f32(*head, _lib.stream_ptr(dev))
-            else:
-                rc = lib.lc_pnp_ransac_init5_f32(*head, 0, None, None, 0, 0, None, None, None, None, None, 0, _lib.stream_ptr(dev))
+            rc = lib.lc_pnp_ransac_init5_f32(*head, 0, None, None, 0, 0, None, None, None, None, None, 0, _lib.stream_ptr(dev))
         assert rc == 0
         return st, mask, n_in, hyp
 
+    # thresholds: equal to the B one-pose calls with the scalar threshold of that pose
+    st, mask, n_in, hyp = raw(0.0, per)
     want = gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], reprojectionError=per, seed=7, refine=False, return_hypothesis=True, split=False)
-    for scalar in (0.0, 2.0):  # the scalar next to per-pose thresholds is ignored by init3
-        st, mask, n_in, hyp = raw(3, scalar, per)
-        assert torch.equal(st, want[0]) and torch.equal(mask.bool(), want[1]) and torch.equal(n_in, want[4]) and torch.equal(hyp, want[3])
-    # init5: 2 / divisor -- equal to the per-pose thresholds 2 / divisor handed to init3; a zero / negative divisor -> the scalar 2
+    assert torch.equal(st, want[0]) and torch.equal(mask.bool(), want[1]) and torch.equal(n_in, want[4]) and torch.equal(hyp, want[3])
+    one = gpu_solver.solve_device(b["K"][:1], b["pts3d"][:1], b["pts2d"][:1], reprojectionError=float(per[0]), seed=7, refine=False, return_hypothesis=True, split=False)
+    assert torch.equal(one[0], st[:1]) and torch.equal(one[4], n_in[:1])
+    assert not torch.equal(raw(-1.0, per * 0.5)[2], n_in)  # the per-pose values do matter
+    # divisors: 2 / divisor -- equal to the per-pose thresholds 2 / divisor; a zero / negative divisor -> the scalar 2
     div = per.clone()
     div[3], div[5] = 0.0, -1.0
     thr = torch.where(div > 0, 2.0 / div, torch.full_like(div, 2.0))
-    a, c = raw(5, 2.0, div), raw(3, 0.0, thr)
+    a, c = raw(2.0, div), raw(0.0, thr)
     assert all(torch.equal(x, y) for x, y in zip(a, c))
     st, inl, bad, hyp, n_in = gpu_solver.solve_device(b["K"], b["pts3d"], b["pts2d"], reprojectionError=2.0, reproj_divisor=div, seed=7, refine=False,
                                                       return_hypothesis=True, split=False)

@@ -67,7 +67,7 @@ def test_ransac_kernel_vs_oracle_fixture(path, split):
                                        (4, 9000, 150), (2, 16384, 150), (3, 4097, 300),  # several LDS tiles / more than 32 chunks per pose
                                        (130, 4100, 64), (100, 5000, 200)])  # wide rows: more / fewer than 128 poses (the two scoring kernels of wide rows)
 def test_split_form_equals_single_launch(B, N, iters, noise):
-    """lc_pnp_ransac_init3_f32 (three launches, point chunks spread over the chip) against the one-workgroup-per-pose launch: same
+    """lc_pnp_ransac_init5_f32 with a workspace (three launches, point chunks spread over the chip) against the one-workgroup-per-pose launch: same
     hypothesis stream, same per-point arithmetic, the same integers in the inlier counts AND the same float in the inlier error
     (both forms add it as even / odd sums per 64-point chunk, chunks in order), so the (count, error, id) arg-max picks the same
     hypothesis and an object gets the same initial pose whichever form its batch size selects -- also on noise-free data, where
@@ -86,7 +86,7 @@ def test_split_form_equals_single_launch(B, N, iters, noise):
     assert torch.equal(bad_a, bad_b) and bool(bad_a[0])
     assert torch.equal(hyp_a, hyp_b), (hyp_a != hyp_b).nonzero().flatten().tolist()
     assert torch.equal(in_a, in_b) and torch.equal(n_a, n_b) and torch.equal(st_a, st_b)
-    # lc_pnp_ransac_init4_f32: the selection inside the scoring launch (the last workgroup of a pose to finish selects) -- same outputs
+    # ticketed form: the selection inside the scoring launch (the last workgroup of a pose to finish selects) -- same outputs
     for x, y in zip(ticketed, outs[0]):
         assert torch.equal(x, y)
 
@@ -95,7 +95,7 @@ def test_split_form_equals_single_launch(B, N, iters, noise):
 @pytest.mark.parametrize("B,N,iters,min_count", [(64, 1024, 150, 4), (5, 300, 64, 4), (3, 2500, 200, 6), (40, 64, 150, 4), (7, 129, 150, 4),
                                                  (3, 6000, 150, 4)])
 def test_fused_inlier_reselection_equals_dense_select(B, N, iters, min_count, split, ticketed):
-    """`select=` of lc_pnp_ransac_init4_f32 (the inliers compacted by the workgroup that writes the inlier mask) against
+    """`select=` of lc_pnp_ransac_init5_f32 (the inliers compacted by the workgroup that writes the inlier mask) against
     lc_dense_select_f32 in 'mask' mode run on that mask in a launch of its own: rows, counts and source indices bit for bit -- incl. a
     pose with too few points, poses RANSAC gives up on (nothing kept: padded with min_count pseudo-random entries) and an input that
     is itself a compacted selection (index != identity)."""

@@ -94,7 +94,7 @@ def test_select_rejects_bad_arguments():
                                                            (4, 64, 64, 3, (2, 1), 6), (2, 16, 16, 4, (0, 0), 12), (3, 86, 86, 2, (0, 0), 4), (2, 128, 128, 2, (0, 0), 4), (2, 96, 80, 1, (0, 0), 4),
                                                            (64, 128, 128, 1, (0, 0), 4), (3, 128, 128, 1, (0, 1), 4), (2, 181, 181, 2, (1, 1), 4)])  # zlmo test time: 16384 candidates per object
 def test_front_end_and_selection_in_one_launch(B, H, W, sample, top_left, min_count, mode):
-    """lc_dense_frontend_select_f32 against lc_dense_frontend_fwd2_f32 followed by lc_dense_select_f32 on its rows and visibility
+    """lc_dense_frontend_select3 (no workspace) against lc_dense_frontend_fwd3 followed by lc_dense_select_f32 on its rows and visibility
     mask: counts, source indices and every selected value bit for bit (same log-sum-exp reduction, same per-pixel arithmetic) --
     incl. an object nothing of which is visible (padded with min_count pseudo-random entries) and one that is visible everywhere."""
     from lc_amd.dense import dense_front_end_select, dense_front_end_with_visibility, dense_select

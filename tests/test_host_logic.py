@@ -21,12 +21,21 @@ def test_library_loads_and_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "lc_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(lc_[a-z0-9_]+|pnp_ceres_f32_omp)\s*\(", hdr))
-    assert {"pnp_ceres_f32_omp", "lc_pnp_lm_f32", "lc_cov_loss_fwd_bwd_f32", "lc_pose_unit_f32", "lc_softargmax2d_fwd_f32"} <= declared
+    assert {"pnp_ceres_f32_omp", "lc_pnp_lm3_f32", "lc_cov_loss3_fwd_bwd_f32", "lc_pose_unit2_f32", "lc_softargmax2d_fwd", "lc_xyz_bin_loss_counts"} <= declared
+    # one entry point per operation (LC_AMD_VERSION 2): no superseded generation is declared or exported any more
+    retired = {"lc_pnp_lm_f32", "lc_pnp_lm2_f32", "lc_pnp_lm_chain_f32", "lc_cov_loss_fwd_bwd_f32", "lc_cov_loss2_fwd_bwd_f32", "lc_pose_unit_f32",
+               "lc_softargmax2d_fwd_f32", "lc_dense_frontend_fwd_f32", "lc_dense_frontend_fwd2_f32", "lc_dense_frontend_select_f32",
+               "lc_dense_frontend_select2", "lc_pnp_ransac_init_f32", "lc_pnp_ransac_init2_f32", "lc_pnp_ransac_init3_f32", "lc_pnp_ransac_init4_f32",
+               "lc_bits_decode_f32", "lc_bits_decode2_f32", "lc_bits_decode_gt_fwd_f32", "lc_bits_decode_gt_fwd2_f32", "lc_sqnorm_f32",
+               "lc_norm_clip_apply_f32", "lc_xyz_bin_loss_fwd_f32", "lc_dense_aux_fwd_f32"}
+    assert not (retired & declared)
     lib = ctypes.CDLL(_lib.lib_path())
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/lc_amd.h but not exported"
+    for name in retired:
+        assert not hasattr(lib, name), f"{name} was retired but is still exported"
     assert set(_lib.EXPORTED_SYMBOLS) == declared
-    assert _lib.load().lc_amd_version() == 1
+    assert _lib.load().lc_amd_version() == 2
 
 
 def test_ransac_workspace_contract():
@@ -44,18 +53,21 @@ def test_ransac_workspace_contract():
     assert lib.lc_pnp_ransac_workspace_bytes(B, 16384, 150) == ctr + B * H * 12 * 12 + B * 256 * H * 8  # every point of a row is scored
     buf = ctypes.create_string_buffer(64)
     p = ctypes.addressof(buf)
-    rc = lib.lc_pnp_ransac_init3_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, p, 64, None)
+    rc = lib.lc_pnp_ransac_init5_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, p, 64, 0, None, None, 4, 0, None, None,
+                                     None, None, None, 0, None)
     assert rc != 0 and b"workspace" in lib.lc_amd_last_error()
-    rc = lib.lc_pnp_ransac_init4_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, p, 64, 0, None, None, 4, 0, None, None,
-                                     None, None, None, None)
-    assert rc != 0 and b"workspace" in lib.lc_amd_last_error()
-    rc = lib.lc_pnp_ransac_init4_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, None, 0, 0, p, None, 4, 0, p, p, p, None,
-                                     None, None)  # selection asked for, no counts output
+    rc = lib.lc_pnp_ransac_init5_f32(p, p, p, None, B, N, 2.0, None, 150, 0, p, p, p, p, None, None, None, 0, 0, p, None, 4, 0, p, p, p, None,
+                                     None, 0, None)  # selection asked for, no counts output
     assert rc != 0 and b"selection" in lib.lc_amd_last_error()
+    # the section offsets the diagnostics read the workspace through come from the library (lc_pnp_init.hip: carve_workspace)
+    lay = (ctypes.c_size_t * 6)()
+    assert lib.lc_pnp_ransac_workspace_layout(B, N, 150, lay) == 0
+    assert list(lay) == [ctr, ctr + B * H * 12 * 8, ctr + B * H * 12 * 12, H, chunks, lib.lc_pnp_ransac_workspace_bytes(B, N, 150)]
+    assert lib.lc_pnp_ransac_workspace_layout(0, N, 150, lay) != 0
 
 
 def test_extended_entry_points_reject_bad_arguments_before_launching():
-    """lc_pnp_lm2_f32 / lc_dense_frontend_fwd2_f32: argument errors are reported by return code + lc_amd_last_error, nothing is
+    """lc_pnp_lm3_f32 / lc_dense_frontend_fwd3: argument errors are reported by return code + lc_amd_last_error, nothing is
     launched (runs without a GPU)."""
     from lc_amd import _lib
 
@@ -64,16 +76,16 @@ def test_extended_entry_points_reject_bad_arguments_before_launching():
     p = ctypes.addressof(buf)
     err = lambda: lib.lc_amd_last_error().decode()
     # two weight forms at once / none at all
-    assert lib.lc_pnp_lm2_f32(p, p, p, p, p, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 0, None) != 0 and "exactly one" in err()
-    assert lib.lc_pnp_lm2_f32(p, p, p, None, None, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 0, None) != 0 and "exactly one" in err()
+    assert lib.lc_pnp_lm3_f32(p, p, p, p, p, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 0, None, 0, None) != 0 and "exactly one" in err()
+    assert lib.lc_pnp_lm3_f32(p, p, p, None, None, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 0, None, 0, None) != 0 and "exactly one" in err()
     # unknown option bit, icov flag without the diagonal weights, shared poses without a separate start
-    assert lib.lc_pnp_lm2_f32(p, p, p, None, p, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 8, 0, None) != 0 and "option" in err()
-    assert lib.lc_pnp_lm2_f32(p, p, p, None, None, p, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 1, 0, None) != 0 and "weights_diag" in err()
-    assert lib.lc_pnp_lm2_f32(p, p, p, None, p, None, None, None, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 1, None) != 0 and "start" in err()
+    assert lib.lc_pnp_lm3_f32(p, p, p, None, p, None, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 8, 0, None, 0, None) != 0 and "option" in err()
+    assert lib.lc_pnp_lm3_f32(p, p, p, None, None, p, None, p, p + 64, p, p, None, 2, 4, 5, 1e-6, 1, 0, None, 0, None) != 0 and "weights_diag" in err()
+    assert lib.lc_pnp_lm3_f32(p, p, p, None, p, None, None, None, p + 64, p, p, None, 2, 4, 5, 1e-6, 0, 1, None, 0, None) != 0 and "start" in err()
     # visibility logits without a mask buffer
-    assert lib.lc_dense_frontend_fwd2_f32(p, p, p, None, p, 0.5, 1, 4, 4, 0, 0, 2, p, p, p, p, None, None) != 0 and "vis_" in err()
+    assert lib.lc_dense_frontend_fwd3(p, p, p, None, p, 0.5, 0, 0, 0, 0, 0, 0, 1, 4, 4, 0, 0, 2, p, p, p, p, None, None) != 0 and "vis_" in err()
     # empty batches are fine
-    assert lib.lc_pnp_lm2_f32(p, p, p, None, p, None, None, p, p + 64, p, p, None, 0, 4, 5, 1e-6, 0, 0, None) == 0
+    assert lib.lc_pnp_lm3_f32(p, p, p, None, p, None, None, p, p + 64, p, p, None, 0, 4, 5, 1e-6, 0, 0, None, 0, None) == 0
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -296,7 +308,7 @@ def test_label_prep_names_pass_through_to_the_reference(monkeypatch):
 
 
 def test_chain_and_round3_entry_points_check_their_arguments_before_launching():
-    """lc_pnp_lm_chain_f32 (plain C struct jobs), lc_dense_frontend_select_f32, lc_dense_aux_fwd_f32, lc_xyz_bin_loss_fwd_f32: argument
+    """lc_pnp_lm_chain2_f32 (plain C struct jobs), lc_dense_frontend_select3, lc_dense_aux_fwd2, lc_xyz_bin_loss_fwd2 / _counts / _finish: argument
     errors come back as return code + lc_amd_last_error and empty batches are no-ops, all without touching a GPU."""
     from lc_amd import _lib
     from lc_amd.pnp.pnp_ceres import _Job
@@ -305,27 +317,33 @@ def test_chain_and_round3_entry_points_check_their_arguments_before_launching():
     buf = ctypes.create_string_buffer(256)
     p = ctypes.addressof(buf)
     empty = _Job(None, None, None, None, None, None, None, None, None, None, None, None, 0, 700, 20, 1e-6, 0, 0)
-    assert lib.lc_pnp_lm_chain_f32(ctypes.byref(empty), ctypes.byref(empty), None) == 0  # two empty batches
-    assert lib.lc_pnp_lm_chain_f32(None, ctypes.byref(empty), None) != 0 and b"null job" in lib.lc_amd_last_error()
+    assert lib.lc_pnp_lm_chain2_f32(ctypes.byref(empty), ctypes.byref(empty), None, 0, None) == 0  # two empty batches
+    assert lib.lc_pnp_lm_chain2_f32(None, ctypes.byref(empty), None, 0, None) != 0 and b"null job" in lib.lc_amd_last_error()
     bad = _Job(p, p, p, None, p, None, None, None, p, p, p, None, 4, 700, 20, 1e-6, 8, 0)  # unknown option bit
-    assert lib.lc_pnp_lm_chain_f32(ctypes.byref(empty), ctypes.byref(bad), None) != 0 and b"option" in lib.lc_amd_last_error()
+    assert lib.lc_pnp_lm_chain2_f32(ctypes.byref(empty), ctypes.byref(bad), None, 0, None) != 0 and b"option" in lib.lc_amd_last_error()
     two = _Job(p, p, p, p, p, None, None, None, p, p, p, None, 4, 700, 20, 1e-6, 0, 0)  # two weight forms at once
-    assert lib.lc_pnp_lm_chain_f32(ctypes.byref(two), ctypes.byref(empty), None) != 0 and b"exactly one" in lib.lc_amd_last_error()
+    assert lib.lc_pnp_lm_chain2_f32(ctypes.byref(two), ctypes.byref(empty), None, 0, None) != 0 and b"exactly one" in lib.lc_amd_last_error()
     # front end + selection: more sampled pixels than the one launch takes; a mask mode without visibility logits
-    rc = lib.lc_dense_frontend_select_f32(p, p, p, None, p, 0.5, 1, 258, 256, 0, 0, 2, 0, 0.5, 1, 4, 0, p, p, p, None, p, None)
+    rc = lib.lc_dense_frontend_select3(p, p, p, None, p, 0.5, 0, 0, 0, 0, 0, 0, 1, 258, 256, 0, 0, 2, 0, 0.5, 1, 4, 0, 0, p, p, p, None, p, None, 0, None)
     assert rc != 0 and b"16384" in lib.lc_amd_last_error()
-    rc = lib.lc_dense_frontend_select_f32(p, p, p, None, None, 0.5, 1, 64, 64, 0, 0, 2, 2, 0.5, 1, 4, 0, p, p, p, None, p, None)
+    rc = lib.lc_dense_frontend_select3(p, p, p, None, None, 0.5, 0, 0, 0, 0, 0, 0, 1, 64, 64, 0, 0, 2, 2, 0.5, 1, 4, 0, 0, p, p, p, None, p, None, 0, None)
     assert rc != 0 and b"visibility" in lib.lc_amd_last_error()
-    assert lib.lc_dense_frontend_select_f32(p, p, p, None, p, 0.5, 0, 64, 64, 0, 0, 2, 0, 0.5, 1, 4, 0, p, p, p, None, p, None) == 0
+    assert lib.lc_dense_frontend_select3(p, p, p, None, p, 0.5, 0, 0, 0, 0, 0, 0, 0, 64, 64, 0, 0, 2, 0, 0.5, 1, 4, 0, 0, p, p, p, None, p, None, 0, None) == 0
     # dense auxiliary losses: xyz without exactly one mask form; unknown loss type; empty batch
-    rc = lib.lc_dense_aux_fwd_f32(p, None, None, p, p, p, None, 2, 64, 0, p, p, p, None)
+    rc = lib.lc_dense_aux_fwd2(p, None, None, p, p, p, None, 0, 0, 0, 0, 2, 64, 0, p, p, p, None)
     assert rc != 0 and b"mask" in lib.lc_amd_last_error()
-    assert lib.lc_dense_aux_fwd_f32(None, None, None, None, p, p, None, 2, 64, 7, p, p, p, None) != 0
-    assert lib.lc_dense_aux_fwd_f32(None, None, None, None, p, p, None, 0, 64, 0, p, p, p, None) == 0
+    assert lib.lc_dense_aux_fwd2(None, None, None, None, p, p, None, 0, 0, 0, 0, 2, 64, 7, p, p, p, None) != 0
+    assert lib.lc_dense_aux_fwd2(None, None, None, None, p, p, None, 0, 0, 0, 0, 0, 64, 0, p, p, p, None) == 0
     # code loss: more bits than the kernel's per-bit tables hold
-    rc = lib.lc_xyz_bin_loss_fwd_f32(p, p, p, 2, 200, 64, 0.05, p, p, p, p, p, None)
+    rc = lib.lc_xyz_bin_loss_fwd2(p, p, p, 0, 0, 0, 2, 200, 64, 0.05, p, p, p, p, p, None)
     assert rc != 0 and b"128" in lib.lc_amd_last_error()
-    assert lib.lc_xyz_bin_loss_fwd_f32(p, p, p, 0, 17, 64, 0.05, p, p, p, p, p, None) == 0
+    assert lib.lc_xyz_bin_loss_fwd2(p, p, p, 0, 0, 0, 0, 17, 64, 0.05, p, p, p, p, p, None) == 0
+    # its sharded form: counts without the place for the BCE means; a finish without counts; an empty batch
+    assert lib.lc_xyz_bin_loss_counts(p, p, p, 0, 0, 0, 2, 17, 64, p, None, p, p, None) != 0 and b"null" in lib.lc_amd_last_error()
+    assert lib.lc_xyz_bin_loss_counts(p, p, p, 0, 0, 0, 2, 17, 64, None, p, p, p, None) != 0
+    assert lib.lc_xyz_bin_loss_counts(p, p, p, 0, 0, 0, 0, 17, 64, p, p, p, p, None) == 0
+    assert lib.lc_xyz_bin_loss_finish(None, p, 17, 0.05, p, p, p, None) != 0 and b"null" in lib.lc_amd_last_error()
+    assert lib.lc_xyz_bin_loss_finish(p, p, 200, 0.05, p, p, p, None) != 0 and b"128" in lib.lc_amd_last_error()
 
 
 def test_training_shape_fixtures_span_the_warm_up_ramp_and_the_reference_shapes():
