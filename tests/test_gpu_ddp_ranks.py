@@ -79,3 +79,28 @@ def test_ranks_match_the_single_process_run(tmp_path, script, extra, world):
     assert torch.equal(r0["params_at_start"], one["params_at_start"])
     u2, u1 = r0["params"] - r0["params_at_start"], one["params"] - one["params_at_start"]
     assert u1.norm() > 0 and ((u2 - u1).norm() / u1.norm()).item() <= 0.05, ((u2 - u1).norm() / u1.norm()).item()
+
+
+def test_comm_report_of_an_eight_rank_zlmo_shaped_job(tmp_path):
+    """`--report-comm` (examples/ddp_common.py: CommReport) on the 8-rank shared-GPU rehearsal of the zlmo-shaped step: the ARITHMETIC of the
+    report, not its timings (gloo stages every collective through the host and the ranks share one GPU) -- per step and rank the gradient
+    payload is the model's parameter bytes, the buckets add up to it, the loss side issues exactly two small all-reduces (the NormClipper's
+    squared norm: 4 bytes; the code histogram's C + 1 int64 counts: 8 x 22 bytes), and the xGMI estimates printed beside them are SURVEY.md
+    section 5's formulas (ring: 2 (w-1)/w of the payload over one 153 GB/s link; direct reduce-scatter + all-gather: 2/w of it per link)."""
+    import json
+
+    dump = str(tmp_path / "comm")
+    ranks = _run("train_dense_ddp.py", ["--dtype", "fp32", "--np-seed", "3", "--zlmo", "--batch", "2", "--report-comm"], dump, 8)
+    rep = json.load(open(dump + ".comm.json"))
+    s, per_rank = rep["summary"], rep["per_rank_steps"]
+    n_params = ranks[0]["params"].numel()
+    assert s["world"] == 8 and s["backend"] == "gloo" and len(per_rank) == 8 and all(len(r) == STEPS for r in per_rank)
+    assert s["grad_payload_bytes"] == 4 * n_params
+    for r in per_rank:
+        for d in r:
+            assert d["grad_bytes"] == 4 * n_params and d["buckets"] >= 1 and len(d["bucket_ms"]) == d["buckets"]
+            assert d["small_calls"] == 2 and d["small_bytes"] == 4 + 8 * (21 + 1)
+            assert 0 < d["grad_window_ms"] <= d["step_ms"] and all(v > 0 for v in d["bucket_ms"])
+    gb = 4 * n_params / 1e9
+    assert abs(s["xgmi_estimate"]["ring_ms"] - 2 * 7 / 8 * gb / 153.0 * 1e3) < 1e-9 and abs(s["xgmi_estimate"]["direct_ms"] - 2 / 8 * gb / 153.0 * 1e3) < 1e-9
+    assert abs(s["survey_estimate_104MB_8gpu"]["ring_ms"] - 1.19) < 0.01 and abs(s["survey_estimate_104MB_8gpu"]["direct_ms"] - 0.17) < 0.005  # SURVEY.md section 5's figures
