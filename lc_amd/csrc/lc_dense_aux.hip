@@ -21,6 +21,9 @@ namespace {
 constexpr int kThreads = 256;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }  // torch.sigmoid's formula
+// the same from the two hardware instructions v_exp_f32 / v_rcp_f32 (<= 1 ulp each): the code loss's backward pass, where ~25 instructions
+// of expf + IEEE division per logit were a third of the kernel
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
 template <int NWAVES = kThreads / 64>
 __device__ __forceinline__ void block_sum3(double (&v)[3], double (*red)[3]) {
     wave_allreduce<3>(v);
@@ -238,12 +241,23 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
 // log-sigmoid, BCE, mean, ...); here one pass: grid (C, chunks), a workgroup reduces its share of ONE code channel -- Hamming errors
 // inside the hard visibility mask, the BCE sum, and (channel 0) the mask's population -- partials in a fixed order, and the last
 // workgroup to arrive finishes: histogram EMA in place, soft histogram, softmax bit weights, the loss.  Backward: one element-wise pass.
+#ifndef LC_BIN_FWD_SKIP_STREAM
+#define LC_BIN_FWD_SKIP_STREAM 0  // diagnostics: the fixed part of the launch (partials, arrival, the last workgroup's tail)
+#endif
+#ifndef LC_BIN_FWD_AHEAD
+#define LC_BIN_FWD_AHEAD 1
+#endif
 constexpr int kBinChunks = 32;   // at most that many workgroups per code channel (their partials are added in chunk order)
 constexpr int kBinThreads = 1024;  // of 1024 threads each: every workgroup ends with ONE counted arrival on the one counter
 
 // (1 - t) z - log_sigmoid(z), log_sigmoid(z) = min(z, 0) - log1p(exp(-|z|)); the hardware exp / log (v_exp_f32, v_log_f32) are good
 // to ~1e-7 absolute on log1p(e), e in (0, 1] -- terms of a MEAN of order 0.1-1 that is compared at 1e-6
-__device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - __logf(1.f + __expf(-fabsf(z)))); }
+// (`__logf` is NOT the bare instruction under hipcc: it adds a denormal-range rescue and a two-term ln 2 product, ~9 instructions; the
+// argument here is in (1, 2], so log2 from v_log_f32 times ln 2 is all that is needed -- 28 of the kernel's 125 VALU instructions per request)
+__device__ __forceinline__ float softplus_neg_abs(float z) {  // log(1 + exp(-|z|))
+    return 0.693147180559945309f * __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(z)));
+}
+__device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t) * z - (fminf(z, 0.f) - softplus_neg_abs(z)); }
 
 // The end of Loss_xyz_bin.forward from the per-bit error counts (losses.py:205-213), shared by the one-launch kernel (its last workgroup)
 // and by the weights-in kernel of the sharded form, so that both give the same bits: histogram EMA in place, soft histogram, softmax
@@ -294,41 +308,51 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
     const unsigned n = (unsigned)p.B * (unsigned)p.HW;  // 32-bit index arithmetic (see lc_dense_aux_fwd_kernel)
     // Hamming errors and visible pixels (channel 0 only) are counted in integers; the BCE terms of the four pixels of a request are
     // added in fp32 and that sum goes into a double (one conversion + one fp64 add per request: the kernel is VALU-bound)
-    int n_err = 0, n_vis = 0;
+    int n_err = 0, n_vis = 0, e4 = 0, v4 = 0;  // e4 / v4 / bce4: the counts and the sum of one request's four pixels
     double bce_sum = 0;
     float bce4 = 0.f;
     auto one = [&](float x, bool t, bool vis) {
-        n_err += (vis && ((x > 0.f) != t)) ? 1 : 0;
+        e4 += (vis && ((x > 0.f) != t)) ? 1 : 0;
         bce4 += bce_logits(vis ? x : 0.f * x, t ? 1.f : 0.f);  // logits * msk_hard (keeps a NaN / inf logit visible like the product)
-        n_vis += (c == 0 && vis) ? 1 : 0;
+        v4 += (c == 0 && vis) ? 1 : 0;
     };
     if (p.vec) {  // HW % 4 == 0, 16-byte aligned maps: four pixels per thread and request
-        const unsigned n4 = n >> 2, hw4 = (unsigned)p.HW >> 2;
-        constexpr int kAhead = 4;  // requests in flight per thread: the loop is a latency chain otherwise (one round trip per iteration)
+        const unsigned hw4 = (unsigned)p.HW >> 2;
+        constexpr int kAhead = LC_BIN_FWD_AHEAD;  // requests in flight per thread: the loop is a latency chain otherwise (one round trip per iteration)
         // (prefetching the NEXT four requests while these are evaluated was tried: 94 VGPRs -> one 1024-thread workgroup per compute
         // unit instead of two, 33 -> 39 us at B=64 128x128)
-        const unsigned stride = (unsigned)chunks * kBinThreads;
-        for (unsigned i0 = (unsigned)chunk * kBinThreads + threadIdx.x; i0 < n4; i0 += kAhead * stride) {
-            float4 x[kAhead], v[kAhead];
+        // The channel's pixels are walked PLANE by plane: a unit = kBinThreads requests (one per thread) of one sample's plane, units dealt
+        // to the channel's workgroups round robin (balanced to one unit: with units of 4 x 1024 requests a third of the workgroups had
+        // twice the work of the others at zlmo's shape, 28 us against 23).  Inside a unit every address is a uniform base + the thread's
+        // offset -- the flat walk over (sample, pixel) paid two integer divisions per request (a quarter of the kernel's VALU
+        // instructions).  kAhead units are in flight per thread: all their requests are issued before the first is used -- raw words in, no
+        // branch between the requests (a unit behind the workgroup's last re-reads that one and is not counted), conversions at the use.
+        const unsigned slabs = (hw4 + kBinThreads - 1) / kBinThreads, units = LC_BIN_FWD_SKIP_STREAM ? 0u : (unsigned)p.B * slabs;
+        for (unsigned u0 = (unsigned)chunk; u0 < units; u0 += kAhead * (unsigned)chunks) {
+            typename MapRaw4<T>::type xr[kAhead], vr[kAhead];
             uchar4 t[kAhead];
+            bool live[kAhead];
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                const unsigned i = i0 + u * stride;
-                if (i < n4) {
-                    const unsigned b = i / hw4, q = i - b * hw4;
-                    const unsigned e = (b * (unsigned)p.C + (unsigned)c) * hw4 + q;
-                    x[u] = map_load4(logits + ((size_t)b * lg_bs + 4 * (size_t)((unsigned)c * hw4 + q)));
-                    t[u] = reinterpret_cast<const uchar4*>(p.gt_bits)[e];
-                    v[u] = map_load4(vis_logits + ((size_t)b * vis_bs + 4 * (size_t)q));
-                }
+                const unsigned unit = min(u0 + u * (unsigned)chunks, units - 1);  // uniform
+                const unsigned b = unit / slabs, q0 = (unit - b * slabs) * kBinThreads + threadIdx.x, q = min(q0, hw4 - 1);
+                live[u] = u0 + u * (unsigned)chunks < units && q0 < hw4;
+                xr[u] = map_raw_load4(logits + ((size_t)b * lg_bs + (size_t)c * (unsigned)p.HW) + 4 * (size_t)q);
+                t[u] = (reinterpret_cast<const uchar4*>(p.gt_bits) + ((size_t)b * (unsigned)p.C + (unsigned)c) * hw4)[q];
+                vr[u] = map_raw_load4(vis_logits + (size_t)b * vis_bs + 4 * (size_t)q);
             }
+            // (evaluated without a branch either: with `if (...) break` here the compiler sinks each request's loads into its guarded
+            // block and the group is one request in flight again)
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                if (i0 + u * stride >= n4) break;
-                one(x[u].x, t[u].x != 0, v[u].x > 0.f); one(x[u].y, t[u].y != 0, v[u].y > 0.f);
-                one(x[u].z, t[u].z != 0, v[u].z > 0.f); one(x[u].w, t[u].w != 0, v[u].w > 0.f);
-                bce_sum += (double)bce4;
-                bce4 = 0.f;
+                const float4 x = map_raw_cvt4<T>(xr[u]), v = map_raw_cvt4<T>(vr[u]);
+                one(x.x, t[u].x != 0, v.x > 0.f); one(x.y, t[u].y != 0, v.y > 0.f);
+                one(x.z, t[u].z != 0, v.z > 0.f); one(x.w, t[u].w != 0, v.w > 0.f);
+                if (live[u]) {
+                    n_err += e4; n_vis += v4;
+                    bce_sum += (double)bce4;
+                }
+                e4 = 0; v4 = 0; bce4 = 0.f;
             }
         }
     } else {
@@ -336,8 +360,9 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
             const unsigned b = i / (unsigned)p.HW, px = i - b * (unsigned)p.HW;
             const unsigned e = (b * (unsigned)p.C + (unsigned)c) * (unsigned)p.HW + px;
             one((float)logits[(size_t)b * lg_bs + (size_t)c * (unsigned)p.HW + px], p.gt_bits[e] != 0, (float)vis_logits[(size_t)b * vis_bs + px] > 0.f);
+            n_err += e4; n_vis += v4;
             bce_sum += (double)bce4;
-            bce4 = 0.f;
+            e4 = 0; v4 = 0; bce4 = 0.f;
         }
     }
     double acc[3] = {(double)n_err, bce_sum, (double)n_vis};
@@ -404,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const Bin
     const unsigned n = (unsigned)p.B * (unsigned)p.C * (unsigned)p.HW, C = (unsigned)p.C;
     const float g = *p.g_loss / (float)((unsigned)p.B * (unsigned)p.HW);
     // d/dx BCE(x * m, t) = (sigmoid(x m) - t) m
-    auto one = [&](float x, bool t, bool vis, float w) { return vis ? g * w * (sigmoidf_(x) - (t ? 1.f : 0.f)) : 0.f; };
+    auto one = [&](float x, bool t, bool vis, float w) { return vis ? g * w * (sigmoid_fast(x) - (t ? 1.f : 0.f)) : 0.f; };  // (the same bits as the plane-shaped kernel below)
     if (p.vec) {
         const unsigned hw4 = (unsigned)p.HW >> 2;
         for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < (n >> 2); e += gridDim.x * kThreads) {
@@ -423,6 +448,92 @@ __global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_kernel(const Bin
         const unsigned bc = e / (unsigned)p.HW, px = e - bc * (unsigned)p.HW, b = bc / C;
         d_logits[e] = map_round<T>(one((float)logits[(size_t)b * lg_bs + (size_t)(bc - b * C) * (unsigned)p.HW + px], p.gt_bits[e] != 0,
                              (float)vis_logits[(size_t)b * vis_bs + px] > 0.f, p.bin_weights[bc - b * C]));
+    }
+}
+
+// The same backward pass shaped by the (sample, code bit) PLANES of the maps: grid (plane chunks, C, B), so a workgroup's plane base
+// addresses, its bit weight and the cotangent are uniform (scalar registers, no integer division per request -- the flat kernel above spends
+// two on every four pixels), and each thread issues 16-byte requests -- E = 4 fp32 or 8 sixteen-bit pixels -- two per thread, all loads of
+// both in flight before the first is used.  sigmoid(x) = v_rcp_f32(1 + v_exp_f32(-x log2 e)): two hardware instructions of <= 1 ulp each
+// against ~25 for expf + an IEEE division (__frcp_rn still expands to v_div_scale / v_div_fmas / v_div_fixup: the builtins are used directly) -- a gradient entry moves by ~1e-7 of itself (the tests compare at 2e-6 of the largest entry).
+// Element-wise: every map type evaluates the same expression per element, so a 16-bit map still gives the fp32 result on its up-cast
+// values, rounded once to the map's type.
+#ifndef LC_BIN_BWD_UNROLL
+#define LC_BIN_BWD_UNROLL 2
+#endif
+constexpr int kBwdPlaneUnroll = LC_BIN_BWD_UNROLL;
+template <int E, typename T>
+struct PlaneChunk {  // one 16-byte request of logits and visibility logits + its E ground-truth bytes, as loaded (converted at the use)
+    uint4 x, v;
+    unsigned t[E / 4];
+};
+template <int E, typename T>
+__device__ __forceinline__ void plane_load(const T* x, const unsigned char* t, const T* v, size_t at, PlaneChunk<E, T>& o) {
+    static_assert(E * sizeof(T) == 16, "16-byte requests");
+    // (`at` counts elements and is a multiple of E: indexing typed 16-byte / E-byte pointers keeps the alignment visible to the compiler --
+    // with byte arithmetic one of the 16-byte requests came out as four unaligned pieces)
+    const size_t chunk = at / E;
+    o.x = static_cast<const uint4*>(__builtin_assume_aligned(x, 16))[chunk];
+    o.v = static_cast<const uint4*>(__builtin_assume_aligned(v, 16))[chunk];
+    if constexpr (E == 4) {
+        o.t[0] = reinterpret_cast<const unsigned*>(t)[chunk];
+    } else {
+        const uint2 b = reinterpret_cast<const uint2*>(t)[chunk];
+        o.t[0] = b.x; o.t[1] = b.y;
+    }
+}
+template <int E, typename T>
+__device__ __forceinline__ void plane_unpack(const PlaneChunk<E, T>& q, float (&x)[E], float (&v)[E], bool (&t)[E]) {
+    const unsigned wx[4] = {q.x.x, q.x.y, q.x.z, q.x.w}, wv[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        if constexpr (sizeof(T) == 4) {
+            x[k] = __builtin_bit_cast(float, wx[k]);
+            v[k] = __builtin_bit_cast(float, wv[k]);
+        } else {  // (extracted by shifts: through a memcpy into T[8] one of the 16-byte requests was split into four narrow loads)
+            x[k] = (float)__builtin_bit_cast(T, (unsigned short)(wx[k / 2] >> (16 * (k % 2))));
+            v[k] = (float)__builtin_bit_cast(T, (unsigned short)(wv[k / 2] >> (16 * (k % 2))));
+        }
+        t[k] = ((q.t[k / 4] >> (8 * (k % 4))) & 0xffu) != 0;
+    }
+}
+template <int E, typename T>
+__device__ __forceinline__ void plane_store(T* d, size_t at, const float (&o)[E]) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<map_v4f_t*>(d + at) = map_v4f_t{o[0], o[1], o[2], o[3]};
+    } else {
+        T h[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = map_round<T>(o[k]);
+        uint4 r;
+        __builtin_memcpy(&r, h, 16);
+        *reinterpret_cast<uint4*>(d + at) = r;
+    }
+}
+template <int E, typename T>
+__global__ __launch_bounds__(kThreads) void lc_xyz_bin_loss_bwd_plane_kernel(const BinLossParams p) {
+    const unsigned c = blockIdx.y, b = blockIdx.z, HW = (unsigned)p.HW, chunks = HW / E;
+    const T* const x = static_cast<const T*>(p.logits) + ((size_t)b * (size_t)p.logits_bs + (size_t)c * HW);
+    const T* const v = static_cast<const T*>(p.msk_vis_logits) + (size_t)b * (size_t)p.vis_bs;
+    const size_t plane = ((size_t)b * (unsigned)p.C + c) * HW;
+    const unsigned char* const t = p.gt_bits + plane;
+    T* const d = static_cast<T*>(p.d_logits) + plane;
+    const float g = *p.g_loss / (float)((unsigned)p.B * HW), w = p.bin_weights[c];
+    // d/dx BCE(x * m, t) = (sigmoid(x m) - t) m, in the flat kernel's operation order
+    PlaneChunk<E, T> q[kBwdPlaneUnroll];
+    const unsigned first = blockIdx.x * (kBwdPlaneUnroll * kThreads) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < kBwdPlaneUnroll; ++u)  // no branch between the requests: one behind the plane's end re-reads the last chunk and is dropped below
+        plane_load<E, T>(x, t, v, (size_t)min(first + u * kThreads, chunks - 1) * E, q[u]);
+#pragma unroll
+    for (int u = 0; u < kBwdPlaneUnroll; ++u) {
+        if (first + u * kThreads >= chunks) break;
+        float xs[E], vs[E], o[E];
+        bool ts[E];
+        plane_unpack<E, T>(q[u], xs, vs, ts);
+#pragma unroll
+        for (int k = 0; k < E; ++k) o[k] = vs[k] > 0.f ? g * w * (sigmoid_fast(xs[k]) - (ts[k] ? 1.f : 0.f)) : 0.f;
+        plane_store<E, T>(d, (size_t)(first + u * kThreads) * E, o);
     }
 }
 
@@ -492,8 +603,10 @@ int launch_xyz_bin_loss_fwd(const BinLossParams& p, hipStream_t stream) {
     // 1024-thread workgroups, a thread at about four requests of four pixels (all in flight at once), at most kBinChunks workgroups
     // per code bit (B=64 128x128: 16 -> 32 chunks 38 -> 33 us; B=32 64x64: eight -> four requests 16.4 -> 12.5 us)
     BinLossParams q = bin_with_dense_strides(p);
-    const long long req = ((long long)p.B * p.HW + 3) / 4;
-    q.chunks = (int)std::min<long long>(kBinChunks, std::max<long long>(1, (req + 4 * kBinThreads - 1) / (4 * kBinThreads)));
+    // the vectorised walk deals units of 1024 requests of ONE sample's plane; the element-wise walk strides over (sample, pixel)
+    const long long per_plane = ((long long)p.HW / 4 + kBinThreads - 1) / kBinThreads;
+    const long long units = p.vec ? (long long)p.B * per_plane : (((long long)p.B * p.HW + 3) / 4 + 4 * kBinThreads - 1) / (4 * kBinThreads);
+    q.chunks = (int)std::min<long long>(kBinChunks, std::max<long long>(1, units));
     q.chunks = std::min(q.chunks, std::max(1, 512 / q.C));  // one round of workgroups: two of 1024 threads fit a compute unit
     LC_MAP_DISPATCH(q.map_dtype, hipLaunchKernelGGL(lc_xyz_bin_loss_fwd_kernel<T>, dim3(q.C * q.chunks), dim3(kBinThreads), 0, stream, q));
     return hipGetLastError() == hipSuccess ? 0 : 2;
@@ -510,6 +623,18 @@ int launch_xyz_bin_loss_bwd(const BinLossParams& p_in, hipStream_t stream) {
     if (p_in.B <= 0 || p_in.C <= 0) return 0;
     const BinLossParams p = bin_with_dense_strides(p_in);
     const long long n = (long long)p.B * p.C * p.HW;
+    // planes of 16-byte requests (the training shapes: 64x64 / 128x128 maps, contiguous or channel-sliced heads), else the flat kernel
+    const int E = 16 / map_elem_bytes(p.map_dtype);
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool planes = p.vec && p.HW % E == 0 && p.logits_bs % E == 0 && p.vis_bs % E == 0 && al16(p.logits) && al16(p.msk_vis_logits) && al16(p.d_logits) &&
+                        (reinterpret_cast<uintptr_t>(p.gt_bits) & (E - 1)) == 0 && p.B <= 65535;
+    if (planes) {
+        const dim3 grid((p.HW / E + kBwdPlaneUnroll * kThreads - 1) / (kBwdPlaneUnroll * kThreads), p.C, p.B);
+        if (p.map_dtype == kMapF32) hipLaunchKernelGGL((lc_xyz_bin_loss_bwd_plane_kernel<4, float>), grid, dim3(kThreads), 0, stream, p);
+        else if (p.map_dtype == kMapF16) hipLaunchKernelGGL((lc_xyz_bin_loss_bwd_plane_kernel<8, _Float16>), grid, dim3(kThreads), 0, stream, p);
+        else hipLaunchKernelGGL((lc_xyz_bin_loss_bwd_plane_kernel<8, __bf16>), grid, dim3(kThreads), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     const int grid = (int)std::min<long long>(2048, std::max<long long>(1, (n + 4 * kThreads - 1) / (4 * kThreads)));
     LC_MAP_DISPATCH(p.map_dtype, hipLaunchKernelGGL(lc_xyz_bin_loss_bwd_kernel<T>, dim3(grid), dim3(kThreads), 0, stream, p));
     return hipGetLastError() == hipSuccess ? 0 : 2;

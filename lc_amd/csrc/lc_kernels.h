@@ -179,6 +179,7 @@ struct BitsParams {
     const int* rows_index;        // (B, rows_N)
     const int* rows_counts;       // (B,)
     int rows_N;
+    int tile_groups;              // set by launch_bits_decode_gt_bwd for its tile-shaped kernel: thread groups that share a tile's channels
 };
 int launch_bits_decode_gt_fwd(const BitsParams& p, hipStream_t stream);
 int launch_bits_decode_gt_bwd(const BitsParams& p, hipStream_t stream);

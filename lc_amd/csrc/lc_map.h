@@ -41,6 +41,31 @@ __device__ __forceinline__ void map_load(const T* q, float (&v)[V]) {
         for (int k = 0; k < 4; ++k) v[k] = (float)h[k];
     }
 }
+// The same four elements as they lie in memory, converted LATER: a kernel that keeps several requests in flight loads the raw words of all of
+// them first -- with the conversion next to the load the compiler waits for each request before it issues the next (seen in the ISA of the
+// code loss: s_waitcnt vmcnt after every request of an unrolled group of four, i.e. one request in flight).
+template <typename T>
+struct MapRaw4 {
+    typedef uint2 type;
+};
+template <>
+struct MapRaw4<float> {
+    typedef float4 type;
+};
+template <typename T>
+__device__ __forceinline__ typename MapRaw4<T>::type map_raw_load4(const T* q) {
+    return *reinterpret_cast<const typename MapRaw4<T>::type*>(q);
+}
+template <typename T>
+__device__ __forceinline__ float4 map_raw_cvt4(const typename MapRaw4<T>::type& r) {
+    if constexpr (sizeof(T) == 4) {
+        return r;
+    } else {
+        T h[4];
+        __builtin_memcpy(h, &r, 8);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+}
 template <typename T>
 __device__ __forceinline__ float4 map_load4(const T* q) {
     float v[4];

@@ -71,13 +71,13 @@ def main():
     b3 = floatbits._bits3(bits3, C)
     timed("decode_gt_fwd", lambda s: floatbits.decode_with_gt_strided(s["lg"], s["raw"], bits3, s["msk"], sample=sample, top_left=(1, 2), out_scale=noc_scale))
     outs = [floatbits.decode_with_gt_strided(x, s["raw"], bits3, s["msk"], sample=sample, top_left=(1, 2), out_scale=noc_scale) for x, s in zip(leaves, sets)]
-    gp = torch.randn(B, N, 3, generator=g).to(dev)
+    gp = torch.randn(outs[0].shape, generator=g).to(dev)
     timed("decode_gt_bwd", lambda s: torch.autograd.grad(outs[idx[id(s)]], leaves[idx[id(s)]], gp, retain_graph=True))
     # front end on the weight logits (binary-code heads: no xyz planes), forward and backward
     wls = [s["wl"].clone().requires_grad_(True) for s in sets]
     timed("frontend_fwd", lambda s: dense.dense_front_end(None, s["wl"], wscale, None, sample=sample, top_left=(1, 2)))
     fo = [dense.dense_front_end(None, w, wscale, None, sample=sample, top_left=(1, 2)) for w in wls]
-    gi = torch.randn(B, N, 2, generator=g).to(dev)
+    gi = torch.randn(fo[0][1].shape, generator=g).to(dev)
     timed("frontend_bwd", lambda s: torch.autograd.grad(fo[idx[id(s)]][1], wls[idx[id(s)]], gi, retain_graph=True))
     # the clipper on the weight logits' gradient
     clip = NormClipper().to(dev)
