@@ -10,6 +10,9 @@ TAG=${1:-r04}
 SHA=${2:-unknown}
 bash scripts/profile_round.sh "$TAG" "$SHA" > gpurun_out/profile_round.log 2>&1 < /dev/null
 O=gpurun_out/prof_$TAG
+# the bench line names the counter passes it prices `traffic` / `valu_issue` with (the newest profiles/<round>/pmc_traffic.json): put THIS run's passes
+# where it looks before it runs, so the round's records name the round's counters (round 5's and the first of round 6's named the round before)
+mkdir -p profiles/$TAG && [ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/$TAG/pmc_traffic.json
 timeout 900 python3 bench.py 2>/dev/null < /dev/null | tail -1 > $O/bench_default.json
 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null < /dev/null | tail -1 > $O/bench_k20.json
 timeout 300 python3 bench_head.py 2>/dev/null < /dev/null | tail -1 > $O/bench_head_f32.json

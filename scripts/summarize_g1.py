@@ -48,9 +48,12 @@ def hbm_table(rows, B=32, S=128, C=21, e=2, sample=3):
     algo = {  # kernel -> (bytes, what)
         "lc_xyz_bin_loss_fwd_kernel": (B * C * HW * (e + 1) + B * HW * e, "code logits + target bits + visibility logits, once"),
         "lc_xyz_bin_loss_bwd_kernel": (B * C * HW * (e + 1 + e) + B * HW * e, "the same + the logits' gradient"),
+        "lc_xyz_bin_loss_bwd_plane_kernel": (B * C * HW * (e + 1 + e) + B * HW * e, "the same + the logits' gradient"),
         "lc_bits_decode_gt_fwd_kernel": (B * N * (C * (e + 1) + 1 + 12), "sampled pixels only: C logits + C raw bits + mask in, 3 floats out (whole sampled rows "
                                          "at sector granularity: %.1f MB)" % (B * C * (-(-S // sample)) * S * (e + 1) / 1e6)),
         "lc_bits_decode_gt_bwd_kernel": (B * C * HW * e + B * N * (C * (e + 1) + 1 + 12), "the logits' gradient map (zero off the sampled pixels) + the forward's reads + the cotangent"),
+        "lc_bits_decode_gt_bwd_tile_kernel": (B * C * HW * e + B * N * (C * (e + 1) + 1 + 12), "the logits' gradient map (zero off the sampled pixels) + the forward's reads + the cotangent"),
+        "lc_bits_decode_gt_fwd_wide_kernel": (B * N * (C * (e + 1) + 1 + 12), "sampled pixels only: C logits + C raw bits + mask in, 3 floats out (latency-shaped: one memory round trip)"),
         "lc_dense_frontend_fwd_kernel": (B * 2 * HW * e + B * N * 16, "weight logits (joint softmax over 2HW) in, pts2d + inv_std out"),
         "lc_dense_frontend_bwd_kernel": (B * 2 * HW * e * 2 + B * N * 8, "weight logits in, their gradient out, the cotangent of inv_std"),
         "lc_dense_aux_fwd_kernel": (B * HW * (e + 4), "visibility logits + mask"),
@@ -61,11 +64,15 @@ def hbm_table(rows, B=32, S=128, C=21, e=2, sample=3):
     print(f"HBM view of the lc_* kernels that stream maps (B={B}, {S}x{S} maps, {C} planes, {e}-byte elements, N={N}); algorithmic bytes = what the operation must move once:\n")
     print("| kernel | avg us | algorithmic MB | GB/s | of 8 TB/s | bytes counted |")
     print("|---|---|---|---|---|---|")
-    for r in rows:
+    merged = {}
+    for r in rows:  # template instances of one kernel (one per sub-sampling phase's tile geometry): one row, weighted
         k = short(r["Name"])
+        c, t = merged.get(k, (0, 0.0))
+        merged[k] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
+    for k, (calls, total) in merged.items():
         if k in algo:
             by, what = algo[k]
-            us = float(r["AverageNs"]) / 1e3
+            us = total / calls / 1e3
             print(f"| {k} | {us:.1f} | {by / 1e6:.2f} | {by / us / 1e3:.0f} | {100 * by / us / 1e3 / 8000:.1f} % | {what} |")
     print()
 
