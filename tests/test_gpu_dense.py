@@ -244,9 +244,11 @@ def test_dense_aux_losses_equal_the_torch_formulas(B, H, W, with_xyz, with_w, ma
             assert (a.grad.cpu().double() - b.grad).abs().max() <= 2e-6 * b.grad.abs().max(), float((a.grad.cpu().double() - b.grad).abs().max())
 
 
-@pytest.mark.parametrize("B,C,H,W", [(32, 17, 64, 64), (3, 21, 37, 29), (2, 72, 16, 16), (4, 5, 128, 128)])
+@pytest.mark.parametrize("B,C,H,W", [(32, 17, 64, 64), (3, 21, 37, 29), (2, 72, 16, 16), (4, 5, 128, 128), (32, 21, 128, 128), (5, 7, 6, 6), (3, 4, 40, 36)])
 def test_xyz_bin_loss_equals_the_torch_formulas(B, C, H, W):
-    """lc_xyz_bin_loss_{fwd,bwd}_f32 against Loss_xyz_bin's torch formulas (losses.py:196-216) over three steps of the EMA histogram:
+    """lc_xyz_bin_loss_fwd2 / _bwd2 against Loss_xyz_bin's torch formulas (losses.py:196-216) over three steps of the EMA histogram -- every launch
+    form: planes of 16-byte requests (64x64, 128x128; zlmo's B=32 x 21 x 128 x 128: two units per workgroup and channel), planes that do not fill a
+    workgroup's share (6x6, 40x36), the element-wise walk (37x29):
     loss to 2e-6, histogram to 1e-6, gradient to 2e-6 of its largest entry (float64 torch on the CPU as the reference)."""
     from lc_amd.losses import Loss_xyz_bin
 

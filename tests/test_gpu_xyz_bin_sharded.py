@@ -44,7 +44,7 @@ def one_rank_group():
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
-@pytest.mark.parametrize("shape", [(4, 21, 128, 128), (3, 17, 16, 16), (2, 9, 15, 13), (1, 128, 8, 8)], ids=["zlmo", "small", "ragged", "C128"])
+@pytest.mark.parametrize("shape", [(4, 21, 128, 128), (3, 17, 16, 16), (2, 9, 15, 13), (1, 128, 8, 8), (2, 9, 6, 6)], ids=["zlmo", "small", "ragged", "C128", "hw36"])
 def test_one_rank_group_is_the_one_launch_kernel(one_rank_group, shape, dt):
     from lc_amd import dense_aux
 
