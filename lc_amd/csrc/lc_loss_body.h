@@ -422,13 +422,13 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
     }
     if (tid < 2) sh.bad[tid] = 0;
     // bbox corner of this lane's Jacobian row, fetched now so its HBM latency hides under passes 1-3
-    double bbx = 0, bby = 0, bbz = 0;
+    // (loaded by EVERY lane, the index clamped, and kept as the floats that arrive: written as `if (tid < grows) { double = load; }` the
+    // conversion sat next to the load inside the branch and the compiler waited for it there -- a memory round trip at the head of every
+    // sample BEFORE the correspondences were even requested, the opposite of the intent)
     constexpr int gdim = COV2D ? 2 : 3;  // rows per bbox corner: projected (u,v) or transformed (x,y,z)   (cov_mixed.py:125-130)
     constexpr int grows = 8 * gdim;
-    if (tid < grows) {
-        const float* bb = p.bbox + ((size_t)b * 8 + tid / gdim) * 3;
-        bbx = bb[0]; bby = bb[1]; bbz = bb[2];
-    }
+    const float* const bb = p.bbox + ((size_t)b * 8 + (tid < grows ? tid : grows - 1) / gdim) * 3;
+    const float bbxf = bb[0], bbyf = bb[1], bbzf = bb[2];
 
     const double max_len = p.max_err_len, rel_thresh = p.rel_thresh, w_e_thresh = p.w_e_thresh;
 
@@ -671,6 +671,7 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
     // cov_mixed.py:42-65):  h_j = S g_j;  diag(G S G^T)_j = g.h;  n_j = Mc h_j;  diag(G S Mc S G^T)_j = h.n;
     // (G S v)_j = h.v;  m_j = S n_j (so that Psi*Mc*S = sum cC_j h_j m_j^T in the reverse section).
     if (tid < grows) {
+        const double bbx = bbxf, bby = bbyf, bbz = bbzf;  // the corner of this lane's row, requested at the kernel's start
         double g[6];
         if constexpr (!COV2D) {  // xform_3d (cov_mixed.py:73-75): rows g = [ -rho (Rt[d,:] x b) | e_d ]
             const int d = tid % 3;

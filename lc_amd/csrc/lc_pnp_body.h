@@ -322,7 +322,15 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
     double x[6];
     {
         // QuaternionToAngleAxis (ceres.cpp:96)
-        const double q0 = fin(st_in[0]), q1 = fin(st_in[1]), q2 = fin(st_in[2]), q3 = fin(st_in[3]);
+        // q0 is only used inside `if (s2 > 0)`, and the compiler sinks its LOAD in there: a second memory round trip after the one that
+        // brought q1..q3 of the same cache line (seen in the ISA of the pose unit: global_load of start[0] behind the first s_waitcnt).  The
+        // empty asm is a use of the seven loaded values in the straight-line code: their loads are issued with the others (with q0 alone
+        // pinned, the compiler moved q1..q3 behind the wait instead).
+        float stf[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) stf[i] = st_in[i];
+        asm volatile("" : "+v"(stf[0]), "+v"(stf[1]), "+v"(stf[2]), "+v"(stf[3]), "+v"(stf[4]), "+v"(stf[5]), "+v"(stf[6]));
+        const double q0 = fin(stf[0]), q1 = fin(stf[1]), q2 = fin(stf[2]), q3 = fin(stf[3]);
         const double s2 = q1 * q1 + q2 * q2 + q3 * q3;
         double kk = 2.0;
         if (s2 > 0.0) {
@@ -333,7 +341,7 @@ __device__ __forceinline__ void solve_pose(const PnpParams& p, int b, int lane, 
             kk = two_theta / s;
         }
         x[0] = q1 * kk; x[1] = q2 * kk; x[2] = q3 * kk;
-        x[3] = fin(st_in[4]); x[4] = fin(st_in[5]); x[5] = fin(st_in[6]);
+        x[3] = fin(stf[4]); x[4] = fin(stf[5]); x[5] = fin(stf[6]);
     }
     LC_PSTAMP(0);
     // Lanes without a correspondence (lane >= n) carry a copy of correspondence 0 with a ZERO information factor: their residuals
