@@ -29,30 +29,47 @@ __device__ __forceinline__ void ms_merge(float& m, float& s, float om, float os)
 
 // One thread's share of the reduction below: thread `ft` of NT takes the groups of four logits ft, ft + NT, ..., AHEAD requests in flight, consumed in
 // index order (the updates and their order do not depend on AHEAD); thread 0 also takes the up to three logits behind the last full group.
+// "In flight" needs three things of the source, each learnt from the ISA (round 6: the first version had the loop, the unroll and the
+// intent, and compiled to load / s_waitcnt vmcnt(0) / load / s_waitcnt ... -- ONE request in flight, 16 dependent round trips for a 128x128
+// map): (1) no branch between the requests -- a request behind the end re-reads the last group and is not consumed; (2) the raw words are
+// loaded and converted at the use -- a conversion next to the load is a wait next to the load; (3) the consumption is branch-free too (a
+// select per request) -- with `if (...) break` the compiler sinks each load into its guarded block.
+template <int NT, int AHEAD, bool VEC, typename T>
+__device__ __forceinline__ void lse_share_loop(const T* __restrict__ lg, int n4, int ft, float& m, float& s) {
+    for (int i = ft; i < n4; i += AHEAD * NT) {
+        typename MapRaw4<T>::type r[AHEAD];
+        T e[AHEAD][4];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const T* q = lg + 4 * (size_t)min(i + u * NT, n4 - 1);
+            if constexpr (VEC) {
+                r[u] = map_raw_load4(q);
+            } else {
+                e[u][0] = q[0]; e[u][1] = q[1]; e[u][2] = q[2]; e[u][3] = q[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const bool live = i + u * NT < n4;
+            float4 v;
+            if constexpr (VEC) v = map_raw_cvt4<T>(r[u]);
+            else v = make_float4((float)e[u][0], (float)e[u][1], (float)e[u][2], (float)e[u][3]);
+            const float mn = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            const float sn = s * __expf(m - mn) + ((__expf(v.x - mn) + __expf(v.y - mn)) + (__expf(v.z - mn) + __expf(v.w - mn)));
+            s = live ? sn : s;
+            m = live ? mn : m;
+        }
+    }
+}
 template <int NT, int AHEAD, typename T>
 __device__ __forceinline__ void lse_thread_share(const T* __restrict__ lg, int n, int ft, float& m, float& s) {
     // Groups of four consecutive logits per request, consumed in index order: the same updates in the same order as one request per
-    // iteration (which was one memory round trip per iteration: 4 for a 64x64 map, 16 for 128x128).
-    // A map whose sample does not start on a four-element boundary (a channel slice with H*W % 4 == 2) takes four scalar loads per
-    // group instead of one vector load -- the SAME groups in the same order, so the result does not depend on where the map lies.
+    // iteration.  A map whose sample does not start on a four-element boundary (a channel slice with H*W % 4 == 2) takes four scalar
+    // loads per group instead of one vector load -- the SAME groups in the same order, so the result does not depend on where the map lies.
     const bool vec = (reinterpret_cast<uintptr_t>(lg) & (4 * sizeof(T) - 1)) == 0;
     const int n4 = n >> 2;
-    for (int i = ft; i < n4; i += AHEAD * NT) {
-        float4 v[AHEAD];
-#pragma unroll
-        for (int u = 0; u < AHEAD; ++u) {
-            if (i + u * NT >= n4) continue;
-            const T* q = lg + 4 * (size_t)(i + u * NT);
-            v[u] = vec ? map_load4(q) : make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
-        }
-#pragma unroll
-        for (int u = 0; u < AHEAD; ++u) {
-            if (i + u * NT >= n4) break;
-            const float mn = fmaxf(fmaxf(m, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
-            s = s * __expf(m - mn) + ((__expf(v[u].x - mn) + __expf(v[u].y - mn)) + (__expf(v[u].z - mn) + __expf(v[u].w - mn)));
-            m = mn;
-        }
-    }
+    if (vec) lse_share_loop<NT, AHEAD, true>(lg, n4, ft, m, s);
+    else lse_share_loop<NT, AHEAD, false>(lg, n4, ft, m, s);
     if (ft == 0)  // the up to three logits behind the last full group (H*W odd: two)
         for (int i = 4 * n4; i < n; ++i) ms_push(m, s, (float)lg[i]);
 }
