@@ -595,7 +595,17 @@ __device__ __forceinline__ void sample(const LossParams& p, const int b, SH& sh,
         grid_arrive_wait(*gc, tid);
         if (T <= kLoopTiles) {
             // all T rows in ONE round trip: every thread fetches a few values around the caches into LDS, 48 threads add the columns in tile order
-            for (int i = tid; i < T * kGridRow; i += nthr) (&sh.p3[0][0])[i] = grid_load(gc->rows + i);
+            // (up to eight requests per thread issued before the first is stored, no branch between them: the plain loop compiled to four in
+            // flight and then one round trip per remaining iteration -- three dependent round trips for zlmo's 29 tiles)
+            const int total = T * kGridRow;
+            for (int i0 = tid; i0 < total; i0 += 8 * nthr) {
+                double tmp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tmp[u] = grid_load(gc->rows + min(i0 + u * nthr, total - 1));
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * nthr < total) (&sh.p3[0][0])[i0 + u * nthr] = tmp[u];
+            }
             __syncthreads();
             if (tid < 48) {
                 double s = 0;
