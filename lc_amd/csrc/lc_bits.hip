@@ -420,31 +420,9 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_kernel(const B
 //      piece written ONCE with the sampled pixels' values merged in from LDS -- no partial writes, no read-modify-write.
 // Per pixel the arithmetic is the flat kernel's (AxisState, OutMap::pull, the same expression for the value): the same bits.
 constexpr int kTileRows = 4;       // at most; fewer where more would give a thread two items of the decode (zlmo: 3 rows = one sampled row of 43 pixels x 3 axes)
-#ifndef LC_BITS_TILE_AXIS_MAJOR
-#define LC_BITS_TILE_AXIS_MAJOR 0
-#endif
-#ifndef LC_BITS_TILE_ZERO_FIRST
-#define LC_BITS_TILE_ZERO_FIRST 1
-#endif
-#ifndef LC_BITS_TILE_NT
-#define LC_BITS_TILE_NT 1
-#endif
-#ifndef LC_BITS_TILE_SKIP_DECODE
-#define LC_BITS_TILE_SKIP_DECODE 0  // diagnostics: the store pattern alone
-#endif
-#ifndef LC_BITS_TILE_SKIP_STORES
-#define LC_BITS_TILE_SKIP_STORES 0  // diagnostics: the decode alone (one store per thread keeps the work alive)
-#endif
 template <int E, typename T>
 __device__ __forceinline__ void tile_store(T* at, const float (&o)[E]) {
-#if LC_BITS_TILE_SKIP_STORES
-    if (o[0] != 123456.f) return;
-#endif
-#if !LC_BITS_TILE_NT
-    map_store<4>(at, reinterpret_cast<const float(&)[4]>(o[0]));
-    if constexpr (E == 8) map_store<4>(at + 4, reinterpret_cast<const float(&)[4]>(o[4]));
-    return;
-#endif
+    // non-temporal: written once, read by the next kernel of the backward pass (plain stores measured +1.7 us at zlmo's shape)
     if constexpr (sizeof(T) == 4) {
         __builtin_nontemporal_store(map_v4f_t{o[0], o[1], o[2], o[3]}, reinterpret_cast<map_v4f_t*>(at));
     } else {
@@ -480,26 +458,16 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_tile_kernel(co
     const int dy = y - p.top;
     const bool row_hit = dy >= 0 && dy % SAMPLE == 0;
     T* const d = static_cast<T*>(p.d_logits) + (size_t)b * p.C * HW + (size_t)y * p.W + x0;
-    // rows without a sampled pixel are zero in every channel
-    auto zero_rows = [&]() {
-        if (writer && !row_hit) {
-            const float z[E] = {};
-            for (int c = grp; c < p.C; c += groups) tile_store<E, T>(d + (size_t)c * HW, z);
-        }
-    };
-#if LC_BITS_TILE_ZERO_FIRST
-    zero_rows();
-#endif
+    // rows without a sampled pixel are zero in every channel: written first (after the decode instead: the same time, measured)
+    if (writer && !row_hit) {
+        const float z[E] = {};
+        for (int c = grp; c < p.C; c += groups) tile_store<E, T>(d + (size_t)c * HW, z);
+    }
     const T* const logits = static_cast<const T*>(p.logits) + (size_t)b * p.logits_bs;
     const unsigned char* const gt = p.gt_bits + (size_t)b * p.C * HW;
     const OutMap om(p, b);
-    if (tid < (LC_BITS_TILE_SKIP_DECODE ? 0 : live)) {  // (the launcher sizes the tile so that live <= kThreads: every item has a thread of its own)
-#if LC_BITS_TILE_AXIS_MAJOR
-        const int npx = rows_live * Wn, a = tid / npx, pxi = tid - a * npx;  // lanes of a wavefront share the axis: a request touches ONE plane
-        const int i = 3 * pxi + a;                                         // (the LDS slot keeps the pixel-major order the merge reads)
-#else
-        const int i = tid, pxi = i / 3, a = i - 3 * pxi;
-#endif
+    if (tid < live) {  // (the launcher sizes the tile so that live <= kThreads: every item has a thread of its own)
+        const int i = tid, pxi = i / 3, a = i - 3 * pxi;  // (pixel-major; an axis-major item order measured slower)
         int rr = 0, j = pxi;
         if constexpr (kLiveRows > 1) { rr = pxi / Wn; j = pxi - rr * Wn; }
         const int r = r_first + rr;
@@ -533,9 +501,6 @@ __global__ __launch_bounds__(kThreads) void lc_bits_decode_gt_bwd_tile_kernel(co
         s_g[i] = in_msk ? pulled * dd.dval / ((float)((1 << nb) - 1) * 0.5f) : 0.f;
     }
     __syncthreads();
-#if !LC_BITS_TILE_ZERO_FIRST
-    zero_rows();
-#endif
     if (!writer || !row_hit) return;
     // the rows that hold sampled pixels: the piece's sampled pixels first move from LDS to registers (bit index and value per axis), then
     // every channel of the piece is ONE 16-byte store with those values merged in

@@ -241,9 +241,6 @@ __global__ __launch_bounds__(kThreads) void lc_dense_aux_bwd_kernel(const DenseA
 // log-sigmoid, BCE, mean, ...); here one pass: grid (C, chunks), a workgroup reduces its share of ONE code channel -- Hamming errors
 // inside the hard visibility mask, the BCE sum, and (channel 0) the mask's population -- partials in a fixed order, and the last
 // workgroup to arrive finishes: histogram EMA in place, soft histogram, softmax bit weights, the loss.  Backward: one element-wise pass.
-#ifndef LC_BIN_FWD_SKIP_STREAM
-#define LC_BIN_FWD_SKIP_STREAM 0  // diagnostics: the fixed part of the launch (partials, arrival, the last workgroup's tail)
-#endif
 #ifndef LC_BIN_FWD_AHEAD
 #define LC_BIN_FWD_AHEAD 1
 #endif
@@ -327,7 +324,7 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
         // offset -- the flat walk over (sample, pixel) paid two integer divisions per request (a quarter of the kernel's VALU
         // instructions).  kAhead units are in flight per thread: all their requests are issued before the first is used -- raw words in, no
         // branch between the requests (a unit behind the workgroup's last re-reads that one and is not counted), conversions at the use.
-        const unsigned slabs = (hw4 + kBinThreads - 1) / kBinThreads, units = LC_BIN_FWD_SKIP_STREAM ? 0u : (unsigned)p.B * slabs;
+        const unsigned slabs = (hw4 + kBinThreads - 1) / kBinThreads, units = (unsigned)p.B * slabs;
         for (unsigned u0 = (unsigned)chunk; u0 < units; u0 += kAhead * (unsigned)chunks) {
             typename MapRaw4<T>::type xr[kAhead], vr[kAhead];
             uchar4 t[kAhead];
