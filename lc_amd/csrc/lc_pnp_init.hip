@@ -427,17 +427,42 @@ struct PointBatch {
     int src[kBatch];
 };
 __device__ __forceinline__ PointBatch load_batch(const RansacParams& p, size_t base, int i0, int cap) {
-    const bool sel = p.sel_w != nullptr;
+    // Every request of the batch is issued before the first value is used: the index is clamped instead of guarded (a slot behind the row's
+    // end re-reads its last point and is zeroed afterwards) and the optional rows are read through pointers that fall back to rows that
+    // exist.  Written as `have ? load : 0` per element, each of the kBatch slots was a branch with its loads and an s_waitcnt vmcnt(0):
+    // four dependent memory round trips at the head of the selection kernel (ISA, round 6).
+    const bool sel = p.sel_w != nullptr, idx = sel && p.sel_in_index != nullptr;
+    const float* const sw = sel ? p.sel_w : p.pts2d;                                        // (B,Nmax,2) either way
+    const int* const si = idx ? p.sel_in_index : reinterpret_cast<const int*>(p.pts2d);     // any readable (B,Nmax) words
     PointBatch q;
+    if (cap <= 0) {  // (uniform) an empty row: nothing may be read
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            q.X[k] = q.Y[k] = q.Z[k] = q.pu[k] = q.pv[k] = 0.f;
+            q.sw[k] = make_float2(0.f, 0.f);
+            q.src[k] = i0 + k * (int)blockDim.x + (int)threadIdx.x;
+        }
+        return q;
+    }
+    float2 u[kBatch];
+    int s[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+        const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x, j = i < cap ? i : cap - 1;
+        const float* X = p.pts3d + (base + j) * 3;
+        q.X[k] = X[0]; q.Y[k] = X[1]; q.Z[k] = X[2];
+        u[k] = *reinterpret_cast<const float2*>(p.pts2d + (base + j) * 2);
+        q.sw[k] = *reinterpret_cast<const float2*>(sw + (base + j) * 2);
+        s[k] = si[base + j];
+    }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
         const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
         const bool have = i < cap;
-        q.X[k] = have ? p.pts3d[(base + i) * 3] : 0.f; q.Y[k] = have ? p.pts3d[(base + i) * 3 + 1] : 0.f;
-        q.Z[k] = have ? p.pts3d[(base + i) * 3 + 2] : 0.f;
-        q.pu[k] = have ? p.pts2d[(base + i) * 2] : 0.f; q.pv[k] = have ? p.pts2d[(base + i) * 2 + 1] : 0.f;
-        q.sw[k] = have && sel ? *reinterpret_cast<const float2*>(p.sel_w + (base + i) * 2) : make_float2(0.f, 0.f);
-        q.src[k] = (have && sel && p.sel_in_index) ? p.sel_in_index[base + i] : i;
+        q.X[k] = have ? q.X[k] : 0.f; q.Y[k] = have ? q.Y[k] : 0.f; q.Z[k] = have ? q.Z[k] : 0.f;
+        q.pu[k] = have ? u[k].x : 0.f; q.pv[k] = have ? u[k].y : 0.f;
+        q.sw[k] = (have && sel) ? q.sw[k] : make_float2(0.f, 0.f);
+        q.src[k] = (have && idx) ? s[k] : i;
     }
     return q;
 }
@@ -989,7 +1014,6 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
     // it over through LDS instead of a dependent load), the chunk partials of this thread's first hypothesis.
     const int n = min(p.counts ? p.counts[b] : p.Nmax, p.Nmax);
     const int chunks = n >= 4 ? (n + kChunkPts - 1) / kChunkPts : 0;
-    const PointBatch first = load_batch(p, (size_t)b * p.Nmax, 0, n);
     double2 mine[6];
     {
         const double2* h = reinterpret_cast<const double2*>(w.hyp64 + 12 * ((size_t)b * w.H + (tid < w.H ? tid : 0)));
@@ -1000,6 +1024,8 @@ __device__ __forceinline__ void select_winner(const RansacParams& p, const Ransa
 #pragma unroll
     for (int c = 0; c < kFirstChunks; ++c)
         pc0[c] = (c < chunks && tid < w.H) ? part_at(((size_t)b * w.C + c) * w.H + tid) : 0ull;
+    // (the batch last: its values pass through selects, i.e. a wait -- requested first, the two groups above were issued behind that wait)
+    const PointBatch first = load_batch(p, (size_t)b * p.Nmax, 0, n);
     const CamInv kin(p.K + 9 * (size_t)b);
     unsigned char* mask = p.inlier_mask + (size_t)b * p.Nmax;
     zero_bytes(mask, 0, p.Nmax);
