@@ -116,6 +116,7 @@ class CommReport:
             return out
 
         self._in_hook = False
+        self._real_all_reduce = real
         dist.all_reduce = counted_all_reduce
 
         def hook(state, bucket):
@@ -179,9 +180,12 @@ class CommReport:
         """All ranks' step records to rank 0; it prints one line per step and rank, the medians, and the estimate for the measured payload."""
         import torch.distributed as dist
 
+        real = getattr(self, "_real_all_reduce", None)
+        if real is not None:  # the wrapper lives for the run only
+            dist.all_reduce, self._real_all_reduce = real, None
         gathered = [None] * self.world
         dist.all_gather_object(gathered, self.steps, group=self.group)
-        if self.rank != 0:
+        if self.rank != 0 or not self.steps:
             return None
         print("comm report (per step, per rank): gradient all-reduce payload / buckets / window, loss-side small all-reduces")
         for s in range(len(self.steps)):
