@@ -260,12 +260,12 @@ __device__ __forceinline__ float bce_logits(float z, float t) { return (1.f - t)
 // and by the weights-in kernel of the sharded form, so that both give the same bits: histogram EMA in place, soft histogram, softmax
 // over the C <= 128 bits, the weighted sum of the per-bit BCE means parked in `ws`.  Called by every thread of the workgroup
 // (blockDim >= C); hamm / ws hold C valid entries and are visible (a barrier has been passed).
-__device__ __forceinline__ void bin_loss_finish(const BinLossParams& p, const long long* hamm, long long vis_total, float* zs, float* ws, int tid) {
+__device__ __forceinline__ void bin_loss_finish(const BinLossParams& p, const long long* hamm, long long vis_total, float h_old, float* zs, float* ws, int tid) {
     __shared__ float es[kBinMaxChannels];
     if (tid < p.C) {
         // losses.py:205-208 in the reference's fp32 operation order (integer tensors divide as float32)
         const float hist = (float)hamm[tid] / (float)(vis_total + 1);
-        float h = p.histogram[tid];
+        float h = h_old;  // p.histogram[tid], requested by the caller before its other loads (a memory round trip at the very end of the launch otherwise)
         h = h * (1.f - p.momentum);
         h = h + hist * p.momentum;
         p.histogram[tid] = h;
@@ -374,6 +374,9 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
     // The last workgroup: every partial is fetched around the caches ONCE, many requests in flight per thread (a thread adding its
     // channel's chunks one dependent load after the other spent ~0.7 us per load), staged in LDS and added in chunk order.
     const int tid = threadIdx.x;
+    // for bin_loss_finish: the histogram's entry in flight together with the partials (the counts-out form has no histogram: any readable word)
+    float h_old = (p.counts_out ? reinterpret_cast<const float*>(p.partials) : p.histogram)[min(tid, p.C - 1)];
+    asm volatile("" : "+v"(h_old));
     __shared__ double stage[32][2][kBinChunks];
     __shared__ double vis_part[kBinChunks];
     __shared__ long long hamm_s[kBinMaxChannels];
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(kBinThreads) void lc_xyz_bin_loss_fwd_kernel(const 
         if (tid < p.C) { p.counts_out[tid] = hamm_s[tid]; p.bce_mean[tid] = ws[tid]; }
         if (tid == 0) p.counts_out[p.C] = vis_s;
     } else {
-        bin_loss_finish(p, hamm_s, vis_s, zs, ws, tid);
+        bin_loss_finish(p, hamm_s, vis_s, h_old, zs, ws, tid);
     }
     arrival_reset(p.ticket, tid);
 }
@@ -412,9 +415,11 @@ __global__ __launch_bounds__(kBinMaxChannels) void lc_xyz_bin_loss_finish_kernel
     __shared__ float zs[kBinMaxChannels], ws[kBinMaxChannels];
     __shared__ long long hamm_s[kBinMaxChannels];
     const int tid = threadIdx.x;
+    const float h_old = p.histogram[min(tid, p.C - 1)];
+    const long long vis_total = p.counts_in[p.C];
     if (tid < p.C) { hamm_s[tid] = p.counts_in[tid]; ws[tid] = p.bce_mean[tid]; }
     __syncthreads();
-    bin_loss_finish(p, hamm_s, p.counts_in[p.C], zs, ws, tid);
+    bin_loss_finish(p, hamm_s, vis_total, h_old, zs, ws, tid);
 }
 
 template <typename T>
